@@ -1,0 +1,262 @@
+"""dftatom_amd -- MI355X (gfx950) radial-DFT inner loop behind a C ABI.
+
+This package is a thin ctypes binding over ``dftatom_amd/libdftatom_hip.so`` (built from
+``dftatom_amd/csrc`` by ``__graft_entry__.build()`` / ``make -C dftatom_amd/csrc``).  There is no CPU
+fallback: if the shared library is missing, or no HIP device is usable, every entry point raises.
+
+When PyTorch is used in the same process (bench.py: device memory, streams, torch.distributed), import
+torch BEFORE this module so that both share one HIP runtime (same libamdhip64 soname).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdftatom_hip.so")
+
+OK = 0
+SWEEP_COUNT, SWEEP_ZERO = 0, 1
+BOUNDARY_DEVICE, BOUNDARY_HOST = 0, 1
+LEVELS_CHAINED, LEVELS_BATCHED = 0, 1
+INT_TRAPEZOID, INT_SIMPSON13, INT_SIMPSON38, INT_BOOLE, INT_ROMBERG = range(5)
+RECORD_DOUBLES = 64
+
+c_dp = C.POINTER(C.c_double)
+c_ip = C.POINTER(C.c_int)
+c_lp = C.POINTER(C.c_long)
+vp = C.c_void_p
+
+
+class DftaError(RuntimeError):
+    pass
+
+
+class LevelResult(C.Structure):
+    _fields_ = [("E", C.c_double), ("top", C.c_double), ("bottom", C.c_double), ("n_count", C.c_int),
+                ("n_zero", C.c_int), ("converged", C.c_int), ("matchPoint", C.c_int)]
+
+
+class Energies(C.Structure):
+    _fields_ = [(k, C.c_double) for k in ("Etotal", "Ekinetic", "Ecoul", "Enuclear", "Exc",
+                                          "Eelectronic", "Ehartree", "eExcDif", "Epotential")]
+
+    def as_list(self):
+        return [self.Etotal, self.Ekinetic, self.Ecoul, self.Enuclear, self.Exc]
+
+
+class StepStats(C.Structure):
+    _fields_ = [("sweeps_issued", C.c_long), ("sweeps_reference", C.c_long), ("points_traversed", C.c_long),
+                ("vcycles", C.c_long), ("rounds", C.c_int), ("ms_levels", C.c_float), ("ms_poisson", C.c_float),
+                ("ms_tail", C.c_float)]
+
+
+# every symbol include/dftatom_hip.h declares: name -> (restype, argtypes)
+SIGNATURES = {
+    "dfta_ctx_create": (C.c_int, [C.c_int, vp, C.POINTER(vp)]),
+    "dfta_ctx_destroy": (None, [vp]),
+    "dfta_ctx_synchronize": (C.c_int, [vp]),
+    "dfta_last_error": (C.c_char_p, [vp]),
+    "dfta_version": (C.c_char_p, []),
+    "dfta_ctx_device_info": (C.c_int, [vp, c_ip, C.c_char_p, C.c_int]),
+    "dfta_ctx_last_kernel_ms": (C.c_int, [vp, C.POINTER(C.c_float)]),
+    "dfta_grid_create": (C.c_int, [vp, C.c_int, C.c_double, C.c_double, C.POINTER(vp)]),
+    "dfta_grid_destroy": (None, [vp]),
+    "dfta_grid_num_nodes": (C.c_int, [vp]),
+    "dfta_grid_rp": (C.c_double, [vp]),
+    "dfta_grid_get_r": (C.c_int, [vp, c_dp]),
+    "dfta_num_nodes": (C.c_int, [C.c_int]),
+    "dfta_numerov_sweeps": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, c_dp, C.c_int, c_ip, c_ip, c_dp, c_ip,
+                                      c_ip, c_dp, c_ip, c_ip]),
+    "dfta_numerov_sweeps_dev": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, C.c_int, c_ip, c_ip, c_ip, vp, vp, vp, vp, vp,
+                                          vp, vp, vp, vp]),
+    "dfta_numerov_match": (C.c_int, [vp, vp, C.c_int, C.c_int, c_dp, C.c_int, c_ip, c_ip, c_dp, c_dp, c_lp]),
+    "dfta_solve_levels": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, c_dp, c_dp, C.c_int, c_ip, c_ip, c_ip, c_ip,
+                                    C.POINTER(LevelResult), c_dp, c_dp, c_dp, c_lp]),
+    "dfta_poisson_create": (C.c_int, [vp, vp, C.c_int, C.POINTER(vp)]),
+    "dfta_poisson_destroy": (None, [vp]),
+    "dfta_poisson_solve": (C.c_int, [vp, c_ip, c_dp, c_dp, c_ip, c_dp]),
+    "dfta_poisson_solve_dev": (C.c_int, [vp, vp, vp, vp]),
+    "dfta_poisson_level_size": (C.c_int, [vp, C.c_int]),
+    "dfta_poisson_set_level": (C.c_int, [vp, C.c_int, c_dp, c_dp]),
+    "dfta_poisson_get_level": (C.c_int, [vp, C.c_int, c_dp, c_dp]),
+    "dfta_poisson_gauss_seidel": (C.c_int, [vp, C.c_int, C.c_int, c_dp]),
+    "dfta_poisson_restrict": (C.c_int, [vp, C.c_int]),
+    "dfta_poisson_prolong": (C.c_int, [vp, C.c_int]),
+    "dfta_poisson_vcycle": (C.c_int, [vp, c_dp]),
+    "dfta_vwn_lda": (C.c_int, [vp, c_dp, C.c_size_t, c_dp, c_dp]),
+    "dfta_vwn_lsda": (C.c_int, [vp, c_dp, c_dp, C.c_size_t, c_dp, c_dp, c_dp, c_dp]),
+    "dfta_integrate": (C.c_int, [vp, C.c_int, C.c_double, c_dp, C.c_int, C.POINTER(C.c_double)]),
+    "dfta_scf_create": (C.c_int, [vp, vp, C.c_int, C.c_int, c_ip, C.c_double, C.c_int, C.c_int, C.POINTER(vp)]),
+    "dfta_scf_destroy": (None, [vp]),
+    "dfta_scf_step": (C.c_int, [vp, C.POINTER(StepStats)]),
+    "dfta_scf_get_energies": (C.c_int, [vp, C.POINTER(Energies), c_ip]),
+    "dfta_scf_num_levels": (C.c_int, [vp, C.c_int, C.c_int]),
+    "dfta_scf_get_levels": (C.c_int, [vp, C.c_int, C.c_int, c_ip, c_ip, c_ip, c_dp, c_ip]),
+    "dfta_scf_get_array": (C.c_int, [vp, C.c_int, C.c_int, c_dp]),
+    "dfta_scf_get_records_dev": (C.c_int, [vp, vp]),
+    "dfta_get_subshells": (C.c_int, [C.c_int, c_ip, c_ip, c_ip, C.c_int]),
+    "dfta_split_spin": (C.c_int, [C.c_int, c_ip, c_ip, c_ip, c_ip, c_ip, c_ip, c_ip, c_ip, C.c_int]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libdftatom_hip.so and bind every declared symbol.  Raises if the library is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise DftaError("%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                        "(there is no CPU fallback)" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        f = getattr(lib, name)       # AttributeError if a declared symbol is not exported
+        f.restype = res
+        f.argtypes = args
+    _lib = lib
+    return lib
+
+
+def _dp(a):
+    return a.ctypes.data_as(c_dp)
+
+
+def _ip(a):
+    return a.ctypes.data_as(c_ip)
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+class Context:
+    """Device context (dfta_ctx).  `stream` may be a raw hipStream_t (int), e.g.
+    torch.cuda.current_stream().cuda_stream; None -> stream owned by the context."""
+
+    def __init__(self, device=0, stream=None):
+        self.lib = load()
+        h = vp()
+        rc = self.lib.dfta_ctx_create(device, vp(stream) if stream else None, C.byref(h))
+        if rc != OK:
+            raise DftaError("dfta_ctx_create failed with status %d (no usable HIP device?)" % rc)
+        self.h = h
+
+    def check(self, rc):
+        if rc != OK:
+            raise DftaError("status %d: %s" % (rc, self.lib.dfta_last_error(self.h).decode()))
+
+    def synchronize(self):
+        self.check(self.lib.dfta_ctx_synchronize(self.h))
+
+    def device_info(self):
+        ncu = C.c_int()
+        name = C.create_string_buffer(128)
+        self.check(self.lib.dfta_ctx_device_info(self.h, C.byref(ncu), name, 128))
+        return ncu.value, name.value.decode()
+
+    def last_kernel_ms(self):
+        ms = C.c_float()
+        self.check(self.lib.dfta_ctx_last_kernel_ms(self.h, C.byref(ms)))
+        return ms.value
+
+    def close(self):
+        if self.h:
+            self.lib.dfta_ctx_destroy(self.h)
+            self.h = None
+
+
+class Grid:
+    def __init__(self, ctx, mg_levels, delta, Rmax):
+        self.ctx = ctx
+        h = vp()
+        ctx.check(ctx.lib.dfta_grid_create(ctx.h, mg_levels, delta, Rmax, C.byref(h)))
+        self.h = h
+        self.levels, self.delta, self.Rmax = mg_levels, delta, Rmax
+        self.N = ctx.lib.dfta_grid_num_nodes(h)
+        self.Rp = ctx.lib.dfta_grid_rp(h)
+
+    def r(self):
+        out = np.zeros(self.N)
+        self.ctx.check(self.ctx.lib.dfta_grid_get_r(self.h, _dp(out)))
+        return out
+
+    def close(self):
+        if self.h:
+            self.ctx.lib.dfta_grid_destroy(self.h)
+            self.h = None
+
+
+def numerov_sweeps(ctx, grid, kind, V, l, E, limit=None, vidx=None, boundary=BOUNDARY_HOST):
+    """Batched SolveSchrodingerCountNodes / SolutionInZero.  Returns dict(count, u0, start, trip)."""
+    V = _f64(V).reshape(-1, grid.N)
+    l = _i32(l)
+    E = _f64(E)
+    nt = len(E)
+    lim = _i32(limit) if limit is not None else np.zeros(nt, np.int32)
+    vi = _i32(vidx) if vidx is not None else np.zeros(nt, np.int32)
+    count = np.zeros(nt, np.int32)
+    u0 = np.zeros(nt)
+    start = np.zeros(nt, np.int32)
+    trip = np.zeros(nt, np.int32)
+    ctx.check(ctx.lib.dfta_numerov_sweeps(ctx.h, grid.h, kind, boundary, V.shape[0], _dp(V), nt, _ip(vi), _ip(l), _dp(E),
+                                          _ip(lim), _ip(count), _dp(u0), _ip(start), _ip(trip)))
+    return {"count": count, "u0": u0, "start": start, "trip": trip}
+
+
+def numerov_match(ctx, grid, V, l, E, vidx=None, boundary=BOUNDARY_HOST):
+    V = _f64(V).reshape(-1, grid.N)
+    l = _i32(l)
+    E = _f64(E)
+    nt = len(E)
+    vi = _i32(vidx) if vidx is not None else np.zeros(nt, np.int32)
+    psi = np.zeros((nt, grid.N))
+    mp = np.zeros(nt, np.int64)
+    ctx.check(ctx.lib.dfta_numerov_match(ctx.h, grid.h, boundary, V.shape[0], _dp(V), nt, _ip(vi), _ip(l), _dp(E),
+                                         _dp(psi), mp.ctypes.data_as(c_lp)))
+    return psi, mp
+
+
+def get_subshells(Z):
+    lib = load()
+    n, l, occ = (np.zeros(32, np.int32) for _ in range(3))
+    c = lib.dfta_get_subshells(Z, _ip(n), _ip(l), _ip(occ), 32)
+    if c < 0:
+        raise DftaError("dfta_get_subshells(%d) failed" % Z)
+    return [(int(n[i]), int(l[i]), int(occ[i])) for i in range(c)]
+
+
+def solve_levels(ctx, grid, V, levels, bottom0, vidx=None, mode=LEVELS_BATCHED, tree_depth=0, want_psi=False):
+    """Device-side LoopOverLevels for `levels` = [(n, l, occ), ...] on potentials V (nV x N).
+    Returns dict(E, top, bottom, n_count, n_zero, converged, matchPoint, newDensity, Eelectronic, psi, issued)."""
+    V = _f64(V).reshape(-1, grid.N)
+    nV = V.shape[0]
+    nl = len(levels)
+    n = _i32([a for a, _, _ in levels])
+    l = _i32([b for _, b, _ in levels])
+    occ = _i32([c for _, _, c in levels])
+    vi = _i32(vidx) if vidx is not None else np.zeros(nl, np.int32)
+    b0 = _f64(np.broadcast_to(np.asarray(bottom0, dtype=np.float64), (nV,)))
+    res = (LevelResult * nl)()
+    nd = np.zeros((nV, grid.N))
+    eel = np.zeros(nV)
+    psi = np.zeros((nl, grid.N)) if want_psi else None
+    issued = C.c_long(0)
+    ctx.check(ctx.lib.dfta_solve_levels(ctx.h, grid.h, mode, tree_depth, nV, _dp(V), _dp(b0), nl, _ip(vi), _ip(n), _ip(l),
+                                        _ip(occ), res, _dp(nd), _dp(eel), _dp(psi) if want_psi else None, C.byref(issued)))
+    out = {k: np.array([getattr(res[i], k) for i in range(nl)]) for k in
+           ("E", "top", "bottom", "n_count", "n_zero", "converged", "matchPoint")}
+    out.update(newDensity=nd, Eelectronic=eel, psi=psi, issued=issued.value)
+    return out
+
+
+def integrate(ctx, rule, delta, values):
+    v = _f64(values)
+    out = C.c_double()
+    ctx.check(ctx.lib.dfta_integrate(ctx.h, rule, delta, _dp(v), len(v), C.byref(out)))
+    return out.value

@@ -1,0 +1,90 @@
+// common.h -- shared host-side plumbing of libdftatom_hip (context, grid tables, error handling).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/dftatom_hip.h"
+
+struct dfta_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int num_cu = 0;
+    char name[128] = {0};
+    mutable char err[512] = {0};
+    hipEvent_t ev[2] = {nullptr, nullptr};   // bracket the dominant kernel of the last host-pointer call
+    bool have_kernel_time = false;
+};
+
+#define DFTA_HIP(ctx, call)                                                                     \
+    do {                                                                                        \
+        hipError_t e_ = (call);                                                                 \
+        if (e_ != hipSuccess) {                                                                 \
+            snprintf((ctx)->err, sizeof((ctx)->err), "%s:%d: %s -> %s", __FILE__, __LINE__, #call, \
+                     hipGetErrorString(e_));                                                    \
+            return DFTA_ERR_HIP;                                                                \
+        }                                                                                       \
+    } while (0)
+
+#define DFTA_CHECK_LAUNCH(ctx) DFTA_HIP(ctx, hipGetLastError())
+
+#define DFTA_REQUIRE(ctx, cond, msg)                                               \
+    do {                                                                           \
+        if (!(cond)) {                                                             \
+            if (ctx) snprintf((ctx)->err, sizeof((ctx)->err), "invalid: %s", msg); \
+            return DFTA_ERR_INVALID;                                               \
+        }                                                                          \
+    } while (0)
+
+// Device-resident tables of one logarithmic grid r_i = Rp (exp(i delta) - 1), i = 0..N-1.
+// All exp() values are produced on the host with libm in the reference's expression order
+// (Numerov.h:79-101,183; DFTAtom.cpp:42,47,334,439-442; PoissonSolver.h:66-74) and uploaded once.
+struct dfta_grid {
+    dfta_ctx* ctx = nullptr;
+    int levels = 0;
+    int N = 0;
+    double delta = 0, Rmax = 0, Rp = 0, twodelta = 0, Rp2delta2 = 0, delta2p4 = 0;
+    double far_arg_threshold = 0;   // exp(a) < 1e-200  <=>  a < far_arg_threshold (host libm, monotone)
+    double zero1[4] = {0, 0, 0, 0};  // GetBoundaryValueZero(1, l), l = 0..3 (Numerov.h:110-116)
+    // host copies
+    std::vector<double> h_r, h_e1, h_e2, h_eh;
+    // device tables (N doubles each unless noted)
+    double* d_r = nullptr;      // r_i
+    double* d_e1 = nullptr;     // exp(i delta)
+    double* d_e2 = nullptr;     // exp(i 2delta)
+    double* d_eh = nullptr;     // exp(i delta / 2)
+    double* d_cl = nullptr;     // 4*N: l(l+1.)/(r_i r_i)*0.5 for l = 0..3 (row 0 is all zeros)
+    double* d_cnst = nullptr;   // (Rp delta) exp(delta i)            (DFTAtom.cpp:47,442)
+    double* d_psrc = nullptr;   // (4 pi Rp^2 delta^2) exp(i 2delta)  (PoissonSolver.h:66-74)
+    double* d_fpr2 = nullptr;   // (4 pi r_i) r_i                     (DFTAtom.cpp:340)
+};
+
+template <typename T>
+static inline int dfta_alloc(dfta_ctx* ctx, T** p, size_t count)
+{
+    DFTA_HIP(ctx, hipMalloc(reinterpret_cast<void**>(p), count * sizeof(T)));
+    return DFTA_OK;
+}
+
+// simple RAII device buffer for call-scoped scratch
+template <typename T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t count)
+    {
+        if (p) { (void)hipFree(p); p = nullptr; }
+        n = count;
+        if (count == 0) return hipSuccess;
+        return hipMalloc(reinterpret_cast<void**>(&p), count * sizeof(T));
+    }
+};

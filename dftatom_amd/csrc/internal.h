@@ -1,0 +1,20 @@
+// internal.h -- launch helpers shared between the translation units of libdftatom_hip (not part of the ABI).
+#pragma once
+#include "common.h"
+
+// numerov.hip
+int dfta_launch_build_tab(dfta_ctx* ctx, const dfta_grid* g, double2* tab, const double* dV, const int* d_slot_v,
+                          const int* d_slot_l, int nslots);
+int dfta_launch_boundary(dfta_ctx* ctx, const dfta_grid* g, const double* dE, int ntrials, int* dStart, double* dUs,
+                         double* dUs1);
+int dfta_launch_sweep(dfta_ctx* ctx, const dfta_grid* g, int kind, const int* blk_kind, int nblocks, const double2* tab,
+                      const int* blk_slot, const int* blk_first, const int* blk_cnt, const double* dE, const int* dLimit,
+                      const int* dStart, const double* dUs, const double* dUs1, int* dCount, double* dU0, int* dTrip,
+                      unsigned long long* dTotalTrips);
+int dfta_launch_match(dfta_ctx* ctx, const dfta_grid* g, int ntrials, const double2* tab, const int* d_trial_slot,
+                      const double* dE, const int* dStart, const double* dUs, const double* dUs1, const int* dL,
+                      double* dPsi, double* dQ, int* dMatch);
+
+// reduce.hip: Integral::Simpson38 (Integral.h:50-73) with the reference's sequential summation order, one wave
+// per vector: out[k] = Simpson38(1, vals + k*stride) for k < nvec
+int dfta_launch_simpson38_ordered(dfta_ctx* ctx, const double* dVals, int n, int nvec, size_t stride, double* dOut);

@@ -1,0 +1,56 @@
+// levels.h -- device-resident eigenvalue search shared by dfta_solve_levels and the SCF driver.
+#pragma once
+#include <vector>
+
+#include "common.h"
+
+namespace dfta {
+
+struct JobSpec { int v, n, l, occ; };
+
+// state of one (potential, level) eigenvalue search; lives in device memory
+struct Job {
+    double toe, boe;        // current interval of the running bisection (Top / Bottom)
+    double bottom0;         // BottomEnergy at entry of LocateInterval
+    double top, bottom;     // interval returned by LocateInterval
+    double E;               // eigenvalue
+    int v, n, l, occ, nodes, slot;
+    int phase;
+    int haveSgn, sgnBottom, iter3, converged;
+    int n_count, n_zero, matchPoint;
+};
+
+struct LevelStats {
+    int rounds = 0;
+    long sweeps_issued = 0;
+    long points_traversed = 0;
+};
+
+struct LevelSolver {
+    dfta_ctx* ctx = nullptr;
+    const dfta_grid* g = nullptr;
+    int mode = 0, nV = 0, njobs = 0, nchains = 0, depth = 0, tpj = 0, nwaves = 0, nslots = 0;
+    long ntrials = 0;
+    std::vector<Job> h_jobs_template;
+    Job* d_jobs = nullptr;
+    int *d_chain_off = nullptr, *d_v_off = nullptr, *d_slot_v = nullptr, *d_slot_l = nullptr;
+    double2* d_tab = nullptr;
+    double *d_E = nullptr, *d_us = nullptr, *d_us1 = nullptr, *d_u0 = nullptr;
+    int *d_limit = nullptr, *d_start = nullptr, *d_count = nullptr;
+    int *d_wave_kind = nullptr, *d_wave_slot = nullptr, *d_wave_first = nullptr, *d_wave_cnt = nullptr;
+    unsigned long long* d_counters = nullptr;   // [0] issued trials, [1] traversed points, [2] scratch
+    double *d_Psi = nullptr, *d_Q = nullptr;     // njobs*N each
+    double *d_jE = nullptr, *d_jus = nullptr, *d_jus1 = nullptr;
+    int *d_jslot = nullptr, *d_jl = nullptr, *d_jstart = nullptr, *d_jmp = nullptr;
+
+    LevelSolver() = default;
+    LevelSolver(const LevelSolver&) = delete;
+    LevelSolver& operator=(const LevelSolver&) = delete;
+    ~LevelSolver();
+    void release();
+    int setup(dfta_ctx* c, const dfta_grid* grid, int mode, int tree_depth, int nV, const std::vector<JobSpec>& specs);
+    int run(const double* dV, const double* bottom0, double* dNewDensity, LevelStats* stats);
+    int fetch_jobs(std::vector<Job>& out);
+};
+
+}  // namespace dfta

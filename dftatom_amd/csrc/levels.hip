@@ -1,0 +1,456 @@
+// levels.hip -- device-side eigenvalue search for a batch of (potential, n, l) levels.
+//
+// Replaces DFTAtom::LoopOverLevels, LocateInterval, NormalizeNonUniform and the accumulation
+// newDensity += occ * Psi^2 (DFTAtom.cpp:36-56, 493-604).
+//
+// The reference finds each eigenvalue with three sequential bisections (node count > n: top of the band;
+// node count < n: bottom of the band; sign of u(0): the eigenvalue), ~140 sweeps per level, each sweep a
+// sequential O(N) recurrence.  Here every bisection is a SPECULATIVE TREE: in one round the 2^d - 1
+// possible midpoints of the next d bisection steps of every level are integrated concurrently (one lane
+// per trial, numerov.hip), then one thread per chain walks its tree with the reference's predicates.
+// The midpoints are generated with the reference's expression (toe + boe) / 2 along the same paths, so the
+// walk reproduces the reference's decision sequence; ~53 sequential sweeps per phase become ceil(53/d) rounds.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <vector>
+
+#include "internal.h"
+#include "levels.h"
+#include "ordered_sum.h"
+
+namespace {
+
+constexpr double kEnergyErr = 1E-12;   // DFTAtom.cpp:348
+constexpr int kMaxIter3 = 500;         // DFTAtom.cpp:517
+
+enum Phase { PH_WAIT = 0, PH_TOP = 1, PH_BOTTOM = 2, PH_ZERO = 3, PH_DONE = 4 };
+
+// ---- expand: trial energies of the current tree of every job, plus their far boundary values ---------------
+__global__ __launch_bounds__(256) void k_expand(const dfta::Job* __restrict__ jobs, int tpj, const double* __restrict__ r,
+                                                int N, double delta, double far_thr, double* __restrict__ E,
+                                                int* __restrict__ limit, int* __restrict__ start, double* __restrict__ us,
+                                                double* __restrict__ us1, int* __restrict__ wave_kind,
+                                                unsigned long long* __restrict__ issued)
+{
+    const int gt = blockIdx.x * blockDim.x + threadIdx.x;
+    const int job = gt / tpj;
+    const int h = gt - job * tpj;
+    const dfta::Job j = jobs[job];
+    bool active = false;
+    double e = 0;
+    if (j.phase == PH_TOP || j.phase == PH_BOTTOM || j.phase == PH_ZERO) {
+        if (h == 0) {
+            if (j.phase == PH_ZERO && !j.haveSgn) { active = true; e = j.boe; }   // DFTAtom.cpp:513
+        } else {
+            double hi = j.toe, lo = j.boe;
+            const int depth = 31 - __clz(h);
+            for (int b = depth - 1; b >= 0; --b) {
+                const double m = (hi + lo) / 2;
+                if ((h >> b) & 1) lo = m; else hi = m;          // child 2h: toe = E ; child 2h+1: boe = E
+            }
+            e = (hi + lo) / 2;
+            if (j.phase == PH_ZERO) active = (depth < kMaxIter3 - j.iter3);
+            else active = (hi - lo > kEnergyErr);                // loop condition of DFTAtom.cpp:571,589
+        }
+    }
+    E[gt] = e;
+    limit[gt] = j.nodes;
+    int st = 0;
+    if (active) {
+        // GetMaxRadiusIndex (Numerov.h:119-136); exp(arg) < 1e-200 <=> arg < far_thr
+        const double s = sqrt(2. * fabs(e));
+        int maxIndex = N - 1, minIndex = 1;
+        while (maxIndex - minIndex > 1) {
+            const int mid = (maxIndex + minIndex) / 2;
+            const double arg = -r[mid] * s - static_cast<double>(mid) * delta * 0.5;
+            if (arg < far_thr) maxIndex = mid; else minIndex = mid;
+        }
+        st = maxIndex;
+        us[gt] = exp(-r[st] * s - static_cast<double>(st) * delta * 0.5);              // Numerov.h:107
+        us1[gt] = exp(-r[st - 1] * s - static_cast<double>(st - 1) * delta * 0.5);
+    }
+    start[gt] = st;
+    if ((gt & 63) == 0) wave_kind[gt >> 6] = (j.phase == PH_ZERO) ? DFTA_SWEEP_ZERO : DFTA_SWEEP_COUNT;
+    if (issued) {
+        const unsigned long long m = __ballot(active);
+        if ((threadIdx.x & 63) == 0 && m) atomicAdd(issued, (unsigned long long)__popcll(m));
+    }
+}
+
+// ---- walk: follow each tree with the reference's predicates --------------------------------------------------
+__device__ void walk_job(dfta::Job& j, const int* __restrict__ count, const double* __restrict__ u0, int tpj, int base)
+{
+    if (j.phase == PH_TOP) {                                        // DFTAtom.cpp:568-585
+        double hi = j.toe, lo = j.boe;
+        int h = 1;
+        while (hi - lo > kEnergyErr) {
+            if (h >= tpj) { j.toe = hi; j.boe = lo; return; }
+            const double e = (hi + lo) / 2;
+            const int c = count[base + h];
+            ++j.n_count;
+            if (c > j.nodes) { hi = e; h = 2 * h; } else { lo = e; h = 2 * h + 1; }
+        }
+        j.top = hi;
+        j.toe = hi;
+        j.boe = j.bottom0;                                          // DFTAtom.cpp:587
+        j.phase = PH_BOTTOM;
+        return;
+    }
+    if (j.phase == PH_BOTTOM) {                                     // DFTAtom.cpp:587-603
+        double hi = j.toe, lo = j.boe;
+        int h = 1;
+        while (hi - lo > kEnergyErr) {
+            if (h >= tpj) { j.toe = hi; j.boe = lo; return; }
+            const double e = (hi + lo) / 2;
+            const int c = count[base + h];
+            ++j.n_count;
+            if (c < j.nodes) { lo = e; h = 2 * h + 1; } else { hi = e; h = 2 * h; }
+        }
+        j.bottom = hi;                                              // BottomEnergy = toe
+        j.toe = j.top;
+        j.boe = hi;
+        j.haveSgn = 0;
+        j.iter3 = 0;
+        j.phase = PH_ZERO;
+        return;
+    }
+    if (j.phase == PH_ZERO) {                                       // DFTAtom.cpp:513-534
+        if (!j.haveSgn) {
+            const double d0 = u0[base];
+            ++j.n_zero;
+            j.sgnBottom = d0 > 0;
+            j.haveSgn = 1;
+        }
+        double hi = j.toe, lo = j.boe;
+        int h = 1;
+        bool conv = false;
+        while (j.iter3 < kMaxIter3) {
+            if (h >= tpj) { j.toe = hi; j.boe = lo; return; }
+            const double e = (hi + lo) / 2;
+            const double d = u0[base + h];
+            ++j.n_zero;
+            ++j.iter3;
+            if ((d > 0) == (j.sgnBottom != 0)) { lo = e; h = 2 * h + 1; } else { hi = e; h = 2 * h; }
+            const double ad = fabs(d);
+            if (hi - lo < kEnergyErr && !isnan(ad) && ad < 1E15) { conv = true; break; }
+        }
+        j.toe = hi;
+        j.boe = lo;
+        j.E = lo;                                                    // level.E = BottomEnergy
+        j.converged = conv ? 1 : 0;
+        j.phase = PH_DONE;
+    }
+}
+
+__global__ void k_walk(dfta::Job* __restrict__ jobs, const int* __restrict__ chain_off, int nchains, int tpj,
+                       const int* __restrict__ count, const double* __restrict__ u0, int* __restrict__ ndone)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= nchains) return;
+    int done = 0;
+    for (int k = chain_off[c]; k < chain_off[c + 1]; ++k) {
+        dfta::Job j = jobs[k];
+        if (j.phase == PH_DONE) { ++done; continue; }
+        if (j.phase == PH_WAIT) {
+            // DFTAtom.cpp:541: BottomEnergy = level.E - 3 handed to the next level of the chain
+            const double bot = (k == chain_off[c]) ? j.bottom0 : jobs[k - 1].E - 3;
+            j.bottom0 = bot;
+            j.toe = 50;                                             // DFTAtom.cpp:499
+            j.boe = bot;
+            j.phase = PH_TOP;
+            jobs[k] = j;
+            break;                                                  // its trials are generated next round
+        }
+        walk_job(j, count, u0, tpj, k * tpj);
+        jobs[k] = j;
+        if (j.phase == PH_DONE) { ++done; continue; }
+        break;
+    }
+    if (done) atomicAdd(ndone, done);
+}
+
+// ---- normalise (DFTAtom.cpp:36-56) ------------------------------------------------------------------------------
+// one 256-thread block per job; wave 0 performs the Simpson 3/8 sum in the reference's order
+__global__ __launch_bounds__(256) void k_normalize(double* __restrict__ Psi, double* __restrict__ G, int N,
+                                                   const double* __restrict__ eh, const double* __restrict__ cnst)
+{
+    __shared__ double lds[dfta::kTile];
+    __shared__ double s_unorm;
+    double* P = Psi + (size_t)blockIdx.x * N;
+    double* g = G + (size_t)blockIdx.x * N;
+    for (int i = threadIdx.x; i < N; i += 256) {
+        const double p = P[i] * eh[i];            // Psi[i] *= exp(i * deltaGrid * 0.5)
+        P[i] = p;
+        double r2 = p * p;
+        r2 *= cnst[i];                            // result2[i] *= Rp * deltaGrid * exp(deltaGrid * i)
+        g[i] = r2;
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const double integral = dfta::wave_simpson38(g, N, 1.0, lds);
+        if (threadIdx.x == 0) s_unorm = 1. / sqrt(integral);
+    }
+    __syncthreads();
+    const double unorm = s_unorm;
+    for (int i = threadIdx.x; i < N; i += 256) P[i] *= unorm;
+}
+
+// newDensity[v][i] += occ * Psi[i] * Psi[i] for i < N-1, levels of a potential in their order (DFTAtom.cpp:558-559)
+__global__ void k_accumulate_density(const double* __restrict__ Psi, const dfta::Job* __restrict__ jobs,
+                                     const int* __restrict__ v_off, int N, double* __restrict__ newDensity)
+{
+    const int v = blockIdx.y;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) {
+        double acc = newDensity[(size_t)v * N + i];
+        if (i < N - 1)
+            for (int k = v_off[v]; k < v_off[v + 1]; ++k) {
+                const double p = Psi[(size_t)k * N + i];
+                acc += jobs[k].occ * p * p;
+            }
+        newDensity[(size_t)v * N + i] = acc;
+    }
+}
+
+__global__ void k_job_energies(const dfta::Job* __restrict__ jobs, int njobs, double* __restrict__ E, int* __restrict__ slot,
+                               int* __restrict__ l)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= njobs) return;
+    E[k] = jobs[k].E;
+    slot[k] = jobs[k].slot;
+    l[k] = jobs[k].l;
+}
+
+__global__ void k_store_match(dfta::Job* __restrict__ jobs, int njobs, const int* __restrict__ mp)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < njobs) jobs[k].matchPoint = mp[k];
+}
+
+}  // namespace
+
+namespace dfta {
+
+LevelSolver::~LevelSolver() { release(); }
+
+void LevelSolver::release()
+{
+    void* ptrs[] = {d_jobs, d_chain_off, d_v_off, d_slot_v, d_slot_l, d_tab, d_E, d_limit, d_start, d_us, d_us1, d_count,
+                    d_u0, d_wave_kind, d_wave_slot, d_wave_first, d_wave_cnt, d_counters, d_Psi, d_Q, d_jE, d_jslot, d_jl,
+                    d_jstart, d_jus, d_jus1, d_jmp};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    d_jobs = nullptr; d_chain_off = nullptr; d_v_off = nullptr; d_slot_v = nullptr; d_slot_l = nullptr; d_tab = nullptr;
+    d_E = nullptr; d_limit = nullptr; d_start = nullptr; d_us = nullptr; d_us1 = nullptr; d_count = nullptr; d_u0 = nullptr;
+    d_wave_kind = nullptr; d_wave_slot = nullptr; d_wave_first = nullptr; d_wave_cnt = nullptr; d_counters = nullptr;
+    d_Psi = nullptr; d_Q = nullptr; d_jE = nullptr; d_jslot = nullptr; d_jl = nullptr; d_jstart = nullptr; d_jus = nullptr;
+    d_jus1 = nullptr; d_jmp = nullptr;
+}
+
+// jobs must be ordered by potential index v (levels of one potential contiguous, in the reference's (N,L) order)
+int LevelSolver::setup(dfta_ctx* c, const dfta_grid* grid, int mode_, int tree_depth, int nV_, const std::vector<JobSpec>& specs)
+{
+    release();
+    ctx = c; g = grid; mode = mode_; nV = nV_;
+    njobs = static_cast<int>(specs.size());
+    if (njobs == 0) return DFTA_OK;
+    const int N = g->N;
+    // chains: CHAINED -> one chain per potential; BATCHED -> one chain per job
+    std::vector<int> chain_off, v_off(nV + 1, 0);
+    for (int k = 0; k < njobs; ++k) {
+        if (specs[k].v < 0 || specs[k].v >= nV || specs[k].l < 0 || specs[k].l > 3) return DFTA_ERR_INVALID;
+        if (k > 0 && specs[k].v < specs[k - 1].v) return DFTA_ERR_INVALID;
+        v_off[specs[k].v + 1]++;
+    }
+    for (int v = 0; v < nV; ++v) v_off[v + 1] += v_off[v];
+    if (mode == DFTA_LEVELS_CHAINED) {
+        for (int v = 0; v < nV; ++v) if (v_off[v + 1] > v_off[v]) chain_off.push_back(v_off[v]);
+        chain_off.push_back(njobs);
+    } else {
+        for (int k = 0; k <= njobs; ++k) chain_off.push_back(k);
+    }
+    nchains = static_cast<int>(chain_off.size()) - 1;
+    // tree depth: fill the machine (one wave per SIMD = 65536 lanes) with the jobs that are active per round
+    int d = tree_depth;
+    if (d <= 0) {
+        const int active = std::max(1, mode == DFTA_LEVELS_CHAINED ? nchains : njobs);
+        d = 6;
+        while (d < 14 && (static_cast<long>(active) << (d + 1)) <= 65536L * 1) ++d;
+    }
+    d = std::min(std::max(d, 6), 16);
+    depth = d;
+    tpj = 1 << d;
+    ntrials = static_cast<long>(njobs) * tpj;
+    nwaves = static_cast<int>(ntrials / 64);
+
+    // table slots: one per distinct (v, l)
+    std::vector<int> slot_v, slot_l;
+    std::vector<Job> jobs(njobs);
+    for (int k = 0; k < njobs; ++k) {
+        int slot = -1;
+        for (size_t s = 0; s < slot_v.size(); ++s) if (slot_v[s] == specs[k].v && slot_l[s] == specs[k].l) slot = (int)s;
+        if (slot < 0) { slot = (int)slot_v.size(); slot_v.push_back(specs[k].v); slot_l.push_back(specs[k].l); }
+        Job& j = jobs[k];
+        memset(&j, 0, sizeof(Job));
+        j.v = specs[k].v; j.n = specs[k].n; j.l = specs[k].l; j.occ = specs[k].occ; j.nodes = specs[k].n - specs[k].l;
+        j.slot = slot;
+    }
+    h_jobs_template = jobs;
+    nslots = static_cast<int>(slot_v.size());
+    std::vector<int> wave_slot(nwaves), wave_first(nwaves), wave_cnt(nwaves, 64);
+    for (int w = 0; w < nwaves; ++w) { wave_slot[w] = jobs[(w * 64) / tpj].slot; wave_first[w] = w * 64; }
+
+    hipStream_t st = ctx->stream;
+#define ALLOC(ptr, type, count) DFTA_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ptr), sizeof(type) * (size_t)(count)))
+#define UPLOAD(ptr, vec) DFTA_HIP(ctx, hipMemcpyAsync(ptr, vec.data(), sizeof(vec[0]) * vec.size(), hipMemcpyHostToDevice, st))
+    ALLOC(d_jobs, Job, njobs);
+    ALLOC(d_chain_off, int, chain_off.size()); UPLOAD(d_chain_off, chain_off);
+    ALLOC(d_v_off, int, v_off.size()); UPLOAD(d_v_off, v_off);
+    ALLOC(d_slot_v, int, nslots); UPLOAD(d_slot_v, slot_v);
+    ALLOC(d_slot_l, int, nslots); UPLOAD(d_slot_l, slot_l);
+    ALLOC(d_tab, double2, (size_t)nslots * N);
+    ALLOC(d_E, double, ntrials); ALLOC(d_limit, int, ntrials); ALLOC(d_start, int, ntrials);
+    ALLOC(d_us, double, ntrials); ALLOC(d_us1, double, ntrials); ALLOC(d_count, int, ntrials); ALLOC(d_u0, double, ntrials);
+    ALLOC(d_wave_kind, int, nwaves);
+    ALLOC(d_wave_slot, int, nwaves); UPLOAD(d_wave_slot, wave_slot);
+    ALLOC(d_wave_first, int, nwaves); UPLOAD(d_wave_first, wave_first);
+    ALLOC(d_wave_cnt, int, nwaves); UPLOAD(d_wave_cnt, wave_cnt);
+    ALLOC(d_counters, unsigned long long, 4);
+    ALLOC(d_Psi, double, (size_t)njobs * N);
+    ALLOC(d_Q, double, (size_t)njobs * N);
+    ALLOC(d_jE, double, njobs); ALLOC(d_jslot, int, njobs); ALLOC(d_jl, int, njobs); ALLOC(d_jstart, int, njobs);
+    ALLOC(d_jus, double, njobs); ALLOC(d_jus1, double, njobs); ALLOC(d_jmp, int, njobs);
+#undef ALLOC
+#undef UPLOAD
+    DFTA_HIP(ctx, hipMemsetAsync(d_count, 0, sizeof(int) * ntrials, st));
+    DFTA_HIP(ctx, hipMemsetAsync(d_u0, 0, sizeof(double) * ntrials, st));
+    DFTA_HIP(ctx, hipStreamSynchronize(st));
+    return DFTA_OK;
+}
+
+// Solve all levels for the potentials dV (device, nV*N).  bottom0: host array nV (BottomEnergy at entry, -Z^2-1).
+int LevelSolver::run(const double* dV, const double* bottom0, double* dNewDensity, LevelStats* stats)
+{
+    if (njobs == 0) return DFTA_OK;
+    const int N = g->N;
+    hipStream_t st = ctx->stream;
+    std::vector<Job> jobs = h_jobs_template;
+    for (int k = 0; k < njobs; ++k) {
+        Job& j = jobs[k];
+        j.bottom0 = bottom0[j.v];
+        if (mode == DFTA_LEVELS_BATCHED) { j.phase = PH_TOP; j.toe = 50; j.boe = j.bottom0; }
+        else j.phase = PH_WAIT;
+    }
+    // CHAINED: the first job of each chain starts immediately
+    if (mode == DFTA_LEVELS_CHAINED)
+        for (int k = 0; k < njobs; ++k)
+            if (k == 0 || jobs[k].v != jobs[k - 1].v) { jobs[k].phase = PH_TOP; jobs[k].toe = 50; jobs[k].boe = jobs[k].bottom0; }
+    DFTA_HIP(ctx, hipMemcpyAsync(d_jobs, jobs.data(), sizeof(Job) * njobs, hipMemcpyHostToDevice, st));
+    DFTA_HIP(ctx, hipMemsetAsync(d_counters, 0, sizeof(unsigned long long) * 4, st));
+    int rc = dfta_launch_build_tab(ctx, g, d_tab, dV, d_slot_v, d_slot_l, nslots);
+    if (rc) return rc;
+
+    int* d_ndone = reinterpret_cast<int*>(d_counters + 2);
+    int rounds = 0;
+    const int max_rounds = 4096;
+    while (rounds < max_rounds) {
+        hipLaunchKernelGGL(k_expand, dim3((unsigned)(ntrials / 256)), dim3(256), 0, st, d_jobs, tpj, g->d_r, N, g->delta,
+                           g->far_arg_threshold, d_E, d_limit, d_start, d_us, d_us1, d_wave_kind, d_counters);
+        DFTA_CHECK_LAUNCH(ctx);
+        rc = dfta_launch_sweep(ctx, g, DFTA_SWEEP_COUNT, d_wave_kind, nwaves, d_tab, d_wave_slot, d_wave_first, d_wave_cnt, d_E,
+                               d_limit, d_start, d_us, d_us1, d_count, d_u0, nullptr, d_counters + 1);
+        if (rc) return rc;
+        DFTA_HIP(ctx, hipMemsetAsync(d_ndone, 0, sizeof(int), st));
+        hipLaunchKernelGGL(k_walk, dim3((nchains + 63) / 64), dim3(64), 0, st, d_jobs, d_chain_off, nchains, tpj, d_count, d_u0, d_ndone);
+        DFTA_CHECK_LAUNCH(ctx);
+        int ndone = 0;
+        DFTA_HIP(ctx, hipMemcpyAsync(&ndone, d_ndone, sizeof(int), hipMemcpyDeviceToHost, st));
+        DFTA_HIP(ctx, hipStreamSynchronize(st));
+        ++rounds;
+        if (ndone >= njobs) break;
+    }
+    if (rounds >= max_rounds) { snprintf(ctx->err, sizeof(ctx->err), "level solver did not terminate"); return DFTA_ERR_NOT_CONVERGED; }
+
+    // wavefunctions: match, normalise, accumulate
+    hipLaunchKernelGGL(k_job_energies, dim3((njobs + 63) / 64), dim3(64), 0, st, d_jobs, njobs, d_jE, d_jslot, d_jl);
+    DFTA_CHECK_LAUNCH(ctx);
+    rc = dfta_launch_boundary(ctx, g, d_jE, njobs, d_jstart, d_jus, d_jus1);
+    if (rc) return rc;
+    rc = dfta_launch_match(ctx, g, njobs, d_tab, d_jslot, d_jE, d_jstart, d_jus, d_jus1, d_jl, d_Psi, d_Q, d_jmp);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_store_match, dim3((njobs + 63) / 64), dim3(64), 0, st, d_jobs, njobs, d_jmp);
+    DFTA_CHECK_LAUNCH(ctx);
+    hipLaunchKernelGGL(k_normalize, dim3(njobs), dim3(256), 0, st, d_Psi, d_Q, N, g->d_eh, g->d_cnst);
+    DFTA_CHECK_LAUNCH(ctx);
+    if (dNewDensity) {
+        hipLaunchKernelGGL(k_accumulate_density, dim3(std::min(256, (N + 255) / 256), nV), dim3(256), 0, st, d_Psi, d_jobs, d_v_off,
+                           N, dNewDensity);
+        DFTA_CHECK_LAUNCH(ctx);
+    }
+    if (stats) {
+        unsigned long long cnt[2];
+        DFTA_HIP(ctx, hipMemcpyAsync(cnt, d_counters, sizeof(cnt), hipMemcpyDeviceToHost, st));
+        DFTA_HIP(ctx, hipStreamSynchronize(st));
+        stats->rounds = rounds;
+        stats->sweeps_issued = static_cast<long>(cnt[0]) + 2L * njobs;    // + inward/outward halves of the match solve
+        stats->points_traversed = static_cast<long>(cnt[1]);
+    }
+    return DFTA_OK;
+}
+
+int LevelSolver::fetch_jobs(std::vector<Job>& out)
+{
+    out.resize(njobs);
+    if (njobs == 0) return DFTA_OK;
+    DFTA_HIP(ctx, hipMemcpyAsync(out.data(), d_jobs, sizeof(Job) * njobs, hipMemcpyDeviceToHost, ctx->stream));
+    DFTA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return DFTA_OK;
+}
+
+}  // namespace dfta
+
+extern "C" int dfta_solve_levels(dfta_ctx* ctx, const dfta_grid* g, int mode, int tree_depth, int nV, const double* V,
+                                 const double* bottom0, int nlevels, const int* vidx, const int* n, const int* l, const int* occ,
+                                 dfta_level_result* results, double* newDensity, double* Eelectronic, double* Psi_out,
+                                 long* issued_sweeps)
+{
+    if (!ctx || !g) return DFTA_ERR_INVALID;
+    DFTA_REQUIRE(ctx, V && bottom0 && n && l && occ && results && nV > 0 && nlevels > 0, "null input");
+    DFTA_REQUIRE(ctx, mode == DFTA_LEVELS_CHAINED || mode == DFTA_LEVELS_BATCHED, "mode");
+    const int N = g->N;
+    std::vector<dfta::JobSpec> specs(nlevels);
+    for (int k = 0; k < nlevels; ++k) specs[k] = {vidx ? vidx[k] : 0, n[k], l[k], occ[k]};
+    dfta::LevelSolver solver;
+    int rc = solver.setup(ctx, g, mode, tree_depth, nV, specs);
+    if (rc) { if (rc == DFTA_ERR_INVALID) snprintf(ctx->err, sizeof(ctx->err), "levels must be grouped by potential, l in 0..3"); return rc; }
+    hipStream_t st = ctx->stream;
+    DevBuf<double> dV, dND;
+    DFTA_HIP(ctx, dV.alloc((size_t)nV * N));
+    DFTA_HIP(ctx, hipMemcpyAsync(dV.p, V, sizeof(double) * (size_t)nV * N, hipMemcpyHostToDevice, st));
+    if (newDensity) {
+        DFTA_HIP(ctx, dND.alloc((size_t)nV * N));
+        DFTA_HIP(ctx, hipMemcpyAsync(dND.p, newDensity, sizeof(double) * (size_t)nV * N, hipMemcpyHostToDevice, st));
+    }
+    dfta::LevelStats stats;
+    rc = solver.run(dV.p, bottom0, dND.p, &stats);
+    if (rc) return rc;
+    std::vector<dfta::Job> jobs;
+    rc = solver.fetch_jobs(jobs);
+    if (rc) return rc;
+    if (Eelectronic) for (int v = 0; v < nV; ++v) Eelectronic[v] = 0;
+    bool allconv = true;
+    for (int k = 0; k < nlevels; ++k) {
+        const dfta::Job& j = jobs[k];
+        results[k].E = j.E; results[k].top = j.top; results[k].bottom = j.bottom; results[k].n_count = j.n_count;
+        results[k].n_zero = j.n_zero; results[k].converged = j.converged; results[k].matchPoint = j.matchPoint;
+        if (Eelectronic) Eelectronic[j.v] += j.occ * j.E;            // DFTAtom.cpp:561
+        allconv = allconv && j.converged;
+    }
+    if (newDensity) DFTA_HIP(ctx, hipMemcpyAsync(newDensity, dND.p, sizeof(double) * (size_t)nV * N, hipMemcpyDeviceToHost, st));
+    if (Psi_out) DFTA_HIP(ctx, hipMemcpyAsync(Psi_out, solver.d_Psi, sizeof(double) * (size_t)nlevels * N, hipMemcpyDeviceToHost, st));
+    DFTA_HIP(ctx, hipStreamSynchronize(st));
+    if (issued_sweeps) *issued_sweeps = stats.sweeps_issued;
+    (void)allconv;
+    return DFTA_OK;
+}

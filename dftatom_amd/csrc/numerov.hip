@@ -1,0 +1,678 @@
+// numerov.hip -- batched Numerov shooting sweeps for gfx950 (wave64).
+//
+// Replaces DFT::Numerov<NumerovFunctionNonUniformGrid>::SolveSchrodingerCountNodes /
+// SolveSchrodingerSolutionInZero / SolveSchrodingerMatchSolutionCompletely (Numerov.h:272-504).
+//
+// Mapping.  A sweep is a strictly sequential three-term recurrence over the grid index, so one LANE owns
+// one trial (potential, l, E) and the 64 lanes of a wavefront march the grid index i together (inward,
+// i = start-2 .. 1).  All lanes of a wave share (potential, l); the per-point inputs
+//     veff_i = V_i + l(l+1)/(r_i r_i)/2      and      e2_i = exp(2 i delta)
+// are therefore wave-uniform: they are read as one 16-byte scalar load per point (SGPR operands of the
+// fp64 VALU ops), the wave never touches LDS or vector memory in the loop.  Only E differs per lane.
+// Arithmetic is the reference's, in its operation order, IEEE fp64 with contraction off:
+//     f_i = 2 (veff_i - E) Rp^2 delta^2 e2_i + delta^2/4           (Numerov.h:96-101)
+//     w_i = 2 w_{i+1} - w_{i+2} + u_{i+1} f_{i+1};  u_i = w_i / (1 - f_i/12)   (Numerov.h:311-321,510-513)
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <numeric>
+#include <vector>
+
+#include "internal.h"
+
+namespace {
+
+constexpr double kH2p12 = 1. / 12.;   // Numerov.h:287
+
+struct GridScalars {
+    int N;
+    double delta, Rp2delta2, delta2p4, far_thr;
+};
+
+__device__ __forceinline__ double f_of(double veff, double e2, double E, const GridScalars& gs)
+{
+    // Numerov.h:100: 2. * (effectivePotential - E) * Rp2delta2 * exp(posIndex * twodelta) + delta2p4
+    return 2. * (veff - E) * gs.Rp2delta2 * e2 + gs.delta2p4;
+}
+
+// ---- table of wave-uniform per-point inputs -----------------------------------------------------------
+// tab[(slot)*N + i] = { V[v][i] + cl[l][i], e2[i] }   (Numerov.h:93: V + l(l+1)/(r r) * 0.5)
+__global__ void k_build_tab(double2* __restrict__ tab, const double* __restrict__ V, const double* __restrict__ cl,
+                            const double* __restrict__ e2, const int* __restrict__ slot_v, const int* __restrict__ slot_l, int N)
+{
+    const int slot = blockIdx.y;
+    const int v = slot_v[slot], l = slot_l[slot];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) {
+        double2 t;
+        t.x = V[(size_t)v * N + i] + cl[(size_t)l * N + i];
+        t.y = e2[i];
+        tab[(size_t)slot * N + i] = t;
+    }
+}
+
+// ---- boundary values on the device (GetMaxRadiusIndex / GetBoundaryValueFar, Numerov.h:103-136) -------
+__device__ __forceinline__ double far_arg(const double* __restrict__ r, int i, double s, double delta)
+{
+    // Numerov.h:107:  -realPosition * sqrt(2|E|) - position * m_delta * 0.5
+    return -r[i] * s - static_cast<double>(i) * delta * 0.5;
+}
+
+__global__ void k_boundary(const double* __restrict__ r, const double* __restrict__ E, int ntrials, GridScalars gs,
+                           int* __restrict__ start, double* __restrict__ us, double* __restrict__ us1)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= ntrials) return;
+    const double s = sqrt(2. * fabs(E[t]));
+    int maxIndex = gs.N - 1, minIndex = 1;
+    while (maxIndex - minIndex > 1) {   // Numerov.h:125-133 with exp(arg) < 1e-200 <=> arg < far_thr
+        const int mid = (maxIndex + minIndex) / 2;
+        if (far_arg(r, mid, s, gs.delta) < gs.far_thr) maxIndex = mid; else minIndex = mid;
+    }
+    start[t] = maxIndex;
+    us[t] = exp(far_arg(r, maxIndex, s, gs.delta));
+    us1[t] = exp(far_arg(r, maxIndex - 1, s, gs.delta));
+}
+
+// ---- the sweep kernel -----------------------------------------------------------------------------------
+struct SweepArgs {
+    const double2* tab;        // slot tables
+    const int* blk_slot;       // per block: table slot
+    const int* blk_first;      // per block: first trial
+    const int* blk_cnt;        // per block: number of trials (<= 64)
+    const int* blk_kind;       // per block: DFTA_SWEEP_COUNT / DFTA_SWEEP_ZERO, or null -> `kind`
+    int kind;
+    const double* E;
+    const int* limit;          // COUNT
+    const int* start;
+    const double* us;
+    const double* us1;
+    int* count;                // COUNT out
+    double* u0;                // out (may be null for COUNT)
+    int* trip;                 // out (may be null)
+    unsigned long long* total_trips;   // optional global counter (points traversed)
+};
+
+// One Numerov step for every lane of the wave (Numerov.h:311-321).  `tv` is wave-uniform (SGPRs).
+struct SweepState {
+    double w, wprev, u, fprev, prevSol;
+};
+
+__device__ __forceinline__ void numerov_step(SweepState& s, const double2 tv, const double E, const GridScalars& gs)
+{
+    const double wnext = 2. * s.w - s.wprev + s.u * s.fprev;   // Numerov.h:311 (h2 == 1)
+    s.wprev = s.w;
+    s.w = wnext;
+    const double f = f_of(tv.x, tv.y, E, gs);
+    s.prevSol = s.u;
+    s.u = wnext / (1. - kH2p12 * f);                            // getU, Numerov.h:510-513
+    s.fprev = f;
+}
+
+// node/turning-point bookkeeping of CountNodes after a step (Numerov.h:323-340), branch-free: every
+// predicate is a wave-wide lane mask, so the compiler emits v_cmp + scalar mask logic and no exec-mask
+// divergence.  Order of the reference's tests: |u| == inf -> return; sign change -> ++count, count > limit ->
+// return; veff <= E -> flag, else flag && veff > E -> return.
+__device__ __forceinline__ void count_step(const SweepState& s, const double veff, const double E, const int limit,
+                                           bool& live, bool& exited, bool& oldSgn, bool& flag, int& count, int& trips)
+{
+    trips += live ? 1 : 0;
+    const bool isinf = (fabs(s.u) == INFINITY);
+    const bool newSgn = (s.u > 0);
+    const bool cross = live & !isinf & (newSgn != oldSgn);
+    count += cross ? 1 : 0;
+    const bool over = cross & (count > limit);
+    oldSgn = newSgn;                          // only observable while the lane is live and not exiting
+    const bool stay = live & !isinf & !over;
+    const bool le = (veff <= E);
+    const bool gt = (veff > E);               // separate compare: both false for NaN, as in the reference
+    const bool tp = stay & flag & gt;
+    flag = flag | (stay & le);
+    live = stay & !tp;
+    exited = exited | isinf | over | tp;      // callers only read `exited` for lanes that were live
+}
+
+// Block = 4 waves (one per SIMD of the CU); every wave owns up to 64 trials that share one table slot.
+// The grid index loop is wave-uniform; table entries are fetched CH points ahead as scalar loads so the
+// scalar-cache latency is hidden behind the previous chunk's arithmetic.
+template <int KIND, int CH>
+__device__ __forceinline__ void sweep_wave(const SweepArgs& a, const GridScalars& gs, const int b, const int lane)
+{
+    const int cnt = a.blk_cnt[b];
+    const int t = a.blk_first[b] + (lane < cnt ? lane : 0);
+    // a trial with start < 2 is a placeholder (unused slot of a bisection tree): the lane idles
+    const bool valid = (lane < cnt) && (a.start[t] >= 2);
+    const double2* __restrict__ T = a.tab + (size_t)a.blk_slot[b] * gs.N;
+
+    const double E = a.E[t];
+    const int start = valid ? a.start[t] : 2;
+    const int limit = (KIND == DFTA_SWEEP_COUNT) ? a.limit[t] : 0;
+    if (__ballot(valid) == 0ull) return;       // whole wave idle
+
+    // prologue (Numerov.h:293-306): the two far boundary points of this lane
+    SweepState s;
+    {
+        const double2 ts = T[start];
+        const double2 t1 = T[start - 1];
+        const double us = a.us[t];
+        s.u = a.us1[t];
+        s.fprev = f_of(ts.x, ts.y, E, gs);
+        s.wprev = (1 - kH2p12 * s.fprev) * us;
+        s.fprev = f_of(t1.x, t1.y, E, gs);
+        s.w = (1 - kH2p12 * s.fprev) * s.u;
+        s.prevSol = us;
+    }
+    bool oldSgn = (s.u > 0);
+    int count = 0;
+    bool flag = false;       // firstClassicalReturnPoint
+    bool exited = false;     // early `return` of CountNodes (skips the u(0) extrapolation)
+    bool live = valid;       // still inside the reference's loop
+    int trips = 0;
+
+    const int my_hi = valid ? start - 2 : 0;   // this lane integrates i = my_hi .. 1
+    int ihi = my_hi, ilo = valid ? my_hi : 0x7fffffff;
+    for (int off = 32; off > 0; off >>= 1) {
+        ihi = max(ihi, __shfl_xor(ihi, off));
+        ilo = min(ilo, __shfl_xor(ilo, off));
+    }
+    ihi = __builtin_amdgcn_readfirstlane(ihi);
+    ilo = __builtin_amdgcn_readfirstlane(ilo);   // from here down every valid lane has started
+
+    int i = ihi;
+    // head: lanes join one by one (per-step masking) until all valid lanes are in
+    for (; i > ilo && i >= 1; --i) {
+        const double2 tv = T[i];
+        if (valid && i <= my_hi) {
+            SweepState n = s;
+            numerov_step(n, tv, E, gs);
+            s = n;
+            if (KIND == DFTA_SWEEP_COUNT) count_step(s, tv.x, E, limit, live, exited, oldSgn, flag, count, trips);
+        }
+    }
+    // body: all valid lanes step together, no exec masking on the arithmetic; table prefetched CH ahead.
+    // Lanes that have left the reference's loop keep integrating (harmless), only their bookkeeping is frozen.
+    if (i >= 2 * CH) {
+        double2 A[CH], B[CH];
+#pragma unroll
+        for (int k = 0; k < CH; ++k) A[k] = T[i - k];
+        while (true) {   // invariant at the top: i >= 2*CH and A = T[i .. i-CH+1]
+            // scalar loads return out of order, so a wait covers everything in flight: drain the chunk that
+            // was requested one chunk ago BEFORE requesting the next one (0xC07F == lgkmcnt(0) only)
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+#pragma unroll
+            for (int k = 0; k < CH; ++k) B[k] = T[i - CH - k];
+#pragma unroll
+            for (int k = 0; k < CH; ++k) {
+                numerov_step(s, A[k], E, gs);
+                if (KIND == DFTA_SWEEP_COUNT) count_step(s, A[k].x, E, limit, live, exited, oldSgn, flag, count, trips);
+            }
+            i -= CH;
+            const bool more = (i >= 3 * CH);   // another full A/B round fits after this B chunk
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            if (more) {
+#pragma unroll
+                for (int k = 0; k < CH; ++k) A[k] = T[i - CH - k];
+            }
+#pragma unroll
+            for (int k = 0; k < CH; ++k) {
+                numerov_step(s, B[k], E, gs);
+                if (KIND == DFTA_SWEEP_COUNT) count_step(s, B[k].x, E, limit, live, exited, oldSgn, flag, count, trips);
+            }
+            i -= CH;
+            if (KIND == DFTA_SWEEP_COUNT) {
+                if (__ballot(live) == 0ull) { i = 0; break; }
+            }
+            if (!more) break;
+        }
+    }
+    // tail
+    for (; i >= 1; --i) {
+        const double2 tv = T[i];
+        numerov_step(s, tv, E, gs);
+        if (KIND == DFTA_SWEEP_COUNT) count_step(s, tv.x, E, limit, live, exited, oldSgn, flag, count, trips);
+    }
+    if (KIND == DFTA_SWEEP_ZERO) trips = my_hi;
+
+    double u0 = NAN;
+    if (valid && !exited) {
+        u0 = s.u * (2 + s.fprev) - s.prevSol;                 // Numerov.h:345 / 398
+        if (KIND == DFTA_SWEEP_COUNT) {
+            if ((u0 > 0) != oldSgn) ++count;                  // Numerov.h:346-347
+        }
+    }
+    if (valid) {
+        if (KIND == DFTA_SWEEP_COUNT) a.count[t] = count;
+        if (a.u0) a.u0[t] = u0;
+        if (a.trip) a.trip[t] = trips;
+    }
+    if (a.total_trips) {
+        int sum = valid ? trips : 0;
+        for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+        if (lane == 0) atomicAdd(a.total_trips, (unsigned long long)sum);
+    }
+}
+
+template <int CH>
+__global__ __launch_bounds__(256) void k_sweep(SweepArgs a, GridScalars gs, int nwaves)
+{
+    const int lane = threadIdx.x & 63;
+    const int b = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (b >= nwaves) return;
+    const int kind = a.blk_kind ? __builtin_amdgcn_readfirstlane(a.blk_kind[b]) : a.kind;
+    if (kind == DFTA_SWEEP_COUNT) sweep_wave<DFTA_SWEEP_COUNT, CH>(a, gs, b, lane);
+    else                          sweep_wave<DFTA_SWEEP_ZERO, CH>(a, gs, b, lane);
+}
+
+// ---- match kernel (Numerov.h:403-504) --------------------------------------------------------------------
+// One wave per trial.  Lane 0 integrates inward from the cut-off until the outermost maximum (the match
+// point), lane 1 integrates outward from the nucleus at the same time; they stop as soon as lane 0 has
+// found the match point and lane 1 has passed it.  The remaining lanes then join to rescale the outer part.
+__global__ __launch_bounds__(64) void k_match(const double2* __restrict__ tab, const int* __restrict__ trial_slot,
+                                              const double* __restrict__ Earr, const int* __restrict__ startArr,
+                                              const double* __restrict__ usArr, const double* __restrict__ us1Arr,
+                                              const int* __restrict__ larr, double zero_l0, double zero_l1, double zero_l2,
+                                              double zero_l3, GridScalars gs, double* __restrict__ Psi,
+                                              double* __restrict__ Q, int* __restrict__ matchPoint)
+{
+    const int t = blockIdx.x;
+    const int lane = threadIdx.x;
+    const int N = gs.N;
+    const double2* __restrict__ T = tab + (size_t)trial_slot[t] * N;
+    double* __restrict__ P = Psi + (size_t)t * N;
+    double* __restrict__ Qt = Q + (size_t)t * N;
+    const double E = Earr[t];
+    const int steps = startArr[t];
+    const int l = larr[t];
+    const double zero1 = l == 0 ? zero_l0 : (l == 1 ? zero_l1 : (l == 2 ? zero_l2 : zero_l3));
+
+    // zero beyond the cut-off (Numerov.h:427-428)
+    for (int i = steps + 1 + lane; i < N; i += 64) P[i] = 0;
+
+    int mp = 2;              // matchPoint default (Numerov.h:449)
+    bool in_done = false;    // lane 0 finished
+    int i = 0;
+    double w = 0, wprev = 0, u = 0, fprev = 0, unext = 0;
+    if (lane == 0) {
+        const double2 ts = T[steps];
+        const double2 t1 = T[steps - 1];
+        const double us = usArr[t];
+        u = us1Arr[t];
+        P[steps] = us;
+        P[steps - 1] = u;
+        fprev = f_of(ts.x, ts.y, E, gs);
+        wprev = (1 - kH2p12 * fprev) * us;
+        fprev = f_of(t1.x, t1.y, E, gs);
+        w = (1 - kH2p12 * fprev) * u;
+        unext = u;           // Psi[i+1]
+        i = steps - 2;
+
+        if (i < 1) in_done = true;
+    } else if (lane == 1) {
+        const double2 t1 = T[1];
+        u = zero1;           // Numerov.h:475
+        Qt[0] = 0;
+        Qt[1] = u;
+        fprev = f_of(t1.x, t1.y, E, gs);
+        wprev = 0;
+        w = (1 - kH2p12 * fprev) * u;
+        i = 2;
+
+    }
+
+    bool running = (lane == 0 && !in_done) || (lane == 1);
+    // lane 1 may stop once it has produced the value AT the match point; until lane 0 is done the bound is lane 0's index
+    while (true) {
+        const int i0 = __shfl(i, 0);
+        const bool d0 = __shfl((int)in_done, 0) != 0;
+        const int mp0 = __shfl(mp, 0);
+        if (lane == 1) {
+            const int bound = d0 ? mp0 : i0 + 1;    // need outward values up to and including `bound`
+            running = (i <= bound) && (i <= steps);
+        }
+        if (lane == 0) running = !in_done;
+        if (__ballot(running) == 0ull) break;
+        if (running) {
+            const double2 tv = T[i];
+            const double wnext = 2. * w - wprev + u * fprev;
+            wprev = w;
+            w = wnext;
+            const double f = f_of(tv.x, tv.y, E, gs);
+            u = w / (1. - kH2p12 * f);
+            fprev = f;
+            if (lane == 0) {
+                P[i] = u;
+                if (u < unext || fabs(u) > 1E15) { mp = i; in_done = true; }   // Numerov.h:463-467
+                unext = u;
+                if (!in_done) { --i; if (i < 1) in_done = true; }
+            } else {
+                Qt[i] = u;
+                ++i;
+            }
+        }
+    }
+    mp = __shfl(mp, 0);
+    __syncthreads();
+
+    // Numerov.h:492-501: value of the outward solution at the match point, rescale the outer part
+    double sol;
+    if (mp >= 2) sol = Qt[mp];
+    else {
+        // matchPoint == 1: the reference steps w once from (Psi[1], wprev = 0) and divides by 1 - f(1)/12
+        const double2 t1 = T[1];
+        const double f1 = f_of(t1.x, t1.y, E, gs);
+        const double w1 = (1 - kH2p12 * f1) * zero1;
+        const double w2 = 2. * w1 - 0. + zero1 * f1;
+        sol = w2 / (1. - kH2p12 * f1);
+    }
+    // Psi[matchPoint] is the inward value, except for matchPoint == 1 where the outward start value has
+    // already overwritten Psi[1] (Numerov.h:475) before the division at Numerov.h:497
+    const double factor = sol / (mp >= 2 ? P[mp] : zero1);
+    __syncthreads();
+    for (int k = lane; k <= steps; k += 64) {
+        double v;
+        if (k < mp) v = (k == 0) ? 0.0 : Qt[k];
+        else if (k == mp) v = sol;
+        else v = P[k] * factor;
+        P[k] = v;
+    }
+    if (lane == 0) matchPoint[t] = mp;
+}
+
+GridScalars scalars_of(const dfta_grid* g)
+{
+    GridScalars gs;
+    gs.N = g->N; gs.delta = g->delta; gs.Rp2delta2 = g->Rp2delta2; gs.delta2p4 = g->delta2p4; gs.far_thr = g->far_arg_threshold;
+    return gs;
+}
+
+// host-side boundary values exactly as the reference evaluates them (libm exp)
+void host_boundary(const dfta_grid* g, double E, int* start, double* us, double* us1)
+{
+    const double s = sqrt(2. * fabs(E));
+    auto far = [&](int i) { return exp(-g->h_r[i] * s - static_cast<double>(i) * g->delta * 0.5); };
+    size_t maxIndex = static_cast<size_t>(g->N - 1), minIndex = 1;
+    while (maxIndex - minIndex > 1) {
+        const size_t mid = (maxIndex + minIndex) / 2;
+        if (far(static_cast<int>(mid)) < 1E-200) maxIndex = mid; else minIndex = mid;
+    }
+    *start = static_cast<int>(maxIndex);
+    *us = far(static_cast<int>(maxIndex));
+    *us1 = far(static_cast<int>(maxIndex) - 1);
+}
+
+}  // namespace
+
+// Launch plumbing shared with levels.hip ------------------------------------------------------------------
+int dfta_launch_build_tab(dfta_ctx* ctx, const dfta_grid* g, double2* tab, const double* dV, const int* d_slot_v,
+                          const int* d_slot_l, int nslots)
+{
+    dim3 grid((g->N + 255) / 256 > 64 ? 64 : (g->N + 255) / 256, nslots);
+    hipLaunchKernelGGL(k_build_tab, grid, dim3(256), 0, ctx->stream, tab, dV, g->d_cl, g->d_e2, d_slot_v, d_slot_l, g->N);
+    DFTA_CHECK_LAUNCH(ctx);
+    return DFTA_OK;
+}
+
+int dfta_launch_boundary(dfta_ctx* ctx, const dfta_grid* g, const double* dE, int ntrials, int* dStart, double* dUs, double* dUs1)
+{
+    hipLaunchKernelGGL(k_boundary, dim3((ntrials + 255) / 256), dim3(256), 0, ctx->stream, g->d_r, dE, ntrials,
+                       scalars_of(g), dStart, dUs, dUs1);
+    DFTA_CHECK_LAUNCH(ctx);
+    return DFTA_OK;
+}
+
+int dfta_launch_sweep(dfta_ctx* ctx, const dfta_grid* g, int kind, const int* blk_kind, int nblocks, const double2* tab,
+                      const int* blk_slot, const int* blk_first, const int* blk_cnt, const double* dE, const int* dLimit,
+                      const int* dStart, const double* dUs, const double* dUs1, int* dCount, double* dU0, int* dTrip,
+                      unsigned long long* dTotalTrips)
+{
+    SweepArgs a;
+    a.kind = kind; a.blk_kind = blk_kind;
+    a.tab = tab; a.blk_slot = blk_slot; a.blk_first = blk_first; a.blk_cnt = blk_cnt; a.E = dE; a.limit = dLimit;
+    a.start = dStart; a.us = dUs; a.us1 = dUs1; a.count = dCount; a.u0 = dU0; a.trip = dTrip; a.total_trips = dTotalTrips;
+    const dim3 grid((nblocks + 3) / 4), block(256);
+    hipLaunchKernelGGL((k_sweep<4>), grid, block, 0, ctx->stream, a, scalars_of(g), nblocks);
+    DFTA_CHECK_LAUNCH(ctx);
+    return DFTA_OK;
+}
+
+int dfta_launch_match(dfta_ctx* ctx, const dfta_grid* g, int ntrials, const double2* tab, const int* d_trial_slot,
+                      const double* dE, const int* dStart, const double* dUs, const double* dUs1, const int* dL,
+                      double* dPsi, double* dQ, int* dMatch)
+{
+    hipLaunchKernelGGL(k_match, dim3(ntrials), dim3(64), 0, ctx->stream, tab, d_trial_slot, dE, dStart, dUs, dUs1, dL,
+                       g->zero1[0], g->zero1[1], g->zero1[2], g->zero1[3], scalars_of(g), dPsi, dQ, dMatch);
+    DFTA_CHECK_LAUNCH(ctx);
+    return DFTA_OK;
+}
+
+// ---- C ABI -----------------------------------------------------------------------------------------------------
+namespace {
+
+struct Grouping {
+    std::vector<int> order;       // sorted trial -> original trial
+    std::vector<int> slot_v, slot_l;
+    std::vector<int> blk_slot, blk_first, blk_cnt;
+    std::vector<int> trial_slot;  // per sorted trial
+};
+
+// group trials by (vidx, l) so every wave shares its per-point inputs
+int make_grouping(int ntrials, const int* vidx, const int* l, int nV, Grouping& G)
+{
+    G.order.resize(ntrials);
+    std::iota(G.order.begin(), G.order.end(), 0);
+    auto key = [&](int t) { return (vidx ? vidx[t] : 0) * 4 + l[t]; };
+    for (int t = 0; t < ntrials; ++t) {
+        const int v = vidx ? vidx[t] : 0;
+        if (v < 0 || v >= nV || l[t] < 0 || l[t] > 3) return DFTA_ERR_INVALID;
+    }
+    std::stable_sort(G.order.begin(), G.order.end(), [&](int a, int b) { return key(a) < key(b); });
+    G.trial_slot.resize(ntrials);
+    int p = 0;
+    while (p < ntrials) {
+        const int k = key(G.order[p]);
+        int q = p;
+        while (q < ntrials && key(G.order[q]) == k) ++q;
+        const int slot = static_cast<int>(G.slot_v.size());
+        G.slot_v.push_back(k / 4);
+        G.slot_l.push_back(k % 4);
+        for (int s = p; s < q; s += 64) {
+            G.blk_slot.push_back(slot);
+            G.blk_first.push_back(s);
+            G.blk_cnt.push_back(std::min(64, q - s));
+        }
+        for (int s = p; s < q; ++s) G.trial_slot[s] = slot;
+        p = q;
+    }
+    return DFTA_OK;
+}
+
+template <typename T>
+hipError_t upload(DevBuf<T>& d, const std::vector<T>& h, hipStream_t s)
+{
+    hipError_t e = d.alloc(h.size());
+    if (e != hipSuccess || h.empty()) return e;
+    return hipMemcpyAsync(d.p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, s);
+}
+
+}  // namespace
+
+extern "C" int dfta_numerov_sweeps(dfta_ctx* ctx, const dfta_grid* g, int kind, int boundary, int nV, const double* V,
+                                   int ntrials, const int* vidx, const int* l, const double* E, const int* nodesLimit,
+                                   int* count_out, double* u0_out, int* start_out, int* trip_out)
+{
+    if (!ctx || !g) return DFTA_ERR_INVALID;
+    DFTA_REQUIRE(ctx, V && l && E && nV > 0 && ntrials >= 0, "null input");
+    DFTA_REQUIRE(ctx, kind == DFTA_SWEEP_COUNT || kind == DFTA_SWEEP_ZERO, "kind");
+    DFTA_REQUIRE(ctx, kind != DFTA_SWEEP_COUNT || (nodesLimit && count_out), "COUNT needs nodesLimit and count_out");
+    DFTA_REQUIRE(ctx, kind != DFTA_SWEEP_ZERO || u0_out, "ZERO needs u0_out");
+    if (ntrials == 0) return DFTA_OK;
+    const int N = g->N;
+    Grouping G;
+    if (make_grouping(ntrials, vidx, l, nV, G) != DFTA_OK) { snprintf(ctx->err, sizeof(ctx->err), "invalid vidx/l"); return DFTA_ERR_INVALID; }
+
+    std::vector<double> sE(ntrials), sUs(ntrials), sUs1(ntrials);
+    std::vector<int> sLim(ntrials, 0), sStart(ntrials);
+    for (int s = 0; s < ntrials; ++s) {
+        const int t = G.order[s];
+        sE[s] = E[t];
+        if (nodesLimit) sLim[s] = nodesLimit[t];
+        if (boundary == DFTA_BOUNDARY_HOST) host_boundary(g, E[t], &sStart[s], &sUs[s], &sUs1[s]);
+    }
+    DevBuf<double> dV, dE, dUs, dUs1, dU0;
+    DevBuf<int> dLim, dStart, dCount, dTrip, dSlotV, dSlotL, dBs, dBf, dBc;
+    DevBuf<double2> dTab;
+    hipStream_t st = ctx->stream;
+    DFTA_HIP(ctx, dV.alloc((size_t)nV * N));
+    DFTA_HIP(ctx, hipMemcpyAsync(dV.p, V, (size_t)nV * N * sizeof(double), hipMemcpyHostToDevice, st));
+    DFTA_HIP(ctx, upload(dE, sE, st));
+    DFTA_HIP(ctx, upload(dLim, sLim, st));
+    DFTA_HIP(ctx, upload(dSlotV, G.slot_v, st));
+    DFTA_HIP(ctx, upload(dSlotL, G.slot_l, st));
+    DFTA_HIP(ctx, upload(dBs, G.blk_slot, st));
+    DFTA_HIP(ctx, upload(dBf, G.blk_first, st));
+    DFTA_HIP(ctx, upload(dBc, G.blk_cnt, st));
+    DFTA_HIP(ctx, dTab.alloc(G.slot_v.size() * (size_t)N));
+    DFTA_HIP(ctx, dCount.alloc(ntrials));
+    DFTA_HIP(ctx, dTrip.alloc(ntrials));
+    DFTA_HIP(ctx, dU0.alloc(ntrials));
+    if (boundary == DFTA_BOUNDARY_HOST) {
+        DFTA_HIP(ctx, upload(dStart, sStart, st));
+        DFTA_HIP(ctx, upload(dUs, sUs, st));
+        DFTA_HIP(ctx, upload(dUs1, sUs1, st));
+    } else {
+        DFTA_HIP(ctx, dStart.alloc(ntrials));
+        DFTA_HIP(ctx, dUs.alloc(ntrials));
+        DFTA_HIP(ctx, dUs1.alloc(ntrials));
+        int rc = dfta_launch_boundary(ctx, g, dE.p, ntrials, dStart.p, dUs.p, dUs1.p);
+        if (rc) return rc;
+    }
+    int rc = dfta_launch_build_tab(ctx, g, dTab.p, dV.p, dSlotV.p, dSlotL.p, (int)G.slot_v.size());
+    if (rc) return rc;
+    DFTA_HIP(ctx, hipEventRecord(ctx->ev[0], st));
+    rc = dfta_launch_sweep(ctx, g, kind, nullptr, (int)G.blk_slot.size(), dTab.p, dBs.p, dBf.p, dBc.p, dE.p, dLim.p, dStart.p,
+                           dUs.p, dUs1.p, dCount.p, dU0.p, dTrip.p, nullptr);
+    if (rc) return rc;
+    DFTA_HIP(ctx, hipEventRecord(ctx->ev[1], st));
+    ctx->have_kernel_time = true;
+    std::vector<int> hCount(ntrials), hTrip(ntrials), hStart(ntrials);
+    std::vector<double> hU0(ntrials);
+    DFTA_HIP(ctx, hipMemcpyAsync(hCount.data(), dCount.p, ntrials * sizeof(int), hipMemcpyDeviceToHost, st));
+    DFTA_HIP(ctx, hipMemcpyAsync(hTrip.data(), dTrip.p, ntrials * sizeof(int), hipMemcpyDeviceToHost, st));
+    DFTA_HIP(ctx, hipMemcpyAsync(hStart.data(), dStart.p, ntrials * sizeof(int), hipMemcpyDeviceToHost, st));
+    DFTA_HIP(ctx, hipMemcpyAsync(hU0.data(), dU0.p, ntrials * sizeof(double), hipMemcpyDeviceToHost, st));
+    DFTA_HIP(ctx, hipStreamSynchronize(st));
+    for (int s = 0; s < ntrials; ++s) {
+        const int t = G.order[s];
+        if (count_out && kind == DFTA_SWEEP_COUNT) count_out[t] = hCount[s];
+        if (u0_out) u0_out[t] = hU0[s];
+        if (start_out) start_out[t] = hStart[s];
+        if (trip_out) trip_out[t] = hTrip[s];
+    }
+    return DFTA_OK;
+}
+
+extern "C" int dfta_numerov_sweeps_dev(dfta_ctx* ctx, const dfta_grid* g, int kind, int nV, const double* dV, int ngroups,
+                                       const int* group_off, const int* group_vidx, const int* group_l, const double* dE,
+                                       const int* dLimit, const int* dStart, const double* dUs, const double* dUs1,
+                                       int* dCount, double* dU0, int* dStartOut, int* dTrip)
+{
+    if (!ctx || !g) return DFTA_ERR_INVALID;
+    DFTA_REQUIRE(ctx, dV && group_off && group_vidx && group_l && dE && ngroups > 0, "null input");
+    const int N = g->N;
+    const int ntrials = group_off[ngroups];
+    std::vector<int> slot_v(group_vidx, group_vidx + ngroups), slot_l(group_l, group_l + ngroups), bs, bf, bc;
+    for (int k = 0; k < ngroups; ++k) {
+        DFTA_REQUIRE(ctx, slot_v[k] >= 0 && slot_v[k] < nV && slot_l[k] >= 0 && slot_l[k] <= 3, "group vidx/l");
+        for (int s = group_off[k]; s < group_off[k + 1]; s += 64) {
+            bs.push_back(k); bf.push_back(s); bc.push_back(std::min(64, group_off[k + 1] - s));
+        }
+    }
+    hipStream_t st = ctx->stream;
+    DevBuf<int> dSlotV, dSlotL, dBs, dBf, dBc, dSt;
+    DevBuf<double> dA, dB;
+    DevBuf<double2> dTab;
+    DFTA_HIP(ctx, upload(dSlotV, slot_v, st));
+    DFTA_HIP(ctx, upload(dSlotL, slot_l, st));
+    DFTA_HIP(ctx, upload(dBs, bs, st));
+    DFTA_HIP(ctx, upload(dBf, bf, st));
+    DFTA_HIP(ctx, upload(dBc, bc, st));
+    DFTA_HIP(ctx, dTab.alloc((size_t)ngroups * N));
+    const int* pStart = dStart;
+    const double *pUs = dUs, *pUs1 = dUs1;
+    if (!dStart || !dUs || !dUs1) {
+        DFTA_HIP(ctx, dSt.alloc(ntrials));
+        DFTA_HIP(ctx, dA.alloc(ntrials));
+        DFTA_HIP(ctx, dB.alloc(ntrials));
+        int rc = dfta_launch_boundary(ctx, g, dE, ntrials, dSt.p, dA.p, dB.p);
+        if (rc) return rc;
+        pStart = dSt.p; pUs = dA.p; pUs1 = dB.p;
+    }
+    int rc = dfta_launch_build_tab(ctx, g, dTab.p, dV, dSlotV.p, dSlotL.p, ngroups);
+    if (rc) return rc;
+    rc = dfta_launch_sweep(ctx, g, kind, nullptr, (int)bs.size(), dTab.p, dBs.p, dBf.p, dBc.p, dE, dLimit, pStart, pUs, pUs1, dCount,
+                           dU0, dTrip, nullptr);
+    if (rc) return rc;
+    if (dStartOut) DFTA_HIP(ctx, hipMemcpyAsync(dStartOut, pStart, ntrials * sizeof(int), hipMemcpyDeviceToDevice, st));
+    DFTA_HIP(ctx, hipStreamSynchronize(st));   // scratch buffers die with this scope
+    return DFTA_OK;
+}
+
+extern "C" int dfta_numerov_match(dfta_ctx* ctx, const dfta_grid* g, int boundary, int nV, const double* V, int ntrials,
+                                  const int* vidx, const int* l, const double* E, double* Psi_out, long* matchPoint_out)
+{
+    if (!ctx || !g) return DFTA_ERR_INVALID;
+    DFTA_REQUIRE(ctx, V && l && E && Psi_out && matchPoint_out && nV > 0 && ntrials >= 0, "null input");
+    if (ntrials == 0) return DFTA_OK;
+    const int N = g->N;
+    Grouping G;
+    if (make_grouping(ntrials, vidx, l, nV, G) != DFTA_OK) { snprintf(ctx->err, sizeof(ctx->err), "invalid vidx/l"); return DFTA_ERR_INVALID; }
+    std::vector<double> sE(ntrials), sUs(ntrials), sUs1(ntrials);
+    std::vector<int> sStart(ntrials), sL(ntrials);
+    for (int s = 0; s < ntrials; ++s) {
+        const int t = G.order[s];
+        sE[s] = E[t];
+        sL[s] = l[t];
+        if (boundary == DFTA_BOUNDARY_HOST) host_boundary(g, E[t], &sStart[s], &sUs[s], &sUs1[s]);
+    }
+    hipStream_t st = ctx->stream;
+    DevBuf<double> dV, dE, dUs, dUs1, dPsi, dQ;
+    DevBuf<int> dStart, dSlotV, dSlotL, dTs, dL, dMp;
+    DevBuf<double2> dTab;
+    DFTA_HIP(ctx, dV.alloc((size_t)nV * N));
+    DFTA_HIP(ctx, hipMemcpyAsync(dV.p, V, (size_t)nV * N * sizeof(double), hipMemcpyHostToDevice, st));
+    DFTA_HIP(ctx, upload(dE, sE, st));
+    DFTA_HIP(ctx, upload(dL, sL, st));
+    DFTA_HIP(ctx, upload(dSlotV, G.slot_v, st));
+    DFTA_HIP(ctx, upload(dSlotL, G.slot_l, st));
+    DFTA_HIP(ctx, upload(dTs, G.trial_slot, st));
+    DFTA_HIP(ctx, dTab.alloc(G.slot_v.size() * (size_t)N));
+    DFTA_HIP(ctx, dPsi.alloc((size_t)ntrials * N));
+    DFTA_HIP(ctx, dQ.alloc((size_t)ntrials * N));
+    DFTA_HIP(ctx, dMp.alloc(ntrials));
+    if (boundary == DFTA_BOUNDARY_HOST) {
+        DFTA_HIP(ctx, upload(dStart, sStart, st));
+        DFTA_HIP(ctx, upload(dUs, sUs, st));
+        DFTA_HIP(ctx, upload(dUs1, sUs1, st));
+    } else {
+        DFTA_HIP(ctx, dStart.alloc(ntrials));
+        DFTA_HIP(ctx, dUs.alloc(ntrials));
+        DFTA_HIP(ctx, dUs1.alloc(ntrials));
+        int rc = dfta_launch_boundary(ctx, g, dE.p, ntrials, dStart.p, dUs.p, dUs1.p);
+        if (rc) return rc;
+    }
+    int rc = dfta_launch_build_tab(ctx, g, dTab.p, dV.p, dSlotV.p, dSlotL.p, (int)G.slot_v.size());
+    if (rc) return rc;
+    rc = dfta_launch_match(ctx, g, ntrials, dTab.p, dTs.p, dE.p, dStart.p, dUs.p, dUs1.p, dL.p, dPsi.p, dQ.p, dMp.p);
+    if (rc) return rc;
+    std::vector<double> hPsi((size_t)ntrials * N);
+    std::vector<int> hMp(ntrials);
+    DFTA_HIP(ctx, hipMemcpyAsync(hPsi.data(), dPsi.p, hPsi.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+    DFTA_HIP(ctx, hipMemcpyAsync(hMp.data(), dMp.p, ntrials * sizeof(int), hipMemcpyDeviceToHost, st));
+    DFTA_HIP(ctx, hipStreamSynchronize(st));
+    for (int s = 0; s < ntrials; ++s) {
+        const int t = G.order[s];
+        memcpy(Psi_out + (size_t)t * N, hPsi.data() + (size_t)s * N, sizeof(double) * N);
+        matchPoint_out[t] = hMp[s];
+    }
+    return DFTA_OK;
+}

@@ -1,0 +1,66 @@
+// ordered_sum.h -- wave-cooperative summation in the REFERENCE'S ORDER (device code).
+//
+// Integral::Simpson38 & co. (Integral.h:11-155) accumulate `sum += values[i]` sequentially.  A tree
+// reduction would differ in the last bits, so the sums here keep the sequential order exactly: the 64
+// lanes of a wave fetch a tile with coalesced loads into LDS, then every lane redundantly performs the
+// same chain of fp64 adds while reading the tile back as LDS broadcasts.  The dependent-add chain costs
+// one issue slot (4.5 cycles on gfx950) per element, i.e. ~0.25 ms for 131073 points on one wave;
+// independent vectors go to different waves.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace dfta {
+
+constexpr int kTile = 768;   // doubles per tile: divisible by 1,2,3,4 (period of every Newton-Cotes rule here) and 64
+
+// Adds v[first + m*stride], m = 0..count-1, in increasing m, to up to three accumulators selected by
+// cls[m % P] (0,1,2).  `lds` points to kTile doubles private to the calling wave.  All 64 lanes must call.
+template <int P>
+__device__ __forceinline__ void wave_ordered_sums(const double* __restrict__ v, long first, long stride, long count,
+                                                  const int (&cls)[P], double (&acc)[3], double* lds)
+{
+    const int lane = threadIdx.x & 63;
+    for (long base = 0; base < count; base += kTile) {
+        const int nt = (count - base) < kTile ? static_cast<int>(count - base) : kTile;
+        // coalesced tile load (stride 1) or strided gather
+#pragma unroll
+        for (int k = 0; k < kTile / 64; ++k) {
+            const int j = k * 64 + lane;
+            if (j < nt) lds[j] = v[first + (base + j) * stride];
+        }
+        __builtin_amdgcn_s_waitcnt(0);          // vmcnt(0) lgkmcnt(0): tile is in LDS
+        __builtin_amdgcn_wave_barrier();
+        // sequential chain; base is a multiple of kTile and kTile % P == 0, so the class pattern restarts per tile
+        int j = 0;
+        for (; j + P <= nt; j += P) {
+#pragma unroll
+            for (int q = 0; q < P; ++q) {
+                const double x = lds[j + q];
+                if (cls[q] == 0) acc[0] += x;
+                else if (cls[q] == 1) acc[1] += x;
+                else acc[2] += x;
+            }
+        }
+        for (int q = 0; j < nt; ++j, ++q) {
+            const double x = lds[j];
+            if (cls[q] == 0) acc[0] += x;
+            else if (cls[q] == 1) acc[1] += x;
+            else acc[2] += x;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// Integral::Simpson38(delta, values) (Integral.h:50-73); every lane returns the same value.
+__device__ __forceinline__ double wave_simpson38(const double* __restrict__ v, int sz, double delta, double* lds)
+{
+    double acc[3] = {0.0, 0.0, 0.0};            // acc[0] = sum1 (i % 3 != 0), acc[1] = sum2 (i % 3 == 0)
+    const int cls[3] = {0, 0, 1};               // i = 1,2,3,...  ->  sum1, sum1, sum2
+    wave_ordered_sums<3>(v, 1, 1, static_cast<long>(sz) - 2, cls, acc, lds);
+    double sum = v[0] + v[sz - 1];
+    sum += 3. * acc[0] + 2. * acc[1];
+    constexpr double coef = 3. / 8.;
+    return sum * delta * coef;
+}
+
+}  // namespace dfta

@@ -1,0 +1,208 @@
+/*
+ * dftatom_hip.h -- C ABI of the MI355X (gfx950) radial-DFT inner loop.
+ *
+ * Drop-in boundary for the numerical core of aromanro/DFTAtom.  The reference has no FFI; its seam is
+ * the public C++ surface of DFT::Numerov / DFT::PoissonSolver / DFT::VWNExchCor / DFT::Integral /
+ * DFT::DFTAtom.  Every entry point below names the reference interface it replaces
+ * (file:line under /root/reference/DFTAtom).  dftatom_amd/compat/ holds C++ classes with the reference's
+ * names and signatures that forward to this ABI.
+ *
+ * Conventions
+ *   - plain C types only; every function returns an int status (DFTA_OK == 0) and never throws;
+ *   - all floating point is IEEE fp64; kernels are built with -ffp-contract=off and use only + - * / sqrt on
+ *     values, with exp() tables built on the host exactly as the reference evaluates them;
+ *   - `_dev` functions take DEVICE pointers and are asynchronous on the context's stream;
+ *     functions without the suffix take HOST pointers, copy, run the same kernels and synchronise;
+ *   - one in-flight call per context (the reference is single threaded: DFTAtomFrame.cpp:176-198);
+ *   - there is NO CPU fallback: without a usable HIP device every call fails with DFTA_ERR_NO_DEVICE.
+ */
+#ifndef DFTATOM_HIP_H
+#define DFTATOM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DFTA_OK              0
+#define DFTA_ERR_INVALID     1   /* bad argument */
+#define DFTA_ERR_NO_DEVICE   2   /* no HIP device / HIP runtime failure at start-up */
+#define DFTA_ERR_HIP         3   /* HIP runtime error, see dfta_last_error() */
+#define DFTA_ERR_NOMEM       4
+#define DFTA_ERR_NOT_CONVERGED 5 /* soft: DFTAtom.cpp:538-539 `didNotConverge` */
+
+typedef struct dfta_ctx     dfta_ctx;      /* device + stream + scratch                              */
+typedef struct dfta_grid    dfta_grid;     /* device-resident tables of one logarithmic radial grid   */
+typedef struct dfta_poisson dfta_poisson;  /* multigrid level storage for a batch of atoms            */
+typedef struct dfta_scf     dfta_scf;      /* device-resident SCF state of a batch of atoms           */
+
+/* ---- context -------------------------------------------------------------------------------------- */
+/* hip_stream: a hipStream_t to launch on (e.g. torch.cuda.current_stream().cuda_stream), or NULL for a
+ * stream owned by the context. */
+int         dfta_ctx_create(int device, void* hip_stream, dfta_ctx** out);
+void        dfta_ctx_destroy(dfta_ctx* ctx);
+int         dfta_ctx_synchronize(dfta_ctx* ctx);
+const char* dfta_last_error(const dfta_ctx* ctx);
+const char* dfta_version(void);
+/* HIP-event duration (ms, on the context's stream) of the dominant kernel of the last host-pointer call */
+int         dfta_ctx_last_kernel_ms(dfta_ctx* ctx, float* ms);
+/* number of compute units / name of the device behind the context (reporting only) */
+int         dfta_ctx_device_info(const dfta_ctx* ctx, int* num_cu, char* name, int name_cap);
+
+/* ---- grid ------------------------------------------------------------------------------------------
+ * Replaces NumerovFunctionNonUniformGrid's constructor and position/exp evaluations (Numerov.h:76-101,
+ * 181-184), PoissonSolver::GetNumberOfNodes (PoissonSolver.h:127-135) and FillRNonuniformR
+ * (PoissonSolver.cpp:212-223).  N = 2^mg_levels + 1.  Tables exp(i d), exp(2 i d), exp(i d / 2), r_i and
+ * l(l+1)/(r_i r_i)*0.5 are evaluated once on the host with libm in the reference's operation order and
+ * uploaded, so device kernels never call exp() on grid quantities. */
+int    dfta_grid_create(dfta_ctx* ctx, int mg_levels, double delta, double Rmax, dfta_grid** out);
+void   dfta_grid_destroy(dfta_grid* g);
+int    dfta_grid_num_nodes(const dfta_grid* g);
+double dfta_grid_rp(const dfta_grid* g);
+int    dfta_grid_get_r(const dfta_grid* g, double* r_host);           /* N doubles */
+int    dfta_num_nodes(int mg_levels);                                  /* PoissonSolver.h:127-135 */
+
+/* ---- batched Numerov sweeps ------------------------------------------------------------------------
+ * One trial = one call of
+ *   DFTA_SWEEP_COUNT  Numerov<NonUniform>::SolveSchrodingerCountNodes     (Numerov.h:272-349)
+ *   DFTA_SWEEP_ZERO   Numerov<NonUniform>::SolveSchrodingerSolutionInZero (Numerov.h:351-401)
+ * for (potential index, l, E[, nodesLimit]).  All trials of a call are integrated concurrently, one lane
+ * per trial, lanes of a wavefront marching the grid index together.
+ *
+ * boundary values (GetMaxRadiusIndex / GetBoundaryValueFar, Numerov.h:103-136):
+ *   DFTA_BOUNDARY_DEVICE  cut-off index and the two start values are computed on the device (device exp());
+ *   DFTA_BOUNDARY_HOST    they are computed on the host with libm exactly as the reference does and
+ *                         uploaded -- sweeps are then bit-identical to the reference's.
+ * The _dev variant always uses DFTA_BOUNDARY_DEVICE unless start/us/us1 are given (non-NULL). */
+#define DFTA_SWEEP_COUNT 0
+#define DFTA_SWEEP_ZERO  1
+#define DFTA_BOUNDARY_DEVICE 0
+#define DFTA_BOUNDARY_HOST   1
+
+int dfta_numerov_sweeps(dfta_ctx* ctx, const dfta_grid* g, int kind, int boundary,
+                        int nV, const double* V,            /* nV potentials, nV*N doubles (host)      */
+                        int ntrials, const int* vidx,       /* potential index per trial (NULL -> 0)   */
+                        const int* l, const double* E, const int* nodesLimit /* COUNT only */,
+                        int* count_out,                     /* COUNT: node count per trial             */
+                        double* u0_out,                     /* ZERO: extrapolated u(0); COUNT: optional */
+                        int* start_out, int* trip_out);     /* optional diagnostics: cut-off index, loop trips */
+
+/* device-pointer form; trials must be grouped: `ngroups` groups, group k covers trials
+ * [group_off[k], group_off[k+1]) which share (group_vidx[k], group_l[k]).  All pointers are device
+ * pointers except the small group_* arrays (host). */
+int dfta_numerov_sweeps_dev(dfta_ctx* ctx, const dfta_grid* g, int kind,
+                            int nV, const double* dV,
+                            int ngroups, const int* group_off, const int* group_vidx, const int* group_l,
+                            const double* dE, const int* dLimit,
+                            const int* dStart, const double* dUs, const double* dUs1,   /* NULL -> device boundary */
+                            int* dCount, double* dU0, int* dStartOut, int* dTrip);
+
+/* Numerov<NonUniform>::SolveSchrodingerMatchSolutionCompletely (Numerov.h:403-504) for a batch of
+ * (vidx, l, E); Psi_out: ntrials*N doubles; matchPoint_out: ntrials. */
+int dfta_numerov_match(dfta_ctx* ctx, const dfta_grid* g, int boundary, int nV, const double* V,
+                       int ntrials, const int* vidx, const int* l, const double* E,
+                       double* Psi_out, long* matchPoint_out);
+
+/* ---- eigenvalue search for a batch of (atom,spin) potentials -----------------------------------------
+ * Replaces DFTAtom::LoopOverLevels + LocateInterval + NormalizeNonUniform + the density update of
+ * CalculateNonUniformDensity (DFTAtom.cpp:36-56, 328-343, 493-604).  All bisections run on the device as
+ * speculative bisection trees of depth `tree_depth` that reproduce the reference's midpoint sequence.
+ *   mode DFTA_LEVELS_CHAINED : BottomEnergy handed from level to level as DFTAtom.cpp:541 (E-3)
+ *   mode DFTA_LEVELS_BATCHED : every level starts at bottom0[v] (documented deviation)    */
+#define DFTA_LEVELS_CHAINED 0
+#define DFTA_LEVELS_BATCHED 1
+
+typedef struct dfta_level_result {
+    double E;            /* eigenvalue (level.E, DFTAtom.cpp:534)                       */
+    double top, bottom;  /* interval returned by LocateInterval                          */
+    int    n_count;      /* reference-equivalent CountNodes sweeps on the bisection path */
+    int    n_zero;       /* reference-equivalent SolutionInZero sweeps                   */
+    int    converged;    /* !didNotConverge                                              */
+    int    matchPoint;
+} dfta_level_result;
+
+int dfta_solve_levels(dfta_ctx* ctx, const dfta_grid* g, int mode, int tree_depth,
+                      int nV, const double* V, const double* bottom0 /* nV */,
+                      int nlevels, const int* vidx, const int* n, const int* l, const int* occ,
+                      dfta_level_result* results,           /* nlevels */
+                      double* newDensity /* nV*N, accumulated occ*Psi^2 (i < N-1), may be NULL */,
+                      double* Eelectronic /* nV, may be NULL */,
+                      double* Psi_out /* nlevels*N normalised, may be NULL */,
+                      long* issued_sweeps /* optional: sweeps actually launched */);
+
+/* ---- multigrid Poisson -------------------------------------------------------------------------------
+ * Replaces DFT::PoissonSolver (PoissonSolver.h:15-171, PoissonSolver.cpp).  `batch` independent atoms are
+ * solved concurrently, one workgroup per atom. */
+int  dfta_poisson_create(dfta_ctx* ctx, const dfta_grid* g, int batch, dfta_poisson** out);  /* PoissonSolver.cpp:8-27 */
+void dfta_poisson_destroy(dfta_poisson* p);
+/* SolvePoissonNonUniform (PoissonSolver.h:51-81): density batch*N (host) -> U batch*N (host).
+ * vcycles_out/err_out (optional, per atom): V-cycles executed (<=100) and last ||dPhi||_2. */
+int  dfta_poisson_solve(dfta_poisson* p, const int* Z, const double* density, double* U,
+                        int* vcycles_out, double* err_out);
+int  dfta_poisson_solve_dev(dfta_poisson* p, const int* dZ, const double* dDensity, double* dU);
+/* unit-parity hooks on level storage of atom 0 (GaussSeidel / Restrict / Prolong / VCycle,
+ * PoissonSolver.cpp:40-64, 110-157; PoissonSolver.h:155-159) */
+int  dfta_poisson_level_size(const dfta_poisson* p, int lvl);
+int  dfta_poisson_set_level(dfta_poisson* p, int lvl, const double* Phi, const double* Src);
+int  dfta_poisson_get_level(dfta_poisson* p, int lvl, double* Phi, double* Src);
+int  dfta_poisson_gauss_seidel(dfta_poisson* p, int lvl, int sweeps, double* err_out /* per sweep */);
+int  dfta_poisson_restrict(dfta_poisson* p, int lvl);
+int  dfta_poisson_prolong(dfta_poisson* p, int lvl_src);
+int  dfta_poisson_vcycle(dfta_poisson* p, double* err_out);
+
+/* ---- VWN exchange-correlation ---------------------------------------------------------------------------
+ * VWNExchCor::Vexc / eexcDif, LDA (VWNExcCor.h:73-128) and LSDA (VWNExcCor.h:134-312). Host pointers. */
+int dfta_vwn_lda(dfta_ctx* ctx, const double* n, size_t sz, double* vexc, double* eexcdif);
+int dfta_vwn_lsda(dfta_ctx* ctx, const double* na, const double* nb, size_t sz,
+                  double* vexc, double* va, double* vb, double* eexcdif);
+
+/* ---- quadrature --------------------------------------------------------------------------------------------
+ * Integral::{Trapezoid,SimpsonOneThird,Simpson38,Boole,Romberg} (Integral.h:11-155); values: host. */
+#define DFTA_INT_TRAPEZOID 0
+#define DFTA_INT_SIMPSON13 1
+#define DFTA_INT_SIMPSON38 2
+#define DFTA_INT_BOOLE     3
+#define DFTA_INT_ROMBERG   4
+int dfta_integrate(dfta_ctx* ctx, int rule, double delta, const double* values, int sz, double* result);
+
+/* ---- SCF on a batch of atoms ---------------------------------------------------------------------------------
+ * Replaces the body of DFTAtom::CalculateNonUniformLDA / LSDA (DFTAtom.cpp:346-491, 847-1022): state lives
+ * in HBM between steps; one call advances every atom of the batch by one SCF iteration. */
+typedef struct dfta_energies {
+    double Etotal, Ekinetic, Ecoul, Enuclear, Exc;     /* as printed at DFTAtom.cpp:472 */
+    double Eelectronic, Ehartree, eExcDif, Epotential;
+} dfta_energies;
+
+typedef struct dfta_step_stats {
+    long   sweeps_issued;        /* Numerov sweeps launched (speculative trees)            */
+    long   sweeps_reference;     /* sweeps on the reference's bisection path (count+zero+match) */
+    long   points_traversed;     /* grid points traversed by issued sweeps                  */
+    long   vcycles;              /* Poisson V-cycles executed over the batch                */
+    int    rounds;               /* bisection rounds (kernel launches of the sweep kernel)  */
+    float  ms_levels, ms_poisson, ms_tail;   /* HIP-event times of the three phases       */
+} dfta_step_stats;
+
+int  dfta_scf_create(dfta_ctx* ctx, const dfta_grid* g, int lsda, int natoms, const int* Z,
+                     double alpha, int levels_mode, int tree_depth, dfta_scf** out);   /* DFTAtom.cpp:351-394 / 852-906 */
+void dfta_scf_destroy(dfta_scf* s);
+int  dfta_scf_step(dfta_scf* s, dfta_step_stats* stats);                               /* DFTAtom.cpp:396-484 / 908-1009 */
+/* results of the last step (host copies): per atom energies; finished flag (the reference's Finished! test) */
+int  dfta_scf_get_energies(dfta_scf* s, dfta_energies* e /* natoms */, int* finished /* natoms */);
+int  dfta_scf_num_levels(const dfta_scf* s, int atom, int spin);
+int  dfta_scf_get_levels(dfta_scf* s, int atom, int spin, int* n, int* l, int* occ, double* E, int* converged);
+int  dfta_scf_get_array(dfta_scf* s, int atom, int which, double* out /* N */);  /* 0 density,1 densityA,2 densityB,3 potA,4 potB,5 U */
+/* fixed-size per-atom record for the periodic-table gather: 64 doubles */
+#define DFTA_RECORD_DOUBLES 64
+int  dfta_scf_get_records_dev(dfta_scf* s, double* dRecords /* natoms*64, device */);
+
+/* ---- Aufbau -------------------------------------------------------------------------------------------------
+ * AufbauPrinciple::GetSubshells + sort (AufbauPrinciple.h:36-75, DFTAtom.cpp:367); integer-only host code. */
+int dfta_get_subshells(int Z, int* n, int* l, int* occ, int cap);
+int dfta_split_spin(int Z, int* nA, int* nB, int* an, int* al, int* aocc, int* bn, int* bl, int* bocc, int cap); /* DFTAtom.cpp:611-638 */
+
+#ifdef __cplusplus
+}
+#endif
+#endif
