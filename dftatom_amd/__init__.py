@@ -260,3 +260,117 @@ def integrate(ctx, rule, delta, values):
     out = C.c_double()
     ctx.check(ctx.lib.dfta_integrate(ctx.h, rule, delta, _dp(v), len(v), C.byref(out)))
     return out.value
+
+
+class Poisson:
+    """DFT::PoissonSolver for a batch of atoms on one grid (dfta_poisson)."""
+
+    def __init__(self, ctx, grid, batch=1):
+        self.ctx, self.grid, self.batch = ctx, grid, batch
+        h = vp()
+        ctx.check(ctx.lib.dfta_poisson_create(ctx.h, grid.h, batch, C.byref(h)))
+        self.h = h
+
+    def solve(self, Z, density):
+        """SolvePoissonNonUniform: density (batch x N) -> U (batch x N), vcycles, err."""
+        Z = _i32(np.atleast_1d(Z))
+        rho = _f64(density).reshape(self.batch, self.grid.N)
+        U = np.zeros_like(rho)
+        vc = np.zeros(self.batch, np.int32)
+        err = np.zeros(self.batch)
+        self.ctx.check(self.ctx.lib.dfta_poisson_solve(self.h, _ip(Z), _dp(rho), _dp(U), _ip(vc), _dp(err)))
+        return U, vc, err
+
+    def level_size(self, lvl):
+        return self.ctx.lib.dfta_poisson_level_size(self.h, lvl)
+
+    def set_level(self, lvl, phi=None, src=None):
+        self.ctx.check(self.ctx.lib.dfta_poisson_set_level(self.h, lvl, _dp(_f64(phi)) if phi is not None else None,
+                                                           _dp(_f64(src)) if src is not None else None))
+
+    def get_level(self, lvl):
+        n = self.level_size(lvl)
+        phi, src = np.zeros(n), np.zeros(n)
+        self.ctx.check(self.ctx.lib.dfta_poisson_get_level(self.h, lvl, _dp(phi), _dp(src)))
+        return phi, src
+
+    def gauss_seidel(self, lvl, sweeps=1):
+        err = np.zeros(sweeps)
+        self.ctx.check(self.ctx.lib.dfta_poisson_gauss_seidel(self.h, lvl, sweeps, _dp(err)))
+        return err
+
+    def restrict(self, lvl):
+        self.ctx.check(self.ctx.lib.dfta_poisson_restrict(self.h, lvl))
+
+    def prolong(self, lvl_src):
+        self.ctx.check(self.ctx.lib.dfta_poisson_prolong(self.h, lvl_src))
+
+    def vcycle(self):
+        err = np.zeros(1)
+        self.ctx.check(self.ctx.lib.dfta_poisson_vcycle(self.h, _dp(err)))
+        return err[0]
+
+    def close(self):
+        if self.h:
+            self.ctx.lib.dfta_poisson_destroy(self.h)
+            self.h = None
+
+
+def vwn_lda(ctx, n):
+    n = _f64(n)
+    v, e = np.zeros_like(n), np.zeros_like(n)
+    ctx.check(ctx.lib.dfta_vwn_lda(ctx.h, _dp(n), n.size, _dp(v), _dp(e)))
+    return v, e
+
+
+def vwn_lsda(ctx, na, nb):
+    na, nb = _f64(na), _f64(nb)
+    r, va, vb, e = (np.zeros_like(na) for _ in range(4))
+    ctx.check(ctx.lib.dfta_vwn_lsda(ctx.h, _dp(na), _dp(nb), na.size, _dp(r), _dp(va), _dp(vb), _dp(e)))
+    return r, va, vb, e
+
+
+class Scf:
+    """Device-resident SCF state of a batch of atoms (dfta_scf): the body of CalculateNonUniformLDA/LSDA."""
+
+    def __init__(self, ctx, grid, Z, lsda=False, alpha=0.5, levels_mode=LEVELS_BATCHED, tree_depth=0):
+        self.ctx, self.grid = ctx, grid
+        self.Z = _i32(np.atleast_1d(Z))
+        self.natoms = len(self.Z)
+        self.lsda = bool(lsda)
+        h = vp()
+        ctx.check(ctx.lib.dfta_scf_create(ctx.h, grid.h, int(self.lsda), self.natoms, _ip(self.Z), alpha, levels_mode,
+                                          tree_depth, C.byref(h)))
+        self.h = h
+
+    def step(self, want_stats=True):
+        st = StepStats()
+        self.ctx.check(self.ctx.lib.dfta_scf_step(self.h, C.byref(st) if want_stats else None))
+        return st
+
+    def energies(self):
+        e = (Energies * self.natoms)()
+        fin = np.zeros(self.natoms, np.int32)
+        self.ctx.check(self.ctx.lib.dfta_scf_get_energies(self.h, e, _ip(fin)))
+        return [e[i] for i in range(self.natoms)], fin
+
+    def levels(self, atom=0, spin=0):
+        cnt = self.ctx.lib.dfta_scf_num_levels(self.h, atom, spin)
+        n, l, occ, conv = (np.zeros(max(cnt, 1), np.int32) for _ in range(4))
+        E = np.zeros(max(cnt, 1))
+        if cnt > 0:
+            self.ctx.check(self.ctx.lib.dfta_scf_get_levels(self.h, atom, spin, _ip(n), _ip(l), _ip(occ), _dp(E), _ip(conv)))
+        return {"n": n[:cnt], "l": l[:cnt], "occ": occ[:cnt], "E": E[:cnt], "converged": conv[:cnt]}
+
+    def array(self, which, atom=0):
+        out = np.zeros(self.grid.N)
+        self.ctx.check(self.ctx.lib.dfta_scf_get_array(self.h, atom, which, _dp(out)))
+        return out
+
+    def records_into(self, device_ptr):
+        self.ctx.check(self.ctx.lib.dfta_scf_get_records_dev(self.h, vp(device_ptr)))
+
+    def close(self):
+        if self.h:
+            self.ctx.lib.dfta_scf_destroy(self.h)
+            self.h = None

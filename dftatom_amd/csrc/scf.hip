@@ -1,0 +1,440 @@
+// scf.hip -- one SCF iteration for a batch of atoms, state resident in HBM.
+//
+// Replaces the body of DFTAtom::CalculateNonUniformLDA (DFTAtom.cpp:346-491) and
+// DFTAtom::CalculateNonUniformLSDA (DFTAtom.cpp:847-1022): flat-density start, level search for every
+// (atom, spin), density mixing, multigrid Poisson, VWN, the pointwise potential/integrand pass, the five
+// Simpson 3/8 integrals (reference summation order) and the energy assembly + convergence test.
+// Potentials are stored as V[(atom * nspin + spin) * N + i].
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <vector>
+
+#include "internal.h"
+#include "levels.h"
+#include "ordered_sum.h"
+#include "xc.h"
+
+namespace {
+
+constexpr double kPi = 3.14159265358979323846;
+constexpr double fourM_PI = 4. * kPi;
+constexpr double kTotalEnergyErr = 1E-11;   // DFTAtom.cpp:349
+
+struct AtomState {          // per atom, device
+    int Z;
+    int nAlphaE, nBetaE;    // electrons per spin (LSDA), DFTAtom.cpp:611-638
+    int job_off, job_end;   // jobs of this atom in the level solver (alpha levels first, then beta)
+    int lastTimeConverged;
+    int finished;
+    int steps;
+    double Eold;
+    dfta_energies e;
+};
+
+// flat start density (DFTAtom.cpp:371-376 / 874-884)
+__global__ void k_init_density(const AtomState* __restrict__ atoms, int lsda, int N, double MaxR, double* __restrict__ density,
+                               double* __restrict__ dA, double* __restrict__ dB)
+{
+    const int a = blockIdx.y;
+    const double volume = fourM_PI / 3. * MaxR * MaxR * MaxR;
+    const AtomState s = atoms[a];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) {
+        const size_t o = (size_t)a * N + i;
+        if (!lsda) density[o] = (i == 0) ? 0. : s.Z / volume;
+        else {
+            const double cA = s.nAlphaE / volume, cB = s.nBetaE / volume;
+            dA[o] = (i == 0) ? 0. : cA;
+            dB[o] = (i == 0) ? 0. : cB;
+            density[o] = (i == 0) ? 0. : cA + cB;
+        }
+    }
+}
+
+// potential from U and v_xc (DFTAtom.cpp:387-392 / 895-904, also the first statement of the tail loop)
+__global__ void k_potential(const AtomState* __restrict__ atoms, int lsda, int N, const double* __restrict__ r,
+                            const double* __restrict__ U, const double* __restrict__ Vexc, const double* __restrict__ va,
+                            const double* __restrict__ vb, double* __restrict__ V)
+{
+    const int a = blockIdx.y;
+    const int Z = atoms[a].Z;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) {
+        const size_t o = (size_t)a * N + i;
+        if (!lsda) V[o] = (i == 0) ? 0. : (-Z + U[o]) / r[i] + Vexc[o];
+        else {
+            const double u = (i == 0) ? 0. : (-Z + U[o]) / r[i];
+            V[((size_t)2 * a) * N + i] = (i == 0) ? 0. : u + va[o];
+            V[((size_t)2 * a + 1) * N + i] = (i == 0) ? 0. : u + vb[o];
+        }
+    }
+}
+
+// newDensity /= 4 pi r^2; density = alpha density + (1-alpha) newDensity (DFTAtom.cpp:332-342); LSDA total (DFTAtom.cpp:933-934)
+__global__ void k_mix(int lsda, int N, double alpha, double oneMinusAlpha, const double* __restrict__ fpr2,
+                      double* __restrict__ newDensity, double* __restrict__ density, double* __restrict__ dA, double* __restrict__ dB)
+{
+    const int a = blockIdx.y;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) {
+        if (i == 0) continue;
+        const size_t o = (size_t)a * N + i;
+        if (!lsda) {
+            double nd = newDensity[o];
+            nd /= fpr2[i];
+            newDensity[o] = nd;
+            density[o] = alpha * density[o] + oneMinusAlpha * nd;
+        } else {
+            const size_t oa = ((size_t)2 * a) * N + i, ob = ((size_t)2 * a + 1) * N + i;
+            double na = newDensity[oa], nb = newDensity[ob];
+            na /= fpr2[i];
+            nb /= fpr2[i];
+            newDensity[oa] = na;
+            newDensity[ob] = nb;
+            const double x = alpha * dA[o] + oneMinusAlpha * na;
+            const double y = alpha * dB[o] + oneMinusAlpha * nb;
+            dA[o] = x;
+            dB[o] = y;
+            density[o] = x + y;
+        }
+    }
+}
+
+// new potential + the five integrands (DFTAtom.cpp:437-457 / 956-983); integrands: [atom][5][N]
+__global__ void k_tail(const AtomState* __restrict__ atoms, int lsda, int N, const double* __restrict__ r,
+                       const double* __restrict__ cnst, const double* __restrict__ density, const double* __restrict__ dA,
+                       const double* __restrict__ dB, const double* __restrict__ U, const double* __restrict__ Vexc,
+                       const double* __restrict__ va, const double* __restrict__ vb, const double* __restrict__ eexc,
+                       double* __restrict__ V, double* __restrict__ integrands)
+{
+    const int a = blockIdx.y;
+    const int Z = atoms[a].Z;
+    double* nuclear = integrands + ((size_t)a * 5 + 0) * N;
+    double* exccor = integrands + ((size_t)a * 5 + 1) * N;
+    double* eexcD = integrands + ((size_t)a * 5 + 2) * N;
+    double* hartree = integrands + ((size_t)a * 5 + 3) * N;
+    double* potentiale = integrands + ((size_t)a * 5 + 4) * N;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) {
+        const size_t o = (size_t)a * N + i;
+        if (i == 0) {
+            if (!lsda) V[o] = 0; else { V[((size_t)2 * a) * N] = 0; V[((size_t)2 * a + 1) * N] = 0; }
+            nuclear[0] = 0; exccor[0] = 0; eexcD[0] = 0; hartree[0] = 0; potentiale[0] = 0;
+            continue;
+        }
+        const double position = r[i];
+        const double c = cnst[i];
+        const double rho = density[o];
+        if (!lsda) {
+            const double pot = (-Z + U[o]) / position + Vexc[o];
+            V[o] = pot;
+            const double positiondensity = position * rho * c;
+            nuclear[i] = Z * positiondensity;
+            const double position2density = position * position * rho * c;
+            exccor[i] = position2density * Vexc[o];
+            eexcD[i] = position2density * eexc[o];
+            hartree[i] = positiondensity * U[o];
+            potentiale[i] = position2density * pot;
+        } else {
+            const double u = (-Z + U[o]) / position;
+            const double pa = u + va[o], pb = u + vb[o];
+            V[((size_t)2 * a) * N + i] = pa;
+            V[((size_t)2 * a + 1) * N + i] = pb;
+            const double positioncnst = position * c;
+            const double positiondensity = positioncnst * rho;
+            nuclear[i] = Z * positiondensity;
+            const double position2cnst = position * positioncnst;
+            const double position2density = position2cnst * rho;
+            const double p2a = position2cnst * dA[o];
+            const double p2b = position2cnst * dB[o];
+            exccor[i] = position2density * Vexc[o];
+            eexcD[i] = position2density * eexc[o];
+            hartree[i] = positiondensity * U[o];
+            potentiale[i] = p2a * pa + p2b * pb;
+        }
+    }
+}
+
+// energy assembly and the reference's stop test (DFTAtom.cpp:459-481 / 985-1006); one thread per atom
+__global__ void k_energies(AtomState* __restrict__ atoms, int natoms, const dfta::Job* __restrict__ jobs,
+                           const double* __restrict__ integrals, double* __restrict__ records)
+{
+    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= natoms) return;
+    AtomState s = atoms[a];
+    double Eelectronic = 0;
+    bool conv = true;
+    for (int k = s.job_off; k < s.job_end; ++k) {
+        Eelectronic += jobs[k].occ * jobs[k].E;                    // DFTAtom.cpp:561
+        conv = conv && (jobs[k].converged != 0);
+    }
+    const double* I = integrals + (size_t)a * 5;
+    const double Enuclear = -fourM_PI * I[0];
+    double Exc = fourM_PI * I[1];
+    const double eExcDif = fourM_PI * I[2];
+    Exc += eExcDif;
+    const double Ehartree = -2 * kPi * I[3];
+    const double Epotential = fourM_PI * I[4];
+    const double Ekinetic = Eelectronic - Epotential;
+    const double Etotal = Eelectronic + Ehartree + eExcDif;
+    s.e.Etotal = Etotal; s.e.Ekinetic = Ekinetic; s.e.Ecoul = -Ehartree; s.e.Enuclear = Enuclear; s.e.Exc = Exc;
+    s.e.Eelectronic = Eelectronic; s.e.Ehartree = Ehartree; s.e.eExcDif = eExcDif; s.e.Epotential = Epotential;
+    s.steps++;
+    if (fabs((s.Eold - Etotal) / Etotal) < kTotalEnergyErr && conv && s.lastTimeConverged) s.finished = 1;
+    else { s.Eold = Etotal; s.lastTimeConverged = conv ? 1 : 0; }
+    atoms[a] = s;
+    if (records) {
+        double* R = records + (size_t)a * DFTA_RECORD_DOUBLES;
+        R[0] = s.Z; R[1] = Etotal; R[2] = Ekinetic; R[3] = -Ehartree; R[4] = Enuclear; R[5] = Exc; R[6] = s.finished;
+        R[7] = s.steps; R[8] = s.job_end - s.job_off; R[9] = conv ? 1. : 0.;
+        int m = 10;
+        for (int k = s.job_off; k < s.job_end && m < DFTA_RECORD_DOUBLES; ++k) R[m++] = jobs[k].E;
+        for (; m < DFTA_RECORD_DOUBLES; ++m) R[m] = 0;
+    }
+}
+
+}  // namespace
+
+struct dfta_scf {
+    dfta_ctx* ctx = nullptr;
+    const dfta_grid* g = nullptr;
+    int lsda = 0, natoms = 0, nspin = 1, nV = 0;
+    double alpha = 0.5;
+    dfta::LevelSolver solver;
+    dfta_poisson* poisson = nullptr;
+    std::vector<AtomState> h_atoms;
+    std::vector<double> h_bottom0;
+    std::vector<int> spin_nlev[2];      // per atom number of levels per spin
+    AtomState* d_atoms = nullptr;
+    int* d_Z = nullptr;
+    double *d_density = nullptr, *d_dA = nullptr, *d_dB = nullptr, *d_V = nullptr, *d_U = nullptr, *d_Vexc = nullptr,
+           *d_va = nullptr, *d_vb = nullptr, *d_eexc = nullptr, *d_newDensity = nullptr, *d_integrands = nullptr,
+           *d_integrals = nullptr, *d_records = nullptr;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+};
+
+static int scf_xc(dfta_scf* s)
+{
+    const size_t sz = (size_t)s->natoms * s->g->N;
+    if (!s->lsda) return dfta_launch_vwn_lda(s->ctx, s->d_density, sz, s->d_Vexc, s->d_eexc);
+    return dfta_launch_vwn_lsda(s->ctx, s->d_dA, s->d_dB, sz, s->d_Vexc, s->d_va, s->d_vb, s->d_eexc);
+}
+
+extern "C" {
+
+void dfta_scf_destroy(dfta_scf* s)
+{
+    if (!s) return;
+    void* ptrs[] = {s->d_atoms, s->d_Z, s->d_density, s->d_dA, s->d_dB, s->d_V, s->d_U, s->d_Vexc, s->d_va, s->d_vb, s->d_eexc,
+                    s->d_newDensity, s->d_integrands, s->d_integrals, s->d_records};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    for (hipEvent_t e : s->ev) if (e) (void)hipEventDestroy(e);
+    if (s->poisson) dfta_poisson_destroy(s->poisson);
+    delete s;
+}
+
+int dfta_scf_create(dfta_ctx* ctx, const dfta_grid* g, int lsda, int natoms, const int* Z, double alpha, int levels_mode,
+                    int tree_depth, dfta_scf** out)
+{
+    if (!ctx || !g || !out) return DFTA_ERR_INVALID;
+    DFTA_REQUIRE(ctx, natoms >= 1 && Z && alpha >= 0 && alpha <= 1, "scf arguments");
+    dfta_scf* s = new dfta_scf();
+    s->ctx = ctx; s->g = g; s->lsda = lsda ? 1 : 0; s->natoms = natoms; s->nspin = lsda ? 2 : 1; s->nV = natoms * s->nspin;
+    s->alpha = alpha;
+    const int N = g->N;
+    std::vector<dfta::JobSpec> specs;
+    s->h_atoms.resize(natoms);
+    s->h_bottom0.resize(s->nV);
+    s->spin_nlev[0].resize(natoms); s->spin_nlev[1].assign(natoms, 0);
+    for (int a = 0; a < natoms; ++a) {
+        DFTA_REQUIRE(ctx, Z[a] >= 1 && Z[a] <= 118, "Z out of range");
+        AtomState& st = s->h_atoms[a];
+        memset(&st, 0, sizeof(st));
+        st.Z = Z[a];
+        st.job_off = (int)specs.size();
+        int an[32], al[32], ao[32], bn[32], bl[32], bo[32], nA = 0, nB = 0;
+        if (!lsda) {
+            nA = dfta_get_subshells(Z[a], an, al, ao, 32);
+            if (nA < 0) { dfta_scf_destroy(s); return DFTA_ERR_INVALID; }
+            for (int k = 0; k < nA; ++k) specs.push_back({a, an[k], al[k], ao[k]});
+            s->h_bottom0[a] = -double(Z[a]) * Z[a] - 1.;                                   // DFTAtom.cpp:407
+        } else {
+            if (dfta_split_spin(Z[a], &nA, &nB, an, al, ao, bn, bl, bo, 32) != DFTA_OK) { dfta_scf_destroy(s); return DFTA_ERR_INVALID; }
+            int ne = 0;
+            for (int k = 0; k < nA; ++k) { specs.push_back({2 * a, an[k], al[k], ao[k]}); ne += ao[k]; }
+            for (int k = 0; k < nB; ++k) specs.push_back({2 * a + 1, bn[k], bl[k], bo[k]});
+            st.nAlphaE = ne;
+            st.nBetaE = Z[a] - ne;
+            s->h_bottom0[2 * a] = s->h_bottom0[2 * a + 1] = -double(Z[a]) * Z[a] - 1.;     // DFTAtom.cpp:919,929
+        }
+        s->spin_nlev[0][a] = nA;
+        s->spin_nlev[1][a] = nB;
+        st.job_end = (int)specs.size();
+    }
+    int rc = s->solver.setup(ctx, g, levels_mode, tree_depth, s->nV, specs);
+    if (rc) { dfta_scf_destroy(s); return rc; }
+    rc = dfta_poisson_create(ctx, g, natoms, &s->poisson);
+    if (rc) { dfta_scf_destroy(s); return rc; }
+
+    hipStream_t st = ctx->stream;
+    const size_t aN = (size_t)natoms * N;
+    hipError_t e = hipSuccess;
+    auto al = [&](double** p, size_t cnt) { if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(p), cnt * sizeof(double)); };
+    al(&s->d_density, aN); al(&s->d_dA, aN); al(&s->d_dB, aN); al(&s->d_V, aN * s->nspin); al(&s->d_U, aN); al(&s->d_Vexc, aN);
+    al(&s->d_va, aN); al(&s->d_vb, aN); al(&s->d_eexc, aN); al(&s->d_newDensity, aN * s->nspin); al(&s->d_integrands, aN * 5);
+    al(&s->d_integrals, (size_t)natoms * 5); al(&s->d_records, (size_t)natoms * DFTA_RECORD_DOUBLES);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&s->d_atoms), sizeof(AtomState) * natoms);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&s->d_Z), sizeof(int) * natoms);
+    for (auto& ev : s->ev) if (e == hipSuccess) e = hipEventCreate(&ev);
+    if (e == hipSuccess) e = hipMemcpyAsync(s->d_atoms, s->h_atoms.data(), sizeof(AtomState) * natoms, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(s->d_Z, Z, sizeof(int) * natoms, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemsetAsync(s->d_records, 0, sizeof(double) * natoms * DFTA_RECORD_DOUBLES, st);
+    if (e != hipSuccess) {
+        snprintf(ctx->err, sizeof(ctx->err), "scf alloc: %s", hipGetErrorString(e));
+        dfta_scf_destroy(s);
+        return DFTA_ERR_HIP;
+    }
+    // DFTAtom.cpp:371-392 / 874-904: flat density, Poisson, v_xc, start potential
+    const dim3 grid(std::min(64, (N + 255) / 256), natoms), block(256);
+    hipLaunchKernelGGL(k_init_density, grid, block, 0, st, s->d_atoms, s->lsda, N, g->Rmax, s->d_density, s->d_dA, s->d_dB);
+    rc = dfta_poisson_solve_launch(s->poisson, s->d_Z, s->d_density, s->d_U, nullptr, nullptr);
+    if (!rc) rc = scf_xc(s);
+    if (rc) { dfta_scf_destroy(s); return rc; }
+    hipLaunchKernelGGL(k_potential, grid, block, 0, st, s->d_atoms, s->lsda, N, g->d_r, s->d_U, s->d_Vexc, s->d_va, s->d_vb, s->d_V);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) {
+        snprintf(ctx->err, sizeof(ctx->err), "scf init: %s", hipGetErrorString(e));
+        dfta_scf_destroy(s);
+        return DFTA_ERR_HIP;
+    }
+    unsigned long long dummy;
+    (void)dfta_poisson_take_vcycles(s->poisson, &dummy);
+    *out = s;
+    return DFTA_OK;
+}
+
+int dfta_scf_step(dfta_scf* s, dfta_step_stats* stats)
+{
+    if (!s) return DFTA_ERR_INVALID;
+    dfta_ctx* ctx = s->ctx;
+    const dfta_grid* g = s->g;
+    const int N = g->N, natoms = s->natoms;
+    hipStream_t st = ctx->stream;
+    const dim3 grid(std::min(64, (N + 255) / 256), natoms), block(256);
+
+    DFTA_HIP(ctx, hipEventRecord(s->ev[0], st));
+    DFTA_HIP(ctx, hipMemsetAsync(s->d_newDensity, 0, sizeof(double) * (size_t)s->nV * N, st));
+    dfta::LevelStats ls;
+    int rc = s->solver.run(s->d_V, s->h_bottom0.data(), s->d_newDensity, stats ? &ls : nullptr);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_mix, grid, block, 0, st, s->lsda, N, s->alpha, 1. - s->alpha, g->d_fpr2, s->d_newDensity, s->d_density,
+                       s->d_dA, s->d_dB);
+    DFTA_CHECK_LAUNCH(ctx);
+    DFTA_HIP(ctx, hipEventRecord(s->ev[1], st));
+    rc = dfta_poisson_solve_launch(s->poisson, s->d_Z, s->d_density, s->d_U, nullptr, nullptr);
+    if (rc) return rc;
+    DFTA_HIP(ctx, hipEventRecord(s->ev[2], st));
+    rc = scf_xc(s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_tail, grid, block, 0, st, s->d_atoms, s->lsda, N, g->d_r, g->d_cnst, s->d_density, s->d_dA, s->d_dB, s->d_U,
+                       s->d_Vexc, s->d_va, s->d_vb, s->d_eexc, s->d_V, s->d_integrands);
+    DFTA_CHECK_LAUNCH(ctx);
+    rc = dfta_launch_simpson38_ordered(ctx, s->d_integrands, N, natoms * 5, (size_t)N, s->d_integrals);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_energies, dim3((natoms + 63) / 64), dim3(64), 0, st, s->d_atoms, natoms, s->solver.d_jobs, s->d_integrals,
+                       s->d_records);
+    DFTA_CHECK_LAUNCH(ctx);
+    DFTA_HIP(ctx, hipEventRecord(s->ev[3], st));
+    if (stats) {
+        DFTA_HIP(ctx, hipEventSynchronize(s->ev[3]));
+        memset(stats, 0, sizeof(*stats));
+        DFTA_HIP(ctx, hipEventElapsedTime(&stats->ms_levels, s->ev[0], s->ev[1]));
+        DFTA_HIP(ctx, hipEventElapsedTime(&stats->ms_poisson, s->ev[1], s->ev[2]));
+        DFTA_HIP(ctx, hipEventElapsedTime(&stats->ms_tail, s->ev[2], s->ev[3]));
+        stats->rounds = ls.rounds;
+        stats->sweeps_issued = ls.sweeps_issued;
+        stats->points_traversed = ls.points_traversed;
+        std::vector<dfta::Job> jobs;
+        rc = s->solver.fetch_jobs(jobs);
+        if (rc) return rc;
+        long ref = 0;
+        for (const auto& j : jobs) ref += j.n_count + j.n_zero + 1;     // + the matched solve of each level
+        stats->sweeps_reference = ref;
+        unsigned long long vc = 0;
+        rc = dfta_poisson_take_vcycles(s->poisson, &vc);
+        if (rc) return rc;
+        stats->vcycles = (long)vc;
+    }
+    return DFTA_OK;
+}
+
+int dfta_scf_get_energies(dfta_scf* s, dfta_energies* e, int* finished)
+{
+    if (!s) return DFTA_ERR_INVALID;
+    dfta_ctx* ctx = s->ctx;
+    DFTA_HIP(ctx, hipMemcpyAsync(s->h_atoms.data(), s->d_atoms, sizeof(AtomState) * s->natoms, hipMemcpyDeviceToHost, ctx->stream));
+    DFTA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int a = 0; a < s->natoms; ++a) {
+        if (e) e[a] = s->h_atoms[a].e;
+        if (finished) finished[a] = s->h_atoms[a].finished;
+    }
+    return DFTA_OK;
+}
+
+int dfta_scf_num_levels(const dfta_scf* s, int atom, int spin)
+{
+    if (!s || atom < 0 || atom >= s->natoms || spin < 0 || spin > 1) return -1;
+    return s->spin_nlev[spin][atom];
+}
+
+int dfta_scf_get_levels(dfta_scf* s, int atom, int spin, int* n, int* l, int* occ, double* E, int* converged)
+{
+    if (!s) return DFTA_ERR_INVALID;
+    dfta_ctx* ctx = s->ctx;
+    DFTA_REQUIRE(ctx, atom >= 0 && atom < s->natoms && spin >= 0 && spin < s->nspin, "atom/spin");
+    std::vector<dfta::Job> jobs;
+    int rc = s->solver.fetch_jobs(jobs);
+    if (rc) return rc;
+    int k0 = s->h_atoms[atom].job_off + (spin ? s->spin_nlev[0][atom] : 0);
+    const int cnt = s->spin_nlev[spin][atom];
+    for (int k = 0; k < cnt; ++k) {
+        const dfta::Job& j = jobs[k0 + k];
+        if (n) n[k] = j.n;
+        if (l) l[k] = j.l;
+        if (occ) occ[k] = j.occ;
+        if (E) E[k] = j.E;
+        if (converged) converged[k] = j.converged;
+    }
+    return DFTA_OK;
+}
+
+int dfta_scf_get_array(dfta_scf* s, int atom, int which, double* out)
+{
+    if (!s) return DFTA_ERR_INVALID;
+    dfta_ctx* ctx = s->ctx;
+    DFTA_REQUIRE(ctx, atom >= 0 && atom < s->natoms && out, "atom/out");
+    const int N = s->g->N;
+    const double* src = nullptr;
+    switch (which) {
+    case 0: src = s->d_density + (size_t)atom * N; break;
+    case 1: src = (s->lsda ? s->d_dA : s->d_density) + (size_t)atom * N; break;
+    case 2: src = (s->lsda ? s->d_dB : s->d_density) + (size_t)atom * N; break;
+    case 3: src = s->d_V + (size_t)atom * s->nspin * N; break;
+    case 4: src = s->d_V + ((size_t)atom * s->nspin + (s->lsda ? 1 : 0)) * N; break;
+    case 5: src = s->d_U + (size_t)atom * N; break;
+    default: DFTA_REQUIRE(ctx, false, "which");
+    }
+    DFTA_HIP(ctx, hipMemcpyAsync(out, src, sizeof(double) * N, hipMemcpyDeviceToHost, ctx->stream));
+    DFTA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return DFTA_OK;
+}
+
+int dfta_scf_get_records_dev(dfta_scf* s, double* dRecords)
+{
+    if (!s || !dRecords) return DFTA_ERR_INVALID;
+    dfta_ctx* ctx = s->ctx;
+    DFTA_HIP(ctx, hipMemcpyAsync(dRecords, s->d_records, sizeof(double) * (size_t)s->natoms * DFTA_RECORD_DOUBLES,
+                                 hipMemcpyDeviceToDevice, ctx->stream));
+    return DFTA_OK;
+}
+
+}  // extern "C"
