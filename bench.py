@@ -1,0 +1,207 @@
+#!/usr/bin/env python3
+"""bench.py -- SCF-step wall time and Numerov sweeps/s for Radon (Z=86) at 131073 grid points on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--atoms B] [--lsda] [--levels 17] [--no-cpu]
+
+Workload (BASELINE.json configs[1]): Rn Z=86 LDA, 17 multigrid levels (131073 nodes), delta = 1e-4, Rmax = 50,
+mixing 0.5 (README.md:54 of the reference); one "step" = one SCF iteration of the atom batch, state resident in
+HBM: level search for all 15 (n,l) subshells (speculative bisection trees of Numerov sweeps, un-chained
+brackets), density mixing, multigrid Poisson (100 V-cycles), VWN and the five Simpson-3/8 energy integrals.
+The timed steps continue the SCF iteration from the warm-up steps (synthetic start: the reference's flat density).
+
+value = reference-equivalent Numerov sweeps per second over the WHOLE step wall time, i.e. the sweeps the
+reference's own bisection path needs for these steps (CountNodes + SolutionInZero + Match) divided by the
+elapsed time including Poisson/XC/integrals -- the same quantity the CPU baseline reports.  Speculative
+sweeps actually launched are reported separately (`sweeps_issued_per_s`) and feed the roofline object.
+
+N > 1 (launched by torch.distributed.run): atoms are independent, so every rank advances its own replica of
+the batch (weak scaling, no data-path collective); the per-atom result records are all_gathered over RCCL
+once after the last step, inside the timed region.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+NUMEROV_BYTES_PER_POINT = 8    # one fp64 V_i per traversed grid point per trial
+POISSON_BYTES_PER_VCYCLE = {14: 6162448, 17: 49285736, 20: 394267840}
+
+
+def cpu_baseline(levels, delta, rmax, lsda, budget_steps):
+    """The oracle (plain-C restatement of the reference, 1 thread) timed on this host: `budget_steps` SCF steps."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import _oracle as O
+    o = O.oracle()
+    t0 = time.time()
+    s = o.dfo_scf_create(int(lsda), 86, levels, 0.5, rmax, delta, 1)
+    t_setup = time.time() - t0
+    e = O.Energies()
+    sweeps = 0
+    vcycles0 = s.contents.ps.contents.n_vcycles
+    t0 = time.time()
+    for _ in range(budget_steps):
+        o.dfo_scf_step(s, C.byref(e))
+        for arr, n in ((s.contents.la, s.contents.nla), (s.contents.lb, s.contents.nlb if lsda else 0)):
+            for i in range(n):
+                sweeps += arr[i].n_count + arr[i].n_zero + 1
+    dt = time.time() - t0
+    vc = s.contents.ps.contents.n_vcycles - vcycles0
+    o.dfo_scf_destroy(s)
+    return {"value": sweeps / dt, "unit": "sweeps/s", "cores": 1, "kind": "port",
+            "sample": "%d SCF steps of Rn %s @ %d levels on the oracle (oracle/dfta_oracle.c, gcc -O2, 1 thread): %.2f s, "
+                      "%d sweeps, %d V-cycles; setup (flat density + Poisson) %.2f s excluded"
+                      % (budget_steps, "LSDA" if lsda else "LDA", levels, dt, sweeps, vc, t_setup),
+            "ms_per_step": 1e3 * dt / budget_steps, "vcycles_per_s": vc / dt}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--atoms", type=int, default=1, help="identical Rn atoms advanced together per GPU")
+    ap.add_argument("--levels", type=int, default=17)
+    ap.add_argument("--lsda", action="store_true")
+    ap.add_argument("--tree-depth", type=int, default=0)
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--cpu-steps", type=int, default=3)
+    args = ap.parse_args()
+
+    import torch            # before dftatom_amd: one HIP runtime per process
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (there is no CPU fallback for the product path)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+
+    import dftatom_amd as D
+    grids = {14: (5e-4, 25.0), 17: (1e-4, 50.0), 20: (1.25e-5, 50.0)}
+    delta, rmax = grids.get(args.levels, (1e-4, 50.0))
+    stream = torch.cuda.current_stream().cuda_stream
+    ctx = D.Context(local_rank, stream)
+    grid = D.Grid(ctx, args.levels, delta, rmax)
+    scf = D.Scf(ctx, grid, [86] * args.atoms, lsda=args.lsda, alpha=0.5, levels_mode=D.LEVELS_BATCHED,
+                tree_depth=args.tree_depth)
+    records = torch.zeros((args.atoms, D.RECORD_DOUBLES), dtype=torch.float64, device="cuda")
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        scf.step()
+    barrier()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    tot = {"issued": 0, "ref": 0, "points": 0, "vcycles": 0, "rounds": 0, "ms_sweep": 0.0, "ms_levels": 0.0,
+           "ms_poisson": 0.0, "ms_tail": 0.0}
+    t0 = time.time()
+    ev0.record()
+    for _ in range(args.steps):
+        st = scf.step()
+        tot["issued"] += st.sweeps_issued
+        tot["ref"] += st.sweeps_reference
+        tot["points"] += st.points_traversed
+        tot["vcycles"] += st.vcycles
+        tot["rounds"] += st.rounds
+        tot["ms_sweep"] += st.ms_sweep_kernels
+        tot["ms_levels"] += st.ms_levels
+        tot["ms_poisson"] += st.ms_poisson
+        tot["ms_tail"] += st.ms_tail
+    scf.records_into(records.data_ptr())
+    if world > 1:
+        gathered = [torch.empty_like(records) for _ in range(world)]
+        dist.all_gather(gathered, records)
+    ev1.record()
+    barrier()
+    elapsed = time.time() - t0
+    ev_ms = ev0.elapsed_time(ev1)
+
+    # max over ranks of the elapsed time, sums of the work
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        w = torch.tensor([tot["ref"], tot["issued"], tot["vcycles"]], dtype=torch.float64, device="cuda")
+        dist.all_reduce(w, op=dist.ReduceOp.SUM)
+        ref_all, issued_all, vc_all = (float(x) for x in w.tolist())
+    else:
+        ref_all, issued_all, vc_all = float(tot["ref"]), float(tot["issued"]), float(tot["vcycles"])
+
+    if rank == 0:
+        en, fin = scf.energies()
+        ncu, devname = ctx.device_info()
+        launches = max(tot["rounds"], 1)
+        bytes_total = NUMEROV_BYTES_PER_POINT * tot["points"]
+        achieved = bytes_total / (tot["ms_sweep"] * 1e-3) / 1e9 if tot["ms_sweep"] > 0 else 0.0
+        out = {
+            "metric": "numerov_sweeps_per_s (reference-equivalent, whole SCF step; Rn Z=86 @ %d pts)" % grid.N,
+            "value": ref_all / elapsed,
+            "unit": "sweeps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic (reference's flat start density, SCF iterations %d..%d)" % (args.warmup, args.warmup + args.steps - 1),
+            "config": {"workload": "Rn Z=86 %s, %d multigrid levels (%d pts), delta=%g, Rmax=%g, mixing 0.5, %d atom(s)/GPU, "
+                                   "un-chained clamped brackets, tree depth %d" % ("LSDA" if args.lsda else "LDA", args.levels, grid.N,
+                                                                           delta, rmax, args.atoms, scf_depth(scf)),
+                       "atoms_per_gpu": args.atoms, "parallelism": "replicas x%d" % world},
+            "scf_step_ms": 1e3 * elapsed / args.steps,
+            "sweeps_issued_per_s": issued_all / elapsed,
+            "poisson_vcycles_per_s": vc_all / elapsed,
+            "poisson_vcycles_per_s_kernel": tot["vcycles"] / (tot["ms_poisson"] * 1e-3) if tot["ms_poisson"] > 0 else None,
+            "phase_ms_per_step": {"levels": tot["ms_levels"] / args.steps, "poisson": tot["ms_poisson"] / args.steps,
+                                  "tail": tot["ms_tail"] / args.steps, "hip_event_total": ev_ms / args.steps},
+            "rounds_per_step": tot["rounds"] / args.steps,
+            "energies_last_step": en[0].as_list(),
+            "device": devname, "compute_units": ncu,
+            "roofline": {"bound": "hbm", "kernel": "k_sweep (Numerov count/zero sweeps)",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None,
+                         "bytes_per_launch": bytes_total / launches, "avg_launch_ms": tot["ms_sweep"] / launches,
+                         "launches": launches,
+                         "note": "algorithmic bytes = 8 B x traversed grid points of every ISSUED trial (SURVEY 8d); trials of a "
+                                 "wave share V through scalar loads, so HBM traffic is far below this figure -- the kernel is "
+                                 "fp64-VALU-issue bound"},
+            "poisson_roofline": {"bound": "hbm", "kernel": "k_poisson_solve (persistent multigrid)",
+                                 "achieved": (POISSON_BYTES_PER_VCYCLE.get(args.levels, 0) * tot["vcycles"] /
+                                              (tot["ms_poisson"] * 1e-3) / 1e9) if tot["ms_poisson"] > 0 else None,
+                                 "peak": HBM_PEAK_GBS, "unit": "GB/s"},
+        }
+        if out["poisson_roofline"]["achieved"]:
+            out["poisson_roofline"]["frac"] = out["poisson_roofline"]["achieved"] / HBM_PEAK_GBS
+        if not args.no_cpu:
+            out["cpu_baseline"] = cpu_baseline(args.levels, delta, rmax, args.lsda, args.cpu_steps)
+        print(json.dumps(out))
+    scf.close()
+    grid.close()
+    ctx.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def scf_depth(scf):
+    return int(getattr(scf, "tree_depth", 0)) or 0
+
+
+if __name__ == "__main__":
+    main()

@@ -48,7 +48,7 @@ class Energies(C.Structure):
 class StepStats(C.Structure):
     _fields_ = [("sweeps_issued", C.c_long), ("sweeps_reference", C.c_long), ("points_traversed", C.c_long),
                 ("vcycles", C.c_long), ("rounds", C.c_int), ("ms_levels", C.c_float), ("ms_poisson", C.c_float),
-                ("ms_tail", C.c_float)]
+                ("ms_tail", C.c_float), ("ms_sweep_kernels", C.c_float), ("ms_poisson_kernel", C.c_float)]
 
 
 # every symbol include/dftatom_hip.h declares: name -> (restype, argtypes)
@@ -71,7 +71,7 @@ SIGNATURES = {
     "dfta_numerov_sweeps_dev": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, C.c_int, c_ip, c_ip, c_ip, vp, vp, vp, vp, vp,
                                           vp, vp, vp, vp]),
     "dfta_numerov_match": (C.c_int, [vp, vp, C.c_int, C.c_int, c_dp, C.c_int, c_ip, c_ip, c_dp, c_dp, c_lp]),
-    "dfta_solve_levels": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, c_dp, c_dp, C.c_int, c_ip, c_ip, c_ip, c_ip,
+    "dfta_solve_levels": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, c_dp, c_dp, c_dp, C.c_int, c_ip, c_ip, c_ip, c_ip,
                                     C.POINTER(LevelResult), c_dp, c_dp, c_dp, c_lp]),
     "dfta_poisson_create": (C.c_int, [vp, vp, C.c_int, C.POINTER(vp)]),
     "dfta_poisson_destroy": (None, [vp]),
@@ -91,6 +91,7 @@ SIGNATURES = {
     "dfta_scf_destroy": (None, [vp]),
     "dfta_scf_step": (C.c_int, [vp, C.POINTER(StepStats)]),
     "dfta_scf_get_energies": (C.c_int, [vp, C.POINTER(Energies), c_ip]),
+    "dfta_scf_info": (C.c_int, [vp, c_ip, c_ip, c_lp]),
     "dfta_scf_num_levels": (C.c_int, [vp, C.c_int, C.c_int]),
     "dfta_scf_get_levels": (C.c_int, [vp, C.c_int, C.c_int, c_ip, c_ip, c_ip, c_dp, c_ip]),
     "dfta_scf_get_array": (C.c_int, [vp, C.c_int, C.c_int, c_dp]),
@@ -231,7 +232,7 @@ def get_subshells(Z):
     return [(int(n[i]), int(l[i]), int(occ[i])) for i in range(c)]
 
 
-def solve_levels(ctx, grid, V, levels, bottom0, vidx=None, mode=LEVELS_BATCHED, tree_depth=0, want_psi=False):
+def solve_levels(ctx, grid, V, levels, bottom0, vidx=None, mode=LEVELS_BATCHED, tree_depth=0, want_psi=False, hints=None):
     """Device-side LoopOverLevels for `levels` = [(n, l, occ), ...] on potentials V (nV x N).
     Returns dict(E, top, bottom, n_count, n_zero, converged, matchPoint, newDensity, Eelectronic, psi, issued)."""
     V = _f64(V).reshape(-1, grid.N)
@@ -247,7 +248,9 @@ def solve_levels(ctx, grid, V, levels, bottom0, vidx=None, mode=LEVELS_BATCHED, 
     eel = np.zeros(nV)
     psi = np.zeros((nl, grid.N)) if want_psi else None
     issued = C.c_long(0)
-    ctx.check(ctx.lib.dfta_solve_levels(ctx.h, grid.h, mode, tree_depth, nV, _dp(V), _dp(b0), nl, _ip(vi), _ip(n), _ip(l),
+    hh = _f64(hints) if hints is not None else None
+    ctx.check(ctx.lib.dfta_solve_levels(ctx.h, grid.h, mode, tree_depth, nV, _dp(V), _dp(b0), _dp(hh) if hh is not None else None,
+                                        nl, _ip(vi), _ip(n), _ip(l),
                                         _ip(occ), res, _dp(nd), _dp(eel), _dp(psi) if want_psi else None, C.byref(issued)))
     out = {k: np.array([getattr(res[i], k) for i in range(nl)]) for k in
            ("E", "top", "bottom", "n_count", "n_zero", "converged", "matchPoint")}
@@ -342,6 +345,9 @@ class Scf:
         ctx.check(ctx.lib.dfta_scf_create(ctx.h, grid.h, int(self.lsda), self.natoms, _ip(self.Z), alpha, levels_mode,
                                           tree_depth, C.byref(h)))
         self.h = h
+        d, nj, tr = C.c_int(), C.c_int(), C.c_long()
+        ctx.check(ctx.lib.dfta_scf_info(h, C.byref(d), C.byref(nj), C.byref(tr)))
+        self.tree_depth, self.njobs, self.trials_per_round = d.value, nj.value, tr.value
 
     def step(self, want_stats=True):
         st = StepStats()

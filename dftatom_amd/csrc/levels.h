@@ -24,16 +24,18 @@ struct LevelStats {
     int rounds = 0;
     long sweeps_issued = 0;
     long points_traversed = 0;
+    float ms_sweep = 0;          // HIP-event time summed over the sweep launches
 };
 
 struct LevelSolver {
     dfta_ctx* ctx = nullptr;
     const dfta_grid* g = nullptr;
-    int mode = 0, nV = 0, njobs = 0, nchains = 0, depth = 0, tpj = 0, nwaves = 0, nslots = 0;
+    int mode = 0, nV = 0, njobs = 0, nchains = 0, nchains_chained = 0, depth = 0, tpj = 0, nwaves = 0, nslots = 0;
     long ntrials = 0;
+    bool clamp_bottoms = true;     // BATCHED runs: bracket bottoms clamped to max(bottom, min Veff_l)
     std::vector<Job> h_jobs_template;
     Job* d_jobs = nullptr;
-    int *d_chain_off = nullptr, *d_v_off = nullptr, *d_slot_v = nullptr, *d_slot_l = nullptr;
+    int *d_chain_off = nullptr, *d_chain_off_b = nullptr, *d_v_off = nullptr, *d_slot_v = nullptr, *d_slot_l = nullptr;
     double2* d_tab = nullptr;
     double *d_E = nullptr, *d_us = nullptr, *d_us1 = nullptr, *d_u0 = nullptr;
     int *d_limit = nullptr, *d_start = nullptr, *d_count = nullptr;
@@ -42,6 +44,9 @@ struct LevelSolver {
     double *d_Psi = nullptr, *d_Q = nullptr;     // njobs*N each
     double *d_jE = nullptr, *d_jus = nullptr, *d_jus1 = nullptr;
     int *d_jslot = nullptr, *d_jl = nullptr, *d_jstart = nullptr, *d_jmp = nullptr;
+    double* d_slot_min = nullptr;   // per table slot: min_i Veff_l(i)
+    double2* d_bounds = nullptr;    // per table slot: fast-division range bounds (numerov.hip)
+    hipEvent_t ev[2] = {nullptr, nullptr};
 
     LevelSolver() = default;
     LevelSolver(const LevelSolver&) = delete;
@@ -49,7 +54,7 @@ struct LevelSolver {
     ~LevelSolver();
     void release();
     int setup(dfta_ctx* c, const dfta_grid* grid, int mode, int tree_depth, int nV, const std::vector<JobSpec>& specs);
-    int run(const double* dV, const double* bottom0, double* dNewDensity, LevelStats* stats);
+    int run(const double* dV, const double* job_bottom, int run_mode, double* dNewDensity, LevelStats* stats);
     int fetch_jobs(std::vector<Job>& out);
 };
 

@@ -213,6 +213,37 @@ __global__ void k_accumulate_density(const double* __restrict__ Psi, const dfta:
     }
 }
 
+// min_i Veff_l(i), i = 1..N-1, of every table slot (one block per slot; NaN entries are ignored)
+__global__ __launch_bounds__(256) void k_slot_min(const double2* __restrict__ tab, int N, double* __restrict__ slot_min)
+{
+    __shared__ double red[4];
+    const double2* T = tab + (size_t)blockIdx.x * N;
+    double m = INFINITY;
+    for (int i = 1 + threadIdx.x; i < N; i += 256) {
+        const double v = T[i].x;
+        if (v < m) m = v;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const double o = __shfl_xor(m, off);
+        if (o < m) m = o;
+    }
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) slot_min[blockIdx.x] = fmin(fmin(red[0], red[1]), fmin(red[2], red[3]));
+}
+
+// BATCHED: every level starts un-chained from max(-Z^2-1, min Veff_l): no eigenvalue lies below the minimum of
+// the effective potential, and below it the node count of l >= 1 misfires
+__global__ void k_clamp_bottoms(dfta::Job* __restrict__ jobs, int njobs, const double* __restrict__ slot_min)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= njobs) return;
+    const double vmin = slot_min[jobs[k].slot];
+    const double b = (vmin > jobs[k].bottom0) ? vmin : jobs[k].bottom0;
+    jobs[k].bottom0 = b;
+    jobs[k].boe = b;
+}
+
 __global__ void k_job_energies(const dfta::Job* __restrict__ jobs, int njobs, double* __restrict__ E, int* __restrict__ slot,
                                int* __restrict__ l)
 {
@@ -237,15 +268,16 @@ LevelSolver::~LevelSolver() { release(); }
 
 void LevelSolver::release()
 {
-    void* ptrs[] = {d_jobs, d_chain_off, d_v_off, d_slot_v, d_slot_l, d_tab, d_E, d_limit, d_start, d_us, d_us1, d_count,
+    void* ptrs[] = {d_jobs, d_chain_off, d_chain_off_b, d_v_off, d_slot_v, d_slot_l, d_tab, d_E, d_limit, d_start, d_us, d_us1, d_count,
                     d_u0, d_wave_kind, d_wave_slot, d_wave_first, d_wave_cnt, d_counters, d_Psi, d_Q, d_jE, d_jslot, d_jl,
-                    d_jstart, d_jus, d_jus1, d_jmp};
+                    d_jstart, d_jus, d_jus1, d_jmp, d_slot_min, d_bounds};
     for (void* p : ptrs) if (p) (void)hipFree(p);
-    d_jobs = nullptr; d_chain_off = nullptr; d_v_off = nullptr; d_slot_v = nullptr; d_slot_l = nullptr; d_tab = nullptr;
+    for (hipEvent_t& e : ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
+    d_jobs = nullptr; d_chain_off = nullptr; d_chain_off_b = nullptr; d_v_off = nullptr; d_slot_v = nullptr; d_slot_l = nullptr; d_tab = nullptr;
     d_E = nullptr; d_limit = nullptr; d_start = nullptr; d_us = nullptr; d_us1 = nullptr; d_count = nullptr; d_u0 = nullptr;
     d_wave_kind = nullptr; d_wave_slot = nullptr; d_wave_first = nullptr; d_wave_cnt = nullptr; d_counters = nullptr;
     d_Psi = nullptr; d_Q = nullptr; d_jE = nullptr; d_jslot = nullptr; d_jl = nullptr; d_jstart = nullptr; d_jus = nullptr;
-    d_jus1 = nullptr; d_jmp = nullptr;
+    d_jus1 = nullptr; d_jmp = nullptr; d_slot_min = nullptr; d_bounds = nullptr;
 }
 
 // jobs must be ordered by potential index v (levels of one potential contiguous, in the reference's (N,L) order)
@@ -256,21 +288,20 @@ int LevelSolver::setup(dfta_ctx* c, const dfta_grid* grid, int mode_, int tree_d
     njobs = static_cast<int>(specs.size());
     if (njobs == 0) return DFTA_OK;
     const int N = g->N;
-    // chains: CHAINED -> one chain per potential; BATCHED -> one chain per job
-    std::vector<int> chain_off, v_off(nV + 1, 0);
+    // chains: CHAINED -> one chain per potential; BATCHED -> one chain per job.  Both layouts are kept on the
+    // device so that a BATCHED solver can run a CHAINED solve (first SCF step, when there are no hints yet).
+    std::vector<int> chain_off, chain_off_b, v_off(nV + 1, 0);
     for (int k = 0; k < njobs; ++k) {
         if (specs[k].v < 0 || specs[k].v >= nV || specs[k].l < 0 || specs[k].l > 3) return DFTA_ERR_INVALID;
         if (k > 0 && specs[k].v < specs[k - 1].v) return DFTA_ERR_INVALID;
         v_off[specs[k].v + 1]++;
     }
     for (int v = 0; v < nV; ++v) v_off[v + 1] += v_off[v];
-    if (mode == DFTA_LEVELS_CHAINED) {
-        for (int v = 0; v < nV; ++v) if (v_off[v + 1] > v_off[v]) chain_off.push_back(v_off[v]);
-        chain_off.push_back(njobs);
-    } else {
-        for (int k = 0; k <= njobs; ++k) chain_off.push_back(k);
-    }
-    nchains = static_cast<int>(chain_off.size()) - 1;
+    for (int v = 0; v < nV; ++v) if (v_off[v + 1] > v_off[v]) chain_off.push_back(v_off[v]);
+    chain_off.push_back(njobs);
+    for (int k = 0; k <= njobs; ++k) chain_off_b.push_back(k);
+    nchains_chained = static_cast<int>(chain_off.size()) - 1;
+    nchains = (mode == DFTA_LEVELS_CHAINED) ? nchains_chained : njobs;
     // tree depth: fill the machine (one wave per SIMD = 65536 lanes) with the jobs that are active per round
     int d = tree_depth;
     if (d <= 0) {
@@ -306,6 +337,7 @@ int LevelSolver::setup(dfta_ctx* c, const dfta_grid* grid, int mode_, int tree_d
 #define UPLOAD(ptr, vec) DFTA_HIP(ctx, hipMemcpyAsync(ptr, vec.data(), sizeof(vec[0]) * vec.size(), hipMemcpyHostToDevice, st))
     ALLOC(d_jobs, Job, njobs);
     ALLOC(d_chain_off, int, chain_off.size()); UPLOAD(d_chain_off, chain_off);
+    ALLOC(d_chain_off_b, int, chain_off_b.size()); UPLOAD(d_chain_off_b, chain_off_b);
     ALLOC(d_v_off, int, v_off.size()); UPLOAD(d_v_off, v_off);
     ALLOC(d_slot_v, int, nslots); UPLOAD(d_slot_v, slot_v);
     ALLOC(d_slot_l, int, nslots); UPLOAD(d_slot_l, slot_l);
@@ -321,52 +353,73 @@ int LevelSolver::setup(dfta_ctx* c, const dfta_grid* grid, int mode_, int tree_d
     ALLOC(d_Q, double, (size_t)njobs * N);
     ALLOC(d_jE, double, njobs); ALLOC(d_jslot, int, njobs); ALLOC(d_jl, int, njobs); ALLOC(d_jstart, int, njobs);
     ALLOC(d_jus, double, njobs); ALLOC(d_jus1, double, njobs); ALLOC(d_jmp, int, njobs);
+    ALLOC(d_slot_min, double, nslots);
+    ALLOC(d_bounds, double2, nslots);
 #undef ALLOC
 #undef UPLOAD
+    DFTA_HIP(ctx, hipEventCreate(&ev[0]));
+    DFTA_HIP(ctx, hipEventCreate(&ev[1]));
     DFTA_HIP(ctx, hipMemsetAsync(d_count, 0, sizeof(int) * ntrials, st));
     DFTA_HIP(ctx, hipMemsetAsync(d_u0, 0, sizeof(double) * ntrials, st));
     DFTA_HIP(ctx, hipStreamSynchronize(st));
     return DFTA_OK;
 }
 
-// Solve all levels for the potentials dV (device, nV*N).  bottom0: host array nV (BottomEnergy at entry, -Z^2-1).
-int LevelSolver::run(const double* dV, const double* bottom0, double* dNewDensity, LevelStats* stats)
+// Solve all levels for the potentials dV (device, nV*N).
+//   job_bottom (host, njobs): BottomEnergy at entry of LocateInterval for every job.  CHAINED uses only the entry
+//   of the first job of each potential (-Z^2-1, DFTAtom.cpp:407) and hands E-3 from level to level (DFTAtom.cpp:541);
+//   BATCHED starts every level from its own entry (the caller's hint: E_{k-1} of the previous SCF step - 3).
+int LevelSolver::run(const double* dV, const double* job_bottom, int run_mode, double* dNewDensity, LevelStats* stats)
 {
     if (njobs == 0) return DFTA_OK;
     const int N = g->N;
     hipStream_t st = ctx->stream;
+    const bool chained = (run_mode == DFTA_LEVELS_CHAINED);
+    const int* d_chains = chained ? d_chain_off : d_chain_off_b;
+    const int run_chains = chained ? nchains_chained : njobs;
     std::vector<Job> jobs = h_jobs_template;
     for (int k = 0; k < njobs; ++k) {
         Job& j = jobs[k];
-        j.bottom0 = bottom0[j.v];
-        if (mode == DFTA_LEVELS_BATCHED) { j.phase = PH_TOP; j.toe = 50; j.boe = j.bottom0; }
+        j.bottom0 = job_bottom[k];
+        const bool first = (k == 0 || jobs[k].v != jobs[k - 1].v);
+        if (!chained || first) { j.phase = PH_TOP; j.toe = 50; j.boe = j.bottom0; }   // DFTAtom.cpp:499
         else j.phase = PH_WAIT;
     }
-    // CHAINED: the first job of each chain starts immediately
-    if (mode == DFTA_LEVELS_CHAINED)
-        for (int k = 0; k < njobs; ++k)
-            if (k == 0 || jobs[k].v != jobs[k - 1].v) { jobs[k].phase = PH_TOP; jobs[k].toe = 50; jobs[k].boe = jobs[k].bottom0; }
     DFTA_HIP(ctx, hipMemcpyAsync(d_jobs, jobs.data(), sizeof(Job) * njobs, hipMemcpyHostToDevice, st));
     DFTA_HIP(ctx, hipMemsetAsync(d_counters, 0, sizeof(unsigned long long) * 4, st));
-    int rc = dfta_launch_build_tab(ctx, g, d_tab, dV, d_slot_v, d_slot_l, nslots);
+    int rc = dfta_launch_build_tab(ctx, g, d_tab, dV, d_slot_v, d_slot_l, nslots, d_bounds);
     if (rc) return rc;
+    if (!chained && clamp_bottoms) {
+        hipLaunchKernelGGL(k_slot_min, dim3(nslots), dim3(256), 0, st, d_tab, N, d_slot_min);
+        DFTA_CHECK_LAUNCH(ctx);
+        hipLaunchKernelGGL(k_clamp_bottoms, dim3((njobs + 63) / 64), dim3(64), 0, st, d_jobs, njobs, d_slot_min);
+        DFTA_CHECK_LAUNCH(ctx);
+    }
 
     int* d_ndone = reinterpret_cast<int*>(d_counters + 2);
     int rounds = 0;
+    float ms_sweep = 0;
     const int max_rounds = 4096;
     while (rounds < max_rounds) {
         hipLaunchKernelGGL(k_expand, dim3((unsigned)(ntrials / 256)), dim3(256), 0, st, d_jobs, tpj, g->d_r, N, g->delta,
                            g->far_arg_threshold, d_E, d_limit, d_start, d_us, d_us1, d_wave_kind, d_counters);
         DFTA_CHECK_LAUNCH(ctx);
+        if (stats) DFTA_HIP(ctx, hipEventRecord(ev[0], st));
         rc = dfta_launch_sweep(ctx, g, DFTA_SWEEP_COUNT, d_wave_kind, nwaves, d_tab, d_wave_slot, d_wave_first, d_wave_cnt, d_E,
-                               d_limit, d_start, d_us, d_us1, d_count, d_u0, nullptr, d_counters + 1);
+                               d_limit, d_start, d_us, d_us1, d_count, d_u0, nullptr, d_counters + 1, d_bounds);
         if (rc) return rc;
+        if (stats) DFTA_HIP(ctx, hipEventRecord(ev[1], st));
         DFTA_HIP(ctx, hipMemsetAsync(d_ndone, 0, sizeof(int), st));
-        hipLaunchKernelGGL(k_walk, dim3((nchains + 63) / 64), dim3(64), 0, st, d_jobs, d_chain_off, nchains, tpj, d_count, d_u0, d_ndone);
+        hipLaunchKernelGGL(k_walk, dim3((run_chains + 63) / 64), dim3(64), 0, st, d_jobs, d_chains, run_chains, tpj, d_count, d_u0, d_ndone);
         DFTA_CHECK_LAUNCH(ctx);
         int ndone = 0;
         DFTA_HIP(ctx, hipMemcpyAsync(&ndone, d_ndone, sizeof(int), hipMemcpyDeviceToHost, st));
         DFTA_HIP(ctx, hipStreamSynchronize(st));
+        if (stats) {
+            float ms = 0;
+            DFTA_HIP(ctx, hipEventElapsedTime(&ms, ev[0], ev[1]));
+            ms_sweep += ms;
+        }
         ++rounds;
         if (ndone >= njobs) break;
     }
@@ -395,6 +448,7 @@ int LevelSolver::run(const double* dV, const double* bottom0, double* dNewDensit
         stats->rounds = rounds;
         stats->sweeps_issued = static_cast<long>(cnt[0]) + 2L * njobs;    // + inward/outward halves of the match solve
         stats->points_traversed = static_cast<long>(cnt[1]);
+        stats->ms_sweep = ms_sweep;
     }
     return DFTA_OK;
 }
@@ -411,7 +465,8 @@ int LevelSolver::fetch_jobs(std::vector<Job>& out)
 }  // namespace dfta
 
 extern "C" int dfta_solve_levels(dfta_ctx* ctx, const dfta_grid* g, int mode, int tree_depth, int nV, const double* V,
-                                 const double* bottom0, int nlevels, const int* vidx, const int* n, const int* l, const int* occ,
+                                 const double* bottom0, const double* bottom_hint, int nlevels, const int* vidx, const int* n,
+                                 const int* l, const int* occ,
                                  dfta_level_result* results, double* newDensity, double* Eelectronic, double* Psi_out,
                                  long* issued_sweeps)
 {
@@ -433,7 +488,10 @@ extern "C" int dfta_solve_levels(dfta_ctx* ctx, const dfta_grid* g, int mode, in
         DFTA_HIP(ctx, hipMemcpyAsync(dND.p, newDensity, sizeof(double) * (size_t)nV * N, hipMemcpyHostToDevice, st));
     }
     dfta::LevelStats stats;
-    rc = solver.run(dV.p, bottom0, dND.p, &stats);
+    std::vector<double> job_bottom(nlevels);
+    for (int k = 0; k < nlevels; ++k) job_bottom[k] = bottom_hint ? bottom_hint[k] : bottom0[specs[k].v];
+    solver.clamp_bottoms = (bottom_hint == nullptr);    // explicit hints are taken as given
+    rc = solver.run(dV.p, job_bottom.data(), mode, dND.p, &stats);
     if (rc) return rc;
     std::vector<dfta::Job> jobs;
     rc = solver.fetch_jobs(jobs);

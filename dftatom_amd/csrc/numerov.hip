@@ -74,9 +74,78 @@ __global__ void k_boundary(const double* __restrict__ r, const double* __restric
     us1[t] = exp(far_arg(r, maxIndex - 1, s, gs.delta));
 }
 
-// ---- the sweep kernel -----------------------------------------------------------------------------------
+// ---- the sweep --------------------------------------------------------------------------------------------------
+typedef unsigned long long lanemask_t;
+constexpr int kChunk = 8;             // grid points per prefetched batch of the sweep body
+constexpr int kBoundFrom = kChunk;    // the sweep body never touches i < kChunk (tail loop)
+
+struct SweepState {
+    double w, wprev, u, fprev, prevSol;
+};
+
+// w / d for d in (0.5, 1.5) and |w| in [1e-270, 1e200] or 0: the instruction sequence hipcc emits for an IEEE fp64
+// division (v_rcp_f64, two Newton steps on the reciprocal, quotient, remainder, final fma) minus v_div_scale /
+// v_div_fmas' scaling / v_div_fixup, which are identities in this range -- so the result is bit-identical to `/`.
+__device__ __forceinline__ double div_in_range(double w, double d)
+{
+    double r = __builtin_amdgcn_rcp(d);
+    double e = __builtin_fma(-d, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-d, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    const double q = w * r;
+    const double rem = __builtin_fma(-d, q, w);
+    return __builtin_fma(rem, r, q);
+}
+
+// One Numerov step for every lane of the wave (Numerov.h:311-321).  `tv` is wave-uniform (SGPRs).
+// R2 = 2 * Rp2delta2: 2.*(veff - E)*Rp2delta2 == (veff - E)*(2*Rp2delta2) exactly (power-of-two scaling).
+template <bool FAST>
+__device__ __forceinline__ void numerov_step(SweepState& s, const double2 tv, const double E, const double R2, const double d2p4)
+{
+    const double wnext = 2. * s.w - s.wprev + s.u * s.fprev;     // Numerov.h:311 (h2 == 1)
+    s.wprev = s.w;
+    s.w = wnext;
+    const double f = (tv.x - E) * R2 * tv.y + d2p4;               // Numerov.h:100
+    const double d = 1. - kH2p12 * f;
+    s.prevSol = s.u;
+    s.u = FAST ? div_in_range(wnext, d) : wnext / d;              // getU, Numerov.h:510-513
+    s.fprev = f;
+}
+
+// Bookkeeping of CountNodes (Numerov.h:323-340) for all 64 lanes at once.  The predicates are 64-bit lane masks in
+// scalar registers (four v_cmp per point, the rest is scalar logic); the per-lane node budget (nodesLimit + 1 - nodes
+// seen) is only touched in the rare wave-uniform branch "some lane crossed zero at this point".
+struct CountState {
+    lanemask_t live;      // still inside the reference's loop
+    lanemask_t oldSgn;    // sign of the previous solution value
+    lanemask_t flag;      // firstClassicalReturnPoint
+};
+
+__device__ __forceinline__ void count_step(CountState& c, int& budget, const int lane, const double u, const double veff,
+                                           const double E, const lanemask_t started)
+{
+    const lanemask_t m_inf = __ballot(fabs(u) == INFINITY);
+    const lanemask_t m_pos = __ballot(u > 0);
+    const lanemask_t m_le = __ballot(veff <= E);
+    const lanemask_t m_gt = __ballot(veff > E);           // separate compare: both false for NaN, as in the reference
+    const lanemask_t act = c.live & started;
+    const lanemask_t cross = act & ~m_inf & (m_pos ^ c.oldSgn);
+    lanemask_t over = 0;
+    if (cross != 0ull) {                                   // ++nodesCount; nodesCount > nodesLimit -> return
+        budget -= (int)((cross >> lane) & 1ull);
+        over = cross & __ballot(budget <= 0);
+    }
+    c.oldSgn = (c.oldSgn & ~act) | (m_pos & act);
+    const lanemask_t stay = act & ~m_inf & ~over;
+    const lanemask_t tp = stay & c.flag & m_gt;            // left the classically allowed region again
+    c.flag |= stay & m_le;
+    c.live = (c.live & ~started) | (stay & ~tp);
+}
+
 struct SweepArgs {
     const double2* tab;        // slot tables
+    const double2* bounds;     // per slot: { max_i |veff_i| R2 e2_i, max_i R2 e2_i } (fast-division range proof), or null
     const int* blk_slot;       // per block: table slot
     const int* blk_first;      // per block: first trial
     const int* blk_cnt;        // per block: number of trials (<= 64)
@@ -89,52 +158,18 @@ struct SweepArgs {
     const double* us1;
     int* count;                // COUNT out
     double* u0;                // out (may be null for COUNT)
-    int* trip;                 // out (may be null)
+    int* trip;                 // out (may be null): loop iterations per trial (diagnostics)
     unsigned long long* total_trips;   // optional global counter (points traversed)
 };
 
-// One Numerov step for every lane of the wave (Numerov.h:311-321).  `tv` is wave-uniform (SGPRs).
-struct SweepState {
-    double w, wprev, u, fprev, prevSol;
-};
-
-__device__ __forceinline__ void numerov_step(SweepState& s, const double2 tv, const double E, const GridScalars& gs)
-{
-    const double wnext = 2. * s.w - s.wprev + s.u * s.fprev;   // Numerov.h:311 (h2 == 1)
-    s.wprev = s.w;
-    s.w = wnext;
-    const double f = f_of(tv.x, tv.y, E, gs);
-    s.prevSol = s.u;
-    s.u = wnext / (1. - kH2p12 * f);                            // getU, Numerov.h:510-513
-    s.fprev = f;
-}
-
-// node/turning-point bookkeeping of CountNodes after a step (Numerov.h:323-340), branch-free: every
-// predicate is a wave-wide lane mask, so the compiler emits v_cmp + scalar mask logic and no exec-mask
-// divergence.  Order of the reference's tests: |u| == inf -> return; sign change -> ++count, count > limit ->
-// return; veff <= E -> flag, else flag && veff > E -> return.
-__device__ __forceinline__ void count_step(const SweepState& s, const double veff, const double E, const int limit,
-                                           bool& live, bool& exited, bool& oldSgn, bool& flag, int& count, int& trips)
-{
-    trips += live ? 1 : 0;
-    const bool isinf = (fabs(s.u) == INFINITY);
-    const bool newSgn = (s.u > 0);
-    const bool cross = live & !isinf & (newSgn != oldSgn);
-    count += cross ? 1 : 0;
-    const bool over = cross & (count > limit);
-    oldSgn = newSgn;                          // only observable while the lane is live and not exiting
-    const bool stay = live & !isinf & !over;
-    const bool le = (veff <= E);
-    const bool gt = (veff > E);               // separate compare: both false for NaN, as in the reference
-    const bool tp = stay & flag & gt;
-    flag = flag | (stay & le);
-    live = stay & !tp;
-    exited = exited | isinf | over | tp;      // callers only read `exited` for lanes that were live
-}
-
-// Block = 4 waves (one per SIMD of the CU); every wave owns up to 64 trials that share one table slot.
-// The grid index loop is wave-uniform; table entries are fetched CH points ahead as scalar loads so the
-// scalar-cache latency is hidden behind the previous chunk's arithmetic.
+// Every wave owns up to 64 trials that share one table slot (potential, l).  The grid index loop is wave-uniform;
+// table entries are fetched one chunk ahead as scalar loads (hidden behind the previous chunk's arithmetic).
+// Every wave owns up to 64 trials that share one table slot (potential, l).  The grid index loop is wave-uniform.
+// Table entries {veff_i, e2_i} are wave-uniform too; they are fetched with vector loads whose 64 lanes carry the same
+// address (one 16-byte request per wave), CH points per batch and two batches ahead of the recurrence, so that the
+// counted vmcnt waits hide the L2 latency.  Each batch is processed in two phases: first everything that does not
+// depend on the recurrence (f, 1 - f/12 and its reciprocal: independent across the CH points), then the dependent
+// chain w -> u -> w.
 template <int KIND, int CH>
 __device__ __forceinline__ void sweep_wave(const SweepArgs& a, const GridScalars& gs, const int b, const int lane)
 {
@@ -142,12 +177,25 @@ __device__ __forceinline__ void sweep_wave(const SweepArgs& a, const GridScalars
     const int t = a.blk_first[b] + (lane < cnt ? lane : 0);
     // a trial with start < 2 is a placeholder (unused slot of a bisection tree): the lane idles
     const bool valid = (lane < cnt) && (a.start[t] >= 2);
-    const double2* __restrict__ T = a.tab + (size_t)a.blk_slot[b] * gs.N;
+    const lanemask_t vmask = __ballot(valid);
+    if (vmask == 0ull) return;       // whole wave idle
+    const int slot = a.blk_slot[b];
+    // per-lane view of the (wave-uniform) table row: a lane offset of zero keeps these on the vector-memory path
+    const double2* __restrict__ T = a.tab + (size_t)slot * gs.N + __builtin_amdgcn_mbcnt_hi(0u, __builtin_amdgcn_mbcnt_lo(0u, 0u));
+    const double R2 = 2. * gs.Rp2delta2;
+    const double d2p4 = gs.delta2p4;
 
     const double E = a.E[t];
     const int start = valid ? a.start[t] : 2;
     const int limit = (KIND == DFTA_SWEEP_COUNT) ? a.limit[t] : 0;
-    if (__ballot(valid) == 0ull) return;       // whole wave idle
+
+    // can the whole wave use the division fast path?  |f| <= max|veff| R2 e2 + |E| max R2 e2 + delta^2/4 < 6 => d in (0.5, 1.5)
+    bool fast = false;
+    if (a.bounds) {
+        const double2 bd = a.bounds[slot];
+        const bool lane_ok = !valid || (bd.x + fabs(E) * bd.y + d2p4 < 6.0);
+        fast = (__ballot(lane_ok) == ~0ull);
+    }
 
     // prologue (Numerov.h:293-306): the two far boundary points of this lane
     SweepState s;
@@ -156,18 +204,20 @@ __device__ __forceinline__ void sweep_wave(const SweepArgs& a, const GridScalars
         const double2 t1 = T[start - 1];
         const double us = a.us[t];
         s.u = a.us1[t];
-        s.fprev = f_of(ts.x, ts.y, E, gs);
+        s.fprev = (ts.x - E) * R2 * ts.y + d2p4;
         s.wprev = (1 - kH2p12 * s.fprev) * us;
-        s.fprev = f_of(t1.x, t1.y, E, gs);
+        s.fprev = (t1.x - E) * R2 * t1.y + d2p4;
         s.w = (1 - kH2p12 * s.fprev) * s.u;
         s.prevSol = us;
     }
-    bool oldSgn = (s.u > 0);
-    int count = 0;
-    bool flag = false;       // firstClassicalReturnPoint
-    bool exited = false;     // early `return` of CountNodes (skips the u(0) extrapolation)
-    bool live = valid;       // still inside the reference's loop
-    int trips = 0;
+    CountState c;
+    c.live = vmask;
+    c.oldSgn = __ballot(s.u > 0);
+    c.flag = 0;
+    int budget = limit + 1;              // nodes this lane may still count before nodesCount > nodesLimit
+    const bool diag = (a.trip != nullptr);
+    int trips = 0;                       // per lane, diagnostics only
+    unsigned long long wave_trips = 0;   // wave-uniform
 
     const int my_hi = valid ? start - 2 : 0;   // this lane integrates i = my_hi .. 1
     int ihi = my_hi, ilo = valid ? my_hi : 0x7fffffff;
@@ -178,65 +228,116 @@ __device__ __forceinline__ void sweep_wave(const SweepArgs& a, const GridScalars
     ihi = __builtin_amdgcn_readfirstlane(ihi);
     ilo = __builtin_amdgcn_readfirstlane(ilo);   // from here down every valid lane has started
 
+    // bookkeeping after a step; runs in wave-uniform control flow only, so that its lane masks stay in scalar registers
+#define SWEEP_COUNT(veff, started)                                                                     \
+    if (KIND == DFTA_SWEEP_COUNT) {                                                                    \
+        const lanemask_t before = c.live & (started);                                                  \
+        if (diag) trips += (int)((before >> lane) & 1ull);                                             \
+        wave_trips += __popcll(before);                                                                \
+        count_step(c, budget, lane, s.u, (veff), E, (started));                                        \
+    }
+
     int i = ihi;
     // head: lanes join one by one (per-step masking) until all valid lanes are in
     for (; i > ilo && i >= 1; --i) {
         const double2 tv = T[i];
-        if (valid && i <= my_hi) {
-            SweepState n = s;
-            numerov_step(n, tv, E, gs);
-            s = n;
-            if (KIND == DFTA_SWEEP_COUNT) count_step(s, tv.x, E, limit, live, exited, oldSgn, flag, count, trips);
-        }
+        const bool in = valid && i <= my_hi;
+        const lanemask_t started = __ballot(in);
+        if (in) numerov_step<false>(s, tv, E, R2, d2p4);
+        SWEEP_COUNT(tv.x, started)
     }
-    // body: all valid lanes step together, no exec masking on the arithmetic; table prefetched CH ahead.
+    // body: all valid lanes step together, no exec masking on the arithmetic.
     // Lanes that have left the reference's loop keep integrating (harmless), only their bookkeeping is frozen.
     if (i >= 2 * CH) {
         double2 A[CH], B[CH];
 #pragma unroll
         for (int k = 0; k < CH; ++k) A[k] = T[i - k];
-        while (true) {   // invariant at the top: i >= 2*CH and A = T[i .. i-CH+1]
-            // scalar loads return out of order, so a wait covers everything in flight: drain the chunk that
-            // was requested one chunk ago BEFORE requesting the next one (0xC07F == lgkmcnt(0) only)
-            __builtin_amdgcn_s_waitcnt(0xC07F);
 #pragma unroll
-            for (int k = 0; k < CH; ++k) B[k] = T[i - CH - k];
-#pragma unroll
-            for (int k = 0; k < CH; ++k) {
-                numerov_step(s, A[k], E, gs);
-                if (KIND == DFTA_SWEEP_COUNT) count_step(s, A[k].x, E, limit, live, exited, oldSgn, flag, count, trips);
-            }
-            i -= CH;
-            const bool more = (i >= 3 * CH);   // another full A/B round fits after this B chunk
-            __builtin_amdgcn_s_waitcnt(0xC07F);
-            if (more) {
-#pragma unroll
-                for (int k = 0; k < CH; ++k) A[k] = T[i - CH - k];
-            }
+        for (int k = 0; k < CH; ++k) B[k] = T[i - CH - k];
+        // one batch: CUR = T[i .. i-CH+1] and OTH = T[i-CH .. i-2CH+1] are both requested and i >= 2*CH.
+        // Returns true when the body is finished (tail loop takes over at the new i).
+        auto batch = [&](double2 (&CUR)[CH], double2 (&OTH)[CH]) -> bool {
+            double f[CH], d[CH], r[CH], veff[CH];
 #pragma unroll
             for (int k = 0; k < CH; ++k) {
-                numerov_step(s, B[k], E, gs);
-                if (KIND == DFTA_SWEEP_COUNT) count_step(s, B[k].x, E, limit, live, exited, oldSgn, flag, count, trips);
+                veff[k] = CUR[k].x;
+                f[k] = (CUR[k].x - E) * R2 * CUR[k].y + d2p4;                // Numerov.h:100
+                d[k] = 1. - kH2p12 * f[k];
+            }
+            if (fast) {
+#pragma unroll
+                for (int k = 0; k < CH; ++k) {                               // reciprocal of hipcc's fp64 division sequence
+                    double rr = __builtin_amdgcn_rcp(d[k]);
+                    double e = __builtin_fma(-d[k], rr, 1.0);
+                    rr = __builtin_fma(rr, e, rr);
+                    e = __builtin_fma(-d[k], rr, 1.0);
+                    r[k] = __builtin_fma(rr, e, rr);
+                }
+            }
+            // CUR is consumed: request the batch below OTH into it
+            if (i - 2 * CH >= CH) {
+#pragma unroll
+                for (int k = 0; k < CH; ++k) CUR[k] = T[i - 2 * CH - k];
+            }
+#pragma unroll
+            for (int k = 0; k < CH; ++k) {
+                const double wnext = 2. * s.w - s.wprev + s.u * s.fprev;     // Numerov.h:311 (h2 == 1)
+                s.wprev = s.w;
+                s.w = wnext;
+                s.prevSol = s.u;
+                if (fast) {
+                    const double q = wnext * r[k];
+                    const double rem = __builtin_fma(-d[k], q, wnext);
+                    s.u = __builtin_fma(rem, r[k], q);
+                } else {
+                    s.u = wnext / d[k];                                       // getU, Numerov.h:510-513
+                }
+                s.fprev = f[k];
+                SWEEP_COUNT(veff[k], vmask)
+            }
+            if (fast) {
+                // the fast path needs |w| in range: leave it for good as soon as any lane gets close to the edges
+                const double au = fabs(s.u);
+                const bool ok = !valid || (au < 1e200 && (au > 1e-270 || s.u == 0.0));
+                fast = (__ballot(ok) == ~0ull);
             }
             i -= CH;
             if (KIND == DFTA_SWEEP_COUNT) {
-                if (__ballot(live) == 0ull) { i = 0; break; }
+                if ((c.live & vmask) == 0ull) { i = 0; return true; }
             }
-            if (!more) break;
+            if (i < 2 * CH) {
+                // OTH (already requested) is the last full batch: process it with the plain step and leave
+#pragma unroll
+                for (int k = 0; k < CH; ++k) {
+                    numerov_step<false>(s, OTH[k], E, R2, d2p4);
+                    SWEEP_COUNT(OTH[k].x, vmask)
+                }
+                i -= CH;
+                return true;
+            }
+            return false;
+        };
+        while (true) {
+            if (batch(A, B)) break;
+            if (batch(B, A)) break;
         }
     }
     // tail
     for (; i >= 1; --i) {
         const double2 tv = T[i];
-        numerov_step(s, tv, E, gs);
-        if (KIND == DFTA_SWEEP_COUNT) count_step(s, tv.x, E, limit, live, exited, oldSgn, flag, count, trips);
+        numerov_step<false>(s, tv, E, R2, d2p4);
+        SWEEP_COUNT(tv.x, vmask)
     }
-    if (KIND == DFTA_SWEEP_ZERO) trips = my_hi;
+#undef SWEEP_COUNT
+    if (KIND == DFTA_SWEEP_ZERO) { trips = my_hi; wave_trips = 0; }
 
+    const bool exited = valid && !((c.live >> lane) & 1ull);
     double u0 = NAN;
-    if (valid && !exited) {
+    int count = (KIND == DFTA_SWEEP_COUNT) ? limit + 1 - budget : 0;
+    if (valid && (KIND == DFTA_SWEEP_ZERO || !exited)) {
         u0 = s.u * (2 + s.fprev) - s.prevSol;                 // Numerov.h:345 / 398
         if (KIND == DFTA_SWEEP_COUNT) {
+            const bool oldSgn = (c.oldSgn >> lane) & 1ull;
             if ((u0 > 0) != oldSgn) ++count;                  // Numerov.h:346-347
         }
     }
@@ -246,9 +347,12 @@ __device__ __forceinline__ void sweep_wave(const SweepArgs& a, const GridScalars
         if (a.trip) a.trip[t] = trips;
     }
     if (a.total_trips) {
-        int sum = valid ? trips : 0;
-        for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
-        if (lane == 0) atomicAdd(a.total_trips, (unsigned long long)sum);
+        if (KIND == DFTA_SWEEP_ZERO) {
+            int sum = valid ? trips : 0;
+            for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+            wave_trips = (unsigned long long)sum;
+        }
+        if (lane == 0) atomicAdd(a.total_trips, wave_trips);
     }
 }
 
@@ -261,6 +365,39 @@ __global__ __launch_bounds__(256) void k_sweep(SweepArgs a, GridScalars gs, int 
     const int kind = a.blk_kind ? __builtin_amdgcn_readfirstlane(a.blk_kind[b]) : a.kind;
     if (kind == DFTA_SWEEP_COUNT) sweep_wave<DFTA_SWEEP_COUNT, CH>(a, gs, b, lane);
     else                          sweep_wave<DFTA_SWEEP_ZERO, CH>(a, gs, b, lane);
+}
+
+// per slot: { max_i |veff_i| R2 e2_i, max_i R2 e2_i } over i = kBoundFrom .. N-1 (NaN poisons the bound -> slow division).
+// The innermost points are excluded: there f ~ l(l+1)/i^2 (f_1 = 12 for l = 3, i.e. 1 - f/12 = 0), and they are always
+// integrated by the tail loop with the plain IEEE division.
+__global__ __launch_bounds__(256) void k_slot_bounds(const double2* __restrict__ tab, int N, double R2, double2* __restrict__ bounds)
+{
+    __shared__ double red[8];
+    const double2* T = tab + (size_t)blockIdx.x * N;
+    double m0 = 0, m1 = 0;
+    bool bad = false;
+    for (int i = kBoundFrom + threadIdx.x; i < N; i += 256) {
+        const double2 t = T[i];
+        const double w = R2 * t.y;
+        const double v = fabs(t.x) * w;
+        if (!(v == v) || !(w == w)) bad = true;
+        m0 = v > m0 ? v : m0;
+        m1 = w > m1 ? w : m1;
+    }
+    if (bad) { m0 = INFINITY; m1 = INFINITY; }
+    for (int off = 32; off > 0; off >>= 1) {
+        const double o0 = __shfl_xor(m0, off), o1 = __shfl_xor(m1, off);
+        m0 = o0 > m0 ? o0 : m0;
+        m1 = o1 > m1 ? o1 : m1;
+    }
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = m0; red[4 + (threadIdx.x >> 6)] = m1; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double2 o;
+        o.x = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+        o.y = fmax(fmax(red[4], red[5]), fmax(red[6], red[7]));
+        bounds[blockIdx.x] = o;
+    }
 }
 
 // ---- match kernel (Numerov.h:403-504) --------------------------------------------------------------------
@@ -404,11 +541,15 @@ void host_boundary(const dfta_grid* g, double E, int* start, double* us, double*
 
 // Launch plumbing shared with levels.hip ------------------------------------------------------------------
 int dfta_launch_build_tab(dfta_ctx* ctx, const dfta_grid* g, double2* tab, const double* dV, const int* d_slot_v,
-                          const int* d_slot_l, int nslots)
+                          const int* d_slot_l, int nslots, double2* bounds)
 {
     dim3 grid((g->N + 255) / 256 > 64 ? 64 : (g->N + 255) / 256, nslots);
     hipLaunchKernelGGL(k_build_tab, grid, dim3(256), 0, ctx->stream, tab, dV, g->d_cl, g->d_e2, d_slot_v, d_slot_l, g->N);
     DFTA_CHECK_LAUNCH(ctx);
+    if (bounds) {
+        hipLaunchKernelGGL(k_slot_bounds, dim3(nslots), dim3(256), 0, ctx->stream, tab, g->N, 2. * g->Rp2delta2, bounds);
+        DFTA_CHECK_LAUNCH(ctx);
+    }
     return DFTA_OK;
 }
 
@@ -423,14 +564,14 @@ int dfta_launch_boundary(dfta_ctx* ctx, const dfta_grid* g, const double* dE, in
 int dfta_launch_sweep(dfta_ctx* ctx, const dfta_grid* g, int kind, const int* blk_kind, int nblocks, const double2* tab,
                       const int* blk_slot, const int* blk_first, const int* blk_cnt, const double* dE, const int* dLimit,
                       const int* dStart, const double* dUs, const double* dUs1, int* dCount, double* dU0, int* dTrip,
-                      unsigned long long* dTotalTrips)
+                      unsigned long long* dTotalTrips, const double2* bounds)
 {
     SweepArgs a;
-    a.kind = kind; a.blk_kind = blk_kind;
+    a.kind = kind; a.blk_kind = blk_kind; a.bounds = bounds;
     a.tab = tab; a.blk_slot = blk_slot; a.blk_first = blk_first; a.blk_cnt = blk_cnt; a.E = dE; a.limit = dLimit;
     a.start = dStart; a.us = dUs; a.us1 = dUs1; a.count = dCount; a.u0 = dU0; a.trip = dTrip; a.total_trips = dTotalTrips;
     const dim3 grid((nblocks + 3) / 4), block(256);
-    hipLaunchKernelGGL((k_sweep<4>), grid, block, 0, ctx->stream, a, scalars_of(g), nblocks);
+    hipLaunchKernelGGL((k_sweep<kChunk>), grid, block, 0, ctx->stream, a, scalars_of(g), nblocks);
     DFTA_CHECK_LAUNCH(ctx);
     return DFTA_OK;
 }
@@ -501,10 +642,14 @@ extern "C" int dfta_numerov_sweeps(dfta_ctx* ctx, const dfta_grid* g, int kind, 
                                    int* count_out, double* u0_out, int* start_out, int* trip_out)
 {
     if (!ctx || !g) return DFTA_ERR_INVALID;
-    DFTA_REQUIRE(ctx, V && l && E && nV > 0 && ntrials >= 0, "null input");
+    DFTA_REQUIRE(ctx, ntrials >= 0, "negative trial count");
+    if (ntrials == 0) return DFTA_OK;                       // empty batch
+    DFTA_REQUIRE(ctx, V && l && E && nV > 0, "null input");
     DFTA_REQUIRE(ctx, kind == DFTA_SWEEP_COUNT || kind == DFTA_SWEEP_ZERO, "kind");
     DFTA_REQUIRE(ctx, kind != DFTA_SWEEP_COUNT || (nodesLimit && count_out), "COUNT needs nodesLimit and count_out");
     DFTA_REQUIRE(ctx, kind != DFTA_SWEEP_ZERO || u0_out, "ZERO needs u0_out");
+    if (kind == DFTA_SWEEP_COUNT)
+        for (int t = 0; t < ntrials; ++t) DFTA_REQUIRE(ctx, nodesLimit[t] >= 0 && nodesLimit[t] < (1 << 30), "nodesLimit out of range");
     if (ntrials == 0) return DFTA_OK;
     const int N = g->N;
     Grouping G;
@@ -546,11 +691,13 @@ extern "C" int dfta_numerov_sweeps(dfta_ctx* ctx, const dfta_grid* g, int kind, 
         int rc = dfta_launch_boundary(ctx, g, dE.p, ntrials, dStart.p, dUs.p, dUs1.p);
         if (rc) return rc;
     }
-    int rc = dfta_launch_build_tab(ctx, g, dTab.p, dV.p, dSlotV.p, dSlotL.p, (int)G.slot_v.size());
+    DevBuf<double2> dBounds;
+    DFTA_HIP(ctx, dBounds.alloc(G.slot_v.size()));
+    int rc = dfta_launch_build_tab(ctx, g, dTab.p, dV.p, dSlotV.p, dSlotL.p, (int)G.slot_v.size(), dBounds.p);
     if (rc) return rc;
     DFTA_HIP(ctx, hipEventRecord(ctx->ev[0], st));
     rc = dfta_launch_sweep(ctx, g, kind, nullptr, (int)G.blk_slot.size(), dTab.p, dBs.p, dBf.p, dBc.p, dE.p, dLim.p, dStart.p,
-                           dUs.p, dUs1.p, dCount.p, dU0.p, dTrip.p, nullptr);
+                           dUs.p, dUs1.p, dCount.p, dU0.p, dTrip.p, nullptr, dBounds.p);
     if (rc) return rc;
     DFTA_HIP(ctx, hipEventRecord(ctx->ev[1], st));
     ctx->have_kernel_time = true;
@@ -607,10 +754,12 @@ extern "C" int dfta_numerov_sweeps_dev(dfta_ctx* ctx, const dfta_grid* g, int ki
         if (rc) return rc;
         pStart = dSt.p; pUs = dA.p; pUs1 = dB.p;
     }
-    int rc = dfta_launch_build_tab(ctx, g, dTab.p, dV, dSlotV.p, dSlotL.p, ngroups);
+    DevBuf<double2> dBounds;
+    DFTA_HIP(ctx, dBounds.alloc(ngroups));
+    int rc = dfta_launch_build_tab(ctx, g, dTab.p, dV, dSlotV.p, dSlotL.p, ngroups, dBounds.p);
     if (rc) return rc;
     rc = dfta_launch_sweep(ctx, g, kind, nullptr, (int)bs.size(), dTab.p, dBs.p, dBf.p, dBc.p, dE, dLimit, pStart, pUs, pUs1, dCount,
-                           dU0, dTrip, nullptr);
+                           dU0, dTrip, nullptr, dBounds.p);
     if (rc) return rc;
     if (dStartOut) DFTA_HIP(ctx, hipMemcpyAsync(dStartOut, pStart, ntrials * sizeof(int), hipMemcpyDeviceToDevice, st));
     DFTA_HIP(ctx, hipStreamSynchronize(st));   // scratch buffers die with this scope
@@ -660,7 +809,7 @@ extern "C" int dfta_numerov_match(dfta_ctx* ctx, const dfta_grid* g, int boundar
         int rc = dfta_launch_boundary(ctx, g, dE.p, ntrials, dStart.p, dUs.p, dUs1.p);
         if (rc) return rc;
     }
-    int rc = dfta_launch_build_tab(ctx, g, dTab.p, dV.p, dSlotV.p, dSlotL.p, (int)G.slot_v.size());
+    int rc = dfta_launch_build_tab(ctx, g, dTab.p, dV.p, dSlotV.p, dSlotL.p, (int)G.slot_v.size(), nullptr);
     if (rc) return rc;
     rc = dfta_launch_match(ctx, g, ntrials, dTab.p, dTs.p, dE.p, dStart.p, dUs.p, dUs1.p, dL.p, dPsi.p, dQ.p, dMp.p);
     if (rc) return rc;

@@ -29,6 +29,9 @@ constexpr int kMaxLevels = 24;
 constexpr int kThreads = 256;
 constexpr int kWarm = 96;   // start-value error decays by <= 0.52^96 < 2^-90: chunked sweep == sequential sweep bit for bit
 constexpr int kSeqBelow = 257;   // levels with n < 257 nodes: one lane, sequential
+constexpr int kSeqCap = 272;     // LDS doubles per array for the sequential levels (129+65+33+17+9+5+3 = 261)
+constexpr int kPF = 8;           // register prefetch depth of the chunked sweep
+constexpr int kPad = 128;        // doubles of padding in front of every atom's level storage (warm-up reads of lane 0)
 
 struct Lvl {
     int n;        // nodes
@@ -36,6 +39,7 @@ struct Lvl {
     int logT;     // lanes = 1 << logT   (n - 1 == C * T)
     int seq;      // 1: swept by a single lane in natural order
     long off;     // offset of this level inside the per-atom level storage
+    long soff;    // sequential levels: offset inside the LDS-resident copy
     double d;     // deltaGridLevel[l]
 };
 
@@ -45,10 +49,11 @@ struct MgDesc {
     Lvl lv[kMaxLevels];
 };
 
-__device__ __forceinline__ long addr(const Lvl& L, int i)
+// storage index of node i RELATIVE to the start of its level
+__device__ __forceinline__ int addr(const Lvl& L, int i)
 {
-    if (i == L.n - 1) return L.off + (L.n - 1);
-    return L.off + ((long)(i & ((1 << L.logC) - 1)) << L.logT) + (i >> L.logC);
+    if (i == L.n - 1) return L.n - 1;
+    return ((i & ((1 << L.logC) - 1)) << L.logT) + (i >> L.logC);
 }
 // inverse: storage index -> node
 __device__ __forceinline__ int node_of(const Lvl& L, int idx)
@@ -57,13 +62,27 @@ __device__ __forceinline__ int node_of(const Lvl& L, int idx)
     return ((idx & ((1 << L.logT) - 1)) << L.logC) + (idx >> L.logT);
 }
 
+// Level storage of one atom.  The chunked levels live in global memory (L2-resident: 6.3 MB per atom at 17
+// levels); the sequential levels (n < 257, 261 nodes in total) live in LDS for the whole solve -- they are visited
+// 6 times per V-cycle by a single lane and would otherwise pay a global-memory round trip per node.
 struct Atom {
-    double* phi0;     // two copies of every level
+    double* phi0;     // two copies of every level (global)
     double* phi1;
     double* src;
+    double* lds;      // shared memory: [phi copy 0 | phi copy 1 | src], kSeqCap doubles each
     unsigned cur;     // bit l: which copy of level l is current (identical in all threads)
-    __device__ __forceinline__ double* cur_phi(int l) const { return ((cur >> l) & 1u) ? phi1 : phi0; }
-    __device__ __forceinline__ double* other_phi(int l) const { return ((cur >> l) & 1u) ? phi0 : phi1; }
+    // pointer to storage element 0 of the level (generic address space: LDS for sequential levels, global otherwise)
+    __device__ __forceinline__ double* cur_phi(int l, const Lvl& L) const
+    {
+        const unsigned c = (cur >> l) & 1u;
+        return L.seq ? lds + c * kSeqCap + L.soff : (c ? phi1 : phi0) + L.off;
+    }
+    __device__ __forceinline__ double* other_phi(int l, const Lvl& L) const
+    {
+        const unsigned c = ((cur >> l) & 1u) ^ 1u;
+        return L.seq ? lds + c * kSeqCap + L.soff : (c ? phi1 : phi0) + L.off;
+    }
+    __device__ __forceinline__ double* src_of(const Lvl& L) const { return L.seq ? lds + 2 * kSeqCap + L.soff : src + L.off; }
 };
 
 __device__ __forceinline__ double block_sum(double v, double* red)
@@ -83,65 +102,140 @@ __device__ __forceinline__ double gs_point(double s, double xm, double xp, doubl
 
 // one lexicographic Gauss-Seidel sweep of level l: PoissonSolver::GaussSeidel (PoissonSolver.cpp:40-64).
 // returns ||dPhi||_2 (same value in every thread)
-__device__ double gauss_seidel(const MgDesc& D, Atom& A, int l, double* red)
+__device__ __forceinline__ double gauss_seidel(const MgDesc& D, Atom& A, int l, double* red)
 {
     const Lvl L = D.lv[l];
-    const double* __restrict__ S = A.src;
-    const double* __restrict__ pin = A.cur_phi(l);
-    double* __restrict__ pout = A.other_phi(l);
     const double dh = L.d * 0.5;
     double err2 = 0;
     const int tid = threadIdx.x;
     if (L.seq) {
         if (tid == 0) {
-            const long o = L.off;
-            double xm = pin[o];
-            pout[o] = xm;
+            const double* S = A.src_of(L);
+            const double* pin = A.cur_phi(l, L);
+            double* pout = A.other_phi(l, L);
+            double xm = pin[0];
+            pout[0] = xm;
             const int limit = L.n - 1;
+            double old = pin[1];
+#pragma unroll 4
             for (int i = 1; i < limit; ++i) {
-                const double old = pin[o + i];
-                const double x = gs_point(S[o + i], xm, pin[o + i + 1], dh);
+                const double xp = pin[i + 1];
+                const double x = gs_point(S[i], xm, xp, dh);
                 const double dif = old - x;
                 err2 += dif * dif;
-                pout[o + i] = x;
-                xm = x;
-            }
-            pout[o + limit] = pin[o + limit];
-        }
-    } else {
-        const int T = 1 << L.logT, C = 1 << L.logC;
-        if (tid < T) {
-            const int lo = tid << L.logC;
-            const int first = lo > 1 ? lo : 1;
-            const int last = lo + C - 1;                       // <= n - 2
-            const int i0 = (lo - kWarm) > 1 ? (lo - kWarm) : 1;
-            double xm = pin[addr(L, i0 - 1)];                  // old value (exact boundary value when i0 == 1)
-            double old = pin[addr(L, i0)];
-#pragma unroll 4
-            for (int i = i0; i <= last; ++i) {
-                const double xp = pin[addr(L, i + 1)];
-                const double x = gs_point(S[addr(L, i)], xm, xp, dh);
-                if (i >= first) {
-                    const double dif = old - x;
-                    err2 += dif * dif;
-                    pout[addr(L, i)] = x;
-                }
+                pout[i] = x;
                 xm = x;
                 old = xp;
             }
+            pout[limit] = pin[limit];
+        }
+    } else {
+        // chunked sweep: lane t owns nodes [t*C, t*C + C), all lanes step through their chunk in lockstep.  With
+        // m = step number (m - W < 0: warm-up inside the previous lanes' chunks) the node of lane t is
+        //     i = t*C + (m - W) = (t + tu)*C + ku,   ku = (m - W) & (C-1),  tu = (m - W) >> logC   (both wave-uniform)
+        // so its storage index is ku*T + tu + t: a uniform base plus the lane id -- no per-lane address arithmetic.
+        // Loads run kPF steps ahead of the recurrence in registers (two buffers), all of them unconditional: lanes
+        // whose node index is still < 1 read in-bounds padding (kPad) and skip the update.
+        const int T = 1 << L.logT, C = 1 << L.logC, logC = L.logC, logT = L.logT;
+        const double* __restrict__ S = A.src + L.off;
+        const double* __restrict__ pin = (((A.cur >> l) & 1u) ? A.phi1 : A.phi0) + L.off;
+        double* __restrict__ pout = (((A.cur >> l) & 1u) ? A.phi0 : A.phi1) + L.off;
+        if (tid < T) {
+            const int lo = tid << logC;
+            const int one_minus_lo = 1 - lo;
+            // first node of this lane's run and its left neighbour (old value; the exact boundary value for node 0)
+            const int i0 = (lo - kWarm) > 1 ? (lo - kWarm) : 1;
+            double xm, old;
+            {
+                const int a0 = i0 - 1, a1 = i0;
+                xm = pin[((a0 & (C - 1)) << logT) + (a0 >> logC)];
+                old = pin[((a1 & (C - 1)) << logT) + (a1 >> logC)];
+            }
+            // right neighbour of the last owned node: node (t+1)*C, which is node n-1 (stored at C*T) for the last lane
+            const double xp_end = pin[(tid == T - 1) ? (C << logT) : (tid + 1)];
+            const int Cm1 = C - 1;
+            // loads of step r (= m - W): S at node i(r), Phi_old at node i(r) + 1 = i(r+1); indices clamped to r <= C-1
+            auto load8 = [&](double (&X)[kPF], double (&SV)[kPF], int rbase) {
+#pragma unroll
+                for (int q = 0; q < kPF; ++q) {
+                    int r0 = rbase + q;
+                    r0 = r0 < Cm1 ? r0 : Cm1;
+                    const int r1 = r0 + 1;
+                    SV[q] = S[(((r0 & Cm1) << logT) + (r0 >> logC)) + tid];
+                    X[q] = pin[(((r1 & Cm1) << logT) + (r1 >> logC)) + tid];
+                }
+            };
+            // warm-up steps (r < 0): recurrence only
+            auto warm8 = [&](const double (&X)[kPF], const double (&SV)[kPF], int rbase) {
+#pragma unroll
+                for (int q = 0; q < kPF; ++q) {
+                    if (rbase + q >= one_minus_lo) {                 // node index lo + r >= 1
+                        xm = gs_point(SV[q], xm, X[q], dh);
+                        old = X[q];
+                    }
+                }
+            };
+            // owned steps (0 <= r < C): recurrence, error norm, store
+            auto main8 = [&](const double (&X)[kPF], const double (&SV)[kPF], int rbase) {
+#pragma unroll
+                for (int q = 0; q < kPF; ++q) {
+                    const int r0 = rbase + q;
+                    if (r0 >= one_minus_lo) {
+                        const double xp = (r0 == Cm1) ? xp_end : X[q];
+                        const double x = gs_point(SV[q], xm, xp, dh);
+                        const double dif = old - x;
+                        err2 += dif * dif;
+                        pout[((r0 & Cm1) << logT) + tid] = x;        // tu == 0 inside the own chunk
+                        xm = x;
+                        old = xp;
+                    }
+                }
+            };
+            double ax[kPF], as[kPF], bx[kPF], bs[kPF];
+            static_assert(kWarm % (2 * kPF) == 0, "warm-up must be a whole number of A/B rounds");
+            load8(ax, as, -kWarm);
+            for (int r = -kWarm; r < 0; r += 2 * kPF) {
+                load8(bx, bs, r + kPF);
+                warm8(ax, as, r);
+                load8(ax, as, r + 2 * kPF);                          // the last one already fetches r = 0 .. kPF-1
+                warm8(bx, bs, r + kPF);
+            }
+            if (C >= 2 * kPF) {
+                for (int r = 0; r < C; r += 2 * kPF) {
+                    load8(bx, bs, r + kPF);
+                    main8(ax, as, r);
+                    load8(ax, as, r + 2 * kPF);
+                    main8(bx, bs, r + kPF);
+                }
+            } else {
+                // C = 1, 2, 4 or 8 owned nodes: ax/as hold r = 0 .. min(C, kPF) - 1 (clamped beyond)
+                for (int r0 = 0; r0 < C; ++r0) {
+                    if (r0 >= one_minus_lo) {
+                        const int r1 = r0 + 1;
+                        const double sv = S[(r0 << logT) + tid];
+                        const double xp = (r0 == Cm1) ? xp_end : pin[(r1 << logT) + tid];
+                        const double x = gs_point(sv, xm, xp, dh);
+                        const double dif = old - x;
+                        err2 += dif * dif;
+                        pout[(r0 << logT) + tid] = x;
+                        xm = x;
+                        old = xp;
+                    }
+                }
+            }
         }
         if (tid == 0) {
-            pout[addr(L, 0)] = pin[addr(L, 0)];
-            pout[addr(L, L.n - 1)] = pin[addr(L, L.n - 1)];
+            pout[0] = pin[0];                                   // node 0
+            pout[C << logT] = pin[C << logT];                   // node n-1
         }
     }
     A.cur ^= (1u << l);
-    const double tot = block_sum(err2, red);   // also orders the global writes of this sweep before the next phase
+    const double tot = block_sum(err2, red);   // also orders the writes of this sweep before the next phase
     return sqrt(tot);
 }
 
 // PoissonSolver::IterateGaussSeidel (PoissonSolver.cpp:66-77)
-__device__ double iterate_gs(const MgDesc& D, Atom& A, int l, double errorMin, int iterno, double* red, long* nsweeps)
+__device__ __forceinline__ double iterate_gs(const MgDesc& D, Atom& A, int l, double errorMin, int iterno, double* red, long* nsweeps)
 {
     double err = 1E10;
     for (int i = 0; i < iterno; ++i) {
@@ -153,36 +247,37 @@ __device__ double iterate_gs(const MgDesc& D, Atom& A, int l, double errorMin, i
 }
 
 // PoissonSolver::Restrict(lvl) (PoissonSolver.cpp:126-157): fine = lvl-1 -> coarse = lvl
-__device__ void restrict_to(const MgDesc& D, Atom& A, int lvl)
+__device__ __forceinline__ void restrict_to(const MgDesc& D, Atom& A, int lvl)
 {
     const Lvl Lc = D.lv[lvl], Lf = D.lv[lvl - 1];
-    const double* __restrict__ Pf = A.cur_phi(lvl - 1);
-    double* __restrict__ Pc = A.cur_phi(lvl);
-    double* __restrict__ S = A.src;
+    const double* Pf = A.cur_phi(lvl - 1, Lf);
+    double* Pc = A.cur_phi(lvl, Lc);
+    const double* Sf = A.src_of(Lf);
+    double* Sc = A.src_of(Lc);
     const int lim = Lc.n - 1;
     for (int idx = threadIdx.x; idx < Lc.n; idx += kThreads) {
         const int i = node_of(Lc, idx);
-        Pc[Lc.off + idx] = 0;
+        Pc[idx] = 0;
         double s = 0;
         if (i > 0 && i < lim) {
             const int twoi = 2 * i;
             const double pm = Pf[addr(Lf, twoi - 1)], p0 = Pf[addr(Lf, twoi)], pp = Pf[addr(Lf, twoi + 1)];
-            s = 4. * (S[addr(Lf, twoi)] + pm - 2. * p0 + pp) - Lc.d * (pp - pm);
+            s = 4. * (Sf[addr(Lf, twoi)] + pm - 2. * p0 + pp) - Lc.d * (pp - pm);
         }
-        S[Lc.off + idx] = s;
+        Sc[idx] = s;
     }
     __syncthreads();
 }
 
 // PoissonSolver::Prolong (PoissonSolver.cpp:110-123): coarse = lvl -> fine = lvl-1 (additive)
-__device__ void prolong_from(const MgDesc& D, Atom& A, int lvl)
+__device__ __forceinline__ void prolong_from(const MgDesc& D, Atom& A, int lvl)
 {
     const Lvl Lc = D.lv[lvl], Lf = D.lv[lvl - 1];
-    const double* __restrict__ Pc = A.cur_phi(lvl);
-    double* __restrict__ Pf = A.cur_phi(lvl - 1);
+    const double* Pc = A.cur_phi(lvl, Lc);
+    double* Pf = A.cur_phi(lvl - 1, Lf);
     for (int idx = threadIdx.x; idx < Lc.n; idx += kThreads) {
         const int i = node_of(Lc, idx);
-        const double c = Pc[Lc.off + idx];
+        const double c = Pc[idx];
         Pf[addr(Lf, 2 * i)] += c;
         if (i > 0) Pf[addr(Lf, 2 * i - 1)] += 0.5 * (Pc[addr(Lc, i - 1)] + c);
     }
@@ -191,35 +286,14 @@ __device__ void prolong_from(const MgDesc& D, Atom& A, int lvl)
 
 struct Counters { long sweeps, vcycles; };
 
-__device__ void ascend(const MgDesc& D, Atom& A, int from, int to, double errorMin, int iterno, double* red, Counters& c)
-{   // PoissonSolver.cpp:162-171
-    for (int i = from; i < to;) {
-        iterate_gs(D, A, i, errorMin, iterno, red, &c.sweeps);
-        restrict_to(D, A, ++i);
-    }
-    iterate_gs(D, A, to, errorMin, iterno, red, &c.sweeps);
-}
-
-__device__ double descend(const MgDesc& D, Atom& A, int from, int to, double errorMin, int iterno, double* red, Counters& c)
-{   // PoissonSolver.cpp:173-186
-    double err = 1E10;
-    for (int i = from; i > to;) {
-        const int im1 = i - 1;
-        prolong_from(D, A, i);
-        err = iterate_gs(D, A, im1, errorMin, iterno, red, &c.sweeps);
-        i = im1;
-    }
-    return err;
-}
-
-// PoissonSolver::Initialize (PoissonSolver.cpp:80-106)
-__device__ void initialize(const MgDesc& D, Atom& A, double lowB, double highB, double errorMin, double* red, Counters& c)
+// PoissonSolver::Initialize without its final smoothing (PoissonSolver.cpp:80-103)
+__device__ __forceinline__ void initialize(const MgDesc& D, Atom& A, double lowB, double highB)
 {
-    double* __restrict__ S = A.src;
     A.cur = 0;
     {
         const Lvl L0 = D.lv[0];
-        for (int idx = threadIdx.x; idx < L0.n; idx += kThreads) A.phi0[L0.off + idx] = 0;
+        double* P0 = A.cur_phi(0, L0);
+        for (int idx = threadIdx.x; idx < L0.n; idx += kThreads) P0[idx] = 0;
     }
     for (int l = 1; l < D.levels; ++l) {
         const Lvl L = D.lv[l], Lf = D.lv[l - 1];
@@ -227,45 +301,69 @@ __device__ void initialize(const MgDesc& D, Atom& A, double lowB, double highB, 
         for (int idx = threadIdx.x; idx < L.n; idx += kThreads) {
             const int p = node_of(L, idx);
             double s = 0;
-            if (p > 0 && p < L.n - 1) s = 4 * S[addr(Lf, 2 * p)];
-            S[L.off + idx] = s;
-            A.phi0[L.off + idx] = 0;
+            if (p > 0 && p < L.n - 1) s = 4 * A.src_of(Lf)[addr(Lf, 2 * p)];
+            A.src_of(L)[idx] = s;
+            A.cur_phi(l, L)[idx] = 0;
         }
     }
     __syncthreads();
     const int cl = D.levels - 1;
     if (threadIdx.x == 0) {
-        A.phi0[addr(D.lv[cl], 0)] = lowB;
-        A.phi0[addr(D.lv[cl], D.lv[cl].n - 1)] = highB;
+        double* Pc = A.cur_phi(cl, D.lv[cl]);
+        Pc[addr(D.lv[cl], 0)] = lowB;
+        Pc[addr(D.lv[cl], D.lv[cl].n - 1)] = highB;
     }
     __syncthreads();
-    iterate_gs(D, A, cl, errorMin, 15, red, &c.sweeps);
 }
 
-// PoissonSolver::FullCycle(1E-3, 1E-14) (PoissonSolver.h:89-124)
-__device__ double full_cycle(const MgDesc& D, Atom& A, double lowB, double highB, double errorMin, double errorMinLast,
-                             double* red, Counters& c)
+// The whole cycle structure of PoissonSolver::FullCycle (PoissonSolver.h:89-124) as ONE loop over "legs", so that
+// the smoother, restriction and prolongation are each inlined exactly once:
+//   step 0                      : the 15 sweeps on the coarsest level that end Initialize (PoissonSolver.cpp:105)
+//   steps 1 .. 2*nramp          : for i = levels-2 .. 1: Descend(last -> i), Ascend(i -> last)     (FMG ramp)
+//   step 2*nramp+1              : Descend(last -> 0, errorMinLast)
+//   then pairs                  : VCycle = Ascend(0 -> last), Descend(last -> 0); stop on err < errorMinLast or 100 cycles
+// Ascend(from,to): { GS(from); Restrict(from+1); GS(from+1); ... ; GS(to) }      (PoissonSolver.cpp:162-171)
+// Descend(from,to): { Prolong(from); GS(from-1); ... ; GS(to) }                  (PoissonSolver.cpp:173-186)
+__device__ __forceinline__ double run_cycles(const MgDesc& D, Atom& A, int first_step, int max_vcycles, double errorMin,
+                                             double errorMinLast, double* red, Counters& c)
 {
-    const int numSweeps = 3;
     const int last = D.levels - 1;
-    initialize(D, A, lowB, highB, errorMin, red, c);
-    for (int i = D.levels - 2; i > 0; --i) {
-        descend(D, A, last, i, errorMin, numSweeps, red, c);
-        ascend(D, A, i, last, errorMin, numSweeps, red, c);
-    }
-    descend(D, A, last, 0, errorMinLast, numSweeps, red, c);
+    const int nramp = D.levels - 2 > 0 ? D.levels - 2 : 0;
     double err = 0;
-    for (int i = 0; i < 100; ++i) {
-        ascend(D, A, 0, last, errorMinLast, numSweeps, red, c);          // VCycle, PoissonSolver.h:155-159
-        err = descend(D, A, last, 0, errorMinLast, numSweeps, red, c);
-        ++c.vcycles;
-        if (err < errorMinLast) break;
+    for (int step = first_step;; ++step) {
+        int from, to, iterno = 3;
+        double emin = errorMin;
+        bool vleg_down = false;
+        if (step == 0) { from = to = last; iterno = 15; }
+        else if (step <= 2 * nramp) {
+            const int q = (step - 1) >> 1;
+            const int i = D.levels - 2 - q;
+            if ((step - 1) & 1) { from = i; to = last; } else { from = last; to = i; }
+        } else if (step == 2 * nramp + 1) { from = last; to = 0; emin = errorMinLast; }
+        else {
+            emin = errorMinLast;
+            if ((step - (2 * nramp + 2)) & 1) { from = last; to = 0; vleg_down = true; } else { from = 0; to = last; }
+        }
+        const int dir = (from > to) ? -1 : 1;
+        err = 1E10;
+        if (!(dir < 0 && from == to)) {
+            for (int lvl = (dir > 0) ? from : from - 1;; lvl += dir) {
+                if (dir > 0) { if (lvl > from) restrict_to(D, A, lvl); }
+                else prolong_from(D, A, lvl + 1);
+                err = iterate_gs(D, A, lvl, emin, iterno, red, &c.sweeps);
+                if (lvl == to) break;
+            }
+        }
+        if (vleg_down) {
+            ++c.vcycles;
+            if (err < errorMinLast || c.vcycles >= max_vcycles) break;
+        }
     }
     return err;
 }
 
 // SolvePoissonNonUniform (PoissonSolver.h:51-81): one block per atom
-__global__ __launch_bounds__(kThreads) void k_poisson_solve(MgDesc D, double* __restrict__ phi0, double* __restrict__ phi1,
+__global__ __launch_bounds__(kThreads) void k_poisson_solve(const MgDesc* __restrict__ Dp, double* __restrict__ phi0, double* __restrict__ phi1,
                                                             double* __restrict__ src, const int* __restrict__ Z,
                                                             const double* __restrict__ density, const double* __restrict__ r,
                                                             const double* __restrict__ psrc, double* __restrict__ U,
@@ -273,11 +371,14 @@ __global__ __launch_bounds__(kThreads) void k_poisson_solve(MgDesc D, double* __
                                                             unsigned long long* __restrict__ total_vcycles)
 {
     __shared__ double red[4];
+    __shared__ double seqmem[3 * kSeqCap];
+    const MgDesc& D = *Dp;
     const int a = blockIdx.x;
     Atom A;
     A.phi0 = phi0 + (size_t)a * D.per_atom;
     A.phi1 = phi1 + (size_t)a * D.per_atom;
     A.src = src + (size_t)a * D.per_atom;
+    A.lds = seqmem;
     A.cur = 0;
     const Lvl L0 = D.lv[0];
     const int N = L0.n;
@@ -287,12 +388,13 @@ __global__ __launch_bounds__(kThreads) void k_poisson_solve(MgDesc D, double* __
         const int i = node_of(L0, idx);
         double s = r[i];
         if (i > 0 && i < N - 1) s *= psrc[i] * rho[i];
-        A.src[L0.off + idx] = s;
+        A.src[L0.off + idx] = s;   // level 0 is never sequential: plain global storage
     }
     __syncthreads();
     Counters c{0, 0};
-    const double err = full_cycle(D, A, 0.0, (double)Z[a], 1E-3, 1E-14, red, c);
-    const double* __restrict__ P = A.cur_phi(0);
+    initialize(D, A, 0.0, (double)Z[a]);
+    const double err = run_cycles(D, A, 0, 100, 1E-3, 1E-14, red, c);      // FullCycle(1E-3, 1E-14), PoissonSolver.h:78
+    const double* __restrict__ P = A.cur_phi(0, L0);
     for (int i = threadIdx.x; i < N; i += kThreads) U[(size_t)a * N + i] = P[addr(L0, i)];
     if (threadIdx.x == 0) {
         if (vcycles) vcycles[a] = (int)c.vcycles;
@@ -302,14 +404,27 @@ __global__ __launch_bounds__(kThreads) void k_poisson_solve(MgDesc D, double* __
 }
 
 // unit-parity kernels on atom 0 ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kThreads) void k_unit(MgDesc D, double* phi0, double* phi1, double* src, int* cur, int op,
+__global__ __launch_bounds__(kThreads) void k_unit(const MgDesc* __restrict__ Dp, double* phi0, double* phi1, double* src, int* cur, int op,
                                                    int lvl, int sweeps, double* out)
 {
     __shared__ double red[4];
+    __shared__ double seqmem[3 * kSeqCap];
+    const MgDesc& D = *Dp;
     Atom A;
-    A.phi0 = phi0; A.phi1 = phi1; A.src = src;
+    A.phi0 = phi0; A.phi1 = phi1; A.src = src; A.lds = seqmem;
     A.cur = 0;
     for (int l = 0; l < D.levels; ++l) A.cur |= (cur[l] ? 1u : 0u) << l;
+    // sequential levels: global -> LDS (the solve kernel initialises them itself)
+    for (int l = 0; l < D.levels; ++l) {
+        const Lvl L = D.lv[l];
+        if (!L.seq) continue;
+        for (int idx = threadIdx.x; idx < L.n; idx += kThreads) {
+            seqmem[L.soff + idx] = phi0[L.off + idx];
+            seqmem[kSeqCap + L.soff + idx] = phi1[L.off + idx];
+            seqmem[2 * kSeqCap + L.soff + idx] = src[L.off + idx];
+        }
+    }
+    __syncthreads();
     Counters c{0, 0};
     if (op == 0) {
         for (int s = 0; s < sweeps; ++s) {
@@ -319,12 +434,20 @@ __global__ __launch_bounds__(kThreads) void k_unit(MgDesc D, double* phi0, doubl
     } else if (op == 1) restrict_to(D, A, lvl);
     else if (op == 2) prolong_from(D, A, lvl);
     else if (op == 3) {
-        const int last = D.levels - 1;
-        ascend(D, A, 0, last, 1E-14, 3, red, c);
-        const double e = descend(D, A, last, 0, 1E-14, 3, red, c);
+        const int nramp = D.levels - 2 > 0 ? D.levels - 2 : 0;
+        const double e = run_cycles(D, A, 2 * nramp + 2, 1, 1E-14, 1E-14, red, c);   // one VCycle(last, 1E-14, 3)
         if (threadIdx.x == 0) out[0] = e;
     }
     __syncthreads();
+    for (int l = 0; l < D.levels; ++l) {
+        const Lvl L = D.lv[l];
+        if (!L.seq) continue;
+        for (int idx = threadIdx.x; idx < L.n; idx += kThreads) {
+            phi0[L.off + idx] = seqmem[L.soff + idx];
+            phi1[L.off + idx] = seqmem[kSeqCap + L.soff + idx];
+            src[L.off + idx] = seqmem[2 * kSeqCap + L.soff + idx];
+        }
+    }
     if (threadIdx.x == 0) for (int l = 0; l < D.levels; ++l) cur[l] = (A.cur >> l) & 1u;
 }
 
@@ -335,6 +458,7 @@ struct dfta_poisson {
     const dfta_grid* g = nullptr;
     int batch = 0;
     MgDesc D;
+    MgDesc* d_desc = nullptr;       // device copy of D (read with scalar loads)
     double *d_phi0 = nullptr, *d_phi1 = nullptr, *d_src = nullptr;
     int* d_cur = nullptr;           // unit hooks: current buffer per level (atom 0)
     std::vector<int> h_cur;
@@ -350,7 +474,7 @@ static long host_addr(const Lvl& L, int i)
 int dfta_poisson_solve_launch(dfta_poisson* p, const int* dZ, const double* dDensity, double* dU, int* dVcycles, double* dErr)
 {
     dfta_ctx* ctx = p->ctx;
-    hipLaunchKernelGGL(k_poisson_solve, dim3(p->batch), dim3(kThreads), 0, ctx->stream, p->D, p->d_phi0, p->d_phi1, p->d_src, dZ,
+    hipLaunchKernelGGL(k_poisson_solve, dim3(p->batch), dim3(kThreads), 0, ctx->stream, p->d_desc, p->d_phi0, p->d_phi1, p->d_src, dZ,
                        dDensity, p->g->d_r, p->g->d_psrc, dU, dVcycles, dErr, p->d_total_vcycles);
     DFTA_CHECK_LAUNCH(ctx);
     return DFTA_OK;
@@ -375,7 +499,7 @@ int dfta_poisson_create(dfta_ctx* ctx, const dfta_grid* g, int batch, dfta_poiss
     p->ctx = ctx; p->g = g; p->batch = batch;
     MgDesc& D = p->D;
     D.levels = g->levels;
-    long off = 0;
+    long off = kPad, soff = 0;
     double d = g->delta;                       // PoissonSolver.cpp:21-26
     int n = g->N;                              // finest level first
     for (int l = 0; l < D.levels; ++l) {
@@ -383,18 +507,21 @@ int dfta_poisson_create(dfta_ctx* ctx, const dfta_grid* g, int batch, dfta_poiss
         L.n = n; L.off = off; L.d = d;
         int lg = 0;
         while ((1 << lg) < n - 1) ++lg;        // n - 1 == 2^lg
-        if (n < kSeqBelow) { L.seq = 1; L.logT = 0; L.logC = lg; }
-        else { L.seq = 0; L.logT = std::min(lg, 8); L.logC = lg - L.logT; }
+        if (n < kSeqBelow) { L.seq = 1; L.logT = 0; L.logC = lg; L.soff = soff; soff += n; }
+        else { L.seq = 0; L.logT = std::min(lg, 8); L.logC = lg - L.logT; L.soff = -1; }
         off += n;
         n = (n + 1) / 2;
         d *= 2;
     }
     D.per_atom = off;
+    if (soff > kSeqCap) { delete p; snprintf(ctx->err, sizeof(ctx->err), "sequential levels exceed LDS budget"); return DFTA_ERR_INVALID; }
     const size_t tot = (size_t)off * batch;
     hipError_t e = hipMalloc(reinterpret_cast<void**>(&p->d_phi0), tot * sizeof(double));
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->d_phi1), tot * sizeof(double));
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->d_src), tot * sizeof(double));
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->d_cur), kMaxLevels * sizeof(int));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->d_desc), sizeof(MgDesc));
+    if (e == hipSuccess) e = hipMemcpyAsync(p->d_desc, &p->D, sizeof(MgDesc), hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->d_total_vcycles), sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMemsetAsync(p->d_phi0, 0, tot * sizeof(double), ctx->stream);
     if (e == hipSuccess) e = hipMemsetAsync(p->d_phi1, 0, tot * sizeof(double), ctx->stream);
@@ -415,7 +542,7 @@ int dfta_poisson_create(dfta_ctx* ctx, const dfta_grid* g, int batch, dfta_poiss
 void dfta_poisson_destroy(dfta_poisson* p)
 {
     if (!p) return;
-    void* ptrs[] = {p->d_phi0, p->d_phi1, p->d_src, p->d_cur, p->d_total_vcycles};
+    void* ptrs[] = {p->d_phi0, p->d_phi1, p->d_src, p->d_cur, p->d_total_vcycles, p->d_desc};
     for (void* q : ptrs) if (q) (void)hipFree(q);
     delete p;
 }
@@ -509,7 +636,7 @@ static int unit_op(dfta_poisson* p, int op, int lvl, int sweeps, double* out_hos
     DevBuf<double> dOut;
     DFTA_HIP(ctx, dOut.alloc(std::max(nout, 1)));
     DFTA_HIP(ctx, hipMemcpyAsync(p->d_cur, p->h_cur.data(), sizeof(int) * kMaxLevels, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(k_unit, dim3(1), dim3(kThreads), 0, st, p->D, p->d_phi0, p->d_phi1, p->d_src, p->d_cur, op, lvl, sweeps, dOut.p);
+    hipLaunchKernelGGL(k_unit, dim3(1), dim3(kThreads), 0, st, p->d_desc, p->d_phi0, p->d_phi1, p->d_src, p->d_cur, op, lvl, sweeps, dOut.p);
     DFTA_CHECK_LAUNCH(ctx);
     DFTA_HIP(ctx, hipMemcpyAsync(p->h_cur.data(), p->d_cur, sizeof(int) * kMaxLevels, hipMemcpyDeviceToHost, st));
     if (out_host && nout > 0) DFTA_HIP(ctx, hipMemcpyAsync(out_host, dOut.p, sizeof(double) * nout, hipMemcpyDeviceToHost, st));

@@ -201,14 +201,18 @@ struct dfta_scf {
     dfta::LevelSolver solver;
     dfta_poisson* poisson = nullptr;
     std::vector<AtomState> h_atoms;
-    std::vector<double> h_bottom0;
+    std::vector<double> h_bottom0;        // per potential: -Z^2-1 (DFTAtom.cpp:407)
+    std::vector<double> h_job_bottom;     // per job: bracket start of the next level solve
+    std::vector<dfta::Job> h_jobs;        // job results of the last step
+    int levels_mode = DFTA_LEVELS_BATCHED;
+    int steps_done = 0;
     std::vector<int> spin_nlev[2];      // per atom number of levels per spin
     AtomState* d_atoms = nullptr;
     int* d_Z = nullptr;
     double *d_density = nullptr, *d_dA = nullptr, *d_dB = nullptr, *d_V = nullptr, *d_U = nullptr, *d_Vexc = nullptr,
            *d_va = nullptr, *d_vb = nullptr, *d_eexc = nullptr, *d_newDensity = nullptr, *d_integrands = nullptr,
            *d_integrals = nullptr, *d_records = nullptr;
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
 };
 
 static int scf_xc(dfta_scf* s)
@@ -269,6 +273,9 @@ int dfta_scf_create(dfta_ctx* ctx, const dfta_grid* g, int lsda, int natoms, con
         s->spin_nlev[1][a] = nB;
         st.job_end = (int)specs.size();
     }
+    s->levels_mode = levels_mode;
+    s->h_job_bottom.resize(specs.size());
+    for (size_t k = 0; k < specs.size(); ++k) s->h_job_bottom[k] = s->h_bottom0[specs[k].v];
     int rc = s->solver.setup(ctx, g, levels_mode, tree_depth, s->nV, specs);
     if (rc) { dfta_scf_destroy(s); return rc; }
     rc = dfta_poisson_create(ctx, g, natoms, &s->poisson);
@@ -324,15 +331,27 @@ int dfta_scf_step(dfta_scf* s, dfta_step_stats* stats)
     DFTA_HIP(ctx, hipEventRecord(s->ev[0], st));
     DFTA_HIP(ctx, hipMemsetAsync(s->d_newDensity, 0, sizeof(double) * (size_t)s->nV * N, st));
     dfta::LevelStats ls;
-    int rc = s->solver.run(s->d_V, s->h_bottom0.data(), s->d_newDensity, stats ? &ls : nullptr);
+    // bracket starts: CHAINED hands E-3 from level to level exactly as DFTAtom.cpp:541 (levels one after the other);
+    // BATCHED starts every level concurrently from max(-Z^2-1, min Veff_l) (LevelSolver::clamp_bottoms)
+    const int run_mode = s->levels_mode;
+    int rc = s->solver.run(s->d_V, s->h_job_bottom.data(), run_mode, s->d_newDensity, stats ? &ls : nullptr);
     if (rc) return rc;
+    {
+        std::vector<dfta::Job>& jobs = s->h_jobs;
+        rc = s->solver.fetch_jobs(jobs);
+        if (rc) return rc;
+        for (size_t k = 0; k < jobs.size(); ++k) {
+            s->h_job_bottom[k] = s->h_bottom0[jobs[k].v];
+        }
+        s->steps_done++;
+    }
     hipLaunchKernelGGL(k_mix, grid, block, 0, st, s->lsda, N, s->alpha, 1. - s->alpha, g->d_fpr2, s->d_newDensity, s->d_density,
                        s->d_dA, s->d_dB);
     DFTA_CHECK_LAUNCH(ctx);
     DFTA_HIP(ctx, hipEventRecord(s->ev[1], st));
     rc = dfta_poisson_solve_launch(s->poisson, s->d_Z, s->d_density, s->d_U, nullptr, nullptr);
     if (rc) return rc;
-    DFTA_HIP(ctx, hipEventRecord(s->ev[2], st));
+    DFTA_HIP(ctx, hipEventRecord(s->ev[2], st));   // ev[1]..ev[2] brackets exactly the persistent multigrid kernel
     rc = scf_xc(s);
     if (rc) return rc;
     hipLaunchKernelGGL(k_tail, grid, block, 0, st, s->d_atoms, s->lsda, N, g->d_r, g->d_cnst, s->d_density, s->d_dA, s->d_dB, s->d_U,
@@ -350,14 +369,13 @@ int dfta_scf_step(dfta_scf* s, dfta_step_stats* stats)
         DFTA_HIP(ctx, hipEventElapsedTime(&stats->ms_levels, s->ev[0], s->ev[1]));
         DFTA_HIP(ctx, hipEventElapsedTime(&stats->ms_poisson, s->ev[1], s->ev[2]));
         DFTA_HIP(ctx, hipEventElapsedTime(&stats->ms_tail, s->ev[2], s->ev[3]));
+        stats->ms_poisson_kernel = stats->ms_poisson;
+        stats->ms_sweep_kernels = ls.ms_sweep;
         stats->rounds = ls.rounds;
         stats->sweeps_issued = ls.sweeps_issued;
         stats->points_traversed = ls.points_traversed;
-        std::vector<dfta::Job> jobs;
-        rc = s->solver.fetch_jobs(jobs);
-        if (rc) return rc;
         long ref = 0;
-        for (const auto& j : jobs) ref += j.n_count + j.n_zero + 1;     // + the matched solve of each level
+        for (const auto& j : s->h_jobs) ref += j.n_count + j.n_zero + 1;   // + the matched solve of each level
         stats->sweeps_reference = ref;
         unsigned long long vc = 0;
         rc = dfta_poisson_take_vcycles(s->poisson, &vc);
@@ -380,6 +398,15 @@ int dfta_scf_get_energies(dfta_scf* s, dfta_energies* e, int* finished)
     return DFTA_OK;
 }
 
+int dfta_scf_info(const dfta_scf* s, int* tree_depth, int* njobs, long* trials_per_round)
+{
+    if (!s) return DFTA_ERR_INVALID;
+    if (tree_depth) *tree_depth = s->solver.depth;
+    if (njobs) *njobs = s->solver.njobs;
+    if (trials_per_round) *trials_per_round = s->solver.ntrials;
+    return DFTA_OK;
+}
+
 int dfta_scf_num_levels(const dfta_scf* s, int atom, int spin)
 {
     if (!s || atom < 0 || atom >= s->natoms || spin < 0 || spin > 1) return -1;
@@ -391,9 +418,8 @@ int dfta_scf_get_levels(dfta_scf* s, int atom, int spin, int* n, int* l, int* oc
     if (!s) return DFTA_ERR_INVALID;
     dfta_ctx* ctx = s->ctx;
     DFTA_REQUIRE(ctx, atom >= 0 && atom < s->natoms && spin >= 0 && spin < s->nspin, "atom/spin");
-    std::vector<dfta::Job> jobs;
-    int rc = s->solver.fetch_jobs(jobs);
-    if (rc) return rc;
+    const std::vector<dfta::Job>& jobs = s->h_jobs;
+    DFTA_REQUIRE(ctx, !jobs.empty(), "no SCF step has run yet");
     int k0 = s->h_atoms[atom].job_off + (spin ? s->spin_nlev[0][atom] : 0);
     const int cnt = s->spin_nlev[spin][atom];
     for (int k = 0; k < cnt; ++k) {

@@ -1,0 +1,62 @@
+"""Host-side sharding of independent atoms over ranks (periodic-table sweep, BASELINE.json config 4).
+
+Atoms are independent SCF problems: there is no exchange during the solve.  Ranks get a
+static longest-processing-time partition (cost ~ number of subshells, i.e. Numerov jobs per SCF step) and
+the only collective is one all_gather of fixed-size result records (RECORD_DOUBLES doubles per atom) at
+the end.  The same code runs over RCCL (backend "nccl", GPU tensors) and, in the CPU tests, over gloo.
+"""
+import numpy as np
+
+RECORD_DOUBLES = 64
+
+
+def subshell_count(Z):
+    """Number of occupied subshells (AufbauPrinciple.h:36-75): the per-step Numerov job count of an atom."""
+    from . import get_subshells
+    return len(get_subshells(Z))
+
+
+def partition_atoms(Zs, world_size, cost=None):
+    """Static LPT assignment: returns a list (per rank) of lists of Z, deterministic on every rank."""
+    cost = cost or subshell_count
+    order = sorted(Zs, key=lambda z: (-cost(z), z))
+    loads = [0] * world_size
+    shards = [[] for _ in range(world_size)]
+    for z in order:
+        r = min(range(world_size), key=lambda k: (loads[k], k))
+        shards[r].append(z)
+        loads[r] += cost(z)
+    return [sorted(s) for s in shards]
+
+
+def pack_records(records, capacity):
+    """records: array (n, RECORD_DOUBLES) -> fixed (capacity, RECORD_DOUBLES) block, unused rows have Z = 0."""
+    out = np.zeros((capacity, RECORD_DOUBLES))
+    rec = np.asarray(records, dtype=np.float64).reshape(-1, RECORD_DOUBLES)
+    out[: len(rec)] = rec
+    return out
+
+
+def gather_records(local_block, dist=None):
+    """all_gather fixed-size record blocks (torch tensors, CPU for gloo / CUDA for RCCL); returns dict Z -> record."""
+    import torch
+    t = local_block if isinstance(local_block, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(local_block))
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        blocks = [t]
+    else:
+        blocks = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+        dist.all_gather(blocks, t)
+    table = {}
+    for b in blocks:
+        for row in b.detach().cpu().numpy().reshape(-1, RECORD_DOUBLES):
+            if row[0] > 0:
+                table[int(row[0])] = row.copy()
+    return table
+
+
+def record_fields(row):
+    """Decode one record written by k_energies (scf.hip)."""
+    nlev = int(row[8])
+    return {"Z": int(row[0]), "Etotal": row[1], "Ekinetic": row[2], "Ecoul": row[3], "Enuclear": row[4], "Exc": row[5],
+            "finished": bool(row[6]), "steps": int(row[7]), "nlevels": nlev, "converged": bool(row[9]),
+            "eigenvalues": row[10:10 + nlev].copy()}

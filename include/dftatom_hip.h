@@ -109,8 +109,14 @@ int dfta_numerov_match(dfta_ctx* ctx, const dfta_grid* g, int boundary, int nV, 
  * Replaces DFTAtom::LoopOverLevels + LocateInterval + NormalizeNonUniform + the density update of
  * CalculateNonUniformDensity (DFTAtom.cpp:36-56, 328-343, 493-604).  All bisections run on the device as
  * speculative bisection trees of depth `tree_depth` that reproduce the reference's midpoint sequence.
- *   mode DFTA_LEVELS_CHAINED : BottomEnergy handed from level to level as DFTAtom.cpp:541 (E-3)
- *   mode DFTA_LEVELS_BATCHED : every level starts at bottom0[v] (documented deviation)    */
+ *   mode DFTA_LEVELS_CHAINED : BottomEnergy handed from level to level as DFTAtom.cpp:541 (E-3); levels of one
+ *                              potential run one after the other (bit-for-bit the reference's bisection path)
+ *   mode DFTA_LEVELS_BATCHED : all levels run concurrently and un-chained; level (v, l) starts from
+ *                              max(bottom0[v], min_i Veff_l(i)) -- no eigenvalue lies below the minimum of the
+ *                              effective potential, and below it the node-count predicate of l >= 1 misfires
+ *                              (SURVEY C.12), which is why plain -Z^2-1 is not safe for f levels.  Documented
+ *                              deviation from DFTAtom.cpp:541: the bisection paths differ, eigenvalues agree with
+ *                              the chained path to ~1e-10 relative (tests).  bottom_hint, if given, is used as is. */
 #define DFTA_LEVELS_CHAINED 0
 #define DFTA_LEVELS_BATCHED 1
 
@@ -125,6 +131,7 @@ typedef struct dfta_level_result {
 
 int dfta_solve_levels(dfta_ctx* ctx, const dfta_grid* g, int mode, int tree_depth,
                       int nV, const double* V, const double* bottom0 /* nV */,
+                      const double* bottom_hint /* BATCHED: per level bracket start, NULL -> bottom0[v] */,
                       int nlevels, const int* vidx, const int* n, const int* l, const int* occ,
                       dfta_level_result* results,           /* nlevels */
                       double* newDensity /* nV*N, accumulated occ*Psi^2 (i < N-1), may be NULL */,
@@ -180,8 +187,10 @@ typedef struct dfta_step_stats {
     long   sweeps_reference;     /* sweeps on the reference's bisection path (count+zero+match) */
     long   points_traversed;     /* grid points traversed by issued sweeps                  */
     long   vcycles;              /* Poisson V-cycles executed over the batch                */
-    int    rounds;               /* bisection rounds (kernel launches of the sweep kernel)  */
+    int    rounds;               /* bisection rounds (= launches of the sweep kernel)       */
     float  ms_levels, ms_poisson, ms_tail;   /* HIP-event times of the three phases       */
+    float  ms_sweep_kernels;     /* HIP-event time summed over the sweep-kernel launches only */
+    float  ms_poisson_kernel;    /* HIP-event time of the persistent multigrid kernel        */
 } dfta_step_stats;
 
 int  dfta_scf_create(dfta_ctx* ctx, const dfta_grid* g, int lsda, int natoms, const int* Z,
@@ -190,6 +199,8 @@ void dfta_scf_destroy(dfta_scf* s);
 int  dfta_scf_step(dfta_scf* s, dfta_step_stats* stats);                               /* DFTAtom.cpp:396-484 / 908-1009 */
 /* results of the last step (host copies): per atom energies; finished flag (the reference's Finished! test) */
 int  dfta_scf_get_energies(dfta_scf* s, dfta_energies* e /* natoms */, int* finished /* natoms */);
+/* geometry of the level search: bisection-tree depth, number of (atom,spin,n,l) jobs, trial lanes per round */
+int  dfta_scf_info(const dfta_scf* s, int* tree_depth, int* njobs, long* trials_per_round);
 int  dfta_scf_num_levels(const dfta_scf* s, int atom, int spin);
 int  dfta_scf_get_levels(dfta_scf* s, int atom, int spin, int* n, int* l, int* occ, double* E, int* converged);
 int  dfta_scf_get_array(dfta_scf* s, int atom, int which, double* out /* N */);  /* 0 density,1 densityA,2 densityB,3 potA,4 potB,5 U */

@@ -308,8 +308,13 @@ void dfo_normalize_nonuniform(const dfo_grid* g, double* Psi)   /* DFTAtom.cpp:3
 }
 
 int dfo_loop_over_levels(const dfo_grid* g, const double* V, dfo_level* levels, int nlevels,
-                         double* newDensity, double* Eelectronic, double* BottomEnergy, int chained)
-/* DFTAtom.cpp:493-563; returns reallyConverged */
+                         double* newDensity, double* Eelectronic, double* BottomEnergy, int chained,
+                         const double* hints)
+/* DFTAtom.cpp:493-563; returns reallyConverged.
+ * chained == 1: the reference (BottomEnergy = E - 3 handed to the next level, DFTAtom.cpp:541)
+ * chained == 0: every level starts from the caller's BottomEnergy (unsafe for f levels, kept for study)
+ * chained == 2: level k starts from hints[k] (study: hints[k] = E_{k-1} of the PREVIOUS SCF step - 3; fragile early in the SCF)
+ * chained == 3: the batched GPU mode: every level starts from max(BottomEnergy, min_i Veff_l(i)) */
 {
     static const double energyErr = 1E-12;   /* DFTAtom.cpp:348 */
     int reallyConverged = 1;
@@ -321,7 +326,18 @@ int dfo_loop_over_levels(const dfo_grid* g, const double* V, dfo_level* levels, 
         dfo_level* level = &levels[k];
         const int NumNodes = level->n - level->l;
         double TopEnergy = 50;
-        if (!chained) *BottomEnergy = Bottom0;
+        if (chained == 0) *BottomEnergy = Bottom0;
+        else if (chained == 2) *BottomEnergy = hints[k];
+        else if (chained == 3) {
+            /* batched GPU mode: un-chained, but never below the minimum of the effective potential of this l --
+             * no eigenvalue lies below it, and below it the node count of l >= 1 misfires */
+            double vmin = INFINITY;
+            for (long i = 1; i < n; ++i) {
+                const double ve = dfo_veff(g, V, (unsigned)level->l, i);
+                if (ve < vmin) vmin = ve;
+            }
+            *BottomEnergy = (vmin > Bottom0) ? vmin : Bottom0;
+        }
 
         int ncalls = 0;
         dfo_locate_interval(g, V, &TopEnergy, BottomEnergy, level->l, NumNodes, energyErr, &ncalls);
@@ -366,11 +382,11 @@ int dfo_loop_over_levels(const dfo_grid* g, const double* V, dfo_level* levels, 
 
 int dfo_calculate_density(const dfo_grid* g, const double* V, dfo_level* levels, int nlevels,
                           double* density, double alpha, double* newDensity, double* Eelectronic,
-                          double BottomEnergy, int chained)   /* DFTAtom.cpp:328-343 */
+                          double BottomEnergy, int chained, const double* hints)   /* DFTAtom.cpp:328-343 */
 {
     const double oneMinusAlpha = 1. - alpha;
     const int conv = dfo_loop_over_levels(g, V, levels, nlevels, newDensity, Eelectronic,
-                                          &BottomEnergy, chained);
+                                          &BottomEnergy, chained, hints);
     for (int i = 1; i < g->N; ++i) {
         const double position = g->Rp * (exp(i * g->delta) - 1.);
         newDensity[i] /= fourM_PI * position * position;
@@ -1002,11 +1018,18 @@ int dfo_scf_step(dfo_scf* s, dfo_energies* e)   /* DFTAtom.cpp:396-484 (LDA) / 9
     double *nuclear = s->tmp[0], *exccor = s->tmp[1], *hartree = s->tmp[2], *potentiale = s->tmp[3];
     double* eexcDeriv = s->eexc;
 
+    /* chained == 2 (hinted): first step chained as the reference, later steps start level k at E_{k-1}(previous step) - 3 */
+    double hintA[32], hintB[32];
+    const int mode = (s->chained == 2 && s->step == 0) ? 1 : s->chained;   /* 3 (clamped un-chained) needs no first chained step */
+    if (mode == 2) {
+        for (int k = 0; k < s->nla; ++k) hintA[k] = (k == 0) ? -(double)Z * Z - 1. : s->la[k - 1].E - 3;
+        for (int k = 0; k < s->nlb; ++k) hintB[k] = (k == 0) ? -(double)Z * Z - 1. : s->lb[k - 1].E - 3;
+    }
     if (!s->lsda) {
         memset(s->newDensity, 0, sizeof(double) * (size_t)N);
         const double BottomEnergy = -(double)Z * Z - 1.;
         conv = dfo_calculate_density(&s->g, s->potA, s->la, s->nla, s->density, s->alpha, s->newDensity,
-                                     &Eelectronic, BottomEnergy, s->chained);
+                                     &Eelectronic, BottomEnergy, mode, hintA);
         dfo_solve_poisson_nonuniform(s->ps, Z, s->MaxR, s->density, s->U);
         dfo_vwn_vexc(s->density, s->Vexc, (size_t)N);
         dfo_vwn_eexcdif(s->density, eexcDeriv, (size_t)N);
@@ -1029,11 +1052,11 @@ int dfo_scf_step(dfo_scf* s, dfo_energies* e)   /* DFTAtom.cpp:396-484 (LDA) / 9
         memset(s->newDensity, 0, sizeof(double) * (size_t)N);
         double BottomEnergy = -(double)Z * Z - 1.;
         const int c1 = dfo_calculate_density(&s->g, s->potA, s->la, s->nla, s->densityA, s->alpha, s->newDensity,
-                                             &Eelectronic, BottomEnergy, s->chained);
+                                             &Eelectronic, BottomEnergy, mode, hintA);
         for (int i = 0; i < N; ++i) s->newDensity[i] = 0;
         BottomEnergy = -(double)Z * Z - 1.;
         const int c2 = dfo_calculate_density(&s->g, s->potB, s->lb, s->nlb, s->densityB, s->alpha, s->newDensity,
-                                             &Eelectronic, BottomEnergy, s->chained);
+                                             &Eelectronic, BottomEnergy, mode, hintB);
         conv = c1 && c2;
         for (int i = 1; i < N; ++i) s->density[i] = s->densityA[i] + s->densityB[i];
 

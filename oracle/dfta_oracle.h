@@ -71,14 +71,16 @@ typedef struct dfo_level {
 void dfo_locate_interval(const dfo_grid* g, const double* V, double* Top, double* Bottom,
                          int L, int NumNodes, double energyErr, int* ncalls); /* DFTAtom.cpp:566-604 */
 void dfo_normalize_nonuniform(const dfo_grid* g, double* Psi);       /* DFTAtom.cpp:36-56 */
-/* chained != 0: BottomEnergy = E-3 hand-over between levels exactly as DFTAtom.cpp:541.
- * chained == 0: every level starts from the caller's BottomEnergy (documented batched deviation). */
+/* chained == 1: BottomEnergy = E-3 hand-over between levels exactly as DFTAtom.cpp:541 (the reference).
+ * chained == 0: every level starts from the caller's BottomEnergy (study only: breaks f levels).
+ * chained == 2: level k starts from hints[k] -- the batched GPU mode, hints[k] = E_{k-1}(previous SCF step) - 3. */
 int  dfo_loop_over_levels(const dfo_grid* g, const double* V, dfo_level* levels, int nlevels,
                           double* newDensity, double* Eelectronic, double* BottomEnergy,
-                          int chained);                              /* DFTAtom.cpp:493-563 */
+                          int chained, const double* hints);         /* DFTAtom.cpp:493-563 */
 int  dfo_calculate_density(const dfo_grid* g, const double* V, dfo_level* levels, int nlevels,
                            double* density, double alpha, double* newDensity,
-                           double* Eelectronic, double BottomEnergy, int chained); /* DFTAtom.cpp:328-343 */
+                           double* Eelectronic, double BottomEnergy, int chained,
+                           const double* hints);                     /* DFTAtom.cpp:328-343 */
 
 /* ---- multigrid Poisson (PoissonSolver.h / PoissonSolver.cpp) ---------------------------- */
 typedef struct dfo_poisson {

@@ -94,9 +94,9 @@ def oracle():
         "dfo_match": (C.c_long, [G, c_dp, C.c_uint, C.c_double, c_dp, c_lp]),
         "dfo_locate_interval": (None, [G, c_dp, c_dp, c_dp, C.c_int, C.c_int, C.c_double, c_ip]),
         "dfo_normalize_nonuniform": (None, [G, c_dp]),
-        "dfo_loop_over_levels": (C.c_int, [G, c_dp, C.POINTER(Level), C.c_int, c_dp, c_dp, c_dp, C.c_int]),
+        "dfo_loop_over_levels": (C.c_int, [G, c_dp, C.POINTER(Level), C.c_int, c_dp, c_dp, c_dp, C.c_int, c_dp]),
         "dfo_calculate_density": (C.c_int, [G, c_dp, C.POINTER(Level), C.c_int, c_dp, C.c_double, c_dp, c_dp,
-                                            C.c_double, C.c_int]),
+                                            C.c_double, C.c_int, c_dp]),
         "dfo_poisson_create": (C.POINTER(Poisson), [C.c_int, C.c_double]),
         "dfo_poisson_destroy": (None, [C.POINTER(Poisson)]),
         "dfo_gauss_seidel": (C.c_double, [C.POINTER(Poisson), C.c_int]),

@@ -48,7 +48,7 @@ def test_level_driver_and_normalise():
     E2, nd2, Eel2, Bot2 = np.zeros(len(lv)), np.zeros(g.N), C.c_double(0), C.c_double(-36.0 * 36 - 1)
     c2 = r.ref_loop_over_levels(h, len(lv), O.ip(n), O.ip(l), O.ip(occ), O.dp(E2), O.dp(nd2), C.byref(Eel2), C.byref(Bot2), g.delta)
     arr, nd1, Eel1, Bot1 = O.levels_array(lv), np.zeros(g.N), C.c_double(0), C.c_double(-36.0 * 36 - 1)
-    c1 = o.dfo_loop_over_levels(C.byref(g), O.dp(V), arr, len(lv), O.dp(nd1), C.byref(Eel1), C.byref(Bot1), 1)
+    c1 = o.dfo_loop_over_levels(C.byref(g), O.dp(V), arr, len(lv), O.dp(nd1), C.byref(Eel1), C.byref(Bot1), 1, None)
     assert np.array_equal(np.array([arr[i].E for i in range(len(lv))]), E2)
     assert np.array_equal(nd1, nd2) and Eel1.value == Eel2.value and Bot1.value == Bot2.value and c1 == c2
     psi = np.random.default_rng(3).standard_normal(g.N)

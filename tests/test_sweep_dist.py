@@ -1,0 +1,59 @@
+"""CPU suite: host logic of the periodic-table sweep -- static atom partition and the one collective
+(all_gather of fixed-size records), exercised with world_size 2 over gloo."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from dftatom_amd import sweep
+
+
+def test_partition_is_balanced_and_complete():
+    Zs = list(range(1, 87))
+    for world in (1, 2, 4, 8):
+        shards = sweep.partition_atoms(Zs, world)
+        assert sorted(z for s in shards for z in s) == Zs
+        loads = [sum(sweep.subshell_count(z) for z in s) for s in shards]
+        assert sum(loads) == 814
+        assert max(loads) - min(loads) <= 15           # LPT: within one atom's cost
+    assert sweep.partition_atoms(Zs, 8) == sweep.partition_atoms(Zs, 8)   # deterministic on every rank
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    shards = sweep.partition_atoms(list(range(1, 21)), world)
+    cap = max(len(s) for s in shards)
+    rec = np.zeros((len(shards[rank]), sweep.RECORD_DOUBLES))
+    for k, z in enumerate(shards[rank]):                # synthetic records: Z, Etotal = -Z^2.4, ..., eigenvalues
+        rec[k, 0], rec[k, 1], rec[k, 6], rec[k, 7], rec[k, 8], rec[k, 9] = z, -float(z) ** 2.4, 1, 30 + rank, 2, 1
+        rec[k, 10:12] = [-z * z / 2.0, -z * z / 8.0]
+    table = sweep.gather_records(torch.from_numpy(sweep.pack_records(rec, cap)), dist)
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, sorted(table), [table[z][1] for z in sorted(table)]))
+
+
+def test_gather_world_size_2_gloo():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, zs, et in res:                              # every rank ends with the full table
+        assert zs == list(range(1, 21))
+        assert np.allclose(et, [-float(z) ** 2.4 for z in zs])
+    f = sweep.record_fields(np.concatenate([[3, -7.3, 7.2, 4.0, -17.0, -1.5, 1, 31, 2, 1, -1.9, -0.08], np.zeros(52)]))
+    assert f["Z"] == 3 and f["finished"] and f["nlevels"] == 2 and f["eigenvalues"].tolist() == [-1.9, -0.08]
