@@ -1,0 +1,83 @@
+// DFTAtom.cpp -- host orchestration of an SCF run on the device path, with the reference's console protocol.
+//
+// One dfta_scf object holds the whole state in HBM; each dfta_scf_step is one iteration of the reference's `for sp`
+// loop (DFTAtom.cpp:396-484, LSDA 908-1009).  The text below reproduces what the reference prints, line for line.
+#include "DFTAtom.h"
+
+#include <algorithm>
+#include <iomanip>
+#include <iostream>
+
+namespace DFT {
+
+const char DFTAtom::orb[] = {'s', 'p', 'd', 'f'};
+int DFTAtom::levelsMode = DFTA_LEVELS_BATCHED;
+
+namespace {
+struct LevelLine { int n, l, occ; double E; };
+
+std::vector<LevelLine> fetch_levels(dfta_scf* scf, int spin)
+{
+    const int cnt = dfta_scf_num_levels(scf, 0, spin);
+    std::vector<int> n(cnt), l(cnt), occ(cnt), conv(cnt);
+    std::vector<double> E(cnt);
+    std::vector<LevelLine> out;
+    if (cnt <= 0) return out;
+    if (dfta_scf_get_levels(scf, 0, spin, n.data(), l.data(), occ.data(), E.data(), conv.data()) != DFTA_OK) throw std::runtime_error("dfta_scf_get_levels");
+    for (int i = 0; i < cnt; ++i) out.push_back({n[i], l[i], occ[i], E[i]});
+    return out;
+}
+
+void print_configuration(std::vector<LevelLine> levels)
+{
+    // levels sorted by energy for the final configuration line (DFTAtom.cpp:487-490)
+    std::sort(levels.begin(), levels.end(), [](const LevelLine& a, const LevelLine& b) { return a.E < b.E; });
+    for (const auto& lv : levels) std::cout << lv.n + 1 << DFTAtom::orb[lv.l] << lv.occ << " ";
+}
+}  // namespace
+
+void DFTAtom::Run(bool lsda, int Z, int MultigridLevels, double alpha, double MaxR, double deltaGrid)
+{
+    auto& rt = dfta_compat::Runtime::instance();
+    dfta_grid* grid = rt.grid(MultigridLevels, deltaGrid, MaxR);
+    std::cout << "Computing atom with Z=" << Z << (lsda ? " using LSDA with non-uniform grid" : " using LSD with non-uniform grid") << std::endl;
+
+    dfta_scf* scf = nullptr;
+    dfta_compat::check(dfta_scf_create(rt.ctx(), grid, lsda ? 1 : 0, 1, &Z, alpha, levelsMode, 0, &scf), rt.ctx(), "dfta_scf_create");
+    const int maxSteps = lsda ? 150 : 100;                                  // DFTAtom.cpp:396 / 908
+    for (int sp = 0; sp < maxSteps; ++sp) {
+        std::cout << "Step: " << sp << std::endl;
+        dfta_compat::check(dfta_scf_step(scf, nullptr), rt.ctx(), "dfta_scf_step");
+        for (int spin = 0; spin < (lsda ? 2 : 1); ++spin)
+            for (const auto& lv : fetch_levels(scf, spin))                 // DFTAtom.cpp:548-556 (the alpha/beta tag is lost on this path)
+                std::cout << "Energy " << lv.n + 1 << orb[lv.l] << ": " << std::fixed << std::setprecision(6) << lv.E << " Num nodes: " << lv.n - lv.l << std::endl;
+        dfta_energies e;
+        int finished = 0;
+        dfta_compat::check(dfta_scf_get_energies(scf, &e, &finished), rt.ctx(), "dfta_scf_get_energies");
+        std::cout << "Etotal = " << std::fixed << std::setprecision(6) << e.Etotal << " Ekin = " << e.Ekinetic << " Ecoul = " << e.Ecoul
+                  << " Eenuc = " << e.Enuclear << " Exc = " << e.Exc << std::endl;
+        if (finished) {
+            std::cout << std::endl << "Finished!" << std::endl << std::endl;
+            break;
+        }
+        std::cout << "********************************************************************************" << std::endl;
+    }
+    if (!lsda) print_configuration(fetch_levels(scf, 0));
+    else {
+        std::cout << "Alpha: ";
+        print_configuration(fetch_levels(scf, 0));
+        std::cout << "\nBeta: ";
+        print_configuration(fetch_levels(scf, 1));
+    }
+    dfta_scf_destroy(scf);
+}
+
+void DFTAtom::CalculateNonUniformLDA(int Z, int MultigridLevels, double alpha, double MaxR, double deltaGrid) { Run(false, Z, MultigridLevels, alpha, MaxR, deltaGrid); }
+void DFTAtom::CalculateNonUniformLSDA(int Z, int MultigridLevels, double alpha, double MaxR, double deltaGrid) { Run(true, Z, MultigridLevels, alpha, MaxR, deltaGrid); }
+
+// the uniform-grid entry points are unreachable from the reference's GUI (DFTAtomFrame.cpp:191,194 are commented out) and
+// outside the accelerated hot path
+void DFTAtom::CalculateUniformLDA(int, int, double, double) { throw std::runtime_error("CalculateUniformLDA: uniform grid is not part of the HIP hot path"); }
+void DFTAtom::CalculateUniformLSDA(int, int, double, double) { throw std::runtime_error("CalculateUniformLSDA: uniform grid is not part of the HIP hot path"); }
+
+}  // namespace DFT

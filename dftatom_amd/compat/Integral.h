@@ -1,0 +1,28 @@
+// Integral.h -- DFT::Integral with the reference's static templates (reference Integral.h:11-155), T = double.
+#pragma once
+
+#include <vector>
+
+#include "dfta_runtime.h"
+
+namespace DFT {
+
+class Integral {
+public:
+    template <typename T> static T Trapezoid(const double delta, const std::vector<T>& values) { return run(DFTA_INT_TRAPEZOID, delta, values); }
+    template <typename T> static T SimpsonOneThird(const double delta, const std::vector<T>& values) { return run(DFTA_INT_SIMPSON13, delta, values); }
+    template <typename T> static T Simpson38(const double delta, const std::vector<T>& values) { return run(DFTA_INT_SIMPSON38, delta, values); }
+    template <typename T> static T Boole(const double delta, const std::vector<T>& values) { return run(DFTA_INT_BOOLE, delta, values); }
+    template <typename T> static T Romberg(const double delta, const std::vector<T>& values) { return run(DFTA_INT_ROMBERG, delta, values); }
+
+private:
+    static double run(int rule, double delta, const std::vector<double>& values)
+    {
+        auto& rt = dfta_compat::Runtime::instance();
+        double r = 0;
+        dfta_compat::check(dfta_integrate(rt.ctx(), rule, delta, values.data(), static_cast<int>(values.size()), &r), rt.ctx(), "dfta_integrate");
+        return r;
+    }
+};
+
+}  // namespace DFT

@@ -1,0 +1,64 @@
+// dfta_runtime.h -- process-wide plumbing shared by the reference-shaped C++ classes in this directory.
+//
+// The classes DFT::Numerov / DFT::PoissonSolver / DFT::VWNExchCor / DFT::Integral / DFT::DFTAtom keep the names,
+// signatures and ownership rules of aromanro/DFTAtom's public surface and forward every call
+// to the C ABI of libdftatom_hip (include/dftatom_hip.h).  There is no CPU implementation behind them: without a
+// usable HIP device the first call throws std::runtime_error.
+#pragma once
+
+#include <map>
+#include <stdexcept>
+#include <string>
+#include <tuple>
+
+#include "../../include/dftatom_hip.h"
+
+namespace dfta_compat {
+
+inline void check(int rc, dfta_ctx* ctx, const char* what)
+{
+    if (rc != DFTA_OK) throw std::runtime_error(std::string(what) + ": status " + std::to_string(rc) + " " + (ctx ? dfta_last_error(ctx) : ""));
+}
+
+// one context per process (the reference is single threaded: DFTAtomFrame.cpp:176-198), grids cached by parameters
+class Runtime {
+public:
+    static Runtime& instance()
+    {
+        static Runtime r;
+        return r;
+    }
+    dfta_ctx* ctx() { return m_ctx; }
+    dfta_grid* grid(int levels, double delta, double Rmax)
+    {
+        const auto key = std::make_tuple(levels, delta, Rmax);
+        auto it = m_grids.find(key);
+        if (it != m_grids.end()) return it->second;
+        dfta_grid* g = nullptr;
+        check(dfta_grid_create(m_ctx, levels, delta, Rmax, &g), m_ctx, "dfta_grid_create");
+        m_grids[key] = g;
+        return g;
+    }
+    // multigrid levels for a node count 2^L + 1 (PoissonSolver.h:127-135 inverted)
+    static int levels_for_nodes(size_t numPoints)
+    {
+        for (int L = 3; L <= 24; ++L) if (static_cast<size_t>(dfta_num_nodes(L)) == numPoints) return L;
+        throw std::runtime_error("node count is not 2^L + 1");
+    }
+
+private:
+    Runtime()
+    {
+        const int rc = dfta_ctx_create(0, nullptr, &m_ctx);
+        if (rc != DFTA_OK) throw std::runtime_error("libdftatom_hip: no usable HIP device (status " + std::to_string(rc) + "); there is no CPU fallback");
+    }
+    ~Runtime()
+    {
+        for (auto& kv : m_grids) dfta_grid_destroy(kv.second);
+        dfta_ctx_destroy(m_ctx);
+    }
+    dfta_ctx* m_ctx = nullptr;
+    std::map<std::tuple<int, double, double>, dfta_grid*> m_grids;
+};
+
+}  // namespace dfta_compat

@@ -1,0 +1,85 @@
+"""GPU suite: the reference-shaped C++ layer (dftatom_amd/compat: DFT::Numerov, DFT::PoissonSolver, DFT::VWNExchCor,
+DFT::Integral, DFT::AufbauPrinciple, DFT::DFTAtom) driven the way the reference's own orchestrator drives its classes,
+checked against the oracle and against the README's published Argon run."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import _oracle as O      # noqa: E402  (checker only)
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+COMPAT = os.path.join(ROOT, "dftatom_amd", "compat")
+
+
+def _run(exe, *args, timeout=600):
+    path = os.path.join(COMPAT, exe)
+    if not os.path.exists(path):
+        subprocess.check_call(["make", "-C", COMPAT])
+    return subprocess.run([path] + [str(a) for a in args], check=True, capture_output=True, text=True, timeout=timeout).stdout
+
+
+def test_reference_shaped_classes_vs_oracle():
+    out = _run("compat_check")
+    o = O.oracle()
+    L, d, R = 12, 2e-3, 25.0
+    g = O.make_grid(L, d, R)
+    rr = O.grid_r(g)
+    m = re.search(r"grid N (\d+) Rp (\S+)", out)
+    assert int(m.group(1)) == g.N and float(m.group(2)) == g.Rp
+    V = O.coulomb_potential(g, 18)
+    P = np.zeros(g.N)
+    n = 0
+    for m in re.finditer(r"numerov l (\d) E (\S+) count (-?\d+) u0 (\S+) mp (-?\d+) psisum (\S+)", out):
+        l, E = int(m.group(1)), float(m.group(2))
+        assert int(m.group(3)) == o.dfo_count_nodes(C.byref(g), O.dp(V), l, E, 3, None, None)      # node counts: exact
+        assert float(m.group(4)) == o.dfo_solution_in_zero(C.byref(g), O.dp(V), l, E, None)         # u(0): bit-exact
+        assert int(m.group(5)) == o.dfo_match(C.byref(g), O.dp(V), l, E, O.dp(P), None)
+        assert float(m.group(6)) == float(np.sum(P)) or abs(float(m.group(6)) - np.sum(P)) <= 1e-12 * abs(np.sum(P))
+        n += 1
+    assert n == 24
+    V10 = O.coulomb_potential(g, 10)
+    assert int(re.search(r"reread count (\d+)", out).group(1)) == o.dfo_count_nodes(C.byref(g), O.dp(V10), 0, -20.0, 3, None, None)
+    rho = 2.0 * np.exp(-2.0 * rr) / np.pi
+    m = re.search(r"poisson vcycles (\d+) maxerr (\S+) usum (\S+)", out)
+    p = o.dfo_poisson_create(L, d)
+    U = np.zeros(g.N)
+    o.dfo_solve_poisson_nonuniform(p, 2, R, O.dp(rho), O.dp(U))
+    assert int(m.group(1)) == p.contents.n_vcycles
+    assert abs(float(m.group(3)) - U.sum()) <= 1e-9 * abs(U.sum()) and float(m.group(2)) < 1e-6
+    o.dfo_poisson_destroy(p)
+    v, e = np.zeros(g.N), np.zeros(g.N)
+    o.dfo_vwn_vexc(O.dp(rho), O.dp(v), g.N)
+    o.dfo_vwn_eexcdif(O.dp(rho), O.dp(e), g.N)
+    m = re.search(r"vwn vexc100 (\S+) eexc100 (\S+) lsda100 (\S+) va100 (\S+) mismatch_empty (\d)", out)
+    assert abs(float(m.group(1)) - v[100]) <= 1e-12 * abs(v[100]) and abs(float(m.group(2)) - e[100]) <= 1e-12 * abs(e[100])
+    assert m.group(5) == "1"                                   # size mismatch -> {} as in the reference (VWNExcCor.h:137)
+    integrand = 4 * np.pi * rr ** 2 * rho * (g.Rp * d * np.exp(d * np.arange(g.N)))
+    m = re.search(r"integral simpson38 (\S+) romberg (\S+)", out)
+    assert abs(float(m.group(1)) - 2.0) < 1e-6 and abs(float(m.group(1)) - o.dfo_simpson38(1.0, O.dp(integrand), g.N)) < 1e-13
+    assert "aufbau Rn 15 first 1s2 last 6p6" in out
+
+
+def test_headless_front_end_reproduces_readme_argon():
+    """BASELINE.json config 1 on the device path: Ar, 14 levels, delta 5e-4, mixing 0.5, Rmax 25 (README.md:76), to
+    convergence, console text in the reference's format; final values equal the README's to its six decimals."""
+    out = _run("dftatom_cli", 18, 14, 0.5, 25, 0.0005, 0)
+    assert out.startswith("Computing atom with Z=18 using LSD with non-uniform grid")
+    assert "Finished!" in out
+    lines = out.strip().splitlines()
+    assert lines[-1].strip() == "1s2 2s2 2p6 3s2 3p6"
+    last_levels = [ln for ln in lines if ln.startswith("Energy")][-5:]
+    got = [float(re.search(r": (\S+) Num", ln).group(1)) for ln in last_levels]
+    assert got == [-113.800134, -10.794172, -8.443439, -0.883384, -0.382330]                       # README.md:63-67
+    assert [ln.split("Num nodes: ")[1] for ln in last_levels] == ["0", "1", "0", "2", "1"]
+    et = [ln for ln in lines if ln.startswith("Etotal")][-1]
+    vals = [float(x) for x in re.findall(r"= (-?\d+\.\d+)", et)]
+    want = [-525.946200, 524.969813, 231.458124, -1253.131983, -29.242154]                          # README.md:68
+    assert all(abs(a - b) <= 1.5e-6 for a, b in zip(vals, want)), (vals, want)
+    nsteps = sum(1 for ln in lines if ln.startswith("Step:"))
+    assert 25 <= nsteps <= 60          # the stop step itself is round-off noise (README: 32, compiled reference here: 35)
