@@ -175,7 +175,7 @@ def main():
             "device": devname, "compute_units": ncu,
             "roofline": {"bound": "hbm", "kernel": "k_sweep (Numerov count/zero sweeps)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None,
+                         "traffic": pmc_traffic("k_sweep"),
                          "bytes_per_launch": bytes_total / launches, "avg_launch_ms": tot["ms_sweep"] / launches,
                          "launches": launches,
                          "note": "algorithmic bytes = 8 B x traversed grid points of every ISSUED trial (SURVEY 8d); trials of a "
@@ -197,6 +197,22 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same command
+    (profiles/*_hbm_traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate passes; raw sum, see the file
+    for the gfx950 FETCH_SIZE caveat).  bench.py cannot run the profiler on itself, so the number is the
+    measured one of the latest committed profile, or null when none is present."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.json")))
+    if not files:
+        return None
+    try:
+        with open(files[-1]) as f:
+            return float(json.load(f)["kernels"][kernel]["hbm_bytes_per_launch_raw"])
+    except Exception:
+        return None
 
 
 def scf_depth(scf):
