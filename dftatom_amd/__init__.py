@@ -81,6 +81,7 @@ SIGNATURES = {
     "dfta_poisson_set_level": (C.c_int, [vp, C.c_int, c_dp, c_dp]),
     "dfta_poisson_get_level": (C.c_int, [vp, C.c_int, c_dp, c_dp]),
     "dfta_poisson_gauss_seidel": (C.c_int, [vp, C.c_int, C.c_int, c_dp]),
+    "dfta_poisson_iterate_gs": (C.c_int, [vp, C.c_int, C.c_double, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "dfta_poisson_restrict": (C.c_int, [vp, C.c_int]),
     "dfta_poisson_prolong": (C.c_int, [vp, C.c_int]),
     "dfta_poisson_vcycle": (C.c_int, [vp, c_dp]),
@@ -301,6 +302,13 @@ class Poisson:
         err = np.zeros(sweeps)
         self.ctx.check(self.ctx.lib.dfta_poisson_gauss_seidel(self.h, lvl, sweeps, _dp(err)))
         return err
+
+    def iterate_gs(self, lvl, error_min, iterno):
+        """IterateGaussSeidel: returns (err of the last sweep, sweeps executed)."""
+        err = C.c_double()
+        n = C.c_int()
+        self.ctx.check(self.ctx.lib.dfta_poisson_iterate_gs(self.h, lvl, error_min, iterno, C.byref(err), C.byref(n)))
+        return err.value, n.value
 
     def restrict(self, lvl):
         self.ctx.check(self.ctx.lib.dfta_poisson_restrict(self.h, lvl))

@@ -457,35 +457,52 @@ __global__ __launch_bounds__(64) void k_match(const double2* __restrict__ tab, c
     }
 
     bool running = (lane == 0 && !in_done) || (lane == 1);
+    // Both lanes advance one node per step (lane 0 downwards, lane 1 upwards) until they stop for good, so their
+    // table reads are known in advance: kMP entries are fetched one batch ahead of the recurrence.
+    constexpr int kMP = 8;
+    const int dir = (lane == 0) ? -1 : 1;
+    auto tab_at = [&](int idx) { idx = idx < 1 ? 1 : (idx > N - 1 ? N - 1 : idx); return T[idx]; };
+    double2 cur[kMP], nxt[kMP];
+#pragma unroll
+    for (int q = 0; q < kMP; ++q) cur[q] = tab_at(i + dir * q);
     // lane 1 may stop once it has produced the value AT the match point; until lane 0 is done the bound is lane 0's index
-    while (true) {
-        const int i0 = __shfl(i, 0);
-        const bool d0 = __shfl((int)in_done, 0) != 0;
-        const int mp0 = __shfl(mp, 0);
-        if (lane == 1) {
-            const int bound = d0 ? mp0 : i0 + 1;    // need outward values up to and including `bound`
-            running = (i <= bound) && (i <= steps);
-        }
-        if (lane == 0) running = !in_done;
-        if (__ballot(running) == 0ull) break;
-        if (running) {
-            const double2 tv = T[i];
-            const double wnext = 2. * w - wprev + u * fprev;
-            wprev = w;
-            w = wnext;
-            const double f = f_of(tv.x, tv.y, E, gs);
-            u = w / (1. - kH2p12 * f);
-            fprev = f;
-            if (lane == 0) {
-                P[i] = u;
-                if (u < unext || fabs(u) > 1E15) { mp = i; in_done = true; }   // Numerov.h:463-467
-                unext = u;
-                if (!in_done) { --i; if (i < 1) in_done = true; }
-            } else {
-                Qt[i] = u;
-                ++i;
+    bool all_done = false;
+    while (!all_done) {
+        const int ibase = i;
+#pragma unroll
+        for (int q = 0; q < kMP; ++q) nxt[q] = tab_at(ibase + dir * (kMP + q));
+#pragma unroll
+        for (int q = 0; q < kMP; ++q) {
+            const int i0 = __shfl(i, 0);
+            const bool d0 = __shfl((int)in_done, 0) != 0;
+            const int mp0 = __shfl(mp, 0);
+            if (lane == 1) {
+                const int bound = d0 ? mp0 : i0 + 1;    // need outward values up to and including `bound`
+                running = running && (i <= bound) && (i <= steps);
+            }
+            if (lane == 0) running = !in_done;
+            if (__ballot(running) == 0ull) { all_done = true; break; }
+            if (running) {
+                const double2 tv = cur[q];              // == T[i]: a running lane has advanced exactly q nodes in this batch
+                const double wnext = 2. * w - wprev + u * fprev;
+                wprev = w;
+                w = wnext;
+                const double f = f_of(tv.x, tv.y, E, gs);
+                u = w / (1. - kH2p12 * f);
+                fprev = f;
+                if (lane == 0) {
+                    P[i] = u;
+                    if (u < unext || fabs(u) > 1E15) { mp = i; in_done = true; }   // Numerov.h:463-467
+                    unext = u;
+                    if (!in_done) { --i; if (i < 1) in_done = true; }
+                } else {
+                    Qt[i] = u;
+                    ++i;
+                }
             }
         }
+#pragma unroll
+        for (int q = 0; q < kMP; ++q) cur[q] = nxt[q];
     }
     mp = __shfl(mp, 0);
     __syncthreads();

@@ -31,7 +31,8 @@ constexpr int kWarm = 96;   // start-value error decays by <= 0.52^96 < 2^-90: c
 constexpr int kSeqBelow = 257;   // levels with n < 257 nodes: one lane, sequential
 constexpr int kSeqCap = 272;     // LDS doubles per array for the sequential levels (129+65+33+17+9+5+3 = 261)
 constexpr int kPF = 8;           // register prefetch depth of the chunked sweep
-constexpr int kPad = 128;        // doubles of padding in front of every atom's level storage (warm-up reads of lane 0)
+constexpr int kFuseMinLogC = 9;  // fuse the three sweeps of a level visit when every lane owns >= 512 nodes
+constexpr int kPad = 320;        // doubles of padding in front of every atom's level storage (warm-up reads of lane 0)
 
 struct Lvl {
     int n;        // nodes
@@ -234,9 +235,161 @@ __device__ __forceinline__ double gauss_seidel(const MgDesc& D, Atom& A, int l, 
     return sqrt(tot);
 }
 
+// Three consecutive Gauss-Seidel sweeps of a chunked level in ONE pass over memory (the smoother is bound by the
+// CU's vector-memory pipe: fusing cuts its traffic to a third).  Sweep k+1 at node j needs sweep k at node j+1, so the
+// three sweeps run as a software pipeline: at step tau the lane computes
+//     x1[tau]   = gs(S[tau],   x1[tau-1], x0[tau+1])
+//     x2[tau-1] = gs(S[tau-1], x2[tau-2], x1[tau])
+//     x3[tau-2] = gs(S[tau-2], x3[tau-3], x2[tau-1])
+// i.e. exactly the arithmetic of three sequential sweeps.  Each lane starts 3W nodes before its chunk (x1 is exact
+// after W nodes, x2 after 2W, x3 after 3W: start-value errors contract by (1+d/2)/2 per node) and runs 2 nodes past it
+// (recomputing what its right neighbour computes).  The input copy stays untouched (the result goes to the other
+// copy), so when the reference would have stopped after the first or second sweep (err < errorMin) the caller redoes
+// the visit with single sweeps.  Returns the three error norms of PoissonSolver::GaussSeidel.
+__device__ __forceinline__ void gs_fused3(const MgDesc& D, Atom& A, int l, double* red, double& e1, double& e2, double& e3)
+{
+    const Lvl L = D.lv[l];
+    const double dh = L.d * 0.5;
+    const int tid = threadIdx.x;
+    const int T = 1 << L.logT, C = 1 << L.logC, logC = L.logC, logT = L.logT, Cm1 = C - 1;
+    const int n = L.n;
+    const double* __restrict__ S = A.src + L.off;
+    const double* __restrict__ pin = (((A.cur >> l) & 1u) ? A.phi1 : A.phi0) + L.off;
+    double* __restrict__ pout = (((A.cur >> l) & 1u) ? A.phi0 : A.phi1) + L.off;
+    double a1 = 0, a2 = 0, a3 = 0;
+    if (tid < T) {
+        const int lo = tid << logC;
+        const int nsteps = (C + 3 * kWarm + 2 + kPF - 1) / kPF * kPF;      // whole prefetch batches; extra steps = extra warm-up
+        const int rstart = (C + 1) - (nsteps - 1);                           // stage-1 node offset of the first step (<= -3W)
+        const double b0 = pin[0], bN = pin[C << logT];                        // fixed values at node 0 and node n-1
+        auto old_at = [&](int j) -> double {
+            if (j <= 0) return b0;
+            if (j >= n - 1) return bN;
+            return pin[((j & Cm1) << logT) + (j >> logC)];
+        };
+        auto src_at = [&](int j) -> double {
+            if (j <= 0 || j >= n - 1) return 0.0;
+            return S[((j & Cm1) << logT) + (j >> logC)];
+        };
+        // pipeline state: left neighbours = values of the previous step; old values and sources of the last three nodes
+        const int t0 = lo + rstart;                         // stage-1 node of the first step
+        double x1m = old_at(t0 - 1), x2m = old_at(t0 - 2), x3m = old_at(t0 - 3);
+        double o0 = old_at(t0), o1 = old_at(t0 - 1), o2 = old_at(t0 - 2);
+        double sA = src_at(t0 - 1), sB = src_at(t0 - 2);
+        // Fixed nodes.  Left: a stage is inactive (its value stays b0) while its node index is < 1, i.e. while
+        // r - (k-1) < rs with rs = 1 - lo; only lanes whose warm-up reaches below node 1 are concerned and only in the
+        // first batches of their wave.  Right: only the last lane, in the last two steps (nodes n-1, n).  Batches that
+        // touch neither run the unguarded step.
+        const int rs = 1 - lo;
+        if (t0 - 1 < 1) { x1m = b0; }                       // stage values at nodes <= 0 are the boundary value
+        if (t0 - 2 < 1) { x2m = b0; }
+        if (t0 - 3 < 1) { x3m = b0; }
+        const int wave_first_lo = (tid & ~63) << logC;
+        const int rs_wave = 1 - wave_first_lo;             // largest rs in this wave
+        const bool wave_has_last = ((tid | 63) >= T - 1) && ((tid & ~63) <= T - 1);
+
+        // loads of the step with stage-1 offset r: S at node lo+r, old Phi at node lo+r+1 (rows are wave-uniform)
+        auto load8 = [&](double (&X)[kPF], double (&SV)[kPF], int rbase) {
+#pragma unroll
+            for (int q = 0; q < kPF; ++q) {
+                int r0 = rbase + q;
+                r0 = r0 < C + 1 ? r0 : C + 1;
+                const int r1 = r0 + 1;
+                SV[q] = S[(((r0 & Cm1) << logT) + (r0 >> logC)) + tid];
+                X[q] = pin[(((r1 & Cm1) << logT) + (r1 >> logC)) + tid];
+            }
+        };
+        // MODE 0: no fixed node in this batch; 1: left end only (stage activation by predicate); 2: anything (selects)
+        auto step8 = [&](const double (&X)[kPF], const double (&SV)[kPF], int rbase, const int mode) {
+#pragma unroll
+            for (int q = 0; q < kPF; ++q) {
+                const int r = rbase + q;               // stage-1 node offset (wave-uniform)
+                double xn = X[q];                      // old value at node tau + 1
+                const double s0 = SV[q];
+                double x1, x2, x3;
+                bool u1 = true, u2 = true, u3 = true;
+                if (mode == 0) {
+                    x1 = gs_point(s0, x1m, xn, dh);
+                    x2 = gs_point(sA, x2m, x1, dh);
+                    x3 = gs_point(sB, x3m, x2, dh);
+                } else if (mode == 1) {
+                    u1 = (r >= rs); u2 = (r - 1 >= rs); u3 = (r - 2 >= rs);
+                    x1 = x1m; x2 = x2m; x3 = x3m;      // == b0 while the stage has not started
+                    if (u1) x1 = gs_point(s0, x1m, xn, dh);
+                    if (u2) x2 = gs_point(sA, x2m, x1, dh);
+                    if (u3) x3 = gs_point(sB, x3m, x2, dh);
+                } else {
+                    const int tau = lo + r;
+                    if (tau + 1 >= n - 1) xn = bN;
+                    if (tau + 1 <= 0) xn = b0;
+                    u1 = (tau >= 1) && (tau <= n - 2);
+                    u2 = (tau - 1 >= 1) && (tau - 1 <= n - 2);
+                    u3 = (tau - 2 >= 1) && (tau - 2 <= n - 2);
+                    x1 = u1 ? gs_point(s0, x1m, xn, dh) : ((tau <= 0) ? b0 : ((tau >= n - 1) ? bN : o0));
+                    x2 = u2 ? gs_point(sA, x2m, x1, dh) : ((tau - 1 <= 0) ? b0 : ((tau - 1 >= n - 1) ? bN : o1));
+                    x3 = u3 ? gs_point(sB, x3m, x2, dh) : ((tau - 2 <= 0) ? b0 : ((tau - 2 >= n - 1) ? bN : o2));
+                }
+                // error norms and the store, own nodes only (wave-uniform ranges); x1m / x2m still hold the stage values
+                // of the previous step, which are x1[tau-1] and x2[tau-2]
+                if (r >= 0 && r <= Cm1) { if (u1) { const double dd = o0 - x1; a1 = __builtin_fma(dd, dd, a1); } }
+                if (r >= 1 && r <= C) { if (u2) { const double dd = x1m - x2; a2 = __builtin_fma(dd, dd, a2); } }
+                if (r >= 2 && r <= C + 1) {
+                    if (u3) { const double dd = x2m - x3; a3 = __builtin_fma(dd, dd, a3); pout[(((r - 2) & Cm1) << logT) + tid] = x3; }
+                }
+                x1m = x1; x2m = x2; x3m = x3;
+                sB = sA; sA = s0;
+                o2 = o1; o1 = o0; o0 = xn;
+            }
+        };
+        auto mode_of = [&](int rbase) -> int {
+            const bool left = (rbase - 2 < rs_wave);                          // some stage of some lane below node 1
+            const bool right = wave_has_last && (rbase + kPF - 1 >= Cm1);      // last lane at / beyond node n-2
+            return right ? 2 : (left ? 1 : 0);
+        };
+        double ax[kPF], as[kPF], bx[kPF], bs[kPF];
+        load8(ax, as, rstart);
+        for (int r = rstart; r <= C + 1; r += 2 * kPF) {
+            load8(bx, bs, r + kPF);
+            {
+                const int m = mode_of(r);
+                if (m == 0) step8(ax, as, r, 0); else if (m == 1) step8(ax, as, r, 1); else step8(ax, as, r, 2);
+            }
+            if (r + kPF > C + 1) break;
+            load8(ax, as, r + 2 * kPF);
+            {
+                const int m = mode_of(r + kPF);
+                if (m == 0) step8(bx, bs, r + kPF, 0); else if (m == 1) step8(bx, bs, r + kPF, 1); else step8(bx, bs, r + kPF, 2);
+            }
+        }
+    }
+    if (tid == 0) {
+        pout[0] = pin[0];                                   // node 0
+        pout[(1 << L.logC) << L.logT] = pin[(1 << L.logC) << L.logT];   // node n-1
+    }
+    // one block reduction for the three norms (also orders this pass's writes before the next phase)
+    for (int off = 32; off > 0; off >>= 1) { a1 += __shfl_xor(a1, off); a2 += __shfl_xor(a2, off); a3 += __shfl_xor(a3, off); }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = a1; red[4 + (threadIdx.x >> 6)] = a2; red[8 + (threadIdx.x >> 6)] = a3; }
+    __syncthreads();
+    e1 = sqrt((red[0] + red[1]) + (red[2] + red[3]));
+    e2 = sqrt((red[4] + red[5]) + (red[6] + red[7]));
+    e3 = sqrt((red[8] + red[9]) + (red[10] + red[11]));
+}
+
 // PoissonSolver::IterateGaussSeidel (PoissonSolver.cpp:66-77)
 __device__ __forceinline__ double iterate_gs(const MgDesc& D, Atom& A, int l, double errorMin, int iterno, double* red, long* nsweeps)
 {
+    // the fused pass pays off only where the chunk is long compared with its 3x96-node warm-up (measured: C >= 512)
+    if (iterno == 3 && !D.lv[l].seq && D.lv[l].logC >= kFuseMinLogC) {
+        double e1, e2, e3;
+        gs_fused3(D, A, l, red, e1, e2, e3);
+        if (!(e1 < errorMin) && !(e2 < errorMin)) {          // the reference runs all three sweeps
+            A.cur ^= (1u << l);
+            *nsweeps += 3;
+            return e3;
+        }
+        __syncthreads();                                      // rare: it stops early -- redo from the untouched input copy
+    }
     double err = 1E10;
     for (int i = 0; i < iterno; ++i) {
         err = gauss_seidel(D, A, l, red);
@@ -370,7 +523,7 @@ __global__ __launch_bounds__(kThreads) void k_poisson_solve(const MgDesc* __rest
                                                             int* __restrict__ vcycles, double* __restrict__ errs,
                                                             unsigned long long* __restrict__ total_vcycles)
 {
-    __shared__ double red[4];
+    __shared__ double red[12];
     __shared__ double seqmem[3 * kSeqCap];
     const MgDesc& D = *Dp;
     const int a = blockIdx.x;
@@ -407,7 +560,7 @@ __global__ __launch_bounds__(kThreads) void k_poisson_solve(const MgDesc* __rest
 __global__ __launch_bounds__(kThreads) void k_unit(const MgDesc* __restrict__ Dp, double* phi0, double* phi1, double* src, int* cur, int op,
                                                    int lvl, int sweeps, double* out)
 {
-    __shared__ double red[4];
+    __shared__ double red[12];
     __shared__ double seqmem[3 * kSeqCap];
     const MgDesc& D = *Dp;
     Atom A;
@@ -433,6 +586,12 @@ __global__ __launch_bounds__(kThreads) void k_unit(const MgDesc* __restrict__ Dp
         }
     } else if (op == 1) restrict_to(D, A, lvl);
     else if (op == 2) prolong_from(D, A, lvl);
+    else if (op == 4) {                                   // IterateGaussSeidel(lvl, errorMin = out[0], iterno = sweeps)
+        const double emin = out[0];
+        __syncthreads();
+        const double e = iterate_gs(D, A, lvl, emin, sweeps, red, &c.sweeps);
+        if (threadIdx.x == 0) { out[0] = e; out[1] = (double)c.sweeps; }
+    }
     else if (op == 3) {
         const int nramp = D.levels - 2 > 0 ? D.levels - 2 : 0;
         const double e = run_cycles(D, A, 2 * nramp + 2, 1, 1E-14, 1E-14, red, c);   // one VCycle(last, 1E-14, 3)
@@ -649,6 +808,26 @@ int dfta_poisson_gauss_seidel(dfta_poisson* p, int lvl, int sweeps, double* err_
     if (!p) return DFTA_ERR_INVALID;
     DFTA_REQUIRE(p->ctx, lvl >= 0 && lvl < p->D.levels && sweeps >= 1 && sweeps <= 1024, "level/sweeps");
     return unit_op(p, 0, lvl, sweeps, err_out, err_out ? sweeps : 0);
+}
+int dfta_poisson_iterate_gs(dfta_poisson* p, int lvl, double errorMin, int iterno, double* err_out, int* sweeps_out)
+{
+    if (!p) return DFTA_ERR_INVALID;
+    dfta_ctx* ctx = p->ctx;
+    DFTA_REQUIRE(ctx, lvl >= 0 && lvl < p->D.levels && iterno >= 1 && iterno <= 1024, "level/iterno");
+    hipStream_t st = ctx->stream;
+    DevBuf<double> dOut;
+    DFTA_HIP(ctx, dOut.alloc(2));
+    DFTA_HIP(ctx, hipMemcpyAsync(dOut.p, &errorMin, sizeof(double), hipMemcpyHostToDevice, st));
+    DFTA_HIP(ctx, hipMemcpyAsync(p->d_cur, p->h_cur.data(), sizeof(int) * kMaxLevels, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_unit, dim3(1), dim3(kThreads), 0, st, p->d_desc, p->d_phi0, p->d_phi1, p->d_src, p->d_cur, 4, lvl, iterno, dOut.p);
+    DFTA_CHECK_LAUNCH(ctx);
+    double out[2] = {0, 0};
+    DFTA_HIP(ctx, hipMemcpyAsync(p->h_cur.data(), p->d_cur, sizeof(int) * kMaxLevels, hipMemcpyDeviceToHost, st));
+    DFTA_HIP(ctx, hipMemcpyAsync(out, dOut.p, sizeof(out), hipMemcpyDeviceToHost, st));
+    DFTA_HIP(ctx, hipStreamSynchronize(st));
+    if (err_out) *err_out = out[0];
+    if (sweeps_out) *sweeps_out = (int)out[1];
+    return DFTA_OK;
 }
 int dfta_poisson_restrict(dfta_poisson* p, int lvl)
 {

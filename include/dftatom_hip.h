@@ -155,6 +155,9 @@ int  dfta_poisson_level_size(const dfta_poisson* p, int lvl);
 int  dfta_poisson_set_level(dfta_poisson* p, int lvl, const double* Phi, const double* Src);
 int  dfta_poisson_get_level(dfta_poisson* p, int lvl, double* Phi, double* Src);
 int  dfta_poisson_gauss_seidel(dfta_poisson* p, int lvl, int sweeps, double* err_out /* per sweep */);
+/* IterateGaussSeidel (PoissonSolver.cpp:66-77): up to iterno sweeps, stops after a sweep with err < errorMin;
+ * three sweeps of a chunked level run as one fused pass (same arithmetic, one third of the memory traffic) */
+int  dfta_poisson_iterate_gs(dfta_poisson* p, int lvl, double errorMin, int iterno, double* err_out, int* sweeps_out);
 int  dfta_poisson_restrict(dfta_poisson* p, int lvl);
 int  dfta_poisson_prolong(dfta_poisson* p, int lvl_src);
 int  dfta_poisson_vcycle(dfta_poisson* p, double* err_out);

@@ -362,3 +362,30 @@ def test_full_size_radon_steps_vs_reference(ctx, grid17):
     assert np.allclose(a, b, rtol=1e-9, atol=0)
     lda.close()
     lsda.close()
+
+
+def test_iterate_gs_fused_equals_single_sweeps(ctx):
+    """IterateGaussSeidel(lvl, errorMin, 3) on the finest level of a 2^17+1 grid runs as one fused pass; it must equal
+    three single sweeps bit for bit, and fall back to the exact sweep count when the reference would stop early."""
+    L, d, R = GRIDS["L17"]
+    grid = D.Grid(ctx, L, d, R)
+    rng = np.random.default_rng(9)
+    n0 = 2 ** 17 + 1
+    phi, src = rng.standard_normal(n0), rng.standard_normal(n0) * 1e-2
+    a, b = D.Poisson(ctx, grid, 1), D.Poisson(ctx, grid, 1)
+    for p in (a, b):
+        p.set_level(0, phi, src)
+    err_f, nsw = a.iterate_gs(0, 0.0, 3)
+    errs = b.gauss_seidel(0, 3)
+    assert nsw == 3 and abs(err_f - errs[2]) <= 1e-12 * errs[2]
+    assert np.array_equal(a.get_level(0)[0], b.get_level(0)[0])
+    # early stop: with errorMin above the first sweep's norm only one sweep may be applied
+    for p in (a, b):
+        p.set_level(0, phi, src)
+    err_1, nsw = a.iterate_gs(0, 1e30, 3)
+    e1 = b.gauss_seidel(0, 1)
+    assert nsw == 1 and abs(err_1 - e1[0]) <= 1e-12 * e1[0]
+    assert np.array_equal(a.get_level(0)[0], b.get_level(0)[0])
+    a.close()
+    b.close()
+    grid.close()
