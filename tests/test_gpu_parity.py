@@ -389,3 +389,22 @@ def test_iterate_gs_fused_equals_single_sweeps(ctx):
     a.close()
     b.close()
     grid.close()
+
+
+def test_open_shell_lsda_vs_oracle(ctx):
+    """Nitrogen (open p shell): alpha and beta levels split; three LSDA SCF steps vs the oracle in the same bracket mode."""
+    L, d, R = 12, 2e-3, 25.0
+    grid = D.Grid(ctx, L, d, R)
+    scf = D.Scf(ctx, grid, [7], lsda=True, levels_mode=D.LEVELS_BATCHED)
+    ref = _oracle_steps(1, 7, L, d, R, 3, 3)
+    for k in range(3):
+        scf.step()
+        en, _ = scf.energies()
+        lv = np.concatenate([scf.levels(0, 0)["E"], scf.levels(0, 1)["E"]])
+        assert len(lv) == 5                                       # alpha 1s 2s 2p, beta 1s 2s
+        assert np.all(np.abs(lv - ref[k][0]) <= 1e-8 + 1e-10 * np.abs(ref[k][0]))
+        assert np.allclose(en[0].as_list(), ref[k][1], rtol=1e-9, atol=0)
+    a, b = scf.levels(0, 0)["E"], scf.levels(0, 1)["E"]
+    assert a[0] < b[0] and a[1] < b[1]                              # majority-spin levels lie deeper
+    scf.close()
+    grid.close()
