@@ -18,6 +18,13 @@ struct Job {
     int phase;
     int haveSgn, sgnBottom, iter3, converged;
     int n_count, n_zero, matchPoint;
+    // path prediction (speculation only, never changes a decision): the decision strings of the three bisections in
+    // the previous SCF step and how many of their leading bits held in the step before -- the next round evaluates
+    // that many nodes along the predicted path (a "spine") and hangs the full speculative tree at its end
+    unsigned long long pred_bits[3], cur_bits[3];
+    int pred_len[3], cur_len[3], trust[3];
+    int phase_done;         // decisions already taken in the running phase
+    int spine;              // spine length of the trial layout of the current round
 };
 
 struct LevelStats {
@@ -34,6 +41,8 @@ struct LevelSolver {
     long ntrials = 0;
     bool clamp_bottoms = true;     // BATCHED runs: bracket bottoms clamped to max(bottom, min Veff_l)
     std::vector<Job> h_jobs_template;
+    std::vector<Job> h_last;       // job records of the previous solve (source of the path predictions)
+    bool use_prediction = true;
     Job* d_jobs = nullptr;
     int *d_chain_off = nullptr, *d_chain_off_b = nullptr, *d_v_off = nullptr, *d_slot_v = nullptr, *d_slot_l = nullptr;
     double2* d_tab = nullptr;

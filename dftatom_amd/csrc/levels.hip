@@ -27,7 +27,26 @@ constexpr int kMaxIter3 = 500;         // DFTAtom.cpp:517
 
 enum Phase { PH_WAIT = 0, PH_TOP = 1, PH_BOTTOM = 2, PH_ZERO = 3, PH_DONE = 4 };
 
-// ---- expand: trial energies of the current tree of every job, plus their far boundary values ---------------
+// ---- trial layout of a round -------------------------------------------------------------------------------------
+// Trial 0 of a job is the Bottom probe of the sign bisection (DFTAtom.cpp:513).  Trials 1..S are the SPINE: the
+// bisection nodes along the predicted decision string (previous SCF step).  Trials S+g, g = 1..2^d'-1, form a full
+// binary tree (heap order) rooted at the end of the spine.  Every node's energy is produced by the reference's own
+// expression (toe + boe) / 2 applied along its path, so whichever nodes the walk visits carry exactly the energies
+// the sequential bisection would have used; the prediction only selects WHICH nodes are integrated speculatively.
+__device__ __forceinline__ int phase_index(int phase) { return phase - 1; }   // PH_TOP, PH_BOTTOM, PH_ZERO -> 0, 1, 2
+
+__device__ __forceinline__ int tree_depth_for(int tpj, int spine)
+{
+    const int room = tpj - spine;            // heap indices 1 .. room-1 are available
+    return room >= 2 ? 31 - __clz(room) : 0; // full levels: nodes 1 .. 2^d' - 1
+}
+
+__device__ __forceinline__ bool pred_bit(const dfta::Job& j, int ph, int k)
+{
+    return (j.pred_bits[ph] >> (k & 63)) & 1ull;
+}
+
+// ---- expand: trial energies of the current round of every job, plus their far boundary values ----------------------
 __global__ __launch_bounds__(256) void k_expand(const dfta::Job* __restrict__ jobs, int tpj, const double* __restrict__ r,
                                                 int N, double delta, double far_thr, double* __restrict__ E,
                                                 int* __restrict__ limit, int* __restrict__ start, double* __restrict__ us,
@@ -44,15 +63,35 @@ __global__ __launch_bounds__(256) void k_expand(const dfta::Job* __restrict__ jo
         if (h == 0) {
             if (j.phase == PH_ZERO && !j.haveSgn) { active = true; e = j.boe; }   // DFTAtom.cpp:513
         } else {
+            const int ph = phase_index(j.phase);
+            const int S = j.spine;
             double hi = j.toe, lo = j.boe;
-            const int depth = 31 - __clz(h);
-            for (int b = depth - 1; b >= 0; --b) {
-                const double m = (hi + lo) / 2;
-                if ((h >> b) & 1) lo = m; else hi = m;          // child 2h: toe = E ; child 2h+1: boe = E
+            int depth;                                        // decisions taken before this node in this round
+            bool exists = true;
+            if (h <= S) {
+                depth = h - 1;
+                for (int k = 0; k < depth; ++k) {
+                    const double m = (hi + lo) / 2;
+                    if (pred_bit(j, ph, j.phase_done + k)) lo = m; else hi = m;
+                }
+            } else {
+                const int g = h - S;
+                const int dsub = tree_depth_for(tpj, S);
+                const int gdepth = 31 - __clz(g);
+                exists = gdepth < dsub;
+                for (int k = 0; k < S; ++k) {
+                    const double m = (hi + lo) / 2;
+                    if (pred_bit(j, ph, j.phase_done + k)) lo = m; else hi = m;
+                }
+                for (int b = gdepth - 1; b >= 0; --b) {
+                    const double m = (hi + lo) / 2;
+                    if ((g >> b) & 1) lo = m; else hi = m;       // child 2g: toe = E ; child 2g+1: boe = E
+                }
+                depth = S + gdepth;
             }
             e = (hi + lo) / 2;
-            if (j.phase == PH_ZERO) active = (depth < kMaxIter3 - j.iter3);
-            else active = (hi - lo > kEnergyErr);                // loop condition of DFTAtom.cpp:571,589
+            if (j.phase == PH_ZERO) active = exists && (depth < kMaxIter3 - j.iter3);
+            else active = exists && (hi - lo > kEnergyErr);       // loop condition of DFTAtom.cpp:571,589
         }
     }
     E[gt] = e;
@@ -79,41 +118,105 @@ __global__ __launch_bounds__(256) void k_expand(const dfta::Job* __restrict__ jo
     }
 }
 
-// ---- walk: follow each tree with the reference's predicates --------------------------------------------------
+// ---- walk: follow each job's spine + tree with the reference's predicates ---------------------------------------------
+// Cursor over the trial layout of a round: returns the trial index of the node reached after the decisions taken so
+// far, or -1 when that node was not part of this round (prediction missed or tree exhausted).
+struct Cursor {
+    int S, dsub, k, g;     // spine length, subtree depth, decisions taken this round, heap index inside the subtree
+    bool off;
+    __device__ void init(int spine, int tpj) { S = spine; dsub = tree_depth_for(tpj, spine); k = 0; g = 1; off = false; }
+    __device__ int node() const
+    {
+        if (off) return -1;
+        if (k < S) return k + 1;
+        const int gdepth = 31 - __clz(g);
+        return gdepth < dsub ? S + g : -1;
+    }
+    __device__ void advance(bool bit, bool predicted)
+    {
+        if (k < S) { if (bit != predicted) off = true; }
+        else g = 2 * g + (bit ? 1 : 0);
+        ++k;
+    }
+};
+
+__device__ __forceinline__ void record_bit(dfta::Job& j, int ph, bool bit)
+{
+    if (j.phase_done < 64) {
+        if (bit) j.cur_bits[ph] |= (1ull << j.phase_done);
+        j.cur_len[ph] = j.phase_done + 1;
+    }
+    ++j.phase_done;
+}
+
+// at the end of a phase: how long did the prediction hold?  Plan the first spine of the next phase.
+__device__ __forceinline__ void finish_phase(dfta::Job& j, int ph)
+{
+    int common = 0;
+    const int m = j.cur_len[ph] < j.pred_len[ph] ? j.cur_len[ph] : j.pred_len[ph];
+    while (common < m && (((j.cur_bits[ph] ^ j.pred_bits[ph]) >> common) & 1ull) == 0ull) ++common;
+    j.trust[ph] = common;       // read by the NEXT solve (after pred := cur)
+    j.phase_done = 0;
+}
+
+__device__ __forceinline__ int plan_spine(const dfta::Job& j, int phase, int tpj)
+{
+    // A miss ON the spine forfeits the tree of that round, so the spine stops one bit short of what held last time
+    // (eigenvalues move by roughly half as much every SCF step: the prediction gains about one bit per step anyway).
+    const int ph = phase_index(phase);
+    int S = j.trust[ph] - 1 - j.phase_done;
+    const int avail = j.pred_len[ph] - j.phase_done;
+    if (S > avail) S = avail;
+    if (S > tpj / 2 - 1) S = tpj / 2 - 1;        // keep at least half of the trials for the tree
+    return S > 0 ? S : 0;
+}
+
 __device__ void walk_job(dfta::Job& j, const int* __restrict__ count, const double* __restrict__ u0, int tpj, int base)
 {
+    Cursor c;
+    c.init(j.spine, tpj);
     if (j.phase == PH_TOP) {                                        // DFTAtom.cpp:568-585
         double hi = j.toe, lo = j.boe;
-        int h = 1;
         while (hi - lo > kEnergyErr) {
-            if (h >= tpj) { j.toe = hi; j.boe = lo; return; }
+            const int h = c.node();
+            if (h < 0) { j.toe = hi; j.boe = lo; j.spine = plan_spine(j, PH_TOP, tpj); return; }
             const double e = (hi + lo) / 2;
-            const int c = count[base + h];
+            const int cn = count[base + h];
             ++j.n_count;
-            if (c > j.nodes) { hi = e; h = 2 * h; } else { lo = e; h = 2 * h + 1; }
+            const bool bit = !(cn > j.nodes);                        // 1: boe = E
+            if (bit) lo = e; else hi = e;
+            c.advance(bit, pred_bit(j, 0, j.phase_done));
+            record_bit(j, 0, bit);
         }
+        finish_phase(j, 0);
         j.top = hi;
         j.toe = hi;
         j.boe = j.bottom0;                                          // DFTAtom.cpp:587
         j.phase = PH_BOTTOM;
+        j.spine = plan_spine(j, PH_BOTTOM, tpj);
         return;
     }
     if (j.phase == PH_BOTTOM) {                                     // DFTAtom.cpp:587-603
         double hi = j.toe, lo = j.boe;
-        int h = 1;
         while (hi - lo > kEnergyErr) {
-            if (h >= tpj) { j.toe = hi; j.boe = lo; return; }
+            const int h = c.node();
+            if (h < 0) { j.toe = hi; j.boe = lo; j.spine = plan_spine(j, PH_BOTTOM, tpj); return; }
             const double e = (hi + lo) / 2;
-            const int c = count[base + h];
+            const int cn = count[base + h];
             ++j.n_count;
-            if (c < j.nodes) { lo = e; h = 2 * h + 1; } else { hi = e; h = 2 * h; }
+            const bool bit = (cn < j.nodes);                         // 1: boe = E
+            if (bit) lo = e; else hi = e;
+            c.advance(bit, pred_bit(j, 1, j.phase_done));
+            record_bit(j, 1, bit);
         }
+        finish_phase(j, 1);
         j.bottom = hi;                                              // BottomEnergy = toe
         j.toe = j.top;
         j.boe = hi;
         j.haveSgn = 0;
         j.iter3 = 0;
         j.phase = PH_ZERO;
+        j.spine = plan_spine(j, PH_ZERO, tpj);
         return;
     }
     if (j.phase == PH_ZERO) {                                       // DFTAtom.cpp:513-534
@@ -124,23 +227,28 @@ __device__ void walk_job(dfta::Job& j, const int* __restrict__ count, const doub
             j.haveSgn = 1;
         }
         double hi = j.toe, lo = j.boe;
-        int h = 1;
         bool conv = false;
         while (j.iter3 < kMaxIter3) {
-            if (h >= tpj) { j.toe = hi; j.boe = lo; return; }
+            const int h = c.node();
+            if (h < 0) { j.toe = hi; j.boe = lo; j.spine = plan_spine(j, PH_ZERO, tpj); return; }
             const double e = (hi + lo) / 2;
             const double d = u0[base + h];
             ++j.n_zero;
             ++j.iter3;
-            if ((d > 0) == (j.sgnBottom != 0)) { lo = e; h = 2 * h + 1; } else { hi = e; h = 2 * h; }
+            const bool bit = ((d > 0) == (j.sgnBottom != 0));        // 1: BottomEnergy = E
+            if (bit) lo = e; else hi = e;
+            c.advance(bit, pred_bit(j, 2, j.phase_done));
+            record_bit(j, 2, bit);
             const double ad = fabs(d);
             if (hi - lo < kEnergyErr && !isnan(ad) && ad < 1E15) { conv = true; break; }
         }
+        finish_phase(j, 2);
         j.toe = hi;
         j.boe = lo;
         j.E = lo;                                                    // level.E = BottomEnergy
         j.converged = conv ? 1 : 0;
         j.phase = PH_DONE;
+        j.spine = 0;
     }
 }
 
@@ -160,6 +268,8 @@ __global__ void k_walk(dfta::Job* __restrict__ jobs, const int* __restrict__ cha
             j.toe = 50;                                             // DFTAtom.cpp:499
             j.boe = bot;
             j.phase = PH_TOP;
+            j.phase_done = 0;
+            j.spine = plan_spine(j, PH_TOP, tpj);
             jobs[k] = j;
             break;                                                  // its trials are generated next round
         }
@@ -384,6 +494,22 @@ int LevelSolver::run(const double* dV, const double* job_bottom, int run_mode, d
         const bool first = (k == 0 || jobs[k].v != jobs[k - 1].v);
         if (!chained || first) { j.phase = PH_TOP; j.toe = 50; j.boe = j.bottom0; }   // DFTAtom.cpp:499
         else j.phase = PH_WAIT;
+        // path prediction from the previous solve of the same job list (speculation only)
+        if (use_prediction && h_last.size() == jobs.size()) {
+            for (int ph = 0; ph < 3; ++ph) {
+                j.pred_bits[ph] = h_last[k].cur_bits[ph];
+                j.pred_len[ph] = h_last[k].cur_len[ph];
+                j.trust[ph] = h_last[k].trust[ph];
+                // the very first comparison has no history: trust what a one-step-old prediction typically gives
+                if (h_last[k].pred_len[ph] == 0) j.trust[ph] = 4;
+            }
+        }
+        if (j.phase == PH_TOP) {
+            int S = j.trust[0] - 1;
+            if (S > j.pred_len[0]) S = j.pred_len[0];
+            if (S > tpj / 2 - 1) S = tpj / 2 - 1;
+            j.spine = S > 0 ? S : 0;
+        }
     }
     DFTA_HIP(ctx, hipMemcpyAsync(d_jobs, jobs.data(), sizeof(Job) * njobs, hipMemcpyHostToDevice, st));
     DFTA_HIP(ctx, hipMemsetAsync(d_counters, 0, sizeof(unsigned long long) * 4, st));
@@ -459,6 +585,7 @@ int LevelSolver::fetch_jobs(std::vector<Job>& out)
     if (njobs == 0) return DFTA_OK;
     DFTA_HIP(ctx, hipMemcpyAsync(out.data(), d_jobs, sizeof(Job) * njobs, hipMemcpyDeviceToHost, ctx->stream));
     DFTA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    h_last = out;            // decision strings of this solve predict the paths of the next one
     return DFTA_OK;
 }
 

@@ -9,6 +9,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <vector>
 
 #include "internal.h"
@@ -344,6 +345,12 @@ int dfta_scf_step(dfta_scf* s, dfta_step_stats* stats)
             s->h_job_bottom[k] = s->h_bottom0[jobs[k].v];
         }
         s->steps_done++;
+        if (getenv("DFTA_DEBUG_LEVELS")) {
+            for (size_t k = 0; k < jobs.size(); ++k)
+                fprintf(stderr, "step %d job %zu n%d l%d: trust %d %d %d  len %d %d %d  pred_len %d %d %d  sweeps %d %d\n", s->steps_done, k, jobs[k].n,
+                        jobs[k].l, jobs[k].trust[0], jobs[k].trust[1], jobs[k].trust[2], jobs[k].cur_len[0], jobs[k].cur_len[1],
+                        jobs[k].cur_len[2], jobs[k].pred_len[0], jobs[k].pred_len[1], jobs[k].pred_len[2], jobs[k].n_count, jobs[k].n_zero);
+        }
     }
     hipLaunchKernelGGL(k_mix, grid, block, 0, st, s->lsda, N, s->alpha, 1. - s->alpha, g->d_fpr2, s->d_newDensity, s->d_density,
                        s->d_dA, s->d_dB);
