@@ -408,6 +408,35 @@ __device__ __forceinline__ void restrict_to(const MgDesc& D, Atom& A, int lvl)
     const double* Sf = A.src_of(Lf);
     double* Sc = A.src_of(Lc);
     const int lim = Lc.n - 1;
+    if (!Lc.seq && !Lf.seq && Lc.logT == Lf.logT && Lc.logC >= 1) {
+        // both levels chunked over the same lanes: coarse node (t, k) sits under fine nodes (t, 2k-1 .. 2k+1), so lane t
+        // streams its own column -- all rows are wave-uniform, every access is coalesced, 4 rows per batch in flight
+        const int T = 1 << Lc.logT, Cc = 1 << Lc.logC, Cf = 1 << Lf.logC, logT = Lc.logT;
+        const int t = threadIdx.x;
+        const double* __restrict__ pf = (((A.cur >> (lvl - 1)) & 1u) ? A.phi1 : A.phi0) + Lf.off;
+        const double* __restrict__ sf = A.src + Lf.off;
+        double* __restrict__ pc = (((A.cur >> lvl) & 1u) ? A.phi1 : A.phi0) + Lc.off;
+        double* __restrict__ sc = A.src + Lc.off;
+        const double dc = Lc.d;
+        if (t < T) {
+            // row -1 of lane t is the last row of lane t-1 (node t*Cf - 1); lane 0 never uses it (coarse node 0 is fixed)
+            double pm = pf[((Cf - 1) << logT) + (t > 0 ? t - 1 : 0)];
+#pragma unroll 4
+            for (int k = 0; k < Cc; ++k) {
+                const double p0 = pf[((2 * k) << logT) + t];
+                const double pp = pf[((2 * k + 1) << logT) + t];
+                const double s0 = sf[((2 * k) << logT) + t];
+                double s = 4. * (s0 + pm - 2. * p0 + pp) - dc * (pp - pm);
+                if (k == 0 && t == 0) s = 0;                       // coarse node 0
+                sc[(k << logT) + t] = s;
+                pc[(k << logT) + t] = 0;
+                pm = pp;
+            }
+        }
+        if (t == 0) { sc[Cc << logT] = 0; pc[Cc << logT] = 0; }    // coarse node n-1
+        __syncthreads();
+        return;
+    }
     for (int idx = threadIdx.x; idx < Lc.n; idx += kThreads) {
         const int i = node_of(Lc, idx);
         Pc[idx] = 0;
@@ -428,6 +457,32 @@ __device__ __forceinline__ void prolong_from(const MgDesc& D, Atom& A, int lvl)
     const Lvl Lc = D.lv[lvl], Lf = D.lv[lvl - 1];
     const double* Pc = A.cur_phi(lvl, Lc);
     double* Pf = A.cur_phi(lvl - 1, Lf);
+    if (!Lc.seq && !Lf.seq && Lc.logT == Lf.logT && Lc.logC >= 1) {
+        // same lane-column structure as in restrict_to: fine (t, 2k) += coarse (t, k); fine (t, 2k-1) += 0.5 (coarse (t, k-1) + coarse (t, k))
+        const int T = 1 << Lc.logT, Cc = 1 << Lc.logC, Cf = 1 << Lf.logC, logT = Lc.logT;
+        const int t = threadIdx.x;
+        const double* __restrict__ pc = (((A.cur >> lvl) & 1u) ? A.phi1 : A.phi0) + Lc.off;
+        double* __restrict__ pf = (((A.cur >> (lvl - 1)) & 1u) ? A.phi1 : A.phi0) + Lf.off;
+        if (t < T) {
+            // coarse value left of this lane's first node: last row of lane t-1 (unused by lane 0: fine node -1 does not exist)
+            double cm = pc[((Cc - 1) << logT) + (t > 0 ? t - 1 : 0)];
+#pragma unroll 4
+            for (int k = 0; k < Cc; ++k) {
+                const double c = pc[(k << logT) + t];
+                pf[((2 * k) << logT) + t] += c;
+                if (k > 0) pf[((2 * k - 1) << logT) + t] += 0.5 * (cm + c);
+                else if (t > 0) pf[((Cf - 1) << logT) + t - 1] += 0.5 * (cm + c);      // fine node t*Cf - 1 lives in lane t-1's column
+                cm = c;
+            }
+            if (t == T - 1) {                                                            // coarse node n-1 and the fine node below it
+                const double cN = pc[Cc << logT];
+                pf[Cf << logT] += cN;
+                pf[((Cf - 1) << logT) + t] += 0.5 * (cm + cN);
+            }
+        }
+        __syncthreads();
+        return;
+    }
     for (int idx = threadIdx.x; idx < Lc.n; idx += kThreads) {
         const int i = node_of(Lc, idx);
         const double c = Pc[idx];
