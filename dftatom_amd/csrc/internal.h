@@ -3,6 +3,8 @@
 #include "common.h"
 
 // numerov.hip
+// doubles2 per table slot in a `bounds` buffer: the fast-division bounds of the slot + { min, max } of veff per block of points
+int dfta_bounds_stride(const dfta_grid* g);
 int dfta_launch_build_tab(dfta_ctx* ctx, const dfta_grid* g, double2* tab, const double* dV, const int* d_slot_v,
                           const int* d_slot_l, int nslots, double2* bounds /* nslots, may be null */);
 int dfta_launch_boundary(dfta_ctx* ctx, const dfta_grid* g, const double* dE, int ntrials, int* dStart, double* dUs,

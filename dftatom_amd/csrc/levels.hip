@@ -412,12 +412,16 @@ int LevelSolver::setup(dfta_ctx* c, const dfta_grid* grid, int mode_, int tree_d
     for (int k = 0; k <= njobs; ++k) chain_off_b.push_back(k);
     nchains_chained = static_cast<int>(chain_off.size()) - 1;
     nchains = (mode == DFTA_LEVELS_CHAINED) ? nchains_chained : njobs;
-    // tree depth: fill the machine (one wave per SIMD = 65536 lanes) with the jobs that are active per round
+    // tree depth.  Few jobs (a handful of atoms): the pipelined sweep kernel runs one 64-trial block per compute unit at
+    // ~1/4 of the fused kernel's time per point, so the best depth keeps the blocks of a round within ~1.5 passes over
+    // the 256 CUs (measured on Rn: depth 10 = 384 blocks beats 9 and 11).  Many jobs: fill the machine with the fused
+    // kernel (one wave per SIMD = 65536 lanes).
     int d = tree_depth;
     if (d <= 0) {
-        const int active = std::max(1, mode == DFTA_LEVELS_CHAINED ? nchains : njobs);
+        const long active = std::max(1, mode == DFTA_LEVELS_CHAINED ? nchains : njobs);
         d = 6;
-        while (d < 14 && (static_cast<long>(active) << (d + 1)) <= 65536L * 1) ++d;
+        if (active <= 768) { while (d < 14 && ((active << (d + 1)) >> 6) <= 384) ++d; }
+        else               { while (d < 14 && (active << (d + 1)) <= 65536L) ++d; }
     }
     d = std::min(std::max(d, 6), 16);
     depth = d;
@@ -464,7 +468,7 @@ int LevelSolver::setup(dfta_ctx* c, const dfta_grid* grid, int mode_, int tree_d
     ALLOC(d_jE, double, njobs); ALLOC(d_jslot, int, njobs); ALLOC(d_jl, int, njobs); ALLOC(d_jstart, int, njobs);
     ALLOC(d_jus, double, njobs); ALLOC(d_jus1, double, njobs); ALLOC(d_jmp, int, njobs);
     ALLOC(d_slot_min, double, nslots);
-    ALLOC(d_bounds, double2, nslots);
+    ALLOC(d_bounds, double2, (size_t)nslots * dfta_bounds_stride(g));
 #undef ALLOC
 #undef UPLOAD
     DFTA_HIP(ctx, hipEventCreate(&ev[0]));

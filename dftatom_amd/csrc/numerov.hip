@@ -16,6 +16,9 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
 #include <numeric>
 #include <vector>
 
@@ -78,6 +81,8 @@ __global__ void k_boundary(const double* __restrict__ r, const double* __restric
 typedef unsigned long long lanemask_t;
 constexpr int kChunk = 8;             // grid points per prefetched batch of the sweep body
 constexpr int kBoundFrom = kChunk;    // the sweep body never touches i < kChunk (tail loop)
+constexpr int kPipeChunk = 16;        // grid points per stage of the pipelined kernel
+constexpr int kPipeMaxBlocks = 768;   // above this many 64-trial blocks the fused kernel fills every SIMD anyway
 
 struct SweepState {
     double w, wprev, u, fprev, prevSol;
@@ -145,7 +150,9 @@ __device__ __forceinline__ void count_step(CountState& c, int& budget, const int
 
 struct SweepArgs {
     const double2* tab;        // slot tables
-    const double2* bounds;     // per slot: { max_i |veff_i| R2 e2_i, max_i R2 e2_i } (fast-division range proof), or null
+    const double2* bounds;     // per slot (stride bstride): { max_i |veff_i| R2 e2_i, max_i R2 e2_i } (fast-division range proof),
+                               // followed by { min, max } of veff over the aligned blocks of kPipeChunk points; or null
+    int bstride;
     const int* blk_slot;       // per block: table slot
     const int* blk_first;      // per block: first trial
     const int* blk_cnt;        // per block: number of trials (<= 64)
@@ -192,7 +199,7 @@ __device__ __forceinline__ void sweep_wave(const SweepArgs& a, const GridScalars
     // can the whole wave use the division fast path?  |f| <= max|veff| R2 e2 + |E| max R2 e2 + delta^2/4 < 6 => d in (0.5, 1.5)
     bool fast = false;
     if (a.bounds) {
-        const double2 bd = a.bounds[slot];
+        const double2 bd = a.bounds[(size_t)slot * a.bstride];
         const bool lane_ok = !valid || (bd.x + fabs(E) * bd.y + d2p4 < 6.0);
         fast = (__ballot(lane_ok) == ~0ull);
     }
@@ -367,10 +374,382 @@ __global__ __launch_bounds__(256) void k_sweep(SweepArgs a, GridScalars gs, int 
     else                          sweep_wave<DFTA_SWEEP_ZERO, CH>(a, gs, b, lane);
 }
 
+// ---- pipelined sweep: one workgroup = one block of 64 trials, its five waves are the stages of a pipeline ----------
+// A SIMD of gfx950 issues one fp64 VALU instruction of a wave64 every 4 cycles, whether it has one wave or several.
+// The fused kernel above spends ~19 of them per grid point in ONE wave (plus exposed v_rcp_f64 / load latency), i.e.
+// 80-90 ns per point and trial block when the machine is not full -- the situation of a single atom (a few hundred
+// blocks on 1024 SIMDs).  Only 5 of those instructions form the loop-carried chain u -> u f -> w -> q -> rem -> u.
+// Here the work of a block is spread over the four SIMDs of a compute unit (wave w runs on SIMD w mod 4):
+//     waves 0,1,3  producers   f_i, d_i = 1 - f_i/12 and the refined reciprocal of d_i, 4/6/6 points of a chunk -> LDS
+//     wave  2      integrator  the loop-carried recurrence only (6 VALU instructions per point)           -> u_i to LDS
+//     wave  4      counter     CountNodes' bookkeeping on u_i (lane masks in scalar registers); shares SIMD 0
+// The stages are chunks of CH grid points apart (software pipeline, one s_barrier per chunk): at iteration `it` the
+// producers write chunk it, the integrator loads chunk it-1 into registers while it integrates chunk it-2, the
+// counter examines chunk it-3.  Every floating-point operation is the one the fused kernel executes, in the same
+// order, so results are bit-identical.
+typedef double v2d __attribute__((ext_vector_type(2)));
+
+template <int CH>
+struct PipeShared {
+    v2d rows[4][CH];             // table rows {veff_i, e2_i} of the last four chunks (wave-uniform data)
+    double prod[3][CH][3][64];   // f, d, r per point and lane
+    double u[2][CH][64];         // integrator -> counter
+    double fin[64];              // u(0) of every lane at the end of a COUNT sweep
+    int stop;                    // set by the counter when every lane has left CountNodes' loop
+};
+
+// One table row per lane, issued without the compiler's bookkeeping ...
+__device__ __forceinline__ void tab_load(v2d& x, const double2* p)
+{
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(x) : "v"(p) : "memory");
+}
+// ... and the matching wait: vector-memory loads return in order, so "at most YOUNGER loads outstanding" means X has
+// landed.  X is an in/out operand so that no use of it can be scheduled above the wait.  (hipcc's own waitcnt
+// insertion drains vmcnt to 0 at a loop header, which would expose the full memory latency once per trip.)
+template <int YOUNGER>
+__device__ __forceinline__ void tab_wait(v2d& X)
+{
+    asm volatile("s_waitcnt vmcnt(%1)" : "+v"(X) : "n"(YOUNGER) : "memory");
+}
+
+// s_barrier without the vmcnt(0) that __syncthreads() implies: table prefetches stay in flight across the barrier
+#define PIPE_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+struct PipeTrial {          // what every wave of the block knows about its lane's trial
+    double E;
+    int my_hi;              // this lane integrates i = my_hi .. 1
+    bool valid;
+    int ihi, ilo;           // wave-uniform: max / min of my_hi over the valid lanes
+    int nch, nit, N;
+};
+
+// Producer of the points OFF .. OFF+CNT-1 of every chunk.  Lane k < CNT fetches the table row of point OFF+k, kPD = 4
+// chunks ahead (one vector load per chunk and producer); when the row set has landed it is parked in LDS, from where
+// every lane reads the rows back as broadcasts -- wave-uniform operands at the cost of LDS instructions, not VALU ones.
+template <bool COUNT, int CH, int OFF, int CNT>
+__device__ __forceinline__ bool pipe_producer(PipeShared<CH>& sh, const double2* __restrict__ T, const PipeTrial& tr, const int lane,
+                                              const double R2, const double d2p4)
+{
+    const double E = tr.E;
+    v2d X0, X1, X2, X3;
+    auto load = [&](v2d& X, int c) {
+        const int i = (tr.nch - c) * CH - OFF - lane;       // rows above ihi (first chunk) and below 1 (past the end) are never used
+        if (lane < CNT) tab_load(X, T + min(max(i, 1), tr.N - 1));
+    };
+    load(X0, 0);
+    load(X1, 1);
+    load(X2, 2);
+    load(X3, 3);
+    int ps = 0;                                            // it % 3
+    volatile int* stop = &sh.stop;
+    auto stage = [&](v2d& X, int it) -> bool {
+        tab_wait<3>(X);                                    // the load of X is older than the three behind it
+        // unconditional (chunks past the end clamp at i = 1 and are never read): the wait counts stay exact
+        v2d* rows = &sh.rows[it & 3][OFF];
+        if (lane < CNT) rows[lane] = X;
+        double* P = &sh.prod[ps][OFF][0][lane];
+        v2d rowv[CNT];
+#pragma unroll
+        for (int kk = 0; kk < CNT; ++kk) rowv[kk] = rows[kk];               // all broadcasts in flight before the first use
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kk = 0; kk < CNT; ++kk) {
+            const v2d row = rowv[kk];
+            const double f = (row.x - E) * R2 * row.y + d2p4;                // Numerov.h:100
+            const double d = 1. - kH2p12 * f;
+            double rr = __builtin_amdgcn_rcp(d);                             // reciprocal of hipcc's fp64 division sequence
+            double e = __builtin_fma(-d, rr, 1.0);
+            rr = __builtin_fma(rr, e, rr);
+            e = __builtin_fma(-d, rr, 1.0);
+            rr = __builtin_fma(rr, e, rr);
+            P[kk * 192] = f;
+            P[kk * 192 + 64] = d;
+            P[kk * 192 + 128] = rr;
+        }
+        load(X, it + 4);
+        ps = ps == 2 ? 0 : ps + 1;
+        PIPE_BARRIER();
+        return COUNT && (it & 1) && *stop != 0;
+    };
+    bool stopped = false;
+    for (int it = 0; it < tr.nit; it += 4) {
+        if (stage(X0, it)) { stopped = true; break; }
+        if (stage(X1, it + 1)) { stopped = true; break; }
+        if (stage(X2, it + 2)) { stopped = true; break; }
+        if (stage(X3, it + 3)) { stopped = true; break; }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // retire the prefetches that ran past the end
+    return stopped;
+}
+
+template <int KIND, int CH>
+__device__ __forceinline__ void sweep_pipe(const SweepArgs& a, const GridScalars& gs, const int b, const int lane, const int role,
+                                           PipeShared<CH>& sh)
+{
+    constexpr bool COUNT = (KIND == DFTA_SWEEP_COUNT);
+    const int cnt = a.blk_cnt[b];
+    const int t = a.blk_first[b] + (lane < cnt ? lane : 0);
+    const bool valid = (lane < cnt) && (a.start[t] >= 2);
+    const lanemask_t vmask = __ballot(valid);
+    if (vmask == 0ull) return;       // same decision in all waves
+    const int slot = a.blk_slot[b];
+    const double2* __restrict__ T = a.tab + (size_t)slot * gs.N;
+    const double R2 = 2. * gs.Rp2delta2;
+    const double d2p4 = gs.delta2p4;
+    const double E = a.E[t];
+    const int start = valid ? a.start[t] : 2;
+    const int limit = COUNT ? a.limit[t] : 0;
+
+    PipeTrial tr;
+    tr.E = E;
+    tr.N = gs.N;
+    tr.valid = valid;
+    tr.my_hi = valid ? start - 2 : 0;
+    const int my_hi = tr.my_hi;
+    int ihi = my_hi, ilo = valid ? my_hi : 0x7fffffff;
+    for (int off = 32; off > 0; off >>= 1) {
+        ihi = max(ihi, __shfl_xor(ihi, off));
+        ilo = min(ilo, __shfl_xor(ilo, off));
+    }
+    ihi = tr.ihi = __builtin_amdgcn_readfirstlane(ihi);
+    ilo = tr.ilo = __builtin_amdgcn_readfirstlane(ilo);
+    const int nch = tr.nch = (ihi + CH - 1) / CH;          // chunk c is the aligned block i = (nch - c) CH .. (nch - c - 1) CH + 1
+    const int nit = tr.nit = (nch + (COUNT ? 3 : 2) + 3) & ~3;   // multiple of four: the stage loops are unrolled by two or four
+    volatile int* stop = &sh.stop;
+    if (threadIdx.x == 0) *stop = 0;
+    PIPE_BARRIER();
+    bool stopped = false;
+    // a chunk can take the straight-line paths when it is complete, inside the range of the division bounds, and
+    // no lane joins the sweep inside it (every lane is in or out for the whole chunk)
+    auto plain_chunk = [&](int top) -> bool {
+        if (top == CH) return false;                       // the innermost block holds i < kBoundFrom
+        if (top <= ilo) return true;                       // everybody joined earlier
+        const bool joins = valid && my_hi < top && my_hi > top - CH;
+        return __ballot(joins) == 0ull;
+    };
+
+    if (role == 0)      stopped = pipe_producer<COUNT, CH, 0, 4>(sh, T, tr, lane, R2, d2p4);
+    else if (role == 1) stopped = pipe_producer<COUNT, CH, 4, 6>(sh, T, tr, lane, R2, d2p4);
+    else if (role == 3) stopped = pipe_producer<COUNT, CH, 10, CH - 10>(sh, T, tr, lane, R2, d2p4);
+    else if (role == 2) {
+        // ---------------- integrator
+        bool fast = false;
+        if (a.bounds) {
+            const double2 bd = a.bounds[(size_t)slot * a.bstride];
+            const bool lane_ok = !valid || (bd.x + fabs(E) * bd.y + d2p4 < 6.0);
+            fast = (__ballot(lane_ok) == ~0ull);
+        }
+        SweepState s;
+        {
+            const double2 ts = T[start];
+            const double2 t1 = T[start - 1];
+            const double us = a.us[t];
+            s.u = a.us1[t];
+            s.fprev = (ts.x - E) * R2 * ts.y + d2p4;
+            s.wprev = (1 - kH2p12 * s.fprev) * us;
+            s.fprev = (t1.x - E) * R2 * t1.y + d2p4;
+            s.w = (1 - kH2p12 * s.fprev) * s.u;
+            s.prevSol = us;
+        }
+        struct Regs { double f[CH], d[CH], r[CH]; };
+        Regs RA, RB;
+        int ls = 0;                                            // (it - 1) % 3: the prod buffer of the chunk to load
+        auto stage = [&](Regs& cur, Regs& nxt, int it) -> bool {
+            const int cl = it - 1;
+            if (cl >= 0 && cl < nch) {
+                const double* P = &sh.prod[ls][0][0][lane];
+#pragma unroll
+                for (int k = 0; k < CH; ++k) { nxt.f[k] = P[k * 192]; nxt.d[k] = P[k * 192 + 64]; nxt.r[k] = P[k * 192 + 128]; }
+            }
+            if (it >= 1) ls = ls == 2 ? 0 : ls + 1;
+            __builtin_amdgcn_sched_barrier(0);
+            const int c = it - 2;
+            if (c >= 0 && c < nch) {
+                const int top = (nch - c) * CH;
+                double* U = &sh.u[c & 1][0][lane];
+                if (fast && plain_chunk(top)) {
+                    if (valid && my_hi >= top) {
+#pragma unroll
+                        for (int k = 0; k < CH; ++k) {
+                            // Numerov.h:311 (h2 == 1): 2 w is exact, so fma(2, w, -wprev) is the reference's 2 w - wprev
+                            const double wnext = __builtin_fma(2., s.w, -s.wprev) + s.u * s.fprev;
+                            s.wprev = s.w;
+                            s.w = wnext;
+                            s.prevSol = s.u;
+                            const double q = wnext * cur.r[k];
+                            const double rem = __builtin_fma(-cur.d[k], q, wnext);
+                            s.u = __builtin_fma(rem, cur.r[k], q);
+                            s.fprev = cur.f[k];
+                            if (COUNT) U[k * 64] = s.u;
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < CH; ++k) {
+                        const int i = top - k;
+                        const bool fdiv = fast && i >= kBoundFrom;
+                        if (valid && i >= 1 && i <= my_hi) {
+                            const double wnext = 2. * s.w - s.wprev + s.u * s.fprev;
+                            s.wprev = s.w;
+                            s.w = wnext;
+                            s.prevSol = s.u;
+                            if (fdiv) {
+                                const double q = wnext * cur.r[k];
+                                const double rem = __builtin_fma(-cur.d[k], q, wnext);
+                                s.u = __builtin_fma(rem, cur.r[k], q);
+                            } else {
+                                s.u = wnext / cur.d[k];                                   // getU, Numerov.h:510-513
+                            }
+                            s.fprev = cur.f[k];
+                        }
+                        if (COUNT) U[k * 64] = s.u;
+                    }
+                }
+                if (fast) {
+                    // the reciprocal path needs |w| in range: leave it for good when any lane gets near the edges
+                    // (16 decades of cancellation + 1.6 decades per step of a chunk above the 2^-969 limit of v_div_scale)
+                    const double au = fabs(s.u);
+                    const bool ok = !valid || (au < 1e200 && (au > 1e-250 || s.u == 0.0));
+                    fast = (__ballot(ok) == ~0ull);
+                }
+            }
+            PIPE_BARRIER();
+            return COUNT && (it & 1) && *stop != 0;
+        };
+        for (int it = 0; it < nit; it += 2) {
+            if (stage(RA, RB, it)) { stopped = true; break; }
+            if (stage(RB, RA, it + 1)) { stopped = true; break; }
+        }
+        if (!COUNT) {
+            if (valid) {
+                if (a.u0) a.u0[t] = s.u * (2 + s.fprev) - s.prevSol;                 // Numerov.h:398
+                if (a.trip) a.trip[t] = my_hi;
+            }
+            if (a.total_trips) {
+                int sum = valid ? my_hi : 0;
+                for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+                if (lane == 0) atomicAdd(a.total_trips, (unsigned long long)sum);
+            }
+        } else if (!stopped) {
+            sh.fin[lane] = s.u * (2 + s.fprev) - s.prevSol;                          // Numerov.h:345
+        }
+    } else {
+        // ---------------- counter
+        CountState c;
+        c.live = vmask;
+        c.oldSgn = __ballot(a.us1[t] > 0);
+        c.flag = 0;
+        int budget = limit + 1;
+        const bool diag = (a.trip != nullptr);
+        int trips = 0;
+        unsigned long long wave_trips = 0;
+        // { min, max } of veff per block, fetched one chunk ahead (vector load with a zero lane offset: a scalar load
+        // would be drained by the lgkmcnt(0) of every barrier)
+        const double2* __restrict__ blkmm =
+            a.bounds ? a.bounds + (size_t)slot * a.bstride + 1 + __builtin_amdgcn_mbcnt_hi(0u, __builtin_amdgcn_mbcnt_lo(0u, 0u)) : nullptr;
+        double2 mm_next = blkmm ? blkmm[max(nch - 1, 0)] : double2{0., 0.};
+        lanemask_t last_le = 0;       // veff <= E at the last point that went through count_step
+        bool poisoned = true;         // last_le unusable (nothing processed yet, or a NaN veff)
+        for (int it = 0; it < nit; ++it) {
+            const int cc = it - 3;
+            if (COUNT && cc >= 0 && cc < nch) {
+                const int top = (nch - cc) * CH;
+                const double* U = &sh.u[cc & 1][0][lane];
+                const v2d* rows = &sh.rows[cc & 3][0];
+                double u[CH];
+#pragma unroll
+                for (int k = 0; k < CH; ++k) u[k] = U[k * 64];
+                const double2 mm = mm_next;                                                  // block nch - 1 - cc
+                if (blkmm) mm_next = blkmm[max(nch - 2 - cc, 0)];
+                bool quiet = false;
+                const lanemask_t started = __ballot(valid && my_hi >= top);
+                const lanemask_t act = c.live & started;
+                if (!poisoned && blkmm && plain_chunk(top)) {
+                    // Nothing can change in this chunk if, for every active lane, veff stays on the side of E it was on
+                    // at the last examined point, u keeps its sign and stays finite: then cross = tp = 0 and flag, live,
+                    // oldSgn are fixed points of count_step (flag already holds stay & m_le, live already lost flag & m_gt).
+                    // Per lane: min, max and max |.| of u over the chunk (a NaN survives to the last point of the chunk
+                    // through the recurrence, and a NaN veff makes u NaN, so the min/max dropping NaNs is harmless).
+                    double mn = u[0], mx = u[0], ma = u[0];
+#pragma unroll
+                    for (int k = 1; k < CH; ++k) {
+                        asm("v_min_f64 %0, %1, %2" : "=v"(mn) : "v"(mn), "v"(u[k]));
+                        asm("v_max_f64 %0, %1, %2" : "=v"(mx) : "v"(mx), "v"(u[k]));
+                        asm("v_max_f64 %0, |%1|, |%2|" : "=v"(ma) : "v"(ma), "v"(u[k]));
+                    }
+                    const lanemask_t fin = __ballot(fabs(ma) < INFINITY && u[CH - 1] == u[CH - 1]);
+                    const lanemask_t allpos = __ballot(mn > 0), nonepos = __ballot(mx <= 0);
+                    const lanemask_t le_all = __ballot(mm.y <= E), gt_all = __ballot(mm.x > E);
+                    const lanemask_t ok = fin & ((c.oldSgn & allpos) | (~c.oldSgn & nonepos)) & ((le_all & last_le) | (gt_all & ~last_le));
+                    quiet = (~ok & act) == 0ull;
+                }
+                if (quiet) {
+                    if (diag) trips += CH * (int)((act >> lane) & 1ull);
+                    wave_trips += (unsigned long long)CH * __popcll(act);
+                } else {
+                    lanemask_t m_le = 0, m_gt = 0;
+#pragma unroll
+                    for (int k = 0; k < CH; ++k) {
+                        const int i = top - k;
+                        if (i >= 1) {
+                            const lanemask_t st = __ballot(valid && i <= my_hi);
+                            const lanemask_t before = c.live & st;
+                            if (diag) trips += (int)((before >> lane) & 1ull);
+                            wave_trips += __popcll(before);
+                            const double veff = rows[k].x;
+                            count_step(c, budget, lane, u[k], veff, E, st);
+                            m_le = __ballot(veff <= E);
+                            m_gt = __ballot(veff > E);
+                        }
+                    }
+                    last_le = m_le;
+                    poisoned = ((m_le | m_gt) != ~0ull);
+                    if ((c.live & vmask) == 0ull && lane == 0) *stop = 1;
+                }
+            }
+            PIPE_BARRIER();
+            if (COUNT && (it & 1) && *stop != 0) { stopped = true; break; }
+        }
+        if (COUNT) {
+            if (!stopped) PIPE_BARRIER();          // pairs with the barrier below: sh.fin is complete
+            const bool exited = valid && !((c.live >> lane) & 1ull);
+            double u0 = NAN;
+            int count = limit + 1 - budget;
+            if (valid && !exited) {
+                u0 = sh.fin[lane];
+                const bool oldSgn = (c.oldSgn >> lane) & 1ull;
+                if ((u0 > 0) != oldSgn) ++count;                                      // Numerov.h:346-347
+            }
+            if (valid) {
+                a.count[t] = count;
+                if (a.u0) a.u0[t] = u0;
+                if (a.trip) a.trip[t] = trips;
+            }
+            if (a.total_trips && lane == 0) atomicAdd(a.total_trips, wave_trips);
+        }
+        return;
+    }
+    if (COUNT && !stopped) PIPE_BARRIER();   // producers and integrator: sh.fin handed to the counter
+}
+
+constexpr int kPipeThreads = 320;
+
+template <int CH>
+__global__ __launch_bounds__(kPipeThreads) void k_sweep_pipe(SweepArgs a, GridScalars gs, int nblocks)
+{
+    __shared__ PipeShared<CH> sh;
+    const int lane = threadIdx.x & 63;
+    const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int b = blockIdx.x;
+    const int kind = a.blk_kind ? __builtin_amdgcn_readfirstlane(a.blk_kind[b]) : a.kind;
+    if (kind == DFTA_SWEEP_COUNT) sweep_pipe<DFTA_SWEEP_COUNT, CH>(a, gs, b, lane, role, sh);
+    else                          sweep_pipe<DFTA_SWEEP_ZERO, CH>(a, gs, b, lane, role, sh);
+}
+
 // per slot: { max_i |veff_i| R2 e2_i, max_i R2 e2_i } over i = kBoundFrom .. N-1 (NaN poisons the bound -> slow division).
 // The innermost points are excluded: there f ~ l(l+1)/i^2 (f_1 = 12 for l = 3, i.e. 1 - f/12 = 0), and they are always
 // integrated by the tail loop with the plain IEEE division.
-__global__ __launch_bounds__(256) void k_slot_bounds(const double2* __restrict__ tab, int N, double R2, double2* __restrict__ bounds)
+__global__ __launch_bounds__(256) void k_slot_bounds(const double2* __restrict__ tab, int N, double R2, double2* __restrict__ bounds, int bstride)
 {
     __shared__ double red[8];
     const double2* T = tab + (size_t)blockIdx.x * N;
@@ -396,8 +775,22 @@ __global__ __launch_bounds__(256) void k_slot_bounds(const double2* __restrict__
         double2 o;
         o.x = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
         o.y = fmax(fmax(red[4], red[5]), fmax(red[6], red[7]));
-        bounds[blockIdx.x] = o;
+        bounds[(size_t)blockIdx.x * bstride] = o;
     }
+}
+
+// per slot and aligned block b of kPipeChunk points (i = b CH + 1 .. (b+1) CH): { min, max } of veff (NaNs are dropped)
+__global__ void k_block_minmax(const double2* __restrict__ tab, int N, double2* __restrict__ bounds, int bstride)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= bstride - 1) return;
+    const double2* T = tab + (size_t)blockIdx.y * N;
+    double mn = INFINITY, mx = -INFINITY;
+    for (int i = b * kPipeChunk + 1; i <= (b + 1) * kPipeChunk && i < N; ++i) { mn = fmin(mn, T[i].x); mx = fmax(mx, T[i].x); }
+    double2 o;
+    o.x = mn;
+    o.y = mx;
+    bounds[(size_t)blockIdx.y * bstride + 1 + b] = o;
 }
 
 // ---- match kernel (Numerov.h:403-504) --------------------------------------------------------------------
@@ -556,6 +949,8 @@ void host_boundary(const dfta_grid* g, double E, int* start, double* us, double*
 
 }  // namespace
 
+int dfta_bounds_stride(const dfta_grid* g) { return 1 + (g->N + kPipeChunk - 1) / kPipeChunk + 1; }
+
 // Launch plumbing shared with levels.hip ------------------------------------------------------------------
 int dfta_launch_build_tab(dfta_ctx* ctx, const dfta_grid* g, double2* tab, const double* dV, const int* d_slot_v,
                           const int* d_slot_l, int nslots, double2* bounds)
@@ -564,7 +959,9 @@ int dfta_launch_build_tab(dfta_ctx* ctx, const dfta_grid* g, double2* tab, const
     hipLaunchKernelGGL(k_build_tab, grid, dim3(256), 0, ctx->stream, tab, dV, g->d_cl, g->d_e2, d_slot_v, d_slot_l, g->N);
     DFTA_CHECK_LAUNCH(ctx);
     if (bounds) {
-        hipLaunchKernelGGL(k_slot_bounds, dim3(nslots), dim3(256), 0, ctx->stream, tab, g->N, 2. * g->Rp2delta2, bounds);
+        const int bstride = dfta_bounds_stride(g);
+        hipLaunchKernelGGL(k_slot_bounds, dim3(nslots), dim3(256), 0, ctx->stream, tab, g->N, 2. * g->Rp2delta2, bounds, bstride);
+        hipLaunchKernelGGL(k_block_minmax, dim3((bstride + 254) / 256, nslots), dim3(256), 0, ctx->stream, tab, g->N, bounds, bstride);
         DFTA_CHECK_LAUNCH(ctx);
     }
     return DFTA_OK;
@@ -584,11 +981,20 @@ int dfta_launch_sweep(dfta_ctx* ctx, const dfta_grid* g, int kind, const int* bl
                       unsigned long long* dTotalTrips, const double2* bounds)
 {
     SweepArgs a;
-    a.kind = kind; a.blk_kind = blk_kind; a.bounds = bounds;
+    a.kind = kind; a.blk_kind = blk_kind; a.bounds = bounds; a.bstride = dfta_bounds_stride(g);
     a.tab = tab; a.blk_slot = blk_slot; a.blk_first = blk_first; a.blk_cnt = blk_cnt; a.E = dE; a.limit = dLimit;
     a.start = dStart; a.us = dUs; a.us1 = dUs1; a.count = dCount; a.u0 = dU0; a.trip = dTrip; a.total_trips = dTotalTrips;
-    const dim3 grid((nblocks + 3) / 4), block(256);
-    hipLaunchKernelGGL((k_sweep<kChunk>), grid, block, 0, ctx->stream, a, scalars_of(g), nblocks);
+    static const int forced = [] {   // DFTA_SWEEP_KERNEL=fused|pipe overrides the choice (measurements)
+        const char* e = getenv("DFTA_SWEEP_KERNEL");
+        return !e ? 0 : (!strcmp(e, "fused") ? 1 : (!strcmp(e, "pipe") ? 2 : 0));
+    }();
+    const bool pipe = forced ? forced == 2 : nblocks <= kPipeMaxBlocks;
+    if (pipe) {
+        hipLaunchKernelGGL((k_sweep_pipe<kPipeChunk>), dim3(nblocks), dim3(kPipeThreads), 0, ctx->stream, a, scalars_of(g), nblocks);
+    } else {
+        const dim3 grid((nblocks + 3) / 4), block(256);
+        hipLaunchKernelGGL((k_sweep<kChunk>), grid, block, 0, ctx->stream, a, scalars_of(g), nblocks);
+    }
     DFTA_CHECK_LAUNCH(ctx);
     return DFTA_OK;
 }
@@ -709,7 +1115,7 @@ extern "C" int dfta_numerov_sweeps(dfta_ctx* ctx, const dfta_grid* g, int kind, 
         if (rc) return rc;
     }
     DevBuf<double2> dBounds;
-    DFTA_HIP(ctx, dBounds.alloc(G.slot_v.size()));
+    DFTA_HIP(ctx, dBounds.alloc(G.slot_v.size() * (size_t)dfta_bounds_stride(g)));
     int rc = dfta_launch_build_tab(ctx, g, dTab.p, dV.p, dSlotV.p, dSlotL.p, (int)G.slot_v.size(), dBounds.p);
     if (rc) return rc;
     DFTA_HIP(ctx, hipEventRecord(ctx->ev[0], st));
@@ -772,7 +1178,7 @@ extern "C" int dfta_numerov_sweeps_dev(dfta_ctx* ctx, const dfta_grid* g, int ki
         pStart = dSt.p; pUs = dA.p; pUs1 = dB.p;
     }
     DevBuf<double2> dBounds;
-    DFTA_HIP(ctx, dBounds.alloc(ngroups));
+    DFTA_HIP(ctx, dBounds.alloc((size_t)ngroups * dfta_bounds_stride(g)));
     int rc = dfta_launch_build_tab(ctx, g, dTab.p, dV, dSlotV.p, dSlotL.p, ngroups, dBounds.p);
     if (rc) return rc;
     rc = dfta_launch_sweep(ctx, g, kind, nullptr, (int)bs.size(), dTab.p, dBs.p, dBf.p, dBc.p, dE, dLimit, pStart, pUs, pUs1, dCount,
