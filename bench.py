@@ -145,6 +145,10 @@ def main():
         en, fin = scf.energies()
         ncu, devname = ctx.device_info()
         launches = max(tot["rounds"], 1)
+        # dfta_launch_sweep picks the pipelined kernel for up to 768 blocks of 64 trials per round (numerov.hip:kPipeMaxBlocks)
+        forced = os.environ.get("DFTA_SWEEP_KERNEL", "")
+        piped = forced == "pipe" or (forced != "fused" and scf.trials_per_round // 64 <= 768)
+        kname = "k_sweep_pipe" if piped else "k_sweep"
         bytes_total = NUMEROV_BYTES_PER_POINT * tot["points"]
         achieved = bytes_total / (tot["ms_sweep"] * 1e-3) / 1e9 if tot["ms_sweep"] > 0 else 0.0
         out = {
@@ -173,14 +177,14 @@ def main():
             "rounds_per_step": tot["rounds"] / args.steps,
             "energies_last_step": en[0].as_list(),
             "device": devname, "compute_units": ncu,
-            "roofline": {"bound": "hbm", "kernel": "k_sweep (Numerov count/zero sweeps)",
+            "roofline": {"bound": "hbm", "kernel": kname + " (Numerov count/zero sweeps)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": pmc_traffic("k_sweep"),
+                         "traffic": pmc_traffic(kname),
                          "bytes_per_launch": bytes_total / launches, "avg_launch_ms": tot["ms_sweep"] / launches,
                          "launches": launches,
-                         "note": "algorithmic bytes = 8 B x traversed grid points of every ISSUED trial (SURVEY 8d); trials of a "
-                                 "wave share V through scalar loads, so HBM traffic is far below this figure -- the kernel is "
-                                 "fp64-VALU-issue bound"},
+                         "note": "algorithmic bytes = 8 B x traversed grid points of every ISSUED trial (SURVEY 8d); the 64 trials "
+                                 "of a block share the potential table, so HBM traffic is far below this figure -- the kernel is "
+                                 "bound by the sequential fp64 recurrence (VALU issue + LDS hand-over), see DESIGN.md"},
             "poisson_roofline": {"bound": "hbm", "kernel": "k_poisson_solve (persistent multigrid)",
                                  "achieved": (POISSON_BYTES_PER_VCYCLE.get(args.levels, 0) * tot["vcycles"] /
                                               (tot["ms_poisson"] * 1e-3) / 1e9) if tot["ms_poisson"] > 0 else None,

@@ -392,7 +392,7 @@ typedef double v2d __attribute__((ext_vector_type(2)));
 template <int CH>
 struct PipeShared {
     v2d rows[4][CH];             // table rows {veff_i, e2_i} of the last four chunks (wave-uniform data)
-    double prod[3][CH][3][64];   // f, d, r per point and lane
+    double prod[3][CH][2][64];   // f_i and the refined reciprocal r_i of d_i = 1 - f_i/12, per point and lane
     double u[2][CH][64];         // integrator -> counter
     double fin[64];              // u(0) of every lane at the end of a COUNT sweep
     int stop;                    // set by the counter when every lane has left CountNodes' loop
@@ -410,6 +410,13 @@ template <int YOUNGER>
 __device__ __forceinline__ void tab_wait(v2d& X)
 {
     asm volatile("s_waitcnt vmcnt(%1)" : "+v"(X) : "n"(YOUNGER) : "memory");
+}
+
+__device__ __forceinline__ double read_lane(double v, int k)
+{
+    const long long b = __builtin_bit_cast(long long, v);
+    const unsigned lo = __builtin_amdgcn_readlane((int)(unsigned)b, k), hi = __builtin_amdgcn_readlane((int)(unsigned)(b >> 32), k);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | lo);
 }
 
 // s_barrier without the vmcnt(0) that __syncthreads() implies: table prefetches stay in flight across the barrier
@@ -445,26 +452,20 @@ __device__ __forceinline__ bool pipe_producer(PipeShared<CH>& sh, const double2*
     auto stage = [&](v2d& X, int it) -> bool {
         tab_wait<3>(X);                                    // the load of X is older than the three behind it
         // unconditional (chunks past the end clamp at i = 1 and are never read): the wait counts stay exact
-        v2d* rows = &sh.rows[it & 3][OFF];
-        if (lane < CNT) rows[lane] = X;
+        if (COUNT && lane < CNT) sh.rows[it & 3][OFF + lane] = X;           // veff_i for the counter's point-by-point path
         double* P = &sh.prod[ps][OFF][0][lane];
-        v2d rowv[CNT];
-#pragma unroll
-        for (int kk = 0; kk < CNT; ++kk) rowv[kk] = rows[kk];               // all broadcasts in flight before the first use
-        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int kk = 0; kk < CNT; ++kk) {
-            const v2d row = rowv[kk];
-            const double f = (row.x - E) * R2 * row.y + d2p4;                // Numerov.h:100
+            const double veff = read_lane(X.x, kk), e2 = read_lane(X.y, kk);   // wave-uniform operands (scalar registers)
+            const double f = (veff - E) * R2 * e2 + d2p4;                    // Numerov.h:100
             const double d = 1. - kH2p12 * f;
             double rr = __builtin_amdgcn_rcp(d);                             // reciprocal of hipcc's fp64 division sequence
             double e = __builtin_fma(-d, rr, 1.0);
             rr = __builtin_fma(rr, e, rr);
             e = __builtin_fma(-d, rr, 1.0);
             rr = __builtin_fma(rr, e, rr);
-            P[kk * 192] = f;
-            P[kk * 192 + 64] = d;
-            P[kk * 192 + 128] = rr;
+            P[kk * 128] = f;
+            P[kk * 128 + 64] = rr;
         }
         load(X, it + 4);
         ps = ps == 2 ? 0 : ps + 1;
@@ -523,8 +524,8 @@ __device__ __forceinline__ void sweep_pipe(const SweepArgs& a, const GridScalars
     // no lane joins the sweep inside it (every lane is in or out for the whole chunk)
     auto plain_chunk = [&](int top) -> bool {
         if (top == CH) return false;                       // the innermost block holds i < kBoundFrom
-        if (top <= ilo) return true;                       // everybody joined earlier
-        const bool joins = valid && my_hi < top && my_hi > top - CH;
+        if (top < ilo) return true;                        // everybody joined earlier
+        const bool joins = valid && my_hi <= top && my_hi > top - CH;   // (a lane that starts at `top` itself must be reset too)
         return __ballot(joins) == 0ull;
     };
 
@@ -551,67 +552,77 @@ __device__ __forceinline__ void sweep_pipe(const SweepArgs& a, const GridScalars
             s.w = (1 - kH2p12 * s.fprev) * s.u;
             s.prevSol = us;
         }
-        struct Regs { double f[CH], d[CH], r[CH]; };
+        const SweepState s0 = s;                               // a lane (re)starts from here at i = my_hi
+        struct Regs { double f[CH], r[CH]; };
         Regs RA, RB;
         int ls = 0;                                            // (it - 1) % 3: the prod buffer of the chunk to load
         auto stage = [&](Regs& cur, Regs& nxt, int it) -> bool {
-            const int cl = it - 1;
-            if (cl >= 0 && cl < nch) {
-                const double* P = &sh.prod[ls][0][0][lane];
-#pragma unroll
-                for (int k = 0; k < CH; ++k) { nxt.f[k] = P[k * 192]; nxt.d[k] = P[k * 192 + 64]; nxt.r[k] = P[k * 192 + 128]; }
-            }
+            // chunk it-1 goes into registers while chunk it-2 is integrated (reads of a chunk that does not exist
+            // return stale LDS contents that are never used)
+            const double* P = &sh.prod[ls][0][0][lane];
             if (it >= 1) ls = ls == 2 ? 0 : ls + 1;
-            __builtin_amdgcn_sched_barrier(0);
             const int c = it - 2;
-            if (c >= 0 && c < nch) {
-                const int top = (nch - c) * CH;
-                double* U = &sh.u[c & 1][0][lane];
-                if (fast && plain_chunk(top)) {
-                    if (valid && my_hi >= top) {
+            const bool have = c >= 0 && c < nch;
+            const int top = (nch - c) * CH;
+            double* U = &sh.u[c & 1][0][lane];
+            if (have && fast && plain_chunk(top)) {
+                // Straight-line code for all 64 lanes: lanes that have not started yet integrate garbage (they are reset
+                // to s0 when they join, in the other branch).  The LDS reads of the next chunk are interleaved with
+                // the recurrence (6 VALU : 2 DS reads per point) -- issued in one burst they would stall the wave.
 #pragma unroll
-                        for (int k = 0; k < CH; ++k) {
-                            // Numerov.h:311 (h2 == 1): 2 w is exact, so fma(2, w, -wprev) is the reference's 2 w - wprev
-                            const double wnext = __builtin_fma(2., s.w, -s.wprev) + s.u * s.fprev;
-                            s.wprev = s.w;
-                            s.w = wnext;
-                            s.prevSol = s.u;
-                            const double q = wnext * cur.r[k];
-                            const double rem = __builtin_fma(-cur.d[k], q, wnext);
-                            s.u = __builtin_fma(rem, cur.r[k], q);
-                            s.fprev = cur.f[k];
-                            if (COUNT) U[k * 64] = s.u;
-                        }
-                    }
-                } else {
+                for (int k = 0; k < CH; ++k) {
+                    // Numerov.h:311 (h2 == 1): 2 w is exact, so fma(2, w, -wprev) is the reference's 2 w - wprev
+                    const double wnext = __builtin_fma(2., s.w, -s.wprev) + s.u * s.fprev;
+                    s.wprev = s.w;
+                    s.w = wnext;
+                    s.prevSol = s.u;
+                    const double d = 1. - kH2p12 * cur.f[k];                 // off the loop-carried chain
+                    const double q = wnext * cur.r[k];
+                    const double rem = __builtin_fma(-d, q, wnext);
+                    s.u = __builtin_fma(rem, cur.r[k], q);
+                    s.fprev = cur.f[k];
+                    if (COUNT) U[k * 64] = s.u;
+                    nxt.f[k] = P[k * 128];
+                    nxt.r[k] = P[k * 128 + 64];
+                    __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    if (COUNT) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < CH; ++k) { nxt.f[k] = P[k * 128]; nxt.r[k] = P[k * 128 + 64]; }
+                __builtin_amdgcn_sched_barrier(0);
+                if (have) {
 #pragma unroll
                     for (int k = 0; k < CH; ++k) {
                         const int i = top - k;
                         const bool fdiv = fast && i >= kBoundFrom;
-                        if (valid && i >= 1 && i <= my_hi) {
+                        if (valid && i <= my_hi) {
+                            if (i == my_hi) s = s0;
                             const double wnext = 2. * s.w - s.wprev + s.u * s.fprev;
                             s.wprev = s.w;
                             s.w = wnext;
                             s.prevSol = s.u;
+                            const double d = 1. - kH2p12 * cur.f[k];
                             if (fdiv) {
                                 const double q = wnext * cur.r[k];
-                                const double rem = __builtin_fma(-cur.d[k], q, wnext);
+                                const double rem = __builtin_fma(-d, q, wnext);
                                 s.u = __builtin_fma(rem, cur.r[k], q);
                             } else {
-                                s.u = wnext / cur.d[k];                                   // getU, Numerov.h:510-513
+                                s.u = wnext / d;                                          // getU, Numerov.h:510-513
                             }
                             s.fprev = cur.f[k];
                         }
                         if (COUNT) U[k * 64] = s.u;
                     }
                 }
-                if (fast) {
-                    // the reciprocal path needs |w| in range: leave it for good when any lane gets near the edges
-                    // (16 decades of cancellation + 1.6 decades per step of a chunk above the 2^-969 limit of v_div_scale)
-                    const double au = fabs(s.u);
-                    const bool ok = !valid || (au < 1e200 && (au > 1e-250 || s.u == 0.0));
-                    fast = (__ballot(ok) == ~0ull);
-                }
+            }
+            if (have && fast) {
+                // the reciprocal path needs |w| in range: leave it for good when any started lane gets near the edges
+                // (16 decades of cancellation + 1.6 decades per step of a chunk above the 2^-969 limit of v_div_scale)
+                const double au = fabs(s.u);
+                const bool ok = !(valid && my_hi > top - CH) || (au < 1e200 && (au > 1e-250 || s.u == 0.0));
+                fast = (__ballot(ok) == ~0ull);
             }
             PIPE_BARRIER();
             return COUNT && (it & 1) && *stop != 0;
@@ -620,6 +631,7 @@ __device__ __forceinline__ void sweep_pipe(const SweepArgs& a, const GridScalars
             if (stage(RA, RB, it)) { stopped = true; break; }
             if (stage(RB, RA, it + 1)) { stopped = true; break; }
         }
+        if (my_hi == 0) s = s0;                                // start == 2: nothing to integrate, u(0) comes from the boundary values
         if (!COUNT) {
             if (valid) {
                 if (a.u0) a.u0[t] = s.u * (2 + s.fprev) - s.prevSol;                 // Numerov.h:398
