@@ -17,6 +17,7 @@ LIB_PATH = os.path.join(_HERE, "libdftatom_hip.so")
 
 OK = 0
 SWEEP_COUNT, SWEEP_ZERO = 0, 1
+SWEEP_KERNEL_AUTO, SWEEP_KERNEL_FUSED, SWEEP_KERNEL_PIPELINED = 0, 1, 2
 BOUNDARY_DEVICE, BOUNDARY_HOST = 0, 1
 LEVELS_CHAINED, LEVELS_BATCHED = 0, 1
 INT_TRAPEZOID, INT_SIMPSON13, INT_SIMPSON38, INT_BOOLE, INT_ROMBERG = range(5)
@@ -60,6 +61,7 @@ SIGNATURES = {
     "dfta_version": (C.c_char_p, []),
     "dfta_ctx_device_info": (C.c_int, [vp, c_ip, C.c_char_p, C.c_int]),
     "dfta_ctx_last_kernel_ms": (C.c_int, [vp, C.POINTER(C.c_float)]),
+    "dfta_ctx_set_sweep_kernel": (C.c_int, [vp, C.c_int]),
     "dfta_grid_create": (C.c_int, [vp, C.c_int, C.c_double, C.c_double, C.POINTER(vp)]),
     "dfta_grid_destroy": (None, [vp]),
     "dfta_grid_num_nodes": (C.c_int, [vp]),
@@ -161,6 +163,10 @@ class Context:
         name = C.create_string_buffer(128)
         self.check(self.lib.dfta_ctx_device_info(self.h, C.byref(ncu), name, 128))
         return ncu.value, name.value.decode()
+
+    def set_sweep_kernel(self, which):
+        """SWEEP_KERNEL_AUTO / _FUSED / _PIPELINED: which (bit-identical) Numerov sweep kernel later calls launch."""
+        self.check(self.lib.dfta_ctx_set_sweep_kernel(self.h, int(which)))
 
     def last_kernel_ms(self):
         ms = C.c_float()

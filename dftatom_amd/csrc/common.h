@@ -19,6 +19,7 @@ struct dfta_ctx {
     mutable char err[512] = {0};
     hipEvent_t ev[2] = {nullptr, nullptr};   // bracket the dominant kernel of the last host-pointer call
     bool have_kernel_time = false;
+    int sweep_kernel = 0;                    // DFTA_SWEEP_AUTO / _FUSED / _PIPELINED (dfta_ctx_set_sweep_kernel)
 };
 
 #define DFTA_HIP(ctx, call)                                                                     \

@@ -996,11 +996,7 @@ int dfta_launch_sweep(dfta_ctx* ctx, const dfta_grid* g, int kind, const int* bl
     a.kind = kind; a.blk_kind = blk_kind; a.bounds = bounds; a.bstride = dfta_bounds_stride(g);
     a.tab = tab; a.blk_slot = blk_slot; a.blk_first = blk_first; a.blk_cnt = blk_cnt; a.E = dE; a.limit = dLimit;
     a.start = dStart; a.us = dUs; a.us1 = dUs1; a.count = dCount; a.u0 = dU0; a.trip = dTrip; a.total_trips = dTotalTrips;
-    static const int forced = [] {   // DFTA_SWEEP_KERNEL=fused|pipe overrides the choice (measurements)
-        const char* e = getenv("DFTA_SWEEP_KERNEL");
-        return !e ? 0 : (!strcmp(e, "fused") ? 1 : (!strcmp(e, "pipe") ? 2 : 0));
-    }();
-    const bool pipe = forced ? forced == 2 : nblocks <= kPipeMaxBlocks;
+    const bool pipe = ctx->sweep_kernel == DFTA_SWEEP_AUTO ? nblocks <= kPipeMaxBlocks : ctx->sweep_kernel == DFTA_SWEEP_PIPELINED;
     if (pipe) {
         hipLaunchKernelGGL((k_sweep_pipe<kPipeChunk>), dim3(nblocks), dim3(kPipeThreads), 0, ctx->stream, a, scalars_of(g), nblocks);
     } else {

@@ -111,15 +111,34 @@ __device__ __forceinline__ double gauss_seidel(const MgDesc& D, Atom& A, int l, 
     const int tid = threadIdx.x;
     if (L.seq) {
         if (tid == 0) {
-            const double* S = A.src_of(L);
-            const double* pin = A.cur_phi(l, L);
-            double* pout = A.other_phi(l, L);
+            // one thread, level in LDS.  The loads of a batch (right neighbours, sources) are independent of the
+            // recurrence: they are issued together ahead of it, so that the chain is not one LDS round trip per node.
+            const double* __restrict__ S = A.src_of(L);
+            const double* __restrict__ pin = A.cur_phi(l, L);
+            double* __restrict__ pout = A.other_phi(l, L);
             double xm = pin[0];
             pout[0] = xm;
             const int limit = L.n - 1;
             double old = pin[1];
-#pragma unroll 4
-            for (int i = 1; i < limit; ++i) {
+            constexpr int kB = 8;
+            int i = 1;
+            for (; i + kB <= limit; i += kB) {
+                double xp[kB], sv[kB], xo[kB];
+#pragma unroll
+                for (int q = 0; q < kB; ++q) { xp[q] = pin[i + q + 1]; sv[q] = S[i + q]; }
+#pragma unroll
+                for (int q = 0; q < kB; ++q) {
+                    const double x = gs_point(sv[q], xm, xp[q], dh);
+                    const double dif = old - x;
+                    err2 += dif * dif;
+                    xo[q] = x;
+                    xm = x;
+                    old = xp[q];
+                }
+#pragma unroll
+                for (int q = 0; q < kB; ++q) pout[i + q] = xo[q];
+            }
+            for (; i < limit; ++i) {
                 const double xp = pin[i + 1];
                 const double x = gs_point(S[i], xm, xp, dh);
                 const double dif = old - x;

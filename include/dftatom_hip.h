@@ -48,6 +48,13 @@ const char* dfta_last_error(const dfta_ctx* ctx);
 const char* dfta_version(void);
 /* HIP-event duration (ms, on the context's stream) of the dominant kernel of the last host-pointer call */
 int         dfta_ctx_last_kernel_ms(dfta_ctx* ctx, float* ms);
+/* Which of the two (bit-identical) Numerov sweep kernels dfta_numerov_sweeps / dfta_solve_levels / dfta_scf_step launch:
+ * AUTO picks the pipelined kernel (one workgroup per block of 64 trials) while a launch has few blocks and the fused
+ * one-wave-per-block kernel when the machine is full.  Initial value: AUTO, or $DFTA_SWEEP_KERNEL = fused | pipe. */
+#define DFTA_SWEEP_AUTO      0
+#define DFTA_SWEEP_FUSED     1
+#define DFTA_SWEEP_PIPELINED 2
+int         dfta_ctx_set_sweep_kernel(dfta_ctx* ctx, int which);
 /* number of compute units / name of the device behind the context (reporting only) */
 int         dfta_ctx_device_info(const dfta_ctx* ctx, int* num_cu, char* name, int name_cap);
 

@@ -46,6 +46,14 @@ def _pots(grid):
     return {"coulomb18": V, "screened18": screened_potential(rr, 18.0), "screened86": screened_potential(rr, 86.0)}
 
 
+@pytest.fixture(params=["fused", "pipelined"])
+def sweep_kernel(ctx, request):
+    """run a test once per Numerov sweep kernel (dfta_ctx_set_sweep_kernel); the two must be indistinguishable"""
+    ctx.set_sweep_kernel(D.SWEEP_KERNEL_FUSED if request.param == "fused" else D.SWEEP_KERNEL_PIPELINED)
+    yield request.param
+    ctx.set_sweep_kernel(D.SWEEP_KERNEL_AUTO)
+
+
 def test_grid_tables_match_oracle(ctx, grid14):
     g = O.make_grid(*GRIDS["L14"])
     assert (grid14.N, grid14.Rp) == (g.N, g.Rp)
@@ -53,7 +61,7 @@ def test_grid_tables_match_oracle(ctx, grid14):
 
 
 @pytest.mark.parametrize("pname", ["coulomb18", "screened18", "screened86"])
-def test_sweeps_bit_exact_vs_golden(ctx, grid14, golden, pname):
+def test_sweeps_bit_exact_vs_golden(ctx, grid14, golden, pname, sweep_kernel):
     """SolveSchrodingerCountNodes / SolutionInZero / MatchSolutionCompletely vs vectors captured from the reference."""
     data, _ = golden
     V = _pots(grid14)[pname]
@@ -70,7 +78,7 @@ def test_sweeps_bit_exact_vs_golden(ctx, grid14, golden, pname):
     assert np.array_equal(psi[:, :: max(1, grid14.N // 64)], sw[:, 7:], equal_nan=True)
 
 
-def test_sweeps_ragged_batches_and_two_potentials(ctx, grid14):
+def test_sweeps_ragged_batches_and_two_potentials(ctx, grid14, sweep_kernel):
     """trial counts that do not fill a wave, mixed l, two potentials, positive and tiny energies, every early exit"""
     o = O.oracle()
     g = O.make_grid(*GRIDS["L14"])
@@ -111,7 +119,7 @@ def test_device_boundary_values(ctx, grid14):
 
 
 @pytest.mark.parametrize("pname,Z", [("screened18", 18), ("screened86", 86)])
-def test_level_solver_chained_vs_golden(ctx, grid14, golden, pname, Z):
+def test_level_solver_chained_vs_golden(ctx, grid14, golden, pname, Z, sweep_kernel):
     """LoopOverLevels with the reference's bracket chaining: eigenvalues within 1e-10 Ha of the reference, the
     bisection path has exactly the reference's length (sweep counts equal the oracle's), density within 1e-12."""
     data, _ = golden
@@ -133,7 +141,7 @@ def test_level_solver_chained_vs_golden(ctx, grid14, golden, pname, Z):
     assert res["issued"] > int((res["n_count"] + res["n_zero"]).sum())       # speculation really issues more sweeps
 
 
-def test_level_solver_batched_two_potentials(ctx, grid14):
+def test_level_solver_batched_two_potentials(ctx, grid14, sweep_kernel):
     """un-chained clamped brackets, two potentials in one call (the LSDA shape): vs the oracle in the same mode"""
     o = O.oracle()
     g = O.make_grid(*GRIDS["L14"])
@@ -318,6 +326,39 @@ def test_full_size_hydrogenic_levels(ctx, grid17):
     sub = lv[:10]
     ch = D.solve_levels(ctx, grid17, V, sub, -86.0 ** 2 - 1.0, mode=D.LEVELS_CHAINED)
     assert np.max(np.abs(ch["E"] - res["E"][:10])) <= 1e-9
+
+
+def test_full_size_sweep_kernels_agree(ctx, grid17):
+    """131073 nodes: the fused and the pipelined kernel return identical counts, cut-offs, loop trips and u(0) bit patterns
+    for thousands of trials (wide and narrow energy windows, every l, small and large node limits); a sample of the
+    trials is also checked against the oracle."""
+    o = O.oracle()
+    g = O.make_grid(*GRIDS["L17"])
+    V = screened_potential(grid17.r(), 86.0)
+    rng = np.random.default_rng(7)
+    nt = 64 * 40 + 17
+    E = np.concatenate([-10.0 ** rng.uniform(-3, 3.9, nt // 2), -(250.0 + rng.uniform(0, 1e-6, nt - nt // 2))])
+    E[::97] = rng.uniform(0, 50, len(E[::97]))
+    l = rng.integers(0, 4, nt).astype(np.int32)
+    lim = np.where(rng.random(nt) < 0.5, rng.integers(0, 7, nt), 1000).astype(np.int32)
+    res = {}
+    try:
+        for name, k in (("fused", D.SWEEP_KERNEL_FUSED), ("pipelined", D.SWEEP_KERNEL_PIPELINED)):
+            ctx.set_sweep_kernel(k)
+            res[name] = (D.numerov_sweeps(ctx, grid17, D.SWEEP_COUNT, V, l, E, lim), D.numerov_sweeps(ctx, grid17, D.SWEEP_ZERO, V, l, E))
+    finally:
+        ctx.set_sweep_kernel(D.SWEEP_KERNEL_AUTO)
+    (cf, zf), (cp, zp) = res["fused"], res["pipelined"]
+    for key in ("count", "start", "trip"):
+        assert np.array_equal(cf[key], cp[key]), key
+    assert np.array_equal(cf["u0"].view(np.int64), cp["u0"].view(np.int64))
+    assert np.array_equal(zf["u0"].view(np.int64), zp["u0"].view(np.int64))
+    for k in rng.choice(nt, 24, replace=False):
+        st, tr = C.c_long(), C.c_long()
+        want = o.dfo_count_nodes(C.byref(g), O.dp(V), int(l[k]), float(E[k]), int(lim[k]), C.byref(st), C.byref(tr))
+        assert cp["count"][k] == want and cp["start"][k] == st.value and cp["trip"][k] == tr.value, k
+        u0 = o.dfo_solution_in_zero(C.byref(g), O.dp(V), int(l[k]), float(E[k]), None)
+        assert zp["u0"][k] == u0 or (np.isnan(u0) and np.isnan(zp["u0"][k]))
 
 
 def test_full_size_poisson_1s(ctx, grid17):
