@@ -15,7 +15,7 @@ int dfta_launch_sweep(dfta_ctx* ctx, const dfta_grid* g, int kind, const int* bl
                       unsigned long long* dTotalTrips, const double2* bounds /* per slot, may be null */);
 int dfta_launch_match(dfta_ctx* ctx, const dfta_grid* g, int ntrials, const double2* tab, const int* d_trial_slot,
                       const double* dE, const int* dStart, const double* dUs, const double* dUs1, const int* dL,
-                      double* dPsi, double* dQ, int* dMatch);
+                      double* dPsi, double* dQ, int* dMatch, const double2* bounds /* per slot (dfta_bounds_stride), may be null */);
 
 // reduce.hip: Integral::Simpson38 (Integral.h:50-73) with the reference's sequential summation order, one wave
 // per vector: out[k] = Simpson38(1, vals + k*stride) for k < nvec

@@ -560,7 +560,7 @@ int LevelSolver::run(const double* dV, const double* job_bottom, int run_mode, d
     DFTA_CHECK_LAUNCH(ctx);
     rc = dfta_launch_boundary(ctx, g, d_jE, njobs, d_jstart, d_jus, d_jus1);
     if (rc) return rc;
-    rc = dfta_launch_match(ctx, g, njobs, d_tab, d_jslot, d_jE, d_jstart, d_jus, d_jus1, d_jl, d_Psi, d_Q, d_jmp);
+    rc = dfta_launch_match(ctx, g, njobs, d_tab, d_jslot, d_jE, d_jstart, d_jus, d_jus1, d_jl, d_Psi, d_Q, d_jmp, d_bounds);
     if (rc) return rc;
     hipLaunchKernelGGL(k_store_match, dim3((njobs + 63) / 64), dim3(64), 0, st, d_jobs, njobs, d_jmp);
     DFTA_CHECK_LAUNCH(ctx);

@@ -529,9 +529,11 @@ __device__ __forceinline__ void sweep_pipe(const SweepArgs& a, const GridScalars
         return __ballot(joins) == 0ull;
     };
 
-    if (role == 0)      stopped = pipe_producer<COUNT, CH, 0, 4>(sh, T, tr, lane, R2, d2p4);
-    else if (role == 1) stopped = pipe_producer<COUNT, CH, 4, 6>(sh, T, tr, lane, R2, d2p4);
-    else if (role == 3) stopped = pipe_producer<COUNT, CH, 10, CH - 10>(sh, T, tr, lane, R2, d2p4);
+    // the producer on SIMD 0 shares it with the counter: it takes a quarter of the chunk, the other two 3/8 each
+    constexpr int kP0 = CH / 4, kP1 = (CH - kP0) / 2;
+    if (role == 0)      stopped = pipe_producer<COUNT, CH, 0, kP0>(sh, T, tr, lane, R2, d2p4);
+    else if (role == 1) stopped = pipe_producer<COUNT, CH, kP0, kP1>(sh, T, tr, lane, R2, d2p4);
+    else if (role == 3) stopped = pipe_producer<COUNT, CH, kP0 + kP1, CH - kP0 - kP1>(sh, T, tr, lane, R2, d2p4);
     else if (role == 2) {
         // ---------------- integrator
         bool fast = false;
@@ -806,33 +808,50 @@ __global__ void k_block_minmax(const double2* __restrict__ tab, int N, double2* 
 }
 
 // ---- match kernel (Numerov.h:403-504) --------------------------------------------------------------------
-// One wave per trial.  Lane 0 integrates inward from the cut-off until the outermost maximum (the match
-// point), lane 1 integrates outward from the nucleus at the same time; they stop as soon as lane 0 has
-// found the match point and lane 1 has passed it.  The remaining lanes then join to rescale the outer part.
+// One wave per trial.  Lane 0 integrates inward from the cut-off until the outermost maximum (the match point), lane 1
+// integrates outward from the nucleus at the same time; they stop as soon as lane 0 has found the match point and lane
+// 1 has passed it.  The two recurrences are serial, but their per-point inputs are not: every kMB steps all 64 lanes
+// compute f_i and the refined reciprocal of 1 - f_i/12 for the next kMB points of BOTH streams (coalesced table loads,
+// ~30 instructions per batch) and park them in LDS; the serial loop then costs one 16-byte LDS read, the 8-instruction
+// recurrence and one store per step.  The remaining lanes finally join to rescale the outer part.
+constexpr int kMB = 64;
+
 __global__ __launch_bounds__(64) void k_match(const double2* __restrict__ tab, const int* __restrict__ trial_slot,
                                               const double* __restrict__ Earr, const int* __restrict__ startArr,
                                               const double* __restrict__ usArr, const double* __restrict__ us1Arr,
                                               const int* __restrict__ larr, double zero_l0, double zero_l1, double zero_l2,
-                                              double zero_l3, GridScalars gs, double* __restrict__ Psi,
-                                              double* __restrict__ Q, int* __restrict__ matchPoint)
+                                              double zero_l3, GridScalars gs, const double2* __restrict__ bounds, int bstride,
+                                              double* __restrict__ Psi, double* __restrict__ Q, int* __restrict__ matchPoint)
 {
+    __shared__ v2d stage[2][kMB];            // [stream][step] = { f, r }
     const int t = blockIdx.x;
     const int lane = threadIdx.x;
     const int N = gs.N;
-    const double2* __restrict__ T = tab + (size_t)trial_slot[t] * N;
+    const int slot = trial_slot[t];
+    const double2* __restrict__ T = tab + (size_t)slot * N;
     double* __restrict__ P = Psi + (size_t)t * N;
     double* __restrict__ Qt = Q + (size_t)t * N;
     const double E = Earr[t];
     const int steps = startArr[t];
     const int l = larr[t];
     const double zero1 = l == 0 ? zero_l0 : (l == 1 ? zero_l1 : (l == 2 ? zero_l2 : zero_l3));
+    const double R2 = 2. * gs.Rp2delta2;
+    const double d2p4 = gs.delta2p4;
 
     // zero beyond the cut-off (Numerov.h:427-428)
     for (int i = steps + 1 + lane; i < N; i += 64) P[i] = 0;
 
+    // may the division use the refined reciprocal?  (same range argument as in the sweeps: d in (0.5, 1.5) from the
+    // slot bounds, |w| checked every 16 steps with 16 steps of margin)
+    bool fast = false;
+    if (bounds) {
+        const double2 bd = bounds[(size_t)slot * bstride];
+        fast = (bd.x + fabs(E) * bd.y + d2p4 < 6.0);
+    }
+
     int mp = 2;              // matchPoint default (Numerov.h:449)
-    bool in_done = false;    // lane 0 finished
-    int i = 0;
+    bool done = true;        // this lane's stream has stopped for good (lanes >= 2 own no stream)
+    int idx = 0;             // next node of this lane's stream
     double w = 0, wprev = 0, u = 0, fprev = 0, unext = 0;
     if (lane == 0) {
         const double2 ts = T[steps];
@@ -846,9 +865,8 @@ __global__ __launch_bounds__(64) void k_match(const double2* __restrict__ tab, c
         fprev = f_of(t1.x, t1.y, E, gs);
         w = (1 - kH2p12 * fprev) * u;
         unext = u;           // Psi[i+1]
-        i = steps - 2;
-
-        if (i < 1) in_done = true;
+        idx = steps - 2;
+        done = idx < 1;
     } else if (lane == 1) {
         const double2 t1 = T[1];
         u = zero1;           // Numerov.h:475
@@ -857,57 +875,90 @@ __global__ __launch_bounds__(64) void k_match(const double2* __restrict__ tab, c
         fprev = f_of(t1.x, t1.y, E, gs);
         wprev = 0;
         w = (1 - kH2p12 * fprev) * u;
-        i = 2;
-
+        idx = 2;
+        done = false;
     }
 
-    bool running = (lane == 0 && !in_done) || (lane == 1);
-    // Both lanes advance one node per step (lane 0 downwards, lane 1 upwards) until they stop for good, so their
-    // table reads are known in advance: kMP entries are fetched one batch ahead of the recurrence.
-    constexpr int kMP = 8;
-    const int dir = (lane == 0) ? -1 : 1;
-    auto tab_at = [&](int idx) { idx = idx < 1 ? 1 : (idx > N - 1 ? N - 1 : idx); return T[idx]; };
-    double2 cur[kMP], nxt[kMP];
+    while (true) {
+        // state of the two streams at the start of the batch (wave-uniform)
+        const int i0 = __shfl(idx, 0), j0 = __shfl(idx, 1);
+        const bool d0 = __shfl((int)done, 0) != 0;
+        const int mp0 = __shfl(mp, 0);
+        // lane 1 needs the outward values up to and including the match point; while that is unknown, up to the node
+        // above lane 0's position (the match point can only lie below it)
+        const int jmax = min(steps, d0 ? mp0 : i0 + 1);
+        if (lane == 1 && idx > jmax) done = true;
+        if (__ballot(!done) == 0ull) break;
+
+        // per-point inputs of the next kMB nodes of both streams, one node per lane
+        {
+            const int ii = max(i0 - lane, 1), jj = min(j0 + lane, N - 1);
+            const double2 ti = T[ii], tj = T[jj];
+            v2d oi, oj;
+            oi.x = (ti.x - E) * R2 * ti.y + d2p4;                                // Numerov.h:100
+            oj.x = (tj.x - E) * R2 * tj.y + d2p4;
+            oi.y = div_in_range(1.0, 1. - kH2p12 * oi.x);                         // == the refined reciprocal (w = 1: q = r, rem ~ 0)
+            oj.y = div_in_range(1.0, 1. - kH2p12 * oj.x);
+            stage[0][lane] = oi;
+            stage[1][lane] = oj;
+        }
+        __syncthreads();
+        if (lane < 2) {
+            const v2d* __restrict__ mine = &stage[lane][0];
+            const bool is0 = (lane == 0);
+            const int dir = is0 ? -1 : 1, is0i = is0 ? 1 : 0;
+            double* __restrict__ out = is0 ? P : Qt;
+            for (int k0 = 0; k0 < kMB; k0 += 16) {
+                // leave the reciprocal path for good when a value gets within 16 steps of the range edges
+                if (fast) {
+                    const double au = fabs(u);
+                    const bool ok = done || (au < 1e200 && (au > 1e-250 || u == 0.0));
+                    fast = (__ballot(ok) == 3ull);
+                }
+                if (__ballot(!done) == 0ull) break;
+                v2d in16[16];
 #pragma unroll
-    for (int q = 0; q < kMP; ++q) cur[q] = tab_at(i + dir * q);
-    // lane 1 may stop once it has produced the value AT the match point; until lane 0 is done the bound is lane 0's index
-    bool all_done = false;
-    while (!all_done) {
-        const int ibase = i;
+                for (int q = 0; q < 16; ++q) in16[q] = mine[k0 + q];             // all 16 reads in flight before the chain starts
+                // the 16 nodes of this group lie in [idx - 15, idx] (lane 0) or [idx, idx + 15] (lane 1): the reciprocal
+                // path needs all of them inside the range of the division bounds (wave-uniform choice, straight-line code)
+                const bool grp_fast = fast && (__ballot(done || (is0 ? idx - 15 : idx) >= kBoundFrom) == 3ull);
+                auto step = [&](const v2d in, const bool use_r) {
+                    if (!done) {
+                        const double wnext = 2. * w - wprev + u * fprev;            // Numerov.h:311 (h2 == 1)
+                        wprev = w;
+                        w = wnext;
+                        const double f = in.x;
+                        const double d = 1. - kH2p12 * f;
+                        if (use_r) {
+                            const double qq = wnext * in.y;
+                            const double rem = __builtin_fma(-d, qq, wnext);
+                            u = __builtin_fma(rem, in.y, qq);
+                        } else {
+                            u = wnext / d;                                          // getU, Numerov.h:510-513
+                        }
+                        fprev = f;
+                        out[idx] = u;                                               // Psi (inward) / outward scratch
+                        // lane 0: the outermost maximum or a blow-up ends the inward sweep (Numerov.h:463-467), and so does
+                        // node 1; lane 1 stops behind jmax
+                        // (integer arithmetic instead of && / ||: straight-line selects, no exec-mask branches per step)
+                        const int hit = is0i & ((int)(u < unext) | (int)(fabs(u) > 1E15));
+                        unext = u;
+                        const int nidx = idx + dir;
+                        mp = hit ? idx : mp;
+                        idx = hit ? idx : nidx;
+                        done = (hit | (is0i ? (int)(nidx < 1) : (int)(nidx > jmax))) != 0;
+                    }
+                };
+                if (grp_fast) {
 #pragma unroll
-        for (int q = 0; q < kMP; ++q) nxt[q] = tab_at(ibase + dir * (kMP + q));
-#pragma unroll
-        for (int q = 0; q < kMP; ++q) {
-            const int i0 = __shfl(i, 0);
-            const bool d0 = __shfl((int)in_done, 0) != 0;
-            const int mp0 = __shfl(mp, 0);
-            if (lane == 1) {
-                const int bound = d0 ? mp0 : i0 + 1;    // need outward values up to and including `bound`
-                running = running && (i <= bound) && (i <= steps);
-            }
-            if (lane == 0) running = !in_done;
-            if (__ballot(running) == 0ull) { all_done = true; break; }
-            if (running) {
-                const double2 tv = cur[q];              // == T[i]: a running lane has advanced exactly q nodes in this batch
-                const double wnext = 2. * w - wprev + u * fprev;
-                wprev = w;
-                w = wnext;
-                const double f = f_of(tv.x, tv.y, E, gs);
-                u = w / (1. - kH2p12 * f);
-                fprev = f;
-                if (lane == 0) {
-                    P[i] = u;
-                    if (u < unext || fabs(u) > 1E15) { mp = i; in_done = true; }   // Numerov.h:463-467
-                    unext = u;
-                    if (!in_done) { --i; if (i < 1) in_done = true; }
+                    for (int q = 0; q < 16; ++q) step(in16[q], true);
                 } else {
-                    Qt[i] = u;
-                    ++i;
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) step(in16[q], false);
                 }
             }
         }
-#pragma unroll
-        for (int q = 0; q < kMP; ++q) cur[q] = nxt[q];
+        __syncthreads();
     }
     mp = __shfl(mp, 0);
     __syncthreads();
@@ -1009,10 +1060,11 @@ int dfta_launch_sweep(dfta_ctx* ctx, const dfta_grid* g, int kind, const int* bl
 
 int dfta_launch_match(dfta_ctx* ctx, const dfta_grid* g, int ntrials, const double2* tab, const int* d_trial_slot,
                       const double* dE, const int* dStart, const double* dUs, const double* dUs1, const int* dL,
-                      double* dPsi, double* dQ, int* dMatch)
+                      double* dPsi, double* dQ, int* dMatch, const double2* bounds)
 {
     hipLaunchKernelGGL(k_match, dim3(ntrials), dim3(64), 0, ctx->stream, tab, d_trial_slot, dE, dStart, dUs, dUs1, dL,
-                       g->zero1[0], g->zero1[1], g->zero1[2], g->zero1[3], scalars_of(g), dPsi, dQ, dMatch);
+                       g->zero1[0], g->zero1[1], g->zero1[2], g->zero1[3], scalars_of(g), bounds, dfta_bounds_stride(g), dPsi, dQ,
+                       dMatch);
     DFTA_CHECK_LAUNCH(ctx);
     return DFTA_OK;
 }
@@ -1240,9 +1292,11 @@ extern "C" int dfta_numerov_match(dfta_ctx* ctx, const dfta_grid* g, int boundar
         int rc = dfta_launch_boundary(ctx, g, dE.p, ntrials, dStart.p, dUs.p, dUs1.p);
         if (rc) return rc;
     }
-    int rc = dfta_launch_build_tab(ctx, g, dTab.p, dV.p, dSlotV.p, dSlotL.p, (int)G.slot_v.size(), nullptr);
+    DevBuf<double2> dBounds;
+    DFTA_HIP(ctx, dBounds.alloc(G.slot_v.size() * (size_t)dfta_bounds_stride(g)));
+    int rc = dfta_launch_build_tab(ctx, g, dTab.p, dV.p, dSlotV.p, dSlotL.p, (int)G.slot_v.size(), dBounds.p);
     if (rc) return rc;
-    rc = dfta_launch_match(ctx, g, ntrials, dTab.p, dTs.p, dE.p, dStart.p, dUs.p, dUs1.p, dL.p, dPsi.p, dQ.p, dMp.p);
+    rc = dfta_launch_match(ctx, g, ntrials, dTab.p, dTs.p, dE.p, dStart.p, dUs.p, dUs1.p, dL.p, dPsi.p, dQ.p, dMp.p, dBounds.p);
     if (rc) return rc;
     std::vector<double> hPsi((size_t)ntrials * N);
     std::vector<int> hMp(ntrials);
