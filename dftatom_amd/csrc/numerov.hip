@@ -852,6 +852,7 @@ __global__ __launch_bounds__(64) void k_match(const double2* __restrict__ tab, c
     int mp = 2;              // matchPoint default (Numerov.h:449)
     bool done = true;        // this lane's stream has stopped for good (lanes >= 2 own no stream)
     int idx = 0;             // next node of this lane's stream
+    int found = 0;           // lane 0: the match point has been seen (sticky)
     double w = 0, wprev = 0, u = 0, fprev = 0, unext = 0;
     if (lane == 0) {
         const double2 ts = T[steps];
@@ -922,32 +923,31 @@ __global__ __launch_bounds__(64) void k_match(const double2* __restrict__ tab, c
                 // the 16 nodes of this group lie in [idx - 15, idx] (lane 0) or [idx, idx + 15] (lane 1): the reciprocal
                 // path needs all of them inside the range of the division bounds (wave-uniform choice, straight-line code)
                 const bool grp_fast = fast && (__ballot(done || (is0 ? idx - 15 : idx) >= kBoundFrom) == 3ull);
+                // No exec masking inside a group (a mask that depends on the previous step's compare costs a VALU -> SGPR ->
+                // EXEC round trip per step): a lane that finishes inside the group keeps stepping to its end.  That is
+                // harmless -- lane 0 then only writes Psi below the match point, which the rescaling loop replaces by the
+                // outward values, and lane 1 writes scratch beyond the node it needed -- as long as the FIRST hit is kept.
                 auto step = [&](const v2d in, const bool use_r) {
-                    if (!done) {
-                        const double wnext = 2. * w - wprev + u * fprev;            // Numerov.h:311 (h2 == 1)
-                        wprev = w;
-                        w = wnext;
-                        const double f = in.x;
-                        const double d = 1. - kH2p12 * f;
-                        if (use_r) {
-                            const double qq = wnext * in.y;
-                            const double rem = __builtin_fma(-d, qq, wnext);
-                            u = __builtin_fma(rem, in.y, qq);
-                        } else {
-                            u = wnext / d;                                          // getU, Numerov.h:510-513
-                        }
-                        fprev = f;
-                        out[idx] = u;                                               // Psi (inward) / outward scratch
-                        // lane 0: the outermost maximum or a blow-up ends the inward sweep (Numerov.h:463-467), and so does
-                        // node 1; lane 1 stops behind jmax
-                        // (integer arithmetic instead of && / ||: straight-line selects, no exec-mask branches per step)
-                        const int hit = is0i & ((int)(u < unext) | (int)(fabs(u) > 1E15));
-                        unext = u;
-                        const int nidx = idx + dir;
-                        mp = hit ? idx : mp;
-                        idx = hit ? idx : nidx;
-                        done = (hit | (is0i ? (int)(nidx < 1) : (int)(nidx > jmax))) != 0;
+                    const double wnext = 2. * w - wprev + u * fprev;                // Numerov.h:311 (h2 == 1)
+                    wprev = w;
+                    w = wnext;
+                    const double f = in.x;
+                    const double d = 1. - kH2p12 * f;
+                    if (use_r) {
+                        const double qq = wnext * in.y;
+                        const double rem = __builtin_fma(-d, qq, wnext);
+                        u = __builtin_fma(rem, in.y, qq);
+                    } else {
+                        u = wnext / d;                                              // getU, Numerov.h:510-513
                     }
+                    fprev = f;
+                    out[min(max(idx, 1), N - 1)] = u;                               // Psi (inward) / outward scratch
+                    // lane 0: the outermost maximum or a blow-up ends the inward sweep (Numerov.h:463-467)
+                    const int hit = is0i & ~found & (int)(idx >= 1) & ((int)(u < unext) | (int)(fabs(u) > 1E15));   // (not past node 1)
+                    unext = u;
+                    mp = hit ? idx : mp;
+                    found |= hit;
+                    idx += dir;
                 };
                 if (grp_fast) {
 #pragma unroll
@@ -956,6 +956,7 @@ __global__ __launch_bounds__(64) void k_match(const double2* __restrict__ tab, c
 #pragma unroll
                     for (int q = 0; q < 16; ++q) step(in16[q], false);
                 }
+                if (!done) done = found != 0 || (is0 ? idx < 1 : idx > jmax);
             }
         }
         __syncthreads();
