@@ -286,7 +286,7 @@ __global__ void k_walk(dfta::Job* __restrict__ jobs, const int* __restrict__ cha
 __global__ __launch_bounds__(256) void k_normalize(double* __restrict__ Psi, double* __restrict__ G, int N,
                                                    const double* __restrict__ eh, const double* __restrict__ cnst)
 {
-    __shared__ double lds[dfta::kTile];
+    __shared__ __attribute__((aligned(16))) double lds[dfta::kTile];
     __shared__ double s_unorm;
     double* P = Psi + (size_t)blockIdx.x * N;
     double* g = G + (size_t)blockIdx.x * N;

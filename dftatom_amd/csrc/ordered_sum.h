@@ -3,8 +3,8 @@
 // Integral::Simpson38 & co. (Integral.h:11-155) accumulate `sum += values[i]` sequentially.  A tree
 // reduction would differ in the last bits, so the sums here keep the sequential order exactly: the 64
 // lanes of a wave fetch a tile with coalesced loads into LDS, then every lane redundantly performs the
-// same chain of fp64 adds while reading the tile back as LDS broadcasts.  The dependent-add chain costs
-// one issue slot (4.5 cycles on gfx950) per element, i.e. ~0.25 ms for 131073 points on one wave;
+// same chain of fp64 adds while reading the tile back as LDS broadcasts (48 elements per batch of reads).
+// The dependent-add chain costs one issue slot (4 cycles on gfx950) per element plus the LDS reads;
 // independent vectors go to different waves.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -30,8 +30,26 @@ __device__ __forceinline__ void wave_ordered_sums(const double* __restrict__ v, 
         }
         __builtin_amdgcn_s_waitcnt(0);          // vmcnt(0) lgkmcnt(0): tile is in LDS
         __builtin_amdgcn_wave_barrier();
-        // sequential chain; base is a multiple of kTile and kTile % P == 0, so the class pattern restarts per tile
+        // sequential chain; base is a multiple of kTile and kTile % P == 0, so the class pattern restarts per tile.
+        // Blocks of kBlk elements are read back with 16-byte broadcasts that are all in flight before the first add:
+        // the chain then costs one dependent v_add_f64 per element instead of one LDS round trip.
+        constexpr int kBlk = 48;                // multiple of every P and of 2; kTile % kBlk == 0
+        typedef double v2 __attribute__((ext_vector_type(2)));
         int j = 0;
+        for (; j + kBlk <= nt; j += kBlk) {
+            v2 x[kBlk / 2];
+            const v2* __restrict__ src = reinterpret_cast<const v2*>(lds + j);
+#pragma unroll
+            for (int q = 0; q < kBlk / 2; ++q) x[q] = src[q];
+#pragma unroll
+            for (int q = 0; q < kBlk; ++q) {
+                const double xv = (q & 1) ? x[q >> 1].y : x[q >> 1].x;
+                const int c = cls[q % P];
+                if (c == 0) acc[0] += xv;
+                else if (c == 1) acc[1] += xv;
+                else acc[2] += xv;
+            }
+        }
         for (; j + P <= nt; j += P) {
 #pragma unroll
             for (int q = 0; q < P; ++q) {

@@ -11,7 +11,7 @@ namespace {
 __global__ __launch_bounds__(64) void k_simpson38_ordered(const double* __restrict__ vals, int n, size_t stride,
                                                           double* __restrict__ out)
 {
-    __shared__ double lds[dfta::kTile];
+    __shared__ __attribute__((aligned(16))) double lds[dfta::kTile];
     const double* v = vals + (size_t)blockIdx.x * stride;
     const double r = dfta::wave_simpson38(v, n, 1.0, lds);
     if (threadIdx.x == 0) out[blockIdx.x] = r;
@@ -21,7 +21,7 @@ __global__ __launch_bounds__(64) void k_simpson38_ordered(const double* __restri
 __global__ __launch_bounds__(64) void k_newton_cotes(const double* __restrict__ v, int sz, double delta, int rule,
                                                      double* __restrict__ out)
 {
-    __shared__ double lds[dfta::kTile];
+    __shared__ __attribute__((aligned(16))) double lds[dfta::kTile];
     double res = 0;
     const long cnt = static_cast<long>(sz) - 2;   // interior points i = 1 .. sz-2
     if (rule == DFTA_INT_TRAPEZOID) {
@@ -56,7 +56,7 @@ __global__ __launch_bounds__(64) void k_newton_cotes(const double* __restrict__ 
 // its sum in order; the extrapolation table is then filled by one thread exactly as the reference does.
 __global__ __launch_bounds__(64) void k_romberg_sums(const double* __restrict__ v, int numPoints, double* __restrict__ sums)
 {
-    __shared__ double lds[dfta::kTile];
+    __shared__ __attribute__((aligned(16))) double lds[dfta::kTile];
     const int i = blockIdx.x + 1;
     const long n = numPoints >> i;
     const long oldStep = numPoints >> (i - 1);   // Integral.h:128-129: oldStep = n before the shift (== 2n only for even n)
