@@ -7,8 +7,9 @@
 // one trial (potential, l, E) and the 64 lanes of a wavefront march the grid index i together (inward,
 // i = start-2 .. 1).  All lanes of a wave share (potential, l); the per-point inputs
 //     veff_i = V_i + l(l+1)/(r_i r_i)/2      and      e2_i = exp(2 i delta)
-// are therefore wave-uniform: they are read as one 16-byte scalar load per point (SGPR operands of the
-// fp64 VALU ops), the wave never touches LDS or vector memory in the loop.  Only E differs per lane.
+// are therefore wave-uniform; only E differs per lane.  Two kernels implement the sweeps with the same arithmetic:
+// k_sweep (one wave per block of 64 trials, everything fused; for a full machine) and k_sweep_pipe (one workgroup
+// per block, the per-point inputs and the loop-carried recurrence on different SIMDs; for a few hundred blocks).
 // Arithmetic is the reference's, in its operation order, IEEE fp64 with contraction off:
 //     f_i = 2 (veff_i - E) Rp^2 delta^2 e2_i + delta^2/4           (Numerov.h:96-101)
 //     w_i = 2 w_{i+1} - w_{i+2} + u_{i+1} f_{i+1};  u_i = w_i / (1 - f_i/12)   (Numerov.h:311-321,510-513)
@@ -380,9 +381,10 @@ __global__ __launch_bounds__(256) void k_sweep(SweepArgs a, GridScalars gs, int 
 // 80-90 ns per point and trial block when the machine is not full -- the situation of a single atom (a few hundred
 // blocks on 1024 SIMDs).  Only 5 of those instructions form the loop-carried chain u -> u f -> w -> q -> rem -> u.
 // Here the work of a block is spread over the four SIMDs of a compute unit (wave w runs on SIMD w mod 4):
-//     waves 0,1,3  producers   f_i, d_i = 1 - f_i/12 and the refined reciprocal of d_i, 4/6/6 points of a chunk -> LDS
-//     wave  2      integrator  the loop-carried recurrence only (6 VALU instructions per point)           -> u_i to LDS
-//     wave  4      counter     CountNodes' bookkeeping on u_i (lane masks in scalar registers); shares SIMD 0
+//     waves 0,1,3  producers   f_i and the refined reciprocal r_i of d_i = 1 - f_i/12, 4/6/6 points of a chunk  -> LDS
+//     wave  2      integrator  the loop-carried recurrence (8 VALU instructions per point, d_i recomputed)  -> u_i to LDS
+//     wave  4      counter     CountNodes' bookkeeping on u_i: whole chunks are skipped when nothing can change,
+//                              else lane masks in scalar registers point by point; shares SIMD 0 with a producer
 // The stages are chunks of CH grid points apart (software pipeline, one s_barrier per chunk): at iteration `it` the
 // producers write chunk it, the integrator loads chunk it-1 into registers while it integrates chunk it-2, the
 // counter examines chunk it-3.  Every floating-point operation is the one the fused kernel executes, in the same
