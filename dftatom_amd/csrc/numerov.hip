@@ -573,6 +573,7 @@ __device__ __forceinline__ void sweep_pipe(const SweepArgs& a, const GridScalars
                 // Straight-line code for all 64 lanes: lanes that have not started yet integrate garbage (they are reset
                 // to s0 when they join, in the other branch).  The LDS reads of the next chunk are interleaved with
                 // the recurrence (6 VALU : 2 DS reads per point) -- issued in one burst they would stall the wave.
+                double uprev = 0;
 #pragma unroll
                 for (int k = 0; k < CH; ++k) {
                     // Numerov.h:311 (h2 == 1): 2 w is exact, so fma(2, w, -wprev) is the reference's 2 w - wprev
@@ -585,12 +586,12 @@ __device__ __forceinline__ void sweep_pipe(const SweepArgs& a, const GridScalars
                     const double rem = __builtin_fma(-d, q, wnext);
                     s.u = __builtin_fma(rem, cur.r[k], q);
                     s.fprev = cur.f[k];
-                    if (COUNT) U[k * 64] = s.u;
+                    if (COUNT) { if (k & 1) { U[(k - 1) * 64] = uprev; U[k * 64] = s.u; } else uprev = s.u; }
                     nxt.f[k] = P[k * 128];
                     nxt.r[k] = P[k * 128 + 64];
                     __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
                     __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                    if (COUNT) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                    if (COUNT && (k & 1)) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
                 }
             } else {
 #pragma unroll
