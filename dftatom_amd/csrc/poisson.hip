@@ -19,6 +19,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <type_traits>
 #include <vector>
 
 #include "internal.h"
@@ -174,58 +175,86 @@ __device__ __forceinline__ double gauss_seidel(const MgDesc& D, Atom& A, int l, 
             // right neighbour of the last owned node: node (t+1)*C, which is node n-1 (stored at C*T) for the last lane
             const double xp_end = pin[(tid == T - 1) ? (C << logT) : (tid + 1)];
             const int Cm1 = C - 1;
+            const unsigned tu = static_cast<unsigned>(tid);
+            // Every access is "wave-uniform row pointer + lane id" (scalar base register + 32-bit lane offset in the
+            // load/store instruction): no per-lane address arithmetic on the VALU.
+            auto row = [&](const double* base, int r) -> const double* {
+                return base + (static_cast<long>((r & Cm1)) << logT) + (r >> logC);
+            };
             // loads of step r (= m - W): S at node i(r), Phi_old at node i(r) + 1 = i(r+1); indices clamped to r <= C-1
             auto load8 = [&](double (&X)[kPF], double (&SV)[kPF], int rbase) {
 #pragma unroll
                 for (int q = 0; q < kPF; ++q) {
                     int r0 = rbase + q;
                     r0 = r0 < Cm1 ? r0 : Cm1;
-                    const int r1 = r0 + 1;
-                    SV[q] = S[(((r0 & Cm1) << logT) + (r0 >> logC)) + tid];
-                    X[q] = pin[(((r1 & Cm1) << logT) + (r1 >> logC)) + tid];
+                    SV[q] = row(S, r0)[tu];
+                    X[q] = row(pin, r0 + 1)[tu];
                 }
             };
+            // Only the first lanes of the workgroup ever see a node index < 1 (lo + r < 1: during the warm-up, and lane 0
+            // at r = 0).  Their wave takes the `careful` variants, which keep xm with a select instead of an exec-mask
+            // branch per node (a mask that depends on a compare costs a VALU -> SGPR -> EXEC round trip per step).
+            const bool careful = __builtin_amdgcn_readfirstlane(lo) <= kWarm;
             // warm-up steps (r < 0): recurrence only
-            auto warm8 = [&](const double (&X)[kPF], const double (&SV)[kPF], int rbase) {
+            auto warm8 = [&](auto CAREFUL, const double (&X)[kPF], const double (&SV)[kPF], int rbase) {
 #pragma unroll
                 for (int q = 0; q < kPF; ++q) {
-                    if (rbase + q >= one_minus_lo) {                 // node index lo + r >= 1
-                        xm = gs_point(SV[q], xm, X[q], dh);
-                        old = X[q];
-                    }
+                    const double x = gs_point(SV[q], xm, X[q], dh);
+                    if (decltype(CAREFUL)::value) xm = (rbase + q >= one_minus_lo) ? x : xm;   // node index lo + r >= 1
+                    else xm = x;
                 }
             };
-            // owned steps (0 <= r < C): recurrence, error norm, store
-            auto main8 = [&](const double (&X)[kPF], const double (&SV)[kPF], int rbase) {
+            // owned steps (0 <= r < C): recurrence, error norm, store.  FIRST: the batch that holds r = 0 (node 0 of lane 0
+            // is a boundary value, not an unknown); LAST: the batch whose last node has xp_end as right neighbour
+            auto main8 = [&](auto FIRST, auto LAST, const double (&X)[kPF], const double (&SV)[kPF], int rbase) {
 #pragma unroll
                 for (int q = 0; q < kPF; ++q) {
                     const int r0 = rbase + q;
-                    if (r0 >= one_minus_lo) {
-                        const double xp = (r0 == Cm1) ? xp_end : X[q];
-                        const double x = gs_point(SV[q], xm, xp, dh);
-                        const double dif = old - x;
-                        err2 += dif * dif;
-                        pout[((r0 & Cm1) << logT) + tid] = x;        // tu == 0 inside the own chunk
+                    const double xp = (decltype(LAST)::value && q == kPF - 1) ? xp_end : X[q];
+                    const double x = gs_point(SV[q], xm, xp, dh);
+                    double dif = old - x;
+                    if (decltype(FIRST)::value && q == 0) {
+                        const bool live = r0 >= one_minus_lo;
+                        dif = live ? dif : 0.0;
+                        xm = live ? x : xm;
+                    } else {
                         xm = x;
-                        old = xp;
                     }
+                    err2 += dif * dif;
+                    const_cast<double*>(row(pout, r0))[tu] = x;          // tu == 0 inside the own chunk; node 0 is rewritten below
+                    old = xp;
                 }
             };
+            using std::true_type;
+            using std::false_type;
             double ax[kPF], as[kPF], bx[kPF], bs[kPF];
             static_assert(kWarm % (2 * kPF) == 0, "warm-up must be a whole number of A/B rounds");
             load8(ax, as, -kWarm);
-            for (int r = -kWarm; r < 0; r += 2 * kPF) {
-                load8(bx, bs, r + kPF);
-                warm8(ax, as, r);
-                load8(ax, as, r + 2 * kPF);                          // the last one already fetches r = 0 .. kPF-1
-                warm8(bx, bs, r + kPF);
+            if (careful) {
+                for (int r = -kWarm; r < 0; r += 2 * kPF) {
+                    load8(bx, bs, r + kPF);
+                    warm8(true_type{}, ax, as, r);
+                    load8(ax, as, r + 2 * kPF);                          // the last one already fetches r = 0 .. kPF-1
+                    warm8(true_type{}, bx, bs, r + kPF);
+                }
+            } else {
+                for (int r = -kWarm; r < 0; r += 2 * kPF) {
+                    load8(bx, bs, r + kPF);
+                    warm8(false_type{}, ax, as, r);
+                    load8(ax, as, r + 2 * kPF);
+                    warm8(false_type{}, bx, bs, r + kPF);
+                }
             }
+            // Phi_old at the first owned node (the last warm-up step's right neighbour); lane 0 keeps the value loaded above
+            if (lo >= 1) old = bx[kPF - 1];
             if (C >= 2 * kPF) {
                 for (int r = 0; r < C; r += 2 * kPF) {
                     load8(bx, bs, r + kPF);
-                    main8(ax, as, r);
+                    if (r == 0) main8(true_type{}, false_type{}, ax, as, r);
+                    else        main8(false_type{}, false_type{}, ax, as, r);
                     load8(ax, as, r + 2 * kPF);
-                    main8(bx, bs, r + kPF);
+                    if (r + 2 * kPF >= C) main8(false_type{}, true_type{}, bx, bs, r + kPF);
+                    else                  main8(false_type{}, false_type{}, bx, bs, r + kPF);
                 }
             } else {
                 // C = 1, 2, 4 or 8 owned nodes: ax/as hold r = 0 .. min(C, kPF) - 1 (clamped beyond)
