@@ -82,7 +82,7 @@ __global__ void k_boundary(const double* __restrict__ r, const double* __restric
 typedef unsigned long long lanemask_t;
 constexpr int kChunk = 8;             // grid points per prefetched batch of the sweep body
 constexpr int kBoundFrom = kChunk;    // the sweep body never touches i < kChunk (tail loop)
-constexpr int kPipeChunk = 16;        // grid points per stage of the pipelined kernel
+constexpr int kPipeChunk = 24;        // grid points per stage of the pipelined kernel
 constexpr int kPipeMaxBlocks = 768;   // above this many 64-trial blocks the fused kernel fills every SIMD anyway
 
 struct SweepState {
