@@ -25,6 +25,18 @@ struct Job {
     int pred_len[3], cur_len[3], trust[3];
     int phase_done;         // decisions already taken in the running phase
     int spine;              // spine length of the trial layout of the current round
+    // scouts (speculation only): while the first two bisections run, the upper part of a job's trials (indices >= cap)
+    // samples the node count on a uniform grid inside (s2_lo, s2_hi), the bracket of the energy at which the count
+    // reaches `nodes` -- the end point of the SECOND bisection.  Every count of the round refines the bracket; when the
+    // second bisection starts, its decisions are predicted from the bracket and verified along a spine, one trial each.
+    double s2_lo, s2_hi;
+    unsigned long long scout_bits;   // predicted decisions of PH_BOTTOM (bit k = decision k of the phase)
+    int scout_len;                   // ... valid for decisions < scout_len
+    int s2_init, use_scout;
+    int s2_seeded;                   // s2_lo/s2_hi hold an unverified guess from the previous solve
+    int s2_stop;                     // scouting has stalled (the counts flicker at the scale of the bracket)
+    int miss;                        // a spine of the running phase mispredicted: no more spines in this phase
+    int cap;                         // trials [0, cap) = probe + spine + tree, [cap, tpj) = scouts (cap == 0: all tpj)
 };
 
 struct LevelStats {

@@ -14,6 +14,8 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 #include "internal.h"
@@ -43,8 +45,11 @@ __device__ __forceinline__ int tree_depth_for(int tpj, int spine)
 
 __device__ __forceinline__ bool pred_bit(const dfta::Job& j, int ph, int k)
 {
+    if (ph == 1 && j.use_scout) return (j.scout_bits >> (k & 63)) & 1ull;
     return (j.pred_bits[ph] >> (k & 63)) & 1ull;
 }
+
+__device__ __forceinline__ int cap_of(const dfta::Job& j, int tpj) { return j.cap > 0 ? j.cap : tpj; }
 
 // ---- expand: trial energies of the current round of every job, plus their far boundary values ----------------------
 __global__ __launch_bounds__(256) void k_expand(const dfta::Job* __restrict__ jobs, int tpj, const double* __restrict__ r,
@@ -59,7 +64,24 @@ __global__ __launch_bounds__(256) void k_expand(const dfta::Job* __restrict__ jo
     const dfta::Job j = jobs[job];
     bool active = false;
     double e = 0;
-    if (j.phase == PH_TOP || j.phase == PH_BOTTOM || j.phase == PH_ZERO) {
+    const int cap = cap_of(j, tpj);
+    if (h >= cap) {
+        // scouts: uniform grid inside the bracket of the count threshold of the second bisection
+        if ((j.phase == PH_TOP || j.phase == PH_BOTTOM) && j.nodes > 0) {
+            const int n = tpj - cap;
+            if (!j.s2_init && j.s2_seeded) {
+                // first round of a solve with a guess from the previous SCF step: the grid includes both ends of the
+                // window, whose counts decide whether the guess holds
+                const double lo = fmax(j.s2_lo, j.bottom0), hi = fmin(j.s2_hi, 50.);
+                e = (h == cap) ? lo : (h == tpj - 1 ? hi : lo + (h - cap) * ((hi - lo) / (n - 1)));
+                active = hi - lo > kEnergyErr;
+            } else {
+                const double lo = j.s2_init ? j.s2_lo : j.bottom0, hi = j.s2_init ? j.s2_hi : 50.;
+                e = lo + (h - cap + 1) * ((hi - lo) / (n + 1));
+                active = (hi - lo > kEnergyErr) && e > lo && e < hi;
+            }
+        }
+    } else if (j.phase == PH_TOP || j.phase == PH_BOTTOM || j.phase == PH_ZERO) {
         if (h == 0) {
             if (j.phase == PH_ZERO && !j.haveSgn) { active = true; e = j.boe; }   // DFTAtom.cpp:513
         } else {
@@ -76,7 +98,7 @@ __global__ __launch_bounds__(256) void k_expand(const dfta::Job* __restrict__ jo
                 }
             } else {
                 const int g = h - S;
-                const int dsub = tree_depth_for(tpj, S);
+                const int dsub = tree_depth_for(cap, S);
                 const int gdepth = 31 - __clz(g);
                 exists = gdepth < dsub;
                 for (int k = 0; k < S; ++k) {
@@ -157,29 +179,68 @@ __device__ __forceinline__ void finish_phase(dfta::Job& j, int ph)
     while (common < m && (((j.cur_bits[ph] ^ j.pred_bits[ph]) >> common) & 1ull) == 0ull) ++common;
     j.trust[ph] = common;       // read by the NEXT solve (after pred := cur)
     j.phase_done = 0;
+    j.miss = 0;
 }
 
-__device__ __forceinline__ int plan_spine(const dfta::Job& j, int phase, int tpj)
+// Predict the decisions of the second bisection (count < nodes -> boe = E, DFTAtom.cpp:587-603) from the scouts' bracket,
+// starting from its current interval: a midpoint at or below s2_lo has fewer nodes, one at or above s2_hi has not
+// (node counts grow with the energy); the prediction ends at the first midpoint inside the bracket.
+__device__ __forceinline__ void scout_predict(dfta::Job& j, double lo, double hi)
 {
-    // A miss ON the spine forfeits the tree of that round, so the spine stops one bit short of what held last time
-    // (eigenvalues move by roughly half as much every SCF step: the prediction gains about one bit per step anyway).
+    unsigned long long bits = 0;
+    int k = j.phase_done;
+    while (hi - lo > kEnergyErr && k < 64) {
+        const double m = (hi + lo) / 2;
+        bool bit;
+        if (j.nodes == 0) bit = false;                   // "count < 0" never holds
+        else if (!j.s2_init) break;
+        else if (m <= j.s2_lo) bit = true;
+        else if (m >= j.s2_hi) bit = false;
+        else break;
+        if (bit) { bits |= 1ull << k; lo = m; } else hi = m;
+        ++k;
+    }
+    j.scout_bits = bits;
+    j.scout_len = k;
+}
+
+// Layout of the job's next round: how many trials scout, where the prediction comes from, how long the spine is.
+__device__ __forceinline__ void plan_round(dfta::Job& j, int phase, int tpj)
+{
     const int ph = phase_index(phase);
+    // scouts run while the count threshold of the second bisection is not pinned down yet
+    const bool scouting = (phase == PH_TOP || phase == PH_BOTTOM) && j.nodes > 0 && tpj >= 64 && !j.s2_stop &&
+                          (!j.s2_init || j.s2_hi - j.s2_lo > kEnergyErr);
+    j.cap = scouting ? tpj / 2 : tpj;
+    // A miss ON the spine forfeits the tree of that round, so a spine from the previous SCF step stops one bit short of
+    // what held last time (eigenvalues move by roughly half as much every SCF step: the prediction gains about one bit
+    // per step anyway).
     int S = j.trust[ph] - 1 - j.phase_done;
     const int avail = j.pred_len[ph] - j.phase_done;
     if (S > avail) S = avail;
-    if (S > tpj / 2 - 1) S = tpj / 2 - 1;        // keep at least half of the trials for the tree
-    return S > 0 ? S : 0;
+    j.use_scout = 0;
+    if (phase == PH_BOTTOM) {
+        scout_predict(j, j.boe, j.toe);
+        // the last decisions before the bracket are left to the tree: at the scale of the bracket itself the counted
+        // nodes need not be monotonic in the energy, and a miss on the spine costs the whole round
+        const int Ss = j.scout_len - j.phase_done - 6;
+        if (Ss > S) { S = Ss; j.use_scout = 1; }
+    }
+    if (S > j.cap / 2 - 1) S = j.cap / 2 - 1;    // keep at least half of the trials for the tree
+    // once a prediction has missed in this phase the predicted path and the real one have parted: plain trees from there
+    if (j.miss) { S = 0; j.use_scout = 0; }
+    j.spine = S > 0 ? S : 0;
 }
 
 __device__ void walk_job(dfta::Job& j, const int* __restrict__ count, const double* __restrict__ u0, int tpj, int base)
 {
     Cursor c;
-    c.init(j.spine, tpj);
+    c.init(j.spine, cap_of(j, tpj));
     if (j.phase == PH_TOP) {                                        // DFTAtom.cpp:568-585
         double hi = j.toe, lo = j.boe;
         while (hi - lo > kEnergyErr) {
             const int h = c.node();
-            if (h < 0) { j.toe = hi; j.boe = lo; j.spine = plan_spine(j, PH_TOP, tpj); return; }
+            if (h < 0) { if (c.off) j.miss = 1; j.toe = hi; j.boe = lo; plan_round(j, PH_TOP, tpj); return; }
             const double e = (hi + lo) / 2;
             const int cn = count[base + h];
             ++j.n_count;
@@ -193,14 +254,17 @@ __device__ void walk_job(dfta::Job& j, const int* __restrict__ count, const doub
         j.toe = hi;
         j.boe = j.bottom0;                                          // DFTAtom.cpp:587
         j.phase = PH_BOTTOM;
-        j.spine = plan_spine(j, PH_BOTTOM, tpj);
+        plan_round(j, PH_BOTTOM, tpj);
         return;
     }
     if (j.phase == PH_BOTTOM) {                                     // DFTAtom.cpp:587-603
         double hi = j.toe, lo = j.boe;
         while (hi - lo > kEnergyErr) {
             const int h = c.node();
-            if (h < 0) { j.toe = hi; j.boe = lo; j.spine = plan_spine(j, PH_BOTTOM, tpj); return; }
+            if (h < 0) {
+                if (c.off) j.miss = 1;
+                j.toe = hi; j.boe = lo; plan_round(j, PH_BOTTOM, tpj); return;
+            }
             const double e = (hi + lo) / 2;
             const int cn = count[base + h];
             ++j.n_count;
@@ -216,7 +280,7 @@ __device__ void walk_job(dfta::Job& j, const int* __restrict__ count, const doub
         j.haveSgn = 0;
         j.iter3 = 0;
         j.phase = PH_ZERO;
-        j.spine = plan_spine(j, PH_ZERO, tpj);
+        plan_round(j, PH_ZERO, tpj);
         return;
     }
     if (j.phase == PH_ZERO) {                                       // DFTAtom.cpp:513-534
@@ -230,7 +294,7 @@ __device__ void walk_job(dfta::Job& j, const int* __restrict__ count, const doub
         bool conv = false;
         while (j.iter3 < kMaxIter3) {
             const int h = c.node();
-            if (h < 0) { j.toe = hi; j.boe = lo; j.spine = plan_spine(j, PH_ZERO, tpj); return; }
+            if (h < 0) { if (c.off) j.miss = 1; j.toe = hi; j.boe = lo; plan_round(j, PH_ZERO, tpj); return; }
             const double e = (hi + lo) / 2;
             const double d = u0[base + h];
             ++j.n_zero;
@@ -249,6 +313,61 @@ __device__ void walk_job(dfta::Job& j, const int* __restrict__ count, const doub
         j.converged = conv ? 1 : 0;
         j.phase = PH_DONE;
         j.spine = 0;
+        j.cap = 0;
+    }
+}
+
+// ---- scouts: every node count of the round narrows the bracket of the second bisection's threshold ------------------
+// one wave per job, before the walk of the round (the trials belong to the job's phase as expanded)
+__global__ __launch_bounds__(64) void k_scout(dfta::Job* __restrict__ jobs, int tpj, const double* __restrict__ E,
+                                              const int* __restrict__ start, const int* __restrict__ count)
+{
+    const int job = blockIdx.x, lane = threadIdx.x;
+    const dfta::Job j = jobs[job];
+    if (!(j.phase == PH_TOP || j.phase == PH_BOTTOM) || j.nodes == 0) return;
+    const int base = job * tpj;
+    double lo = j.s2_init ? j.s2_lo : j.bottom0, hi = j.s2_init ? j.s2_hi : 50.;
+    if (!j.s2_init && j.s2_seeded) {
+        // the guessed window holds if its lower end has fewer nodes and its upper end has reached `nodes`
+        const int cap = cap_of(j, tpj);
+        const bool ok = cap < tpj && start[base + cap] >= 2 && start[base + tpj - 1] >= 2 && count[base + cap] < j.nodes &&
+                        count[base + tpj - 1] >= j.nodes;
+        if (ok) { lo = E[base + cap]; hi = E[base + tpj - 1]; }
+    }
+    auto wave_min = [](double v) { for (int off = 32; off > 0; off >>= 1) v = fmin(v, __shfl_xor(v, off)); return v; };
+    auto wave_max = [](double v) { for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off)); return v; };
+    // lowest sample inside the bracket at which the count has reached `nodes`, highest one at which it has not
+    double minGE = hi, maxLT = lo;
+    for (int h = lane; h < tpj; h += 64) {
+        const double e = E[base + h];
+        if (start[base + h] < 2 || !(e > lo && e < hi)) continue;
+        if (count[base + h] >= j.nodes) minGE = fmin(minGE, e); else maxLT = fmax(maxLT, e);
+    }
+    minGE = wave_min(minGE);
+    maxLT = wave_max(maxLT);
+    double nlo = maxLT, nhi = minGE;
+    if (!(maxLT < minGE)) {
+        // the samples are not monotonic (at the scale of the far cut-off jumps the counted nodes flicker): keep the
+        // whole inconsistent zone inside the bracket -- from the last "fewer" sample below the first "reached" one to
+        // the first "reached" sample above the last "fewer" one
+        nlo = lo;
+        nhi = hi;
+        for (int h = lane; h < tpj; h += 64) {
+            const double e = E[base + h];
+            if (start[base + h] < 2 || !(e > lo && e < hi)) continue;
+            if (count[base + h] >= j.nodes) { if (e > maxLT) nhi = fmin(nhi, e); }
+            else if (e < minGE) nlo = fmax(nlo, e);
+        }
+        nlo = wave_max(nlo);
+        nhi = wave_min(nhi);
+    }
+    if (lane == 0) {
+        // scouting stops when the bracket no longer shrinks (flicker zone reached) or is as narrow as the bisection's end
+        const bool stalled = j.s2_init && !((nhi - nlo) * 2 < hi - lo);
+        jobs[job].s2_lo = nlo;
+        jobs[job].s2_hi = nhi;
+        jobs[job].s2_init = 1;
+        if (stalled) jobs[job].s2_stop = 1;
     }
 }
 
@@ -269,7 +388,10 @@ __global__ void k_walk(dfta::Job* __restrict__ jobs, const int* __restrict__ cha
             j.boe = bot;
             j.phase = PH_TOP;
             j.phase_done = 0;
-            j.spine = plan_spine(j, PH_TOP, tpj);
+            j.s2_init = 0;
+            j.s2_stop = 0;
+            j.miss = 0;
+            plan_round(j, PH_TOP, tpj);
             jobs[k] = j;
             break;                                                  // its trials are generated next round
         }
@@ -508,10 +630,27 @@ int LevelSolver::run(const double* dV, const double* job_bottom, int run_mode, d
                 if (h_last[k].pred_len[ph] == 0) j.trust[ph] = 4;
             }
         }
+        j.s2_init = 0;
+        j.s2_stop = 0;
+        j.miss = 0;
+        j.s2_seeded = 0;
+        if (use_prediction && h_last.size() == jobs.size() && h_last[k].pred_len[1] > 0) {
+            // guess for the scouts' bracket: the end point of the second bisection of the previous solve, +- what the
+            // agreement of the last two decision strings says about how far it moves between solves
+            const double w0 = 50. - j.bottom0;
+            const double w = 4. * std::ldexp(w0, -std::max(h_last[k].trust[1], 1));
+            j.s2_lo = h_last[k].bottom - w;
+            j.s2_hi = h_last[k].bottom + w;
+            j.s2_seeded = 1;
+        }
+        j.use_scout = 0;
+        j.scout_len = 0;
+        j.cap = 0;
         if (j.phase == PH_TOP) {
+            j.cap = (j.nodes > 0 && tpj >= 64) ? tpj / 2 : tpj;      // plan_round on the device does the same
             int S = j.trust[0] - 1;
             if (S > j.pred_len[0]) S = j.pred_len[0];
-            if (S > tpj / 2 - 1) S = tpj / 2 - 1;
+            if (S > j.cap / 2 - 1) S = j.cap / 2 - 1;
             j.spine = S > 0 ? S : 0;
         }
     }
@@ -539,6 +678,8 @@ int LevelSolver::run(const double* dV, const double* job_bottom, int run_mode, d
                                d_limit, d_start, d_us, d_us1, d_count, d_u0, nullptr, d_counters + 1, d_bounds);
         if (rc) return rc;
         if (stats) DFTA_HIP(ctx, hipEventRecord(ev[1], st));
+        hipLaunchKernelGGL(k_scout, dim3(njobs), dim3(64), 0, st, d_jobs, tpj, d_E, d_start, d_count);
+        DFTA_CHECK_LAUNCH(ctx);
         DFTA_HIP(ctx, hipMemsetAsync(d_ndone, 0, sizeof(int), st));
         hipLaunchKernelGGL(k_walk, dim3((run_chains + 63) / 64), dim3(64), 0, st, d_jobs, d_chains, run_chains, tpj, d_count, d_u0, d_ndone);
         DFTA_CHECK_LAUNCH(ctx);
@@ -551,6 +692,14 @@ int LevelSolver::run(const double* dV, const double* job_bottom, int run_mode, d
             ms_sweep += ms;
         }
         ++rounds;
+        if (getenv("DFTA_DEBUG_ROUNDS")) {      // per-round census of the jobs (phase/decisions taken), stderr
+            std::vector<Job> dbg(njobs);
+            DFTA_HIP(ctx, hipMemcpy(dbg.data(), d_jobs, sizeof(Job) * njobs, hipMemcpyDeviceToHost));
+            fprintf(stderr, "round %2d |", rounds);
+            for (int q = 0; q < njobs; ++q)
+                if (dbg[q].phase != PH_DONE) fprintf(stderr, " %d:%d/%d", q, dbg[q].phase, dbg[q].phase_done);
+            fprintf(stderr, "\n");
+        }
         if (ndone >= njobs) break;
     }
     if (rounds >= max_rounds) { snprintf(ctx->err, sizeof(ctx->err), "level solver did not terminate"); return DFTA_ERR_NOT_CONVERGED; }
