@@ -25,18 +25,23 @@ struct Job {
     int pred_len[3], cur_len[3], trust[3];
     int phase_done;         // decisions already taken in the running phase
     int spine;              // spine length of the trial layout of the current round
-    // scouts (speculation only): while the first two bisections run, the upper part of a job's trials (indices >= cap)
-    // samples the node count on a uniform grid inside (s2_lo, s2_hi), the bracket of the energy at which the count
-    // reaches `nodes` -- the end point of the SECOND bisection.  Every count of the round refines the bracket; when the
-    // second bisection starts, its decisions are predicted from the bracket and verified along a spine, one trial each.
-    double s2_lo, s2_hi;
-    unsigned long long scout_bits;   // predicted decisions of PH_BOTTOM (bit k = decision k of the phase)
-    int scout_len;                   // ... valid for decisions < scout_len
-    int s2_init, use_scout;
-    int s2_seeded;                   // s2_lo/s2_hi hold an unverified guess from the previous solve
-    int s2_stop;                     // scouting has stalled (the counts flicker at the scale of the bracket)
+    // Predictions from the structure of the problem (speculation only).  A node enters the inward solution through
+    // r = 0 exactly when u(0) changes sign, i.e. at an eigenvalue.  Hence (i) the energy at which the count reaches
+    // `nodes` -- the end point of the SECOND bisection -- is where the count of the level with one node less (same
+    // potential and l: job `sib`) exceeds nodes-1, which is the end point of ITS first bisection; (ii) the sign change
+    // of the THIRD bisection lies at the upper end of its interval, the end point of the job's own first bisection.
+    int sib;                // job of (v, n-1, l), or -1
+    unsigned long long sp_bits;      // predicted decisions of the running phase (bit k = decision k of the phase) ...
+    int sp_len;                      // ... valid for decisions < sp_len
+    int use_sp;                      // the spine of this round follows sp_bits instead of pred_bits
     int miss;                        // a spine of the running phase mispredicted: no more spines in this phase
-    int cap;                         // trials [0, cap) = probe + spine + tree, [cap, tpj) = scouts (cap == 0: all tpj)
+    // l > 0: the sign change of u(0) lies INSIDE the band between the two count thresholds (the count stops at the inner
+    // turning point).  While the first two bisections run, the upper half of the job's trials (indices >= capz, whole
+    // 64-trial blocks of kind ZERO) samples u(0) inside the part of the band that is already certain, then inside the
+    // bracket of the sign change; the third bisection is predicted from that bracket.
+    int capz;                        // trials [0, capz) = probe + spine + tree, [capz, tpj) = scouts (0: all tpj)
+    double se_lo, se_hi;
+    int se_state, se_sl, se_stop;    // bracketed? / sign of u(0) at se_lo / no longer shrinking
 };
 
 struct LevelStats {

@@ -43,13 +43,28 @@ __device__ __forceinline__ int tree_depth_for(int tpj, int spine)
     return room >= 2 ? 31 - __clz(room) : 0; // full levels: nodes 1 .. 2^d' - 1
 }
 
-__device__ __forceinline__ bool pred_bit(const dfta::Job& j, int ph, int k)
+__device__ __forceinline__ int capz_of(const dfta::Job& j, int tpj) { return j.capz > 0 ? j.capz : tpj; }
+
+// the part of the band (count == nodes) that is certain so far, from the running first bisections of the job and its sibling
+__device__ __forceinline__ void band_of(const dfta::Job& j, const dfta::Job* __restrict__ jobs, double& blo, double& bhi)
 {
-    if (ph == 1 && j.use_scout) return (j.scout_bits >> (k & 63)) & 1ull;
-    return (j.pred_bits[ph] >> (k & 63)) & 1ull;
+    blo = j.bottom0;
+    if (j.nodes > 0) {
+        blo = 1e300;                                                   // unknown: no band
+        if (j.sib >= 0) {
+            const dfta::Job sb = jobs[j.sib];
+            if (sb.phase == PH_TOP) blo = sb.toe;                      // count > nodes-1 there
+            else if (sb.phase == PH_BOTTOM || sb.phase == PH_ZERO || sb.phase == PH_DONE) blo = sb.top;
+        }
+    }
+    bhi = j.phase == PH_TOP ? j.boe : j.top - kEnergyErr;             // count <= nodes there
 }
 
-__device__ __forceinline__ int cap_of(const dfta::Job& j, int tpj) { return j.cap > 0 ? j.cap : tpj; }
+__device__ __forceinline__ bool pred_bit(const dfta::Job& j, int ph, int k)
+{
+    if (j.use_sp) return (j.sp_bits >> (k & 63)) & 1ull;
+    return (j.pred_bits[ph] >> (k & 63)) & 1ull;
+}
 
 // ---- expand: trial energies of the current round of every job, plus their far boundary values ----------------------
 __global__ __launch_bounds__(256) void k_expand(const dfta::Job* __restrict__ jobs, int tpj, const double* __restrict__ r,
@@ -64,21 +79,25 @@ __global__ __launch_bounds__(256) void k_expand(const dfta::Job* __restrict__ jo
     const dfta::Job j = jobs[job];
     bool active = false;
     double e = 0;
-    const int cap = cap_of(j, tpj);
-    if (h >= cap) {
-        // scouts: uniform grid inside the bracket of the count threshold of the second bisection
-        if ((j.phase == PH_TOP || j.phase == PH_BOTTOM) && j.nodes > 0) {
-            const int n = tpj - cap;
-            if (!j.s2_init && j.s2_seeded) {
-                // first round of a solve with a guess from the previous SCF step: the grid includes both ends of the
-                // window, whose counts decide whether the guess holds
-                const double lo = fmax(j.s2_lo, j.bottom0), hi = fmin(j.s2_hi, 50.);
-                e = (h == cap) ? lo : (h == tpj - 1 ? hi : lo + (h - cap) * ((hi - lo) / (n - 1)));
-                active = hi - lo > kEnergyErr;
+    const int capz = capz_of(j, tpj);
+    if (h >= capz) {
+        // eigenvalue scouts: u(0) on a grid inside the band, later inside the bracket of its sign change
+        if (j.phase == PH_TOP || j.phase == PH_BOTTOM) {
+            const int n = tpj - capz, i = h - capz;
+            if (j.se_state == 1) {
+                e = j.se_lo + (i + 1) * ((j.se_hi - j.se_lo) / (n + 1));
+                active = e > j.se_lo && e < j.se_hi;
             } else {
-                const double lo = j.s2_init ? j.s2_lo : j.bottom0, hi = j.s2_init ? j.s2_hi : 50.;
-                e = lo + (h - cap + 1) * ((hi - lo) / (n + 1));
-                active = (hi - lo > kEnergyErr) && e > lo && e < hi;
+                // scan of the band: uniform in the middle, geometric towards both edges (1.5 bits per sample)
+                double blo, bhi;
+                band_of(j, jobs, blo, bhi);
+                const int q = n / 4 < 32 ? n / 4 : 32;           // 48 bits towards each edge
+                double u;
+                if (i < q) u = exp2(-1.5 * (q - i) - 1.);
+                else if (i >= n - q) u = 1. - exp2(-1.5 * (i - (n - q) + 1) - 1.);
+                else u = 0.25 + (i - q + 1) * (0.5 / (n - 2 * q + 1));
+                e = blo + u * (bhi - blo);
+                active = bhi > blo && e > blo && e < bhi;
             }
         }
     } else if (j.phase == PH_TOP || j.phase == PH_BOTTOM || j.phase == PH_ZERO) {
@@ -98,7 +117,7 @@ __global__ __launch_bounds__(256) void k_expand(const dfta::Job* __restrict__ jo
                 }
             } else {
                 const int g = h - S;
-                const int dsub = tree_depth_for(cap, S);
+                const int dsub = tree_depth_for(capz, S);
                 const int gdepth = 31 - __clz(g);
                 exists = gdepth < dsub;
                 for (int k = 0; k < S; ++k) {
@@ -133,7 +152,7 @@ __global__ __launch_bounds__(256) void k_expand(const dfta::Job* __restrict__ jo
         us1[gt] = exp(-r[st - 1] * s - static_cast<double>(st - 1) * delta * 0.5);
     }
     start[gt] = st;
-    if ((gt & 63) == 0) wave_kind[gt >> 6] = (j.phase == PH_ZERO) ? DFTA_SWEEP_ZERO : DFTA_SWEEP_COUNT;
+    if ((gt & 63) == 0) wave_kind[gt >> 6] = (j.phase == PH_ZERO || h >= capz) ? DFTA_SWEEP_ZERO : DFTA_SWEEP_COUNT;
     if (issued) {
         const unsigned long long m = __ballot(active);
         if ((threadIdx.x & 63) == 0 && m) atomicAdd(issued, (unsigned long long)__popcll(m));
@@ -182,65 +201,78 @@ __device__ __forceinline__ void finish_phase(dfta::Job& j, int ph)
     j.miss = 0;
 }
 
-// Predict the decisions of the second bisection (count < nodes -> boe = E, DFTAtom.cpp:587-603) from the scouts' bracket,
-// starting from its current interval: a midpoint at or below s2_lo has fewer nodes, one at or above s2_hi has not
-// (node counts grow with the energy); the prediction ends at the first midpoint inside the bracket.
-__device__ __forceinline__ void scout_predict(dfta::Job& j, double lo, double hi)
+// Simulate the running bisection from its current interval against a bracket [blo, bhi] of the energy at which its
+// predicate flips: a midpoint at or below blo takes the "boe = E" branch (bit 1), one at or above bhi the other one.
+__device__ __forceinline__ void predict_from_bracket(dfta::Job& j, double lo, double hi, double blo, double bhi, bool strict_end)
 {
     unsigned long long bits = 0;
     int k = j.phase_done;
-    while (hi - lo > kEnergyErr && k < 64) {
+    while (k < 64 && (strict_end ? !(hi - lo < kEnergyErr) : (hi - lo > kEnergyErr))) {
         const double m = (hi + lo) / 2;
         bool bit;
-        if (j.nodes == 0) bit = false;                   // "count < 0" never holds
-        else if (!j.s2_init) break;
-        else if (m <= j.s2_lo) bit = true;
-        else if (m >= j.s2_hi) bit = false;
+        if (m <= blo) bit = true;
+        else if (m >= bhi) bit = false;
         else break;
         if (bit) { bits |= 1ull << k; lo = m; } else hi = m;
         ++k;
     }
-    j.scout_bits = bits;
-    j.scout_len = k;
+    j.sp_bits = bits;
+    j.sp_len = k;
 }
 
-// Layout of the job's next round: how many trials scout, where the prediction comes from, how long the spine is.
-__device__ __forceinline__ void plan_round(dfta::Job& j, int phase, int tpj)
+// Spine of the job's next round.  `jobs` is read for the sibling only (k_plan runs after every walk of the round).
+__device__ __forceinline__ void plan_round(dfta::Job& j, const dfta::Job* __restrict__ jobs, int tpj)
 {
-    const int ph = phase_index(phase);
-    // scouts run while the count threshold of the second bisection is not pinned down yet
-    const bool scouting = (phase == PH_TOP || phase == PH_BOTTOM) && j.nodes > 0 && tpj >= 64 && !j.s2_stop &&
-                          (!j.s2_init || j.s2_hi - j.s2_lo > kEnergyErr);
-    j.cap = scouting ? tpj / 2 : tpj;
+    const int ph = phase_index(j.phase);
     // A miss ON the spine forfeits the tree of that round, so a spine from the previous SCF step stops one bit short of
     // what held last time (eigenvalues move by roughly half as much every SCF step: the prediction gains about one bit
     // per step anyway).
     int S = j.trust[ph] - 1 - j.phase_done;
     const int avail = j.pred_len[ph] - j.phase_done;
     if (S > avail) S = avail;
-    j.use_scout = 0;
-    if (phase == PH_BOTTOM) {
-        scout_predict(j, j.boe, j.toe);
-        // the last decisions before the bracket are left to the tree: at the scale of the bracket itself the counted
-        // nodes need not be monotonic in the energy, and a miss on the spine costs the whole round
-        const int Ss = j.scout_len - j.phase_done - 6;
-        if (Ss > S) { S = Ss; j.use_scout = 1; }
+    j.use_sp = 0;
+    j.sp_len = 0;
+    // the last decisions before the predicted flip are left to the tree: at that scale (a few 1e-11) the counted nodes
+    // and the sign of u(0) are not monotonic in the energy, and a miss on the spine costs the whole round
+    constexpr double kGuard = 64 * kEnergyErr;
+    if (j.phase == PH_BOTTOM) {
+        if (j.nodes == 0) predict_from_bracket(j, j.boe, j.toe, -1e300, -1e300, false);   // "count < 0" never holds
+        else if (j.sib >= 0) {
+            const dfta::Job sb = jobs[j.sib];
+            if (sb.phase == PH_BOTTOM || sb.phase == PH_ZERO || sb.phase == PH_DONE)
+                predict_from_bracket(j, j.boe, j.toe, sb.top - kGuard, sb.top + kGuard, false);
+            else if (sb.phase == PH_TOP)
+                predict_from_bracket(j, j.boe, j.toe, sb.boe - kGuard, sb.toe + kGuard, false);
+        }
+    } else if (j.phase == PH_ZERO) {
+        // l == 0: no inner turning point, the count changes exactly where u(0) changes sign -- at the upper end
+        if (j.l == 0) predict_from_bracket(j, j.boe, j.toe, j.top - kGuard, j.top + kGuard, true);
+        else if (j.se_state == 1) predict_from_bracket(j, j.boe, j.toe, j.se_lo - kGuard, j.se_hi + kGuard, true);
     }
-    if (S > j.cap / 2 - 1) S = j.cap / 2 - 1;    // keep at least half of the trials for the tree
+    // scouts for the third bisection of l > 0 (whole blocks of their own kind: tpj >= 128)
+    j.capz = tpj;
+    if (j.l > 0 && tpj >= 128 && (j.phase == PH_TOP || j.phase == PH_BOTTOM) && !j.se_stop &&
+        !(j.se_state == 1 && j.se_hi - j.se_lo <= kEnergyErr)) {
+        double blo, bhi;
+        band_of(j, jobs, blo, bhi);
+        if (j.se_state == 1 || bhi > blo) j.capz = tpj / 2;
+    }
+    if (j.sp_len - j.phase_done > S) { S = j.sp_len - j.phase_done; j.use_sp = 1; }
+    if (S > j.capz / 2 - 1) S = j.capz / 2 - 1;  // keep at least half of the trials for the tree
     // once a prediction has missed in this phase the predicted path and the real one have parted: plain trees from there
-    if (j.miss) { S = 0; j.use_scout = 0; }
+    if (j.miss) { S = 0; j.use_sp = 0; }
     j.spine = S > 0 ? S : 0;
 }
 
 __device__ void walk_job(dfta::Job& j, const int* __restrict__ count, const double* __restrict__ u0, int tpj, int base)
 {
     Cursor c;
-    c.init(j.spine, cap_of(j, tpj));
+    c.init(j.spine, capz_of(j, tpj));
     if (j.phase == PH_TOP) {                                        // DFTAtom.cpp:568-585
         double hi = j.toe, lo = j.boe;
         while (hi - lo > kEnergyErr) {
             const int h = c.node();
-            if (h < 0) { if (c.off) j.miss = 1; j.toe = hi; j.boe = lo; plan_round(j, PH_TOP, tpj); return; }
+            if (h < 0) { if (c.off) j.miss = 1; j.toe = hi; j.boe = lo; return; }
             const double e = (hi + lo) / 2;
             const int cn = count[base + h];
             ++j.n_count;
@@ -254,17 +286,13 @@ __device__ void walk_job(dfta::Job& j, const int* __restrict__ count, const doub
         j.toe = hi;
         j.boe = j.bottom0;                                          // DFTAtom.cpp:587
         j.phase = PH_BOTTOM;
-        plan_round(j, PH_BOTTOM, tpj);
         return;
     }
     if (j.phase == PH_BOTTOM) {                                     // DFTAtom.cpp:587-603
         double hi = j.toe, lo = j.boe;
         while (hi - lo > kEnergyErr) {
             const int h = c.node();
-            if (h < 0) {
-                if (c.off) j.miss = 1;
-                j.toe = hi; j.boe = lo; plan_round(j, PH_BOTTOM, tpj); return;
-            }
+            if (h < 0) { if (c.off) j.miss = 1; j.toe = hi; j.boe = lo; return; }
             const double e = (hi + lo) / 2;
             const int cn = count[base + h];
             ++j.n_count;
@@ -280,7 +308,6 @@ __device__ void walk_job(dfta::Job& j, const int* __restrict__ count, const doub
         j.haveSgn = 0;
         j.iter3 = 0;
         j.phase = PH_ZERO;
-        plan_round(j, PH_ZERO, tpj);
         return;
     }
     if (j.phase == PH_ZERO) {                                       // DFTAtom.cpp:513-534
@@ -294,7 +321,7 @@ __device__ void walk_job(dfta::Job& j, const int* __restrict__ count, const doub
         bool conv = false;
         while (j.iter3 < kMaxIter3) {
             const int h = c.node();
-            if (h < 0) { if (c.off) j.miss = 1; j.toe = hi; j.boe = lo; plan_round(j, PH_ZERO, tpj); return; }
+            if (h < 0) { if (c.off) j.miss = 1; j.toe = hi; j.boe = lo; return; }
             const double e = (hi + lo) / 2;
             const double d = u0[base + h];
             ++j.n_zero;
@@ -313,61 +340,56 @@ __device__ void walk_job(dfta::Job& j, const int* __restrict__ count, const doub
         j.converged = conv ? 1 : 0;
         j.phase = PH_DONE;
         j.spine = 0;
-        j.cap = 0;
+        j.capz = 0;
     }
 }
 
-// ---- scouts: every node count of the round narrows the bracket of the second bisection's threshold ------------------
-// one wave per job, before the walk of the round (the trials belong to the job's phase as expanded)
+// ---- scouts: bracket of the sign change of u(0) inside the band, one wave per job, before the walk of the round ------
 __global__ __launch_bounds__(64) void k_scout(dfta::Job* __restrict__ jobs, int tpj, const double* __restrict__ E,
-                                              const int* __restrict__ start, const int* __restrict__ count)
+                                              const int* __restrict__ start, const double* __restrict__ u0)
 {
     const int job = blockIdx.x, lane = threadIdx.x;
     const dfta::Job j = jobs[job];
-    if (!(j.phase == PH_TOP || j.phase == PH_BOTTOM) || j.nodes == 0) return;
+    const int capz = capz_of(j, tpj);
+    if (!(j.phase == PH_TOP || j.phase == PH_BOTTOM) || capz >= tpj) return;
     const int base = job * tpj;
-    double lo = j.s2_init ? j.s2_lo : j.bottom0, hi = j.s2_init ? j.s2_hi : 50.;
-    if (!j.s2_init && j.s2_seeded) {
-        // the guessed window holds if its lower end has fewer nodes and its upper end has reached `nodes`
-        const int cap = cap_of(j, tpj);
-        const bool ok = cap < tpj && start[base + cap] >= 2 && start[base + tpj - 1] >= 2 && count[base + cap] < j.nodes &&
-                        count[base + tpj - 1] >= j.nodes;
-        if (ok) { lo = E[base + cap]; hi = E[base + tpj - 1]; }
+    // samples [capz, tpj) in ascending energy, m consecutive ones per lane
+    const int n = tpj - capz, m = n / 64;
+    const bool bracketed = j.se_state == 1;
+    bool all_active = true;
+    int first = 0x7fffffff;                  // first sample whose sign differs from its left neighbour / from se_sl
+    int prev;                                // sign of the sample to the left of this lane's first one (-1: none)
+    {
+        const int last = base + capz + lane * m + m - 1;
+        const int mine = start[last] >= 2 ? (u0[last] > 0 ? 1 : 0) : -1;
+        prev = __shfl_up(mine, 1);
+        if (lane == 0) prev = bracketed ? j.se_sl : -1;
     }
-    auto wave_min = [](double v) { for (int off = 32; off > 0; off >>= 1) v = fmin(v, __shfl_xor(v, off)); return v; };
-    auto wave_max = [](double v) { for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off)); return v; };
-    // lowest sample inside the bracket at which the count has reached `nodes`, highest one at which it has not
-    double minGE = hi, maxLT = lo;
-    for (int h = lane; h < tpj; h += 64) {
-        const double e = E[base + h];
-        if (start[base + h] < 2 || !(e > lo && e < hi)) continue;
-        if (count[base + h] >= j.nodes) minGE = fmin(minGE, e); else maxLT = fmax(maxLT, e);
+    for (int q = 0; q < m; ++q) {
+        const int i = lane * m + q, idx = base + capz + i;
+        if (start[idx] < 2) { all_active = false; prev = -1; continue; }
+        const int sg = u0[idx] > 0 ? 1 : 0;
+        const bool flip = bracketed ? (sg != j.se_sl) : (prev >= 0 && sg != prev);
+        if (flip && i < first) first = i;
+        prev = sg;
     }
-    minGE = wave_min(minGE);
-    maxLT = wave_max(maxLT);
-    double nlo = maxLT, nhi = minGE;
-    if (!(maxLT < minGE)) {
-        // the samples are not monotonic (at the scale of the far cut-off jumps the counted nodes flicker): keep the
-        // whole inconsistent zone inside the bracket -- from the last "fewer" sample below the first "reached" one to
-        // the first "reached" sample above the last "fewer" one
-        nlo = lo;
-        nhi = hi;
-        for (int h = lane; h < tpj; h += 64) {
-            const double e = E[base + h];
-            if (start[base + h] < 2 || !(e > lo && e < hi)) continue;
-            if (count[base + h] >= j.nodes) { if (e > maxLT) nhi = fmin(nhi, e); }
-            else if (e < minGE) nlo = fmax(nlo, e);
+    for (int off = 32; off > 0; off >>= 1) first = min(first, __shfl_xor(first, off));
+    all_active = __ballot(all_active) == ~0ull;
+    if (lane != 0 || !all_active) return;
+    const double* Es = E + base + capz;
+    if (!bracketed) {
+        if (first < n) {                     // first >= 1 here
+            jobs[job].se_lo = Es[first - 1];
+            jobs[job].se_hi = Es[first];
+            jobs[job].se_sl = u0[base + capz + first - 1] > 0 ? 1 : 0;
+            jobs[job].se_state = 1;
         }
-        nlo = wave_max(nlo);
-        nhi = wave_min(nhi);
-    }
-    if (lane == 0) {
-        // scouting stops when the bracket no longer shrinks (flicker zone reached) or is as narrow as the bisection's end
-        const bool stalled = j.s2_init && !((nhi - nlo) * 2 < hi - lo);
-        jobs[job].s2_lo = nlo;
-        jobs[job].s2_hi = nhi;
-        jobs[job].s2_init = 1;
-        if (stalled) jobs[job].s2_stop = 1;
+    } else {
+        const double nlo = first < n ? (first > 0 ? Es[first - 1] : j.se_lo) : Es[n - 1];
+        const double nhi = first < n ? Es[first] : j.se_hi;
+        if (!((nhi - nlo) * 2 < j.se_hi - j.se_lo)) jobs[job].se_stop = 1;
+        jobs[job].se_lo = nlo;
+        jobs[job].se_hi = nhi;
     }
 }
 
@@ -388,10 +410,10 @@ __global__ void k_walk(dfta::Job* __restrict__ jobs, const int* __restrict__ cha
             j.boe = bot;
             j.phase = PH_TOP;
             j.phase_done = 0;
-            j.s2_init = 0;
-            j.s2_stop = 0;
             j.miss = 0;
-            plan_round(j, PH_TOP, tpj);
+            j.capz = 0;
+            j.se_state = 0;
+            j.se_stop = 0;
             jobs[k] = j;
             break;                                                  // its trials are generated next round
         }
@@ -401,6 +423,21 @@ __global__ void k_walk(dfta::Job* __restrict__ jobs, const int* __restrict__ cha
         break;
     }
     if (done) atomicAdd(ndone, done);
+}
+
+// spines of the next round, after every walk of this one (a job reads its sibling's first-bisection result)
+__global__ void k_plan(dfta::Job* __restrict__ jobs, int njobs, int tpj)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= njobs) return;
+    dfta::Job j = jobs[k];
+    if (j.phase != PH_TOP && j.phase != PH_BOTTOM && j.phase != PH_ZERO) return;
+    plan_round(j, jobs, tpj);
+    jobs[k].spine = j.spine;
+    jobs[k].capz = j.capz;
+    jobs[k].use_sp = j.use_sp;
+    jobs[k].sp_bits = j.sp_bits;
+    jobs[k].sp_len = j.sp_len;
 }
 
 // ---- normalise (DFTAtom.cpp:36-56) ------------------------------------------------------------------------------
@@ -627,30 +664,25 @@ int LevelSolver::run(const double* dV, const double* job_bottom, int run_mode, d
                 j.pred_len[ph] = h_last[k].cur_len[ph];
                 j.trust[ph] = h_last[k].trust[ph];
                 // the very first comparison has no history: trust what a one-step-old prediction typically gives
-                if (h_last[k].pred_len[ph] == 0) j.trust[ph] = 4;
+                // (no spine from it: a miss forfeits the whole tree of a round, three predicted bits are not worth that)
+                if (h_last[k].pred_len[ph] == 0) j.trust[ph] = 0;
             }
         }
-        j.s2_init = 0;
-        j.s2_stop = 0;
         j.miss = 0;
-        j.s2_seeded = 0;
-        if (use_prediction && h_last.size() == jobs.size() && h_last[k].pred_len[1] > 0) {
-            // guess for the scouts' bracket: the end point of the second bisection of the previous solve, +- what the
-            // agreement of the last two decision strings says about how far it moves between solves
-            const double w0 = 50. - j.bottom0;
-            const double w = 4. * std::ldexp(w0, -std::max(h_last[k].trust[1], 1));
-            j.s2_lo = h_last[k].bottom - w;
-            j.s2_hi = h_last[k].bottom + w;
-            j.s2_seeded = 1;
-        }
-        j.use_scout = 0;
-        j.scout_len = 0;
-        j.cap = 0;
+        j.capz = 0;
+        j.se_state = 0;
+        j.se_stop = 0;
+        j.se_sl = 0;
+        j.use_sp = 0;
+        j.sp_len = 0;
+        j.sp_bits = 0;
+        j.sib = -1;
+        for (int q = 0; q < njobs; ++q)
+            if (jobs[q].v == j.v && jobs[q].l == j.l && jobs[q].nodes == j.nodes - 1) j.sib = q;
         if (j.phase == PH_TOP) {
-            j.cap = (j.nodes > 0 && tpj >= 64) ? tpj / 2 : tpj;      // plan_round on the device does the same
             int S = j.trust[0] - 1;
             if (S > j.pred_len[0]) S = j.pred_len[0];
-            if (S > j.cap / 2 - 1) S = j.cap / 2 - 1;
+            if (S > tpj / 2 - 1) S = tpj / 2 - 1;
             j.spine = S > 0 ? S : 0;
         }
     }
@@ -678,10 +710,12 @@ int LevelSolver::run(const double* dV, const double* job_bottom, int run_mode, d
                                d_limit, d_start, d_us, d_us1, d_count, d_u0, nullptr, d_counters + 1, d_bounds);
         if (rc) return rc;
         if (stats) DFTA_HIP(ctx, hipEventRecord(ev[1], st));
-        hipLaunchKernelGGL(k_scout, dim3(njobs), dim3(64), 0, st, d_jobs, tpj, d_E, d_start, d_count);
+        hipLaunchKernelGGL(k_scout, dim3(njobs), dim3(64), 0, st, d_jobs, tpj, d_E, d_start, d_u0);
         DFTA_CHECK_LAUNCH(ctx);
         DFTA_HIP(ctx, hipMemsetAsync(d_ndone, 0, sizeof(int), st));
         hipLaunchKernelGGL(k_walk, dim3((run_chains + 63) / 64), dim3(64), 0, st, d_jobs, d_chains, run_chains, tpj, d_count, d_u0, d_ndone);
+        DFTA_CHECK_LAUNCH(ctx);
+        hipLaunchKernelGGL(k_plan, dim3((njobs + 63) / 64), dim3(64), 0, st, d_jobs, njobs, tpj);
         DFTA_CHECK_LAUNCH(ctx);
         int ndone = 0;
         DFTA_HIP(ctx, hipMemcpyAsync(&ndone, d_ndone, sizeof(int), hipMemcpyDeviceToHost, st));
