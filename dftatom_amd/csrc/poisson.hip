@@ -19,6 +19,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <type_traits>
 #include <vector>
 
@@ -47,6 +48,9 @@ struct Lvl {
 
 struct MgDesc {
     int levels;
+    int G;           // workgroups per atom (power of two); 1: the whole solve runs in one workgroup
+    int logG;
+    int kcoop;       // levels 0 .. kcoop-1 are swept by all G workgroups together (256 G lanes), the others by workgroup 0
     long per_atom;   // doubles per atom and per array (sum of n)
     Lvl lv[kMaxLevels];
 };
@@ -73,6 +77,12 @@ struct Atom {
     double* src;
     double* lds;      // shared memory: [phi copy 0 | phi copy 1 | src], kSeqCap doubles each
     unsigned cur;     // bit l: which copy of level l is current (identical in all threads)
+    // group of G workgroups that share the fine levels of this atom (G == 1: none of this is touched)
+    int g, G;               // member index, group size
+    unsigned* ctr;          // monotonic arrival counter of the group (zeroed before the launch)
+    unsigned bar;           // barriers passed so far
+    double* part;           // [2][3][G] partial sums of the members (double-buffered by barrier parity) + [1] published `cur`
+    __device__ __forceinline__ int lane() const { return g * kThreads + static_cast<int>(threadIdx.x); }
     // pointer to storage element 0 of the level (generic address space: LDS for sequential levels, global otherwise)
     __device__ __forceinline__ double* cur_phi(int l, const Lvl& L) const
     {
@@ -87,6 +97,28 @@ struct Atom {
     __device__ __forceinline__ double* src_of(const Lvl& L) const { return L.seq ? lds + 2 * kSeqCap + L.soff : src + L.off; }
 };
 
+// Barrier of the G workgroups of an atom: every store made before it by any member is visible to every member after it
+// (agent-scope release before the arrival, acquire after the last one; MI355X_MICROARCH.md: the per-XCD L2s are not
+// coherent).  ~2 us for 8 members (profiles/microbench).  The spin is bounded so that a lost member cannot hang the GPU.
+__device__ __forceinline__ void group_sync(Atom& A)
+{
+    if (A.G == 1) { __syncthreads(); return; }
+    __syncthreads();
+    ++A.bar;
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __hip_atomic_fetch_add(A.ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned target = A.bar * static_cast<unsigned>(A.G);
+        int spins = 0;
+        while (__hip_atomic_load(A.ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > (1 << 24)) break;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+}
+
 __device__ __forceinline__ double block_sum(double v, double* red)
 {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
@@ -94,6 +126,21 @@ __device__ __forceinline__ double block_sum(double v, double* red)
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
     __syncthreads();
     return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// Sum over all lanes of the group (cooperative levels): the members' block sums are exchanged through global memory around
+// a group barrier and added in member order by everybody, so that every member takes the same decisions.
+// `which` = 0..2 selects one of three concurrent sums (the fused three-sweep pass is never cooperative, kept for symmetry).
+__device__ __forceinline__ double group_sum(Atom& A, double v, double* red)
+{
+    const double mine = block_sum(v, red);
+    if (A.G == 1) return mine;
+    double* slot = A.part + ((A.bar + 1) & 1u) * 3 * A.G;      // parity of the barrier that follows
+    if (threadIdx.x == 0) slot[A.g] = mine;
+    group_sync(A);
+    double tot = 0;
+    for (int m = 0; m < A.G; ++m) tot += slot[m];
+    return tot;
 }
 
 __device__ __forceinline__ double gs_point(double s, double xm, double xp, double dh)
@@ -109,7 +156,8 @@ __device__ __forceinline__ double gauss_seidel(const MgDesc& D, Atom& A, int l, 
     const Lvl L = D.lv[l];
     const double dh = L.d * 0.5;
     double err2 = 0;
-    const int tid = threadIdx.x;
+    const bool coop = l < D.kcoop;         // swept by the whole group: lane ids run over all members
+    const int tid = coop ? A.lane() : static_cast<int>(threadIdx.x);
     if (L.seq) {
         if (tid == 0) {
             // one thread, level in LDS.  The loads of a batch (right neighbours, sources) are independent of the
@@ -279,7 +327,8 @@ __device__ __forceinline__ double gauss_seidel(const MgDesc& D, Atom& A, int l, 
         }
     }
     A.cur ^= (1u << l);
-    const double tot = block_sum(err2, red);   // also orders the writes of this sweep before the next phase
+    // also orders the writes of this sweep before the next phase (group barrier inside for cooperative levels)
+    const double tot = coop ? group_sum(A, err2, red) : block_sum(err2, red);
     return sqrt(tot);
 }
 
@@ -428,7 +477,7 @@ __device__ __forceinline__ void gs_fused3(const MgDesc& D, Atom& A, int l, doubl
 __device__ __forceinline__ double iterate_gs(const MgDesc& D, Atom& A, int l, double errorMin, int iterno, double* red, long* nsweeps)
 {
     // the fused pass pays off only where the chunk is long compared with its 3x96-node warm-up (measured: C >= 512)
-    if (iterno == 3 && !D.lv[l].seq && D.lv[l].logC >= kFuseMinLogC) {
+    if (iterno == 3 && !D.lv[l].seq && D.lv[l].logC >= kFuseMinLogC && l >= D.kcoop) {
         double e1, e2, e3;
         gs_fused3(D, A, l, red, e1, e2, e3);
         if (!(e1 < errorMin) && !(e2 < errorMin)) {          // the reference runs all three sweeps
@@ -456,11 +505,12 @@ __device__ __forceinline__ void restrict_to(const MgDesc& D, Atom& A, int lvl)
     const double* Sf = A.src_of(Lf);
     double* Sc = A.src_of(Lc);
     const int lim = Lc.n - 1;
+    const bool coop = lvl < D.kcoop;       // both levels are shared by the group
     if (!Lc.seq && !Lf.seq && Lc.logT == Lf.logT && Lc.logC >= 1) {
         // both levels chunked over the same lanes: coarse node (t, k) sits under fine nodes (t, 2k-1 .. 2k+1), so lane t
         // streams its own column -- all rows are wave-uniform, every access is coalesced, 4 rows per batch in flight
         const int T = 1 << Lc.logT, Cc = 1 << Lc.logC, Cf = 1 << Lf.logC, logT = Lc.logT;
-        const int t = threadIdx.x;
+        const int t = coop ? A.lane() : static_cast<int>(threadIdx.x);
         const double* __restrict__ pf = (((A.cur >> (lvl - 1)) & 1u) ? A.phi1 : A.phi0) + Lf.off;
         const double* __restrict__ sf = A.src + Lf.off;
         double* __restrict__ pc = (((A.cur >> lvl) & 1u) ? A.phi1 : A.phi0) + Lc.off;
@@ -482,10 +532,10 @@ __device__ __forceinline__ void restrict_to(const MgDesc& D, Atom& A, int lvl)
             }
         }
         if (t == 0) { sc[Cc << logT] = 0; pc[Cc << logT] = 0; }    // coarse node n-1
-        __syncthreads();
+        if (coop) group_sync(A); else __syncthreads();
         return;
     }
-    for (int idx = threadIdx.x; idx < Lc.n; idx += kThreads) {
+    for (int idx = coop ? A.lane() : static_cast<int>(threadIdx.x); idx < Lc.n; idx += coop ? kThreads * A.G : kThreads) {
         const int i = node_of(Lc, idx);
         Pc[idx] = 0;
         double s = 0;
@@ -496,7 +546,7 @@ __device__ __forceinline__ void restrict_to(const MgDesc& D, Atom& A, int lvl)
         }
         Sc[idx] = s;
     }
-    __syncthreads();
+    if (coop) group_sync(A); else __syncthreads();
 }
 
 // PoissonSolver::Prolong (PoissonSolver.cpp:110-123): coarse = lvl -> fine = lvl-1 (additive)
@@ -505,10 +555,11 @@ __device__ __forceinline__ void prolong_from(const MgDesc& D, Atom& A, int lvl)
     const Lvl Lc = D.lv[lvl], Lf = D.lv[lvl - 1];
     const double* Pc = A.cur_phi(lvl, Lc);
     double* Pf = A.cur_phi(lvl - 1, Lf);
+    const bool coop = lvl - 1 < D.kcoop;   // the fine level is shared by the group (the coarse one may be workgroup 0's)
     if (!Lc.seq && !Lf.seq && Lc.logT == Lf.logT && Lc.logC >= 1) {
         // same lane-column structure as in restrict_to: fine (t, 2k) += coarse (t, k); fine (t, 2k-1) += 0.5 (coarse (t, k-1) + coarse (t, k))
         const int T = 1 << Lc.logT, Cc = 1 << Lc.logC, Cf = 1 << Lf.logC, logT = Lc.logT;
-        const int t = threadIdx.x;
+        const int t = coop ? A.lane() : static_cast<int>(threadIdx.x);
         const double* __restrict__ pc = (((A.cur >> lvl) & 1u) ? A.phi1 : A.phi0) + Lc.off;
         double* __restrict__ pf = (((A.cur >> (lvl - 1)) & 1u) ? A.phi1 : A.phi0) + Lf.off;
         if (t < T) {
@@ -528,16 +579,16 @@ __device__ __forceinline__ void prolong_from(const MgDesc& D, Atom& A, int lvl)
                 pf[((Cf - 1) << logT) + t] += 0.5 * (cm + cN);
             }
         }
-        __syncthreads();
+        if (coop) group_sync(A); else __syncthreads();
         return;
     }
-    for (int idx = threadIdx.x; idx < Lc.n; idx += kThreads) {
+    for (int idx = coop ? A.lane() : static_cast<int>(threadIdx.x); idx < Lc.n; idx += coop ? kThreads * A.G : kThreads) {
         const int i = node_of(Lc, idx);
         const double c = Pc[idx];
         Pf[addr(Lf, 2 * i)] += c;
         if (i > 0) Pf[addr(Lf, 2 * i - 1)] += 0.5 * (Pc[addr(Lc, i - 1)] + c);
     }
-    __syncthreads();
+    if (coop) group_sync(A); else __syncthreads();
 }
 
 struct Counters { long sweeps, vcycles; };
@@ -549,12 +600,17 @@ __device__ __forceinline__ void initialize(const MgDesc& D, Atom& A, double lowB
     {
         const Lvl L0 = D.lv[0];
         double* P0 = A.cur_phi(0, L0);
-        for (int idx = threadIdx.x; idx < L0.n; idx += kThreads) P0[idx] = 0;
+        const bool coop = D.kcoop > 0;
+        if (coop || A.g == 0)
+            for (int idx = coop ? A.lane() : static_cast<int>(threadIdx.x); idx < L0.n; idx += coop ? kThreads * A.G : kThreads) P0[idx] = 0;
     }
     for (int l = 1; l < D.levels; ++l) {
         const Lvl L = D.lv[l], Lf = D.lv[l - 1];
-        __syncthreads();
-        for (int idx = threadIdx.x; idx < L.n; idx += kThreads) {
+        const bool coop = l < D.kcoop;
+        // the source of level l-1 must be complete: it was written by the whole group for l <= kcoop
+        if (A.G > 1 && l <= D.kcoop) group_sync(A); else __syncthreads();
+        if (!coop && A.g != 0) continue;
+        for (int idx = coop ? A.lane() : static_cast<int>(threadIdx.x); idx < L.n; idx += coop ? kThreads * A.G : kThreads) {
             const int p = node_of(L, idx);
             double s = 0;
             if (p > 0 && p < L.n - 1) s = 4 * A.src_of(Lf)[addr(Lf, 2 * p)];
@@ -564,7 +620,7 @@ __device__ __forceinline__ void initialize(const MgDesc& D, Atom& A, double lowB
     }
     __syncthreads();
     const int cl = D.levels - 1;
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0 && A.g == 0) {
         double* Pc = A.cur_phi(cl, D.lv[cl]);
         Pc[addr(D.lv[cl], 0)] = lowB;
         Pc[addr(D.lv[cl], D.lv[cl].n - 1)] = highB;
@@ -580,6 +636,34 @@ __device__ __forceinline__ void initialize(const MgDesc& D, Atom& A, double lowB
 //   then pairs                  : VCycle = Ascend(0 -> last), Descend(last -> 0); stop on err < errorMinLast or 100 cycles
 // Ascend(from,to): { GS(from); Restrict(from+1); GS(from+1); ... ; GS(to) }      (PoissonSolver.cpp:162-171)
 // Descend(from,to): { Prolong(from); GS(from-1); ... ; GS(to) }                  (PoissonSolver.cpp:173-186)
+// The operations as the members of a group execute them: levels below kcoop by everybody, the others by workgroup 0
+// alone (the other members skip them and meet workgroup 0 again at the barrier in front of the first shared operation).
+__device__ __forceinline__ void do_restrict(const MgDesc& D, Atom& A, int lvl)
+{
+    if (lvl < D.kcoop || A.g == 0) restrict_to(D, A, lvl);
+}
+
+__device__ __forceinline__ void do_prolong(const MgDesc& D, Atom& A, int lvl)
+{
+    if (lvl - 1 < D.kcoop) {
+        if (lvl >= D.kcoop && A.G > 1) {
+            // the coarse level is workgroup 0's: wait for it, and learn which of its two copies is current
+            unsigned* pub = reinterpret_cast<unsigned*>(A.part + 6 * A.G);
+            if (A.g == 0 && threadIdx.x == 0) *pub = A.cur;
+            group_sync(A);
+            const unsigned shared = (1u << D.kcoop) - 1u;
+            A.cur = (A.cur & shared) | (*pub & ~shared);
+        }
+        prolong_from(D, A, lvl);
+    } else if (A.g == 0) prolong_from(D, A, lvl);
+}
+
+__device__ __forceinline__ double do_iterate(const MgDesc& D, Atom& A, int l, double errorMin, int iterno, double* red, long* nsweeps)
+{
+    if (l < D.kcoop || A.g == 0) return iterate_gs(D, A, l, errorMin, iterno, red, nsweeps);
+    return 1E10;
+}
+
 __device__ __forceinline__ double run_cycles(const MgDesc& D, Atom& A, int first_step, int max_vcycles, double errorMin,
                                              double errorMinLast, double* red, Counters& c)
 {
@@ -604,9 +688,9 @@ __device__ __forceinline__ double run_cycles(const MgDesc& D, Atom& A, int first
         err = 1E10;
         if (!(dir < 0 && from == to)) {
             for (int lvl = (dir > 0) ? from : from - 1;; lvl += dir) {
-                if (dir > 0) { if (lvl > from) restrict_to(D, A, lvl); }
-                else prolong_from(D, A, lvl + 1);
-                err = iterate_gs(D, A, lvl, emin, iterno, red, &c.sweeps);
+                if (dir > 0) { if (lvl > from) do_restrict(D, A, lvl); }
+                else do_prolong(D, A, lvl + 1);
+                err = do_iterate(D, A, lvl, emin, iterno, red, &c.sweeps);
                 if (lvl == to) break;
             }
         }
@@ -624,23 +708,32 @@ __global__ __launch_bounds__(kThreads) void k_poisson_solve(const MgDesc* __rest
                                                             const double* __restrict__ density, const double* __restrict__ r,
                                                             const double* __restrict__ psrc, double* __restrict__ U,
                                                             int* __restrict__ vcycles, double* __restrict__ errs,
-                                                            unsigned long long* __restrict__ total_vcycles)
+                                                            unsigned long long* __restrict__ total_vcycles,
+                                                            unsigned* __restrict__ group_ctr, double* __restrict__ group_part)
 {
     __shared__ double red[12];
     __shared__ double seqmem[3 * kSeqCap];
     const MgDesc& D = *Dp;
-    const int a = blockIdx.x;
+    // consecutive blocks are the members of one group (they land on different XCDs, where the barrier is cheapest)
+    const int a = blockIdx.x >> D.logG;
     Atom A;
     A.phi0 = phi0 + (size_t)a * D.per_atom;
     A.phi1 = phi1 + (size_t)a * D.per_atom;
     A.src = src + (size_t)a * D.per_atom;
     A.lds = seqmem;
     A.cur = 0;
+    A.G = D.G;
+    A.g = blockIdx.x & (D.G - 1);
+    A.ctr = group_ctr + a;
+    A.bar = 0;
+    A.part = group_part + (size_t)a * (6 * D.G + 2);
     const Lvl L0 = D.lv[0];
     const int N = L0.n;
     const double* rho = density + (size_t)a * N;
+    const bool coop0 = D.kcoop > 0;        // level 0 is shared by the group
     // source: Source[i] = r_i; Source[i] *= (4 pi Rp^2 delta^2) exp(2 i delta) * density[i], 1 <= i <= N-2
-    for (int idx = threadIdx.x; idx < N; idx += kThreads) {
+    if (coop0 || A.g == 0)
+    for (int idx = coop0 ? A.lane() : static_cast<int>(threadIdx.x); idx < N; idx += coop0 ? kThreads * A.G : kThreads) {
         const int i = node_of(L0, idx);
         double s = r[i];
         if (i > 0 && i < N - 1) s *= psrc[i] * rho[i];
@@ -651,8 +744,10 @@ __global__ __launch_bounds__(kThreads) void k_poisson_solve(const MgDesc* __rest
     initialize(D, A, 0.0, (double)Z[a]);
     const double err = run_cycles(D, A, 0, 100, 1E-3, 1E-14, red, c);      // FullCycle(1E-3, 1E-14), PoissonSolver.h:78
     const double* __restrict__ P = A.cur_phi(0, L0);
-    for (int i = threadIdx.x; i < N; i += kThreads) U[(size_t)a * N + i] = P[addr(L0, i)];
-    if (threadIdx.x == 0) {
+    if (coop0 || A.g == 0)
+        for (int i = coop0 ? A.lane() : static_cast<int>(threadIdx.x); i < N; i += coop0 ? kThreads * A.G : kThreads)
+            U[(size_t)a * N + i] = P[addr(L0, i)];
+    if (threadIdx.x == 0 && A.g == 0) {
         if (vcycles) vcycles[a] = (int)c.vcycles;
         if (errs) errs[a] = err;
         if (total_vcycles) atomicAdd(total_vcycles, (unsigned long long)c.vcycles);
@@ -661,17 +756,22 @@ __global__ __launch_bounds__(kThreads) void k_poisson_solve(const MgDesc* __rest
 
 // unit-parity kernels on atom 0 ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kThreads) void k_unit(const MgDesc* __restrict__ Dp, double* phi0, double* phi1, double* src, int* cur, int op,
-                                                   int lvl, int sweeps, double* out)
+                                                   int lvl, int sweeps, double* out, unsigned* group_ctr, double* group_part)
 {
     __shared__ double red[12];
     __shared__ double seqmem[3 * kSeqCap];
     const MgDesc& D = *Dp;
     Atom A;
     A.phi0 = phi0; A.phi1 = phi1; A.src = src; A.lds = seqmem;
+    A.G = D.G;
+    A.g = blockIdx.x;
+    A.ctr = group_ctr;
+    A.bar = 0;
+    A.part = group_part;
     A.cur = 0;
     for (int l = 0; l < D.levels; ++l) A.cur |= (cur[l] ? 1u : 0u) << l;
-    // sequential levels: global -> LDS (the solve kernel initialises them itself)
-    for (int l = 0; l < D.levels; ++l) {
+    // sequential levels: global -> LDS (the solve kernel initialises them itself); they are workgroup 0's
+    for (int l = 0; l < D.levels && A.g == 0; ++l) {
         const Lvl L = D.lv[l];
         if (!L.seq) continue;
         for (int idx = threadIdx.x; idx < L.n; idx += kThreads) {
@@ -682,26 +782,28 @@ __global__ __launch_bounds__(kThreads) void k_unit(const MgDesc* __restrict__ Dp
     }
     __syncthreads();
     Counters c{0, 0};
+    const bool lead = A.g == 0;
     if (op == 0) {
-        for (int s = 0; s < sweeps; ++s) {
-            const double e = gauss_seidel(D, A, lvl, red);
-            if (threadIdx.x == 0) out[s] = e;
-        }
-    } else if (op == 1) restrict_to(D, A, lvl);
-    else if (op == 2) prolong_from(D, A, lvl);
+        if (lvl < D.kcoop || lead)
+            for (int s = 0; s < sweeps; ++s) {
+                const double e = gauss_seidel(D, A, lvl, red);
+                if (threadIdx.x == 0 && lead) out[s] = e;
+            }
+    } else if (op == 1) do_restrict(D, A, lvl);
+    else if (op == 2) do_prolong(D, A, lvl);
     else if (op == 4) {                                   // IterateGaussSeidel(lvl, errorMin = out[0], iterno = sweeps)
         const double emin = out[0];
-        __syncthreads();
-        const double e = iterate_gs(D, A, lvl, emin, sweeps, red, &c.sweeps);
-        if (threadIdx.x == 0) { out[0] = e; out[1] = (double)c.sweeps; }
+        group_sync(A);                                    // everybody has read out[0]
+        const double e = do_iterate(D, A, lvl, emin, sweeps, red, &c.sweeps);
+        if (threadIdx.x == 0 && lead) { out[0] = e; out[1] = (double)c.sweeps; }
     }
     else if (op == 3) {
         const int nramp = D.levels - 2 > 0 ? D.levels - 2 : 0;
         const double e = run_cycles(D, A, 2 * nramp + 2, 1, 1E-14, 1E-14, red, c);   // one VCycle(last, 1E-14, 3)
-        if (threadIdx.x == 0) out[0] = e;
+        if (threadIdx.x == 0 && lead) out[0] = e;
     }
     __syncthreads();
-    for (int l = 0; l < D.levels; ++l) {
+    for (int l = 0; l < D.levels && lead; ++l) {
         const Lvl L = D.lv[l];
         if (!L.seq) continue;
         for (int idx = threadIdx.x; idx < L.n; idx += kThreads) {
@@ -710,7 +812,7 @@ __global__ __launch_bounds__(kThreads) void k_unit(const MgDesc* __restrict__ Dp
             src[L.off + idx] = seqmem[2 * kSeqCap + L.soff + idx];
         }
     }
-    if (threadIdx.x == 0) for (int l = 0; l < D.levels; ++l) cur[l] = (A.cur >> l) & 1u;
+    if (threadIdx.x == 0 && lead) for (int l = 0; l < D.levels; ++l) cur[l] = (A.cur >> l) & 1u;
 }
 
 }  // namespace
@@ -725,6 +827,8 @@ struct dfta_poisson {
     int* d_cur = nullptr;           // unit hooks: current buffer per level (atom 0)
     std::vector<int> h_cur;
     unsigned long long* d_total_vcycles = nullptr;
+    unsigned* d_group_ctr = nullptr;    // per atom: arrival counter of its group of workgroups (zeroed before every launch)
+    double* d_group_part = nullptr;     // per atom: 6 G + 2 doubles (partial sums of the members, published state)
 };
 
 static long host_addr(const Lvl& L, int i)
@@ -736,8 +840,10 @@ static long host_addr(const Lvl& L, int i)
 int dfta_poisson_solve_launch(dfta_poisson* p, const int* dZ, const double* dDensity, double* dU, int* dVcycles, double* dErr)
 {
     dfta_ctx* ctx = p->ctx;
-    hipLaunchKernelGGL(k_poisson_solve, dim3(p->batch), dim3(kThreads), 0, ctx->stream, p->d_desc, p->d_phi0, p->d_phi1, p->d_src, dZ,
-                       dDensity, p->g->d_r, p->g->d_psrc, dU, dVcycles, dErr, p->d_total_vcycles);
+    DFTA_HIP(ctx, hipMemsetAsync(p->d_group_ctr, 0, sizeof(unsigned) * p->batch, ctx->stream));
+    hipLaunchKernelGGL(k_poisson_solve, dim3(p->batch * p->D.G), dim3(kThreads), 0, ctx->stream, p->d_desc, p->d_phi0, p->d_phi1,
+                       p->d_src, dZ, dDensity, p->g->d_r, p->g->d_psrc, dU, dVcycles, dErr, p->d_total_vcycles, p->d_group_ctr,
+                       p->d_group_part);
     DFTA_CHECK_LAUNCH(ctx);
     return DFTA_OK;
 }
@@ -761,6 +867,23 @@ int dfta_poisson_create(dfta_ctx* ctx, const dfta_grid* g, int batch, dfta_poiss
     p->ctx = ctx; p->g = g; p->batch = batch;
     MgDesc& D = p->D;
     D.levels = g->levels;
+    // Workgroups per atom: a solve is bound by ONE compute unit's vector-memory path, so while the batch leaves compute
+    // units idle the fine levels of every atom are shared by a group of G workgroups (all of them must be resident:
+    // batch * G <= 256 CUs).  A level is shared when every lane of the group still owns >= 8 nodes.
+    int logG = batch <= 32 ? 3 : (batch <= 64 ? 2 : (batch <= 128 ? 1 : 0));
+    if (const char* e = getenv("DFTA_POISSON_GROUP")) {      // measurements: force log2 of the group size
+        const int v = atoi(e);
+        if (v >= 0 && v <= 4 && (batch << v) <= 256) logG = v;
+    }
+    D.kcoop = 0;
+    {
+        int n = g->N;
+        for (int l = 0; l < D.levels; ++l, n = (n + 1) / 2)
+            if (logG > 0 && (n - 1) >= (kThreads << logG) * 8) D.kcoop = l + 1;
+    }
+    if (D.kcoop == 0) logG = 0;
+    D.logG = logG;
+    D.G = 1 << logG;
     long off = kPad, soff = 0;
     double d = g->delta;                       // PoissonSolver.cpp:21-26
     int n = g->N;                              // finest level first
@@ -770,7 +893,7 @@ int dfta_poisson_create(dfta_ctx* ctx, const dfta_grid* g, int batch, dfta_poiss
         int lg = 0;
         while ((1 << lg) < n - 1) ++lg;        // n - 1 == 2^lg
         if (n < kSeqBelow) { L.seq = 1; L.logT = 0; L.logC = lg; L.soff = soff; soff += n; }
-        else { L.seq = 0; L.logT = std::min(lg, 8); L.logC = lg - L.logT; L.soff = -1; }
+        else { L.seq = 0; L.logT = std::min(lg, l < D.kcoop ? 8 + logG : 8); L.logC = lg - L.logT; L.soff = -1; }
         off += n;
         n = (n + 1) / 2;
         d *= 2;
@@ -785,6 +908,8 @@ int dfta_poisson_create(dfta_ctx* ctx, const dfta_grid* g, int batch, dfta_poiss
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->d_desc), sizeof(MgDesc));
     if (e == hipSuccess) e = hipMemcpyAsync(p->d_desc, &p->D, sizeof(MgDesc), hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->d_total_vcycles), sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->d_group_ctr), sizeof(unsigned) * batch);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->d_group_part), sizeof(double) * (size_t)batch * (6 * D.G + 2));
     if (e == hipSuccess) e = hipMemsetAsync(p->d_phi0, 0, tot * sizeof(double), ctx->stream);
     if (e == hipSuccess) e = hipMemsetAsync(p->d_phi1, 0, tot * sizeof(double), ctx->stream);
     if (e == hipSuccess) e = hipMemsetAsync(p->d_src, 0, tot * sizeof(double), ctx->stream);
@@ -804,7 +929,7 @@ int dfta_poisson_create(dfta_ctx* ctx, const dfta_grid* g, int batch, dfta_poiss
 void dfta_poisson_destroy(dfta_poisson* p)
 {
     if (!p) return;
-    void* ptrs[] = {p->d_phi0, p->d_phi1, p->d_src, p->d_cur, p->d_total_vcycles, p->d_desc};
+    void* ptrs[] = {p->d_phi0, p->d_phi1, p->d_src, p->d_cur, p->d_total_vcycles, p->d_desc, p->d_group_ctr, p->d_group_part};
     for (void* q : ptrs) if (q) (void)hipFree(q);
     delete p;
 }
@@ -898,7 +1023,9 @@ static int unit_op(dfta_poisson* p, int op, int lvl, int sweeps, double* out_hos
     DevBuf<double> dOut;
     DFTA_HIP(ctx, dOut.alloc(std::max(nout, 1)));
     DFTA_HIP(ctx, hipMemcpyAsync(p->d_cur, p->h_cur.data(), sizeof(int) * kMaxLevels, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(k_unit, dim3(1), dim3(kThreads), 0, st, p->d_desc, p->d_phi0, p->d_phi1, p->d_src, p->d_cur, op, lvl, sweeps, dOut.p);
+    DFTA_HIP(ctx, hipMemsetAsync(p->d_group_ctr, 0, sizeof(unsigned), st));
+    hipLaunchKernelGGL(k_unit, dim3(p->D.G), dim3(kThreads), 0, st, p->d_desc, p->d_phi0, p->d_phi1, p->d_src, p->d_cur, op, lvl, sweeps, dOut.p,
+                       p->d_group_ctr, p->d_group_part);
     DFTA_CHECK_LAUNCH(ctx);
     DFTA_HIP(ctx, hipMemcpyAsync(p->h_cur.data(), p->d_cur, sizeof(int) * kMaxLevels, hipMemcpyDeviceToHost, st));
     if (out_host && nout > 0) DFTA_HIP(ctx, hipMemcpyAsync(out_host, dOut.p, sizeof(double) * nout, hipMemcpyDeviceToHost, st));
@@ -922,7 +1049,9 @@ int dfta_poisson_iterate_gs(dfta_poisson* p, int lvl, double errorMin, int itern
     DFTA_HIP(ctx, dOut.alloc(2));
     DFTA_HIP(ctx, hipMemcpyAsync(dOut.p, &errorMin, sizeof(double), hipMemcpyHostToDevice, st));
     DFTA_HIP(ctx, hipMemcpyAsync(p->d_cur, p->h_cur.data(), sizeof(int) * kMaxLevels, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(k_unit, dim3(1), dim3(kThreads), 0, st, p->d_desc, p->d_phi0, p->d_phi1, p->d_src, p->d_cur, 4, lvl, iterno, dOut.p);
+    DFTA_HIP(ctx, hipMemsetAsync(p->d_group_ctr, 0, sizeof(unsigned), st));
+    hipLaunchKernelGGL(k_unit, dim3(p->D.G), dim3(kThreads), 0, st, p->d_desc, p->d_phi0, p->d_phi1, p->d_src, p->d_cur, 4, lvl, iterno, dOut.p,
+                       p->d_group_ctr, p->d_group_part);
     DFTA_CHECK_LAUNCH(ctx);
     double out[2] = {0, 0};
     DFTA_HIP(ctx, hipMemcpyAsync(p->h_cur.data(), p->d_cur, sizeof(int) * kMaxLevels, hipMemcpyDeviceToHost, st));
