@@ -229,6 +229,31 @@ def test_poisson_solve_vs_golden(ctx, golden, tag, Z):
     grid.close()
 
 
+def test_poisson_workgroup_groups_are_bit_identical(ctx, grid17):
+    """131073 nodes: the solve with 1, 2, 4 and 8 cooperating workgroups per atom returns the same bits (same arithmetic
+    per node; only the order of the error-norm sums differs, which never reaches the result), for a batch of two atoms"""
+    rr = grid17.r()
+    rho = np.stack([86 * np.exp(-2 * rr) / np.pi, 18 * np.exp(-1.3 * rr) * 1.3 ** 3 / (8 * np.pi)])
+    ref = None
+    old = os.environ.get("DFTA_POISSON_GROUP")
+    try:
+        for logG in (0, 1, 2, 3):
+            os.environ["DFTA_POISSON_GROUP"] = str(logG)            # read by dfta_poisson_create
+            ps = D.Poisson(ctx, grid17, 2)
+            U, vc, err = ps.solve([86, 18], rho)
+            ps.close()
+            if ref is None:
+                ref = (U.copy(), vc.copy())
+            else:
+                assert np.array_equal(U.view(np.int64), ref[0].view(np.int64)), logG
+                assert np.array_equal(vc, ref[1])
+    finally:
+        if old is None:
+            os.environ.pop("DFTA_POISSON_GROUP", None)
+        else:
+            os.environ["DFTA_POISSON_GROUP"] = old
+
+
 def test_vwn_vs_golden(ctx, golden):
     data, _ = golden
     n = data["vwn_n"]
