@@ -109,10 +109,14 @@ __device__ __forceinline__ void group_sync(Atom& A)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         __hip_atomic_fetch_add(A.ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const unsigned target = A.bar * static_cast<unsigned>(A.G);
+        // a member that never arrives (its workgroup was not scheduled: the group does not fit the free compute units)
+        // must not hang the GPU: after ~1 s the waiting member raises the group's abort flag (the counter's top bit),
+        // which releases every later barrier at once; the host sees the flag and reports the failure
         int spins = 0;
-        while (__hip_atomic_load(A.ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        unsigned seen;
+        while ((seen = __hip_atomic_load(A.ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < target) {
             __builtin_amdgcn_s_sleep(1);
-            if (++spins > (1 << 24)) break;
+            if (++spins > (1 << 23)) { __hip_atomic_fetch_or(A.ctr, 0x80000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
@@ -848,11 +852,29 @@ int dfta_poisson_solve_launch(dfta_poisson* p, const int* dZ, const double* dDen
     return DFTA_OK;
 }
 
+// after a solve has completed: did a group of workgroups give up on one of its barriers (a member was never scheduled)?
+static int check_groups(dfta_poisson* p)
+{
+    dfta_ctx* ctx = p->ctx;
+    if (p->D.G == 1) return DFTA_OK;
+    std::vector<unsigned> h(p->batch);
+    DFTA_HIP(ctx, hipMemcpyAsync(h.data(), p->d_group_ctr, sizeof(unsigned) * p->batch, hipMemcpyDeviceToHost, ctx->stream));
+    DFTA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (unsigned v : h)
+        if (v & 0x80000000u) {
+            snprintf(ctx->err, sizeof(ctx->err), "poisson: a group of %d workgroups lost a member at a barrier (the %d workgroups of "
+                     "the launch were not all resident); set DFTA_POISSON_GROUP=0", p->D.G, p->batch * p->D.G);
+            return DFTA_ERR_HIP;
+        }
+    return DFTA_OK;
+}
+
 int dfta_poisson_take_vcycles(dfta_poisson* p, unsigned long long* out)   // reads and clears the V-cycle counter
 {
     dfta_ctx* ctx = p->ctx;
     DFTA_HIP(ctx, hipMemcpyAsync(out, p->d_total_vcycles, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
     DFTA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (int rc = check_groups(p)) return rc;
     DFTA_HIP(ctx, hipMemsetAsync(p->d_total_vcycles, 0, sizeof(unsigned long long), ctx->stream));
     return DFTA_OK;
 }
@@ -874,6 +896,12 @@ int dfta_poisson_create(dfta_ctx* ctx, const dfta_grid* g, int batch, dfta_poiss
     if (const char* e = getenv("DFTA_POISSON_GROUP")) {      // measurements: force log2 of the group size
         const int v = atoi(e);
         if (v >= 0 && v <= 4 && (batch << v) <= 256) logG = v;
+    }
+    {
+        // every workgroup of the launch must be resident at once (the members wait for each other)
+        int per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_poisson_solve, kThreads, 0) != hipSuccess) per_cu = 1;
+        while (logG > 0 && (batch << logG) > per_cu * ctx->num_cu) --logG;
     }
     D.kcoop = 0;
     {
@@ -956,7 +984,7 @@ int dfta_poisson_solve(dfta_poisson* p, const int* Z, const double* density, dou
     if (vcycles_out) DFTA_HIP(ctx, hipMemcpyAsync(vcycles_out, dVc.p, sizeof(int) * B, hipMemcpyDeviceToHost, st));
     if (err_out) DFTA_HIP(ctx, hipMemcpyAsync(err_out, dErr.p, sizeof(double) * B, hipMemcpyDeviceToHost, st));
     DFTA_HIP(ctx, hipStreamSynchronize(st));
-    return DFTA_OK;
+    return check_groups(p);
 }
 
 int dfta_poisson_solve_dev(dfta_poisson* p, const int* dZ, const double* dDensity, double* dU)
