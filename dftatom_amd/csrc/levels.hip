@@ -67,13 +67,14 @@ __device__ __forceinline__ bool pred_bit(const dfta::Job& j, int ph, int k)
 }
 
 // ---- expand: trial energies of the current round of every job, plus their far boundary values ----------------------
-__global__ __launch_bounds__(256) void k_expand(const dfta::Job* __restrict__ jobs, int tpj, const double* __restrict__ r,
+__global__ __launch_bounds__(256) void k_expand(const dfta::Job* __restrict__ jobs, int tpj, int ntrials, const double* __restrict__ r,
                                                 int N, double delta, double far_thr, double* __restrict__ E,
                                                 int* __restrict__ limit, int* __restrict__ start, double* __restrict__ us,
                                                 double* __restrict__ us1, int* __restrict__ wave_kind,
                                                 unsigned long long* __restrict__ issued)
 {
     const int gt = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gt >= ntrials) return;       // ntrials is a multiple of 64: whole waves leave
     const int job = gt / tpj;
     const int h = gt - job * tpj;
     const dfta::Job j = jobs[job];
@@ -702,7 +703,7 @@ int LevelSolver::run(const double* dV, const double* job_bottom, int run_mode, d
     float ms_sweep = 0;
     const int max_rounds = 4096;
     while (rounds < max_rounds) {
-        hipLaunchKernelGGL(k_expand, dim3((unsigned)(ntrials / 256)), dim3(256), 0, st, d_jobs, tpj, g->d_r, N, g->delta,
+        hipLaunchKernelGGL(k_expand, dim3((unsigned)((ntrials + 255) / 256)), dim3(256), 0, st, d_jobs, tpj, (int)ntrials, g->d_r, N, g->delta,
                            g->far_arg_threshold, d_E, d_limit, d_start, d_us, d_us1, d_wave_kind, d_counters);
         DFTA_CHECK_LAUNCH(ctx);
         if (stats) DFTA_HIP(ctx, hipEventRecord(ev[0], st));

@@ -320,6 +320,25 @@ def test_scf_batch_of_atoms_matches_single(ctx, grid14):
     batch.close()
 
 
+def test_scf_odd_batches_are_uniform(ctx, grid14):
+    """batches whose job count is not a multiple of 4 (64-trial trees: the trial array is not a multiple of the expand
+    kernel's block) and that use 8 / 4 / 2 workgroups per atom in the Poisson solver: every copy of the atom gets the
+    single atom's energies, bit for bit"""
+    one = D.Scf(ctx, grid14, [18], lsda=False)
+    one.step()
+    one.step()
+    ref = one.energies()[0][0].as_list()
+    one.close()
+    for n in (5, 33, 67):                         # 35, 231, 469 jobs
+        b = D.Scf(ctx, grid14, [18] * n, lsda=False)
+        b.step()
+        b.step()
+        en, _ = b.energies()
+        for k in range(n):
+            assert en[k].as_list() == ref, (n, k)
+        b.close()
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # full size: 131073 nodes (BASELINE.json configs 2 and 3)
 # ---------------------------------------------------------------------------------------------------------------
