@@ -10,6 +10,10 @@
 // per trial, numerov.hip), then one thread per chain walks its tree with the reference's predicates.
 // The midpoints are generated with the reference's expression (toe + boe) / 2 along the same paths, so the
 // walk reproduces the reference's decision sequence; ~53 sequential sweeps per phase become ceil(53/d) rounds.
+// A tree may hang at the end of a SPINE, a predicted decision path that costs one trial per decision; predictions come
+// from the previous SCF step, from the sibling level (the second bisection evaluates the predicate of the sibling's
+// first one), from the position of the sign change of u(0) (upper end of the band for l = 0, scouted for l > 0).
+// They select which midpoints are integrated speculatively and never enter a decision (k_plan, plan_round).
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -117,10 +121,18 @@ __global__ __launch_bounds__(256) void k_expand(const dfta::Job* __restrict__ jo
                     if (pred_bit(j, ph, j.phase_done + k)) lo = m; else hi = m;
                 }
             } else {
-                const int g = h - S;
+                // the tree's trials are laid out in ENERGY order (in-order rank of the heap node): the 64 trials of a
+                // sweep block then have neighbouring energies -- similar cut-off radii, and whole blocks above the count
+                // threshold leave CountNodes early and free their compute unit
+                const int rank = h - S;
                 const int dsub = tree_depth_for(capz, S);
-                const int gdepth = 31 - __clz(g);
-                exists = gdepth < dsub;
+                int g = 1, gdepth = 0;
+                exists = dsub > 0 && rank < (1 << dsub);
+                if (exists) {
+                    const int tz = __ffs(rank) - 1;
+                    gdepth = dsub - 1 - tz;
+                    g = (1 << gdepth) + (rank >> (tz + 1));
+                }
                 for (int k = 0; k < S; ++k) {
                     const double m = (hi + lo) / 2;
                     if (pred_bit(j, ph, j.phase_done + k)) lo = m; else hi = m;
@@ -172,7 +184,9 @@ struct Cursor {
         if (off) return -1;
         if (k < S) return k + 1;
         const int gdepth = 31 - __clz(g);
-        return gdepth < dsub ? S + g : -1;
+        if (gdepth >= dsub) return -1;
+        const int p = g - (1 << gdepth);
+        return S + ((2 * p + 1) << (dsub - 1 - gdepth));      // in-order rank of heap node g (see k_expand)
     }
     __device__ void advance(bool bit, bool predicted)
     {
