@@ -237,13 +237,20 @@ __device__ __forceinline__ void sweep_wave(const SweepArgs& a, const GridScalars
     ilo = __builtin_amdgcn_readfirstlane(ilo);   // from here down every valid lane has started
 
     // bookkeeping after a step; runs in wave-uniform control flow only, so that its lane masks stay in scalar registers
-#define SWEEP_COUNT(veff, started)                                                                     \
+#define SWEEP_COUNT_U(uval, veff, started)                                                             \
     if (KIND == DFTA_SWEEP_COUNT) {                                                                    \
         const lanemask_t before = c.live & (started);                                                  \
         if (diag) trips += (int)((before >> lane) & 1ull);                                             \
         wave_trips += __popcll(before);                                                                \
-        count_step(c, budget, lane, s.u, (veff), E, (started));                                        \
+        count_step(c, budget, lane, (uval), (veff), E, (started));                                     \
+        poisoned = true;                                                                               \
     }
+#define SWEEP_COUNT(veff, started) SWEEP_COUNT_U(s.u, veff, started)
+    // Whole batches of the body are skipped by the bookkeeping when nothing can change in them (see the counter of the
+    // pipelined kernel below: u keeps its sign and stays finite, veff stays on one side of E, for every live lane);
+    // last_le = "veff <= E" at the last point that went through count_step, unusable while `poisoned`.
+    lanemask_t last_le = 0;
+    bool poisoned = true;
 
     int i = ihi;
     // head: lanes join one by one (per-step masking) until all valid lanes are in
@@ -287,6 +294,7 @@ __device__ __forceinline__ void sweep_wave(const SweepArgs& a, const GridScalars
 #pragma unroll
                 for (int k = 0; k < CH; ++k) CUR[k] = T[i - 2 * CH - k];
             }
+            double uu[CH];
 #pragma unroll
             for (int k = 0; k < CH; ++k) {
                 const double wnext = 2. * s.w - s.wprev + s.u * s.fprev;     // Numerov.h:311 (h2 == 1)
@@ -301,7 +309,37 @@ __device__ __forceinline__ void sweep_wave(const SweepArgs& a, const GridScalars
                     s.u = wnext / d[k];                                       // getU, Numerov.h:510-513
                 }
                 s.fprev = f[k];
-                SWEEP_COUNT(veff[k], vmask)
+                uu[k] = s.u;
+            }
+            if (KIND == DFTA_SWEEP_COUNT) {
+                const lanemask_t act = c.live & vmask;
+                bool quiet = false;
+                if (!poisoned) {
+                    double mn = uu[0], mx = uu[0], ma = uu[0], vmn = veff[0], vmx = veff[0];
+#pragma unroll
+                    for (int k = 1; k < CH; ++k) {
+                        asm("v_min_f64 %0, %1, %2" : "=v"(mn) : "v"(mn), "v"(uu[k]));
+                        asm("v_max_f64 %0, %1, %2" : "=v"(mx) : "v"(mx), "v"(uu[k]));
+                        asm("v_max_f64 %0, |%1|, |%2|" : "=v"(ma) : "v"(ma), "v"(uu[k]));
+                        asm("v_min_f64 %0, %1, %2" : "=v"(vmn) : "v"(vmn), "v"(veff[k]));
+                        asm("v_max_f64 %0, %1, %2" : "=v"(vmx) : "v"(vmx), "v"(veff[k]));
+                    }
+                    const lanemask_t fin = __ballot(fabs(ma) < INFINITY && uu[CH - 1] == uu[CH - 1]);
+                    const lanemask_t allpos = __ballot(mn > 0), nonepos = __ballot(mx <= 0);
+                    const lanemask_t le_all = __ballot(vmx <= E), gt_all = __ballot(vmn > E);
+                    const lanemask_t ok = fin & ((c.oldSgn & allpos) | (~c.oldSgn & nonepos)) & ((le_all & last_le) | (gt_all & ~last_le));
+                    quiet = (~ok & act) == 0ull;
+                }
+                if (quiet) {
+                    if (diag) trips += CH * (int)((act >> lane) & 1ull);
+                    wave_trips += (unsigned long long)CH * __popcll(act);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < CH; ++k) { SWEEP_COUNT_U(uu[k], veff[k], vmask) }
+                    const lanemask_t m_le = __ballot(veff[CH - 1] <= E), m_gt = __ballot(veff[CH - 1] > E);
+                    last_le = m_le;
+                    poisoned = ((m_le | m_gt) != ~0ull);
+                }
             }
             if (fast) {
                 // the fast path needs |w| in range: leave it for good as soon as any lane gets close to the edges
@@ -337,6 +375,7 @@ __device__ __forceinline__ void sweep_wave(const SweepArgs& a, const GridScalars
         SWEEP_COUNT(tv.x, vmask)
     }
 #undef SWEEP_COUNT
+#undef SWEEP_COUNT_U
     if (KIND == DFTA_SWEEP_ZERO) { trips = my_hi; wave_trips = 0; }
 
     const bool exited = valid && !((c.live >> lane) & 1ull);
