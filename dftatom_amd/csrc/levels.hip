@@ -272,6 +272,8 @@ __device__ __forceinline__ void plan_round(dfta::Job& j, const dfta::Job* __rest
         band_of(j, jobs, blo, bhi);
         if (j.se_state == 1 || bhi > blo) j.capz = tpj / 2;
     }
+    // a long predicted spine needs the whole tree behind it to finish the bisection in this round: the scouts pause
+    if (j.sp_len - j.phase_done >= 40) j.capz = tpj;
     if (j.sp_len - j.phase_done > S) { S = j.sp_len - j.phase_done; j.use_sp = 1; }
     if (S > j.capz / 2 - 1) S = j.capz / 2 - 1;  // keep at least half of the trials for the tree
     // once a prediction has missed in this phase the predicted path and the real one have parted: plain trees from there
