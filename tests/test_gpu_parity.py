@@ -502,6 +502,21 @@ def test_iterate_gs_fused_equals_single_sweeps(ctx):
     e1 = b.gauss_seidel(0, 1)
     assert nsw == 1 and abs(err_1 - e1[0]) <= 1e-12 * e1[0]
     assert np.array_equal(a.get_level(0)[0], b.get_level(0)[0])
+    # the LDS-resident sequential levels (129 ... 3 nodes) run the three sweeps as a pipeline over three lanes
+    for lvl in (10, 11, 13, 15, 16):
+        n = a.level_size(lvl)
+        phi, src = rng.standard_normal(n), rng.standard_normal(n) * 1e-2
+        for p in (a, b):
+            p.set_level(lvl, phi, src)
+        err_f, nsw = a.iterate_gs(lvl, 0.0, 3)
+        errs = b.gauss_seidel(lvl, 3)
+        assert nsw == 3 and abs(err_f - errs[2]) <= 1e-12 * max(errs[2], 1e-300), lvl
+        assert np.array_equal(a.get_level(lvl)[0], b.get_level(lvl)[0]), lvl
+        for p in (a, b):
+            p.set_level(lvl, phi, src)
+        err_1, nsw = a.iterate_gs(lvl, 1e30, 3)
+        e1 = b.gauss_seidel(lvl, 1)
+        assert nsw == 1 and np.array_equal(a.get_level(lvl)[0], b.get_level(lvl)[0]), lvl
     a.close()
     b.close()
     grid.close()
