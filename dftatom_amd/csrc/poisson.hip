@@ -34,6 +34,9 @@ constexpr int kSeqBelow = 257;   // levels with n < 257 nodes: one lane, sequent
 constexpr int kSeqCap = 272;     // LDS doubles per array for the sequential levels (129+65+33+17+9+5+3 = 261)
 constexpr int kPF = 8;           // register prefetch depth of the chunked sweep
 constexpr int kFuseMinLogC = 9;  // fuse the three sweeps of a level visit when every lane owns >= 512 nodes
+constexpr int kStageMaxN = 4097;   // chunked levels of workgroup 0 up to this size are swept from an LDS copy
+constexpr int kStagePad = 128;     // doubles in front of each staged array (warm-up reads of the first lanes)
+constexpr int kStageCap = kStageMaxN + kStagePad;
 constexpr int kPad = 320;        // doubles of padding in front of every atom's level storage (warm-up reads of lane 0)
 
 struct Lvl {
@@ -41,6 +44,7 @@ struct Lvl {
     int logC;     // chunk = 1 << logC
     int logT;     // lanes = 1 << logT   (n - 1 == C * T)
     int seq;      // 1: swept by a single lane in natural order
+    int stage;    // 1: chunked, small enough to be swept from a copy in LDS (the CU's vector-memory path is the bound otherwise)
     long off;     // offset of this level inside the per-atom level storage
     long soff;    // sequential levels: offset inside the LDS-resident copy
     double d;     // deltaGridLevel[l]
@@ -76,6 +80,7 @@ struct Atom {
     double* phi1;
     double* src;
     double* lds;      // shared memory: [phi copy 0 | phi copy 1 | src], kSeqCap doubles each
+    double* stage;    // shared memory: three arrays of kStageCap doubles for the staged sweeps of one level visit
     unsigned cur;     // bit l: which copy of level l is current (identical in all threads)
     // group of G workgroups that share the fine levels of this atom (G == 1: none of this is touched)
     int g, G;               // member index, group size
@@ -153,66 +158,23 @@ __device__ __forceinline__ double gs_point(double s, double xm, double xp, doubl
     return 0.5 * (s + xm + xp - dh * (xp - xm));
 }
 
-// one lexicographic Gauss-Seidel sweep of level l: PoissonSolver::GaussSeidel (PoissonSolver.cpp:40-64).
-// returns ||dPhi||_2 (same value in every thread)
-__device__ __forceinline__ double gauss_seidel(const MgDesc& D, Atom& A, int l, double* red)
+// Chunked sweep of one level (S, pin, pout: storage element 0 of the level's source / current / other copy, in global
+// memory or in LDS); LOGT = log2(lanes) as a compile-time constant (row strides become instruction offsets) or -1 for any
+// value.  Returns this thread's share of sum dPhi^2.
+template <int LOGT>
+__device__ __forceinline__ double gs_chunked(const Lvl& L, const double* __restrict__ S, const double* __restrict__ pin,
+                                             double* __restrict__ pout, const int tid, const double dh)
 {
-    const Lvl L = D.lv[l];
-    const double dh = L.d * 0.5;
     double err2 = 0;
-    const bool coop = l < D.kcoop;         // swept by the whole group: lane ids run over all members
-    const int tid = coop ? A.lane() : static_cast<int>(threadIdx.x);
-    if (L.seq) {
-        if (tid == 0) {
-            // one thread, level in LDS.  The loads of a batch (right neighbours, sources) are independent of the
-            // recurrence: they are issued together ahead of it, so that the chain is not one LDS round trip per node.
-            const double* __restrict__ S = A.src_of(L);
-            const double* __restrict__ pin = A.cur_phi(l, L);
-            double* __restrict__ pout = A.other_phi(l, L);
-            double xm = pin[0];
-            pout[0] = xm;
-            const int limit = L.n - 1;
-            double old = pin[1];
-            constexpr int kB = 8;
-            int i = 1;
-            for (; i + kB <= limit; i += kB) {
-                double xp[kB], sv[kB], xo[kB];
-#pragma unroll
-                for (int q = 0; q < kB; ++q) { xp[q] = pin[i + q + 1]; sv[q] = S[i + q]; }
-#pragma unroll
-                for (int q = 0; q < kB; ++q) {
-                    const double x = gs_point(sv[q], xm, xp[q], dh);
-                    const double dif = old - x;
-                    err2 += dif * dif;
-                    xo[q] = x;
-                    xm = x;
-                    old = xp[q];
-                }
-#pragma unroll
-                for (int q = 0; q < kB; ++q) pout[i + q] = xo[q];
-            }
-            for (; i < limit; ++i) {
-                const double xp = pin[i + 1];
-                const double x = gs_point(S[i], xm, xp, dh);
-                const double dif = old - x;
-                err2 += dif * dif;
-                pout[i] = x;
-                xm = x;
-                old = xp;
-            }
-            pout[limit] = pin[limit];
-        }
-    } else {
+    {
         // chunked sweep: lane t owns nodes [t*C, t*C + C), all lanes step through their chunk in lockstep.  With
         // m = step number (m - W < 0: warm-up inside the previous lanes' chunks) the node of lane t is
         //     i = t*C + (m - W) = (t + tu)*C + ku,   ku = (m - W) & (C-1),  tu = (m - W) >> logC   (both wave-uniform)
         // so its storage index is ku*T + tu + t: a uniform base plus the lane id -- no per-lane address arithmetic.
         // Loads run kPF steps ahead of the recurrence in registers (two buffers), all of them unconditional: lanes
         // whose node index is still < 1 read in-bounds padding (kPad) and skip the update.
-        const int T = 1 << L.logT, C = 1 << L.logC, logC = L.logC, logT = L.logT;
-        const double* __restrict__ S = A.src + L.off;
-        const double* __restrict__ pin = (((A.cur >> l) & 1u) ? A.phi1 : A.phi0) + L.off;
-        double* __restrict__ pout = (((A.cur >> l) & 1u) ? A.phi0 : A.phi1) + L.off;
+        const int logT = LOGT >= 0 ? LOGT : L.logT;
+        const int T = 1 << logT, C = 1 << L.logC, logC = L.logC;
         if (tid < T) {
             const int lo = tid << logC;
             const int one_minus_lo = 1 - lo;
@@ -235,6 +197,18 @@ __device__ __forceinline__ double gauss_seidel(const MgDesc& D, Atom& A, int l, 
             };
             // loads of step r (= m - W): S at node i(r), Phi_old at node i(r) + 1 = i(r+1); indices clamped to r <= C-1
             auto load8 = [&](double (&X)[kPF], double (&SV)[kPF], int rbase) {
+                // a batch that neither wraps into the neighbouring lane's column nor runs past the chunk is 9 consecutive
+                // rows: one base pointer per array, the row strides are instruction offsets
+                if (LOGT >= 0 && C >= kPF && rbase + kPF <= Cm1 && ((rbase + kPF) & Cm1) != 0) {
+                    const double* __restrict__ bs = row(S, rbase);
+                    const double* __restrict__ bp = row(pin, rbase) + T;
+#pragma unroll
+                    for (int q = 0; q < kPF; ++q) {
+                        SV[q] = bs[(q << logT) + tu];
+                        X[q] = bp[(q << logT) + tu];
+                    }
+                    return;
+                }
 #pragma unroll
                 for (int q = 0; q < kPF; ++q) {
                     int r0 = rbase + q;
@@ -259,6 +233,7 @@ __device__ __forceinline__ double gauss_seidel(const MgDesc& D, Atom& A, int l, 
             // owned steps (0 <= r < C): recurrence, error norm, store.  FIRST: the batch that holds r = 0 (node 0 of lane 0
             // is a boundary value, not an unknown); LAST: the batch whose last node has xp_end as right neighbour
             auto main8 = [&](auto FIRST, auto LAST, const double (&X)[kPF], const double (&SV)[kPF], int rbase) {
+                double* __restrict__ bo = pout + (static_cast<long>(rbase) << logT);   // rows rbase .. rbase+7 of the own chunk
 #pragma unroll
                 for (int q = 0; q < kPF; ++q) {
                     const int r0 = rbase + q;
@@ -273,7 +248,8 @@ __device__ __forceinline__ double gauss_seidel(const MgDesc& D, Atom& A, int l, 
                         xm = x;
                     }
                     err2 += dif * dif;
-                    const_cast<double*>(row(pout, r0))[tu] = x;          // tu == 0 inside the own chunk; node 0 is rewritten below
+                    if (LOGT >= 0) bo[(q << logT) + tu] = x;             // node 0 (lane 0, r = 0) is rewritten below
+                    else const_cast<double*>(row(pout, r0))[tu] = x;     // tu == 0 inside the own chunk
                     old = xp;
                 }
             };
@@ -329,6 +305,64 @@ __device__ __forceinline__ double gauss_seidel(const MgDesc& D, Atom& A, int l, 
             pout[0] = pin[0];                                   // node 0
             pout[C << logT] = pin[C << logT];                   // node n-1
         }
+    }
+    return err2;
+}
+
+// one lexicographic Gauss-Seidel sweep of level l: PoissonSolver::GaussSeidel (PoissonSolver.cpp:40-64).
+// returns ||dPhi||_2 (same value in every thread)
+__device__ __forceinline__ double gauss_seidel(const MgDesc& D, Atom& A, int l, double* red)
+{
+    const Lvl L = D.lv[l];
+    const double dh = L.d * 0.5;
+    double err2 = 0;
+    const bool coop = l < D.kcoop;         // swept by the whole group: lane ids run over all members
+    const int tid = coop ? A.lane() : static_cast<int>(threadIdx.x);
+    if (L.seq) {
+        if (tid == 0) {
+            // one thread, level in LDS.  The loads of a batch (right neighbours, sources) are independent of the
+            // recurrence: they are issued together ahead of it, so that the chain is not one LDS round trip per node.
+            const double* __restrict__ S = A.src_of(L);
+            const double* __restrict__ pin = A.cur_phi(l, L);
+            double* __restrict__ pout = A.other_phi(l, L);
+            double xm = pin[0];
+            pout[0] = xm;
+            const int limit = L.n - 1;
+            double old = pin[1];
+            constexpr int kB = 8;
+            int i = 1;
+            for (; i + kB <= limit; i += kB) {
+                double xp[kB], sv[kB], xo[kB];
+#pragma unroll
+                for (int q = 0; q < kB; ++q) { xp[q] = pin[i + q + 1]; sv[q] = S[i + q]; }
+#pragma unroll
+                for (int q = 0; q < kB; ++q) {
+                    const double x = gs_point(sv[q], xm, xp[q], dh);
+                    const double dif = old - x;
+                    err2 += dif * dif;
+                    xo[q] = x;
+                    xm = x;
+                    old = xp[q];
+                }
+#pragma unroll
+                for (int q = 0; q < kB; ++q) pout[i + q] = xo[q];
+            }
+            for (; i < limit; ++i) {
+                const double xp = pin[i + 1];
+                const double x = gs_point(S[i], xm, xp, dh);
+                const double dif = old - x;
+                err2 += dif * dif;
+                pout[i] = x;
+                xm = x;
+                old = xp;
+            }
+            pout[limit] = pin[limit];
+        }
+    } else {
+        const double* S = A.src + L.off;
+        const double* pin = (((A.cur >> l) & 1u) ? A.phi1 : A.phi0) + L.off;
+        double* pout = (((A.cur >> l) & 1u) ? A.phi0 : A.phi1) + L.off;
+        err2 = gs_chunked<-1>(L, S, pin, pout, tid, dh);
     }
     A.cur ^= (1u << l);
     // also orders the writes of this sweep before the next phase (group barrier inside for cooperative levels)
@@ -490,6 +524,41 @@ __device__ __forceinline__ double iterate_gs(const MgDesc& D, Atom& A, int l, do
             return e3;
         }
         __syncthreads();                                      // rare: it stops early -- redo from the untouched input copy
+    }
+    if (D.lv[l].stage) {
+        // Mid-size levels of workgroup 0: the level (current copy + source) is copied to LDS once, the sweeps of the visit
+        // ping-pong between two LDS copies (same interleaved layout, same arithmetic), the result goes back once.  A
+        // smoother step then costs LDS issue slots instead of the 12 vector-memory instructions that bound it in HBM/L2.
+        const Lvl L = D.lv[l];
+        const double dh = L.d * 0.5;
+        const int tid = threadIdx.x;
+        const unsigned c0 = (A.cur >> l) & 1u;
+        double* G0 = (c0 ? A.phi1 : A.phi0) + L.off;
+        double* G1 = (c0 ? A.phi0 : A.phi1) + L.off;
+        const double* Sg = A.src + L.off;
+        double* SA = A.stage + kStagePad;
+        double* SB = SA + kStageCap;
+        double* SS = SB + kStageCap;
+        for (int idx = tid; idx < L.n; idx += kThreads) { SA[idx] = G0[idx]; SS[idx] = Sg[idx]; }
+        __syncthreads();
+        double err = 1E10;
+        int done = 0;
+        for (int i = 0; i < iterno; ++i) {
+            const double* pin = (done & 1) ? SB : SA;
+            double* pout = (done & 1) ? SA : SB;
+            const double err2 = gs_chunked<8>(L, SS, pin, pout, tid, dh);
+            err = sqrt(block_sum(err2, red));
+            ++done;
+            ++*nsweeps;
+            if (err < errorMin) break;
+        }
+        // after `done` sweeps the current copy is G1 for odd counts, G0 for even ones
+        const double* res = (done & 1) ? SB : SA;
+        double* Gout = (done & 1) ? G1 : G0;
+        for (int idx = tid; idx < L.n; idx += kThreads) Gout[idx] = res[idx];
+        if (done & 1) A.cur ^= (1u << l);
+        __syncthreads();
+        return err;
     }
     double err = 1E10;
     for (int i = 0; i < iterno; ++i) {
@@ -717,6 +786,7 @@ __global__ __launch_bounds__(kThreads) void k_poisson_solve(const MgDesc* __rest
 {
     __shared__ double red[12];
     __shared__ double seqmem[3 * kSeqCap];
+    __shared__ double stagemem[3 * kStageCap];
     const MgDesc& D = *Dp;
     // consecutive blocks are the members of one group (they land on different XCDs, where the barrier is cheapest)
     const int a = blockIdx.x >> D.logG;
@@ -725,6 +795,7 @@ __global__ __launch_bounds__(kThreads) void k_poisson_solve(const MgDesc* __rest
     A.phi1 = phi1 + (size_t)a * D.per_atom;
     A.src = src + (size_t)a * D.per_atom;
     A.lds = seqmem;
+    A.stage = stagemem;
     A.cur = 0;
     A.G = D.G;
     A.g = blockIdx.x & (D.G - 1);
@@ -764,9 +835,11 @@ __global__ __launch_bounds__(kThreads) void k_unit(const MgDesc* __restrict__ Dp
 {
     __shared__ double red[12];
     __shared__ double seqmem[3 * kSeqCap];
+    __shared__ double stagemem[3 * kStageCap];
     const MgDesc& D = *Dp;
     Atom A;
     A.phi0 = phi0; A.phi1 = phi1; A.src = src; A.lds = seqmem;
+    A.stage = stagemem;
     A.G = D.G;
     A.g = blockIdx.x;
     A.ctr = group_ctr;
@@ -920,8 +993,12 @@ int dfta_poisson_create(dfta_ctx* ctx, const dfta_grid* g, int batch, dfta_poiss
         L.n = n; L.off = off; L.d = d;
         int lg = 0;
         while ((1 << lg) < n - 1) ++lg;        // n - 1 == 2^lg
+        L.stage = 0;
         if (n < kSeqBelow) { L.seq = 1; L.logT = 0; L.logC = lg; L.soff = soff; soff += n; }
-        else { L.seq = 0; L.logT = std::min(lg, l < D.kcoop ? 8 + logG : 8); L.logC = lg - L.logT; L.soff = -1; }
+        else {
+            L.seq = 0; L.logT = std::min(lg, l < D.kcoop ? 8 + logG : 8); L.logC = lg - L.logT; L.soff = -1;
+            L.stage = (l >= D.kcoop && n <= kStageMaxN && L.logT == 8 && !getenv("DFTA_POISSON_NOSTAGE")) ? 1 : 0;
+        }
         off += n;
         n = (n + 1) / 2;
         d *= 2;

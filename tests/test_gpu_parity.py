@@ -502,8 +502,9 @@ def test_iterate_gs_fused_equals_single_sweeps(ctx):
     e1 = b.gauss_seidel(0, 1)
     assert nsw == 1 and abs(err_1 - e1[0]) <= 1e-12 * e1[0]
     assert np.array_equal(a.get_level(0)[0], b.get_level(0)[0])
-    # the LDS-resident sequential levels (129 ... 3 nodes) run the three sweeps as a pipeline over three lanes
-    for lvl in (10, 11, 13, 15, 16):
+    # levels 5..9 (4097 ... 257 nodes) are swept from a copy staged in LDS (result written back to the copy that is current
+    # after an odd / even number of sweeps); the sequential levels (129 ... 3 nodes) live in LDS for the whole solve
+    for lvl in (5, 6, 8, 9, 10, 11, 13, 15, 16):
         n = a.level_size(lvl)
         phi, src = rng.standard_normal(n), rng.standard_normal(n) * 1e-2
         for p in (a, b):
@@ -511,6 +512,10 @@ def test_iterate_gs_fused_equals_single_sweeps(ctx):
         err_f, nsw = a.iterate_gs(lvl, 0.0, 3)
         errs = b.gauss_seidel(lvl, 3)
         assert nsw == 3 and abs(err_f - errs[2]) <= 1e-12 * max(errs[2], 1e-300), lvl
+        assert np.array_equal(a.get_level(lvl)[0], b.get_level(lvl)[0]), lvl
+        err_f, nsw = a.iterate_gs(lvl, 0.0, 2)                    # continue from there: even count
+        errs = b.gauss_seidel(lvl, 2)
+        assert nsw == 2 and abs(err_f - errs[1]) <= 1e-12 * max(errs[1], 1e-300), lvl
         assert np.array_equal(a.get_level(lvl)[0], b.get_level(lvl)[0]), lvl
         for p in (a, b):
             p.set_level(lvl, phi, src)
