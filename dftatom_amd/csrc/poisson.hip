@@ -309,6 +309,117 @@ __device__ __forceinline__ double gs_chunked(const Lvl& L, const double* __restr
     return err2;
 }
 
+// Chunked sweep of a level staged in LDS: 256 lanes, C = 2^LOGC <= 16 nodes per lane, interleaved layout (node t*C + k at
+// k*256 + t; node n-1 at C*256).  Same arithmetic as gs_chunked.  A lone wave on a SIMD issues one instruction of any kind
+// per ~4.5 cycles, so the step is priced in instructions: with C a compile-time constant every LDS access of a 16-step
+// block is "per-lane base register + immediate offset" (the uniform part of the index, (q & (C-1))*256 + (q >> LOGC), is
+// known at compile time; the base advances by 16/C per block) -- 2 reads + 6 flops per warm-up step, nothing else.
+template <int LOGC>
+__device__ __forceinline__ double gs_staged(const double* __restrict__ SS, const double* __restrict__ pin,
+                                            double* __restrict__ pout, const int tid, const double dh)
+{
+    constexpr int C = 1 << LOGC, Cm1 = C - 1, T = 256, kH = 8;
+    static_assert(kWarm % (2 * kH) == 0 && (2 * kH) % C == 0, "blocks of 16 steps must be whole chunk rows");
+    auto uoff = [](int q) constexpr -> int { return (q & Cm1) * T + (q >> LOGC); };    // q >= 0
+    const int lo = tid << LOGC;
+    const int one_minus_lo = 1 - lo;
+    // explicit LDS pointers, each pinned in its own register: otherwise the compiler rebuilds every address from one
+    // base plus a literal (the three arrays are > 64 KB apart, beyond the instruction offset) -- one VALU add per access
+    typedef __attribute__((address_space(3))) double lds_f64;
+    typedef __attribute__((address_space(3))) const double lds_cf64;
+    lds_cf64* ps = (lds_cf64*)(SS) + tid;
+    lds_cf64* pp = (lds_cf64*)(pin) + tid;
+    lds_f64* po = (lds_f64*)(pout) + tid;
+    asm volatile("" : "+v"(ps), "+v"(pp), "+v"(po));
+    // start values: first node of the run and its left neighbour (old values; the exact boundary value for node 0)
+    double xm, old;
+    {
+        const int i0 = (lo - kWarm) > 1 ? (lo - kWarm) : 1;
+        const int a0 = i0 - 1, a1 = i0;
+        xm = pin[((a0 & Cm1) << 8) + (a0 >> LOGC)];
+        old = pin[((a1 & Cm1) << 8) + (a1 >> LOGC)];
+    }
+    const double xp_end = pin[(tid == T - 1) ? (C << 8) : (tid + 1)];
+    // operands of the owned steps: independent of the recurrence, fetched first
+    double ms[C], mx[C];
+#pragma unroll
+    for (int r = 0; r < C; ++r) {
+        ms[r] = ps[r * T];
+        mx[r] = (r == Cm1) ? xp_end : pp[(r + 1) * T];
+    }
+    const bool careful = __builtin_amdgcn_readfirstlane(lo) <= kWarm;
+    lds_cf64* bs = ps - (kWarm >> LOGC);
+    lds_cf64* bp = pp - (kWarm >> LOGC);
+    double ax[kH], as[kH], bx[kH], bv[kH];
+    auto loadA = [&]() {
+#pragma unroll
+        for (int q = 0; q < kH; ++q) { as[q] = bs[uoff(q)]; ax[q] = bp[uoff(q + 1)]; }
+    };
+    auto loadB = [&]() {
+#pragma unroll
+        for (int q = 0; q < kH; ++q) { bv[q] = bs[uoff(kH + q)]; bx[q] = bp[uoff(kH + q + 1)]; }
+    };
+    auto warm = [&](auto CAREFUL, const double (&X)[kH], const double (&SV)[kH], int rbase) {
+#pragma unroll
+        for (int q = 0; q < kH; ++q) {
+            const double x = gs_point(SV[q], xm, X[q], dh);
+            if (decltype(CAREFUL)::value) xm = (rbase + q >= one_minus_lo) ? x : xm;   // node index lo + r >= 1
+            else xm = x;
+        }
+    };
+    using std::true_type;
+    using std::false_type;
+    loadA();
+    if (careful) {
+        for (int r = -kWarm; r < 0; r += 2 * kH) {
+            loadB();
+            __builtin_amdgcn_sched_barrier(0);  // keep the reads a whole half block ahead of their use
+            warm(true_type{}, ax, as, r);
+            bs += (2 * kH) >> LOGC;
+            bp += (2 * kH) >> LOGC;
+            asm volatile("" : "+v"(bs), "+v"(bp));
+            loadA();                            // the last one fetches owned nodes (in bounds, unused)
+            __builtin_amdgcn_sched_barrier(0);
+            warm(true_type{}, bx, bv, r + kH);
+        }
+    } else {
+        for (int r = -kWarm; r < 0; r += 2 * kH) {
+            loadB();
+            __builtin_amdgcn_sched_barrier(0);
+            warm(false_type{}, ax, as, r);
+            bs += (2 * kH) >> LOGC;
+            bp += (2 * kH) >> LOGC;
+            asm volatile("" : "+v"(bs), "+v"(bp));
+            loadA();                            // the last one fetches owned nodes (in bounds, unused)
+            __builtin_amdgcn_sched_barrier(0);
+            warm(false_type{}, bx, bv, r + kH);
+        }
+    }
+    if (lo >= 1) old = bx[kH - 1];              // Phi_old at the first owned node; lane 0 keeps the value loaded above
+    double err2 = 0;
+#pragma unroll
+    for (int r = 0; r < C; ++r) {
+        const double xp = mx[r];
+        const double x = gs_point(ms[r], xm, xp, dh);
+        double dif = old - x;
+        if (r == 0) {
+            const bool live = lo >= 1;          // node 0 is a boundary value, not an unknown
+            dif = live ? dif : 0.0;
+            xm = live ? x : xm;
+        } else {
+            xm = x;
+        }
+        err2 += dif * dif;
+        po[r * T] = x;                          // node 0 (lane 0, r = 0) is rewritten below
+        old = xp;
+    }
+    if (tid == 0) {
+        pout[0] = pin[0];                       // node 0
+        pout[C << 8] = pin[C << 8];             // node n-1
+    }
+    return err2;
+}
+
 // one lexicographic Gauss-Seidel sweep of level l: PoissonSolver::GaussSeidel (PoissonSolver.cpp:40-64).
 // returns ||dPhi||_2 (same value in every thread)
 __device__ __forceinline__ double gauss_seidel(const MgDesc& D, Atom& A, int l, double* red)
@@ -546,7 +657,14 @@ __device__ __forceinline__ double iterate_gs(const MgDesc& D, Atom& A, int l, do
         for (int i = 0; i < iterno; ++i) {
             const double* pin = (done & 1) ? SB : SA;
             double* pout = (done & 1) ? SA : SB;
-            const double err2 = gs_chunked<8>(L, SS, pin, pout, tid, dh);
+            double err2;
+            switch (L.logC) {
+                case 0:  err2 = gs_staged<0>(SS, pin, pout, tid, dh); break;
+                case 1:  err2 = gs_staged<1>(SS, pin, pout, tid, dh); break;
+                case 2:  err2 = gs_staged<2>(SS, pin, pout, tid, dh); break;
+                case 3:  err2 = gs_staged<3>(SS, pin, pout, tid, dh); break;
+                default: err2 = gs_staged<4>(SS, pin, pout, tid, dh); break;
+            }
             err = sqrt(block_sum(err2, red));
             ++done;
             ++*nsweeps;
@@ -997,7 +1115,7 @@ int dfta_poisson_create(dfta_ctx* ctx, const dfta_grid* g, int batch, dfta_poiss
         if (n < kSeqBelow) { L.seq = 1; L.logT = 0; L.logC = lg; L.soff = soff; soff += n; }
         else {
             L.seq = 0; L.logT = std::min(lg, l < D.kcoop ? 8 + logG : 8); L.logC = lg - L.logT; L.soff = -1;
-            L.stage = (l >= D.kcoop && n <= kStageMaxN && L.logT == 8 && !getenv("DFTA_POISSON_NOSTAGE")) ? 1 : 0;
+            L.stage = (l >= D.kcoop && n <= kStageMaxN && L.logT == 8 && L.logC <= 4 && !getenv("DFTA_POISSON_NOSTAGE")) ? 1 : 0;
         }
         off += n;
         n = (n + 1) / 2;
