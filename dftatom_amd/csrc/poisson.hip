@@ -29,14 +29,19 @@ namespace {
 
 constexpr int kMaxLevels = 24;
 constexpr int kThreads = 256;
-constexpr int kWarm = 96;   // start-value error decays by <= 0.52^96 < 2^-90: chunked sweep == sequential sweep bit for bit
+#ifndef DFTA_KWARM
+#define DFTA_KWARM 96
+#endif
+constexpr int kWarm = DFTA_KWARM;   // start-value error decays by <= 0.52^96 < 2^-90: chunked sweep == sequential sweep bit for bit
 constexpr int kSeqBelow = 257;   // levels with n < 257 nodes: one lane, sequential
 constexpr int kSeqCap = 272;     // LDS doubles per array for the sequential levels (129+65+33+17+9+5+3 = 261)
 constexpr int kPF = 8;           // register prefetch depth of the chunked sweep
 constexpr int kFuseMinLogC = 9;  // fuse the three sweeps of a level visit when every lane owns >= 512 nodes
-constexpr int kStageMaxN = 4097;   // chunked levels of workgroup 0 up to this size are swept from an LDS copy
-constexpr int kStagePad = 128;     // doubles in front of each staged array (warm-up reads of the first lanes)
-constexpr int kStageCap = kStageMaxN + kStagePad;
+constexpr int kStageMaxLogC = 5;   // chunked levels with <= 32 nodes per lane are swept from a copy in LDS (Phi, S)
+constexpr int kStagePad = 128;     // one workgroup: doubles in front of each staged array (warm-up reads of the first lanes)
+constexpr int kStageH = 16;        // group members: halo columns in front of every staged row (>= 96/C lanes, C >= 8)
+constexpr int kStageRS = kThreads + kStageH;          // row stride of a member's staged part
+constexpr int kStageArr = 8736;    // doubles per staged array: >= kStagePad + 8193 and >= kStageH + 32*kStageRS + 1
 constexpr int kPad = 320;        // doubles of padding in front of every atom's level storage (warm-up reads of lane 0)
 
 struct Lvl {
@@ -44,7 +49,7 @@ struct Lvl {
     int logC;     // chunk = 1 << logC
     int logT;     // lanes = 1 << logT   (n - 1 == C * T)
     int seq;      // 1: swept by a single lane in natural order
-    int stage;    // 1: chunked, small enough to be swept from a copy in LDS (the CU's vector-memory path is the bound otherwise)
+    int stage;    // swept from a copy in LDS (the CU's vector-memory path is the bound otherwise): 1 = one workgroup's level, 2 = shared level
     long off;     // offset of this level inside the per-atom level storage
     long soff;    // sequential levels: offset inside the LDS-resident copy
     double d;     // deltaGridLevel[l]
@@ -80,7 +85,7 @@ struct Atom {
     double* phi1;
     double* src;
     double* lds;      // shared memory: [phi copy 0 | phi copy 1 | src], kSeqCap doubles each
-    double* stage;    // shared memory: three arrays of kStageCap doubles for the staged sweeps of one level visit
+    double* stage;    // shared memory: two arrays of kStageArr doubles (Phi, S) for the staged sweeps of one level visit
     unsigned cur;     // bit l: which copy of level l is current (identical in all threads)
     // group of G workgroups that share the fine levels of this atom (G == 1: none of this is touched)
     int g, G;               // member index, group size
@@ -156,6 +161,17 @@ __device__ __forceinline__ double gs_point(double s, double xm, double xp, doubl
 {
     // PoissonSolver.cpp:56-57; d * t * 0.5 == (0.5 d) * t exactly
     return 0.5 * (s + xm + xp - dh * (xp - xm));
+}
+
+// The same update with the recurrence carried as y = 2x: 0.5*y is exact, so fma(y, 0.5, s) = fl(s + x) and
+// fma(y, -0.5, xp) = fl(xp - x) are the reference's roundings, and the dependent chain per node is three fp64 operations
+// instead of four (the sweeps that run out of LDS are bound by exactly that latency: ~16 cycles per dependent operation).
+// Returns 2 * gs_point(s, 0.5*y, xp, dh) before its (exact) halving.
+__device__ __forceinline__ double gs_point2(double s, double y, double xp, double dh)
+{
+    const double t1 = __builtin_fma(y, 0.5, s);
+    const double t2 = __builtin_fma(y, -0.5, xp);
+    return (t1 + xp) - dh * t2;
 }
 
 // Chunked sweep of one level (S, pin, pout: storage element 0 of the level's source / current / other copy, in global
@@ -309,114 +325,133 @@ __device__ __forceinline__ double gs_chunked(const Lvl& L, const double* __restr
     return err2;
 }
 
-// Chunked sweep of a level staged in LDS: 256 lanes, C = 2^LOGC <= 16 nodes per lane, interleaved layout (node t*C + k at
-// k*256 + t; node n-1 at C*256).  Same arithmetic as gs_chunked.  A lone wave on a SIMD issues one instruction of any kind
-// per ~4.5 cycles, so the step is priced in instructions: with C a compile-time constant every LDS access of a 16-step
-// block is "per-lane base register + immediate offset" (the uniform part of the index, (q & (C-1))*256 + (q >> LOGC), is
-// known at compile time; the base advances by 16/C per block) -- 2 reads + 6 flops per warm-up step, nothing else.
-template <int LOGC>
-__device__ __forceinline__ double gs_staged(const double* __restrict__ SS, const double* __restrict__ pin,
-                                            double* __restrict__ pout, const int tid, const double dh)
+// Chunked sweep, IN PLACE, of (a workgroup's part of) a level staged in LDS: 256 lanes, C = 2^LOGC nodes per lane; node
+// t*C + k of the part lives at k*RS + t relative to SSbase / PPbase, lanes t < 0 (the 96 nodes in front of the part: the
+// previous lanes' columns for RS == 256, halo columns otherwise) included; Phi of the node behind the part at C*RS.  Same
+// arithmetic as gs_chunked.  A lone wave on a SIMD issues one instruction of any kind per ~4.5 cycles, so the step is
+// priced in instructions: with C a compile-time constant every LDS access of a 16-step block is "per-lane base register +
+// immediate offset" (the uniform part of the index, (q & (C-1))*RS + (q >> LOGC), is known at compile time; the base
+// advances by 16/C per block) -- 2 reads + 6 flops per warm-up step, nothing else.  Everything a lane reads from other
+// lanes' nodes (warm-up, start values, right neighbour of its last node) is read before the barrier in the middle, the
+// owned nodes are overwritten after it.  lo_g = index of the lane's first node within the level.
+template <int LOGC, int RS>
+__device__ __forceinline__ double gs_lds(const double* __restrict__ SSbase, double* __restrict__ PPbase, const int tid,
+                                         const int lo_g, const double dh)
 {
-    constexpr int C = 1 << LOGC, Cm1 = C - 1, T = 256, kH = 8;
-    static_assert(kWarm % (2 * kH) == 0 && (2 * kH) % C == 0, "blocks of 16 steps must be whole chunk rows");
-    auto uoff = [](int q) constexpr -> int { return (q & Cm1) * T + (q >> LOGC); };    // q >= 0
-    const int lo = tid << LOGC;
-    const int one_minus_lo = 1 - lo;
+    constexpr int C = 1 << LOGC, Cm1 = C - 1, kH = 8;
+    auto uoff = [](int q) constexpr -> int { return (q & Cm1) * RS + (q >> LOGC); };    // q >= 0
+    const int one_minus_lo = 1 - lo_g;
     // explicit LDS pointers, each pinned in its own register: otherwise the compiler rebuilds every address from one
-    // base plus a literal (the three arrays are > 64 KB apart, beyond the instruction offset) -- one VALU add per access
+    // base plus a literal (the arrays are > 64 KB apart, beyond the instruction offset) -- one VALU add per access
     typedef __attribute__((address_space(3))) double lds_f64;
     typedef __attribute__((address_space(3))) const double lds_cf64;
-    lds_cf64* ps = (lds_cf64*)(SS) + tid;
-    lds_cf64* pp = (lds_cf64*)(pin) + tid;
-    lds_f64* po = (lds_f64*)(pout) + tid;
-    asm volatile("" : "+v"(ps), "+v"(pp), "+v"(po));
+    lds_cf64* ps = (lds_cf64*)(SSbase) + tid;
+    lds_f64* pp = (lds_f64*)(PPbase) + tid;
+    asm volatile("" : "+v"(ps), "+v"(pp));
     // start values: first node of the run and its left neighbour (old values; the exact boundary value for node 0)
     double xm, old;
     {
-        const int i0 = (lo - kWarm) > 1 ? (lo - kWarm) : 1;
-        const int a0 = i0 - 1, a1 = i0;
-        xm = pin[((a0 & Cm1) << 8) + (a0 >> LOGC)];
-        old = pin[((a1 & Cm1) << 8) + (a1 >> LOGC)];
+        const int j = ((lo_g - kWarm) > 1 ? (lo_g - kWarm) : 1) - lo_g;       // first node of the run relative to lo
+        const int a0 = j - 1, a1 = j;
+        xm = pp[(a0 & Cm1) * RS + (a0 >> LOGC)];
+        old = pp[(a1 & Cm1) * RS + (a1 >> LOGC)];
     }
-    const double xp_end = pin[(tid == T - 1) ? (C << 8) : (tid + 1)];
-    // operands of the owned steps: independent of the recurrence, fetched first
-    double ms[C], mx[C];
-#pragma unroll
-    for (int r = 0; r < C; ++r) {
-        ms[r] = ps[r * T];
-        mx[r] = (r == Cm1) ? xp_end : pp[(r + 1) * T];
-    }
-    const bool careful = __builtin_amdgcn_readfirstlane(lo) <= kWarm;
+    double y = 2.0 * xm;                        // the recurrence is carried as y = 2x (gs_point2)
+    const double xp_end = (tid == kThreads - 1) ? PPbase[C * RS] : pp[1];
+    const double node0 = pp[0];
+    const bool careful = __builtin_amdgcn_readfirstlane(lo_g) <= kWarm;
     lds_cf64* bs = ps - (kWarm >> LOGC);
     lds_cf64* bp = pp - (kWarm >> LOGC);
     double ax[kH], as[kH], bx[kH], bv[kH];
-    auto loadA = [&]() {
+    // the warm-up runs in blocks of BS = max(16, C) steps (whole chunk rows and whole A/B rounds); h = half block of 8
+    constexpr int BS = C > 2 * kH ? C : 2 * kH;
+    static_assert(kWarm % BS == 0, "warm-up must be a whole number of blocks");
+    auto load = [&](double (&X)[kH], double (&SV)[kH], auto HH) {
+        constexpr int h = decltype(HH)::value;
 #pragma unroll
-        for (int q = 0; q < kH; ++q) { as[q] = bs[uoff(q)]; ax[q] = bp[uoff(q + 1)]; }
-    };
-    auto loadB = [&]() {
-#pragma unroll
-        for (int q = 0; q < kH; ++q) { bv[q] = bs[uoff(kH + q)]; bx[q] = bp[uoff(kH + q + 1)]; }
+        for (int q = 0; q < kH; ++q) { SV[q] = bs[uoff(h * kH + q)]; X[q] = bp[uoff(h * kH + q + 1)]; }
     };
     auto warm = [&](auto CAREFUL, const double (&X)[kH], const double (&SV)[kH], int rbase) {
 #pragma unroll
         for (int q = 0; q < kH; ++q) {
-            const double x = gs_point(SV[q], xm, X[q], dh);
-            if (decltype(CAREFUL)::value) xm = (rbase + q >= one_minus_lo) ? x : xm;   // node index lo + r >= 1
-            else xm = x;
+            const double yn = gs_point2(SV[q], y, X[q], dh);
+            if (decltype(CAREFUL)::value) y = (rbase + q >= one_minus_lo) ? yn : y;   // node index lo + r >= 1
+            else y = yn;
         }
+    };
+    using std::integral_constant;
+    auto block = [&](auto CAREFUL, int r) {
+        // halves 0, 2, 4 .. in A, 1, 3, 5 .. in B; the reads stay a whole half block ahead of their use
+        auto pair = [&](auto H0) {
+            constexpr int h = decltype(H0)::value;
+            load(bx, bv, integral_constant<int, h + 1>{});
+            __builtin_amdgcn_sched_barrier(0);
+            warm(CAREFUL, ax, as, r + h * kH);
+            if constexpr ((h + 2) * kH < BS) {
+                load(ax, as, integral_constant<int, h + 2>{});
+            } else {
+                bs += BS >> LOGC;
+                bp += BS >> LOGC;
+                asm volatile("" : "+v"(bs), "+v"(bp));
+                load(ax, as, integral_constant<int, 0>{});      // the last one fetches the first owned nodes
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            warm(CAREFUL, bx, bv, r + (h + 1) * kH);
+        };
+        pair(integral_constant<int, 0>{});
+        if constexpr (BS > 2 * kH) pair(integral_constant<int, 2>{});
+        static_assert(BS <= 4 * kH, "chunks of more than 32 nodes are not staged");
     };
     using std::true_type;
     using std::false_type;
-    loadA();
+    load(ax, as, integral_constant<int, 0>{});
     if (careful) {
-        for (int r = -kWarm; r < 0; r += 2 * kH) {
-            loadB();
-            __builtin_amdgcn_sched_barrier(0);  // keep the reads a whole half block ahead of their use
-            warm(true_type{}, ax, as, r);
-            bs += (2 * kH) >> LOGC;
-            bp += (2 * kH) >> LOGC;
-            asm volatile("" : "+v"(bs), "+v"(bp));
-            loadA();                            // the last one fetches owned nodes (in bounds, unused)
-            __builtin_amdgcn_sched_barrier(0);
-            warm(true_type{}, bx, bv, r + kH);
-        }
+        for (int r = -kWarm; r < 0; r += BS) block(true_type{}, r);
     } else {
-        for (int r = -kWarm; r < 0; r += 2 * kH) {
-            loadB();
-            __builtin_amdgcn_sched_barrier(0);
-            warm(false_type{}, ax, as, r);
-            bs += (2 * kH) >> LOGC;
-            bp += (2 * kH) >> LOGC;
-            asm volatile("" : "+v"(bs), "+v"(bp));
-            loadA();                            // the last one fetches owned nodes (in bounds, unused)
-            __builtin_amdgcn_sched_barrier(0);
-            warm(false_type{}, bx, bv, r + kH);
-        }
+        for (int r = -kWarm; r < 0; r += BS) block(false_type{}, r);
     }
-    if (lo >= 1) old = bx[kH - 1];              // Phi_old at the first owned node; lane 0 keeps the value loaded above
+    if (lo_g >= 1) old = bx[kH - 1];            // Phi_old at the first owned node; the lane of node 0 keeps the value loaded above
+    __syncthreads();                            // all reads of other lanes' old values are done
     double err2 = 0;
+    auto own = [&](const double (&X)[kH], const double (&SV)[kH], int r0) {
 #pragma unroll
-    for (int r = 0; r < C; ++r) {
-        const double xp = mx[r];
-        const double x = gs_point(ms[r], xm, xp, dh);
-        double dif = old - x;
-        if (r == 0) {
-            const bool live = lo >= 1;          // node 0 is a boundary value, not an unknown
-            dif = live ? dif : 0.0;
-            xm = live ? x : xm;
-        } else {
-            xm = x;
+        for (int q = 0; q < (C < kH ? C : kH); ++q) {
+            const int r = r0 + q;
+            const double xp = (r == Cm1) ? xp_end : X[q];
+            const double yn = gs_point2(SV[q], y, xp, dh);
+            const double x = 0.5 * yn;
+            double dif = old - x;
+            if (r == 0) {
+                const bool live = lo_g >= 1;    // node 0 is a boundary value, not an unknown
+                dif = live ? dif : 0.0;
+                y = live ? yn : y;
+            } else {
+                y = yn;
+            }
+            err2 += dif * dif;
+            pp[r * RS] = x;                     // node 0 is restored below
+            old = xp;
         }
-        err2 += dif * dif;
-        po[r * T] = x;                          // node 0 (lane 0, r = 0) is rewritten below
-        old = xp;
+    };
+    if constexpr (C <= kH) {
+        own(ax, as, 0);
+    } else {
+        // rows r .. r+7 in A (fetched by the last warm-up block for r = 0), r+8 .. r+15 in B
+#pragma unroll
+        for (int r = 0; r < C; r += 2 * kH) {
+#pragma unroll
+            for (int q = 0; q < kH; ++q) { bv[q] = ps[(r + kH + q) * RS]; bx[q] = pp[((r + kH + q + 1) & Cm1) * RS]; }
+            __builtin_amdgcn_sched_barrier(0);
+            own(ax, as, r);
+            if (r + 2 * kH < C) {
+#pragma unroll
+                for (int q = 0; q < kH; ++q) { as[q] = ps[(r + 2 * kH + q) * RS]; ax[q] = pp[(r + 2 * kH + q + 1) * RS]; }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            own(bx, bv, r + kH);
+        }
     }
-    if (tid == 0) {
-        pout[0] = pin[0];                       // node 0
-        pout[C << 8] = pin[C << 8];             // node n-1
-    }
+    if (lo_g == 0) pp[0] = node0;
     return err2;
 }
 
@@ -436,8 +471,9 @@ __device__ __forceinline__ double gauss_seidel(const MgDesc& D, Atom& A, int l, 
             const double* __restrict__ S = A.src_of(L);
             const double* __restrict__ pin = A.cur_phi(l, L);
             double* __restrict__ pout = A.other_phi(l, L);
-            double xm = pin[0];
-            pout[0] = xm;
+            const double x0 = pin[0];
+            pout[0] = x0;
+            double y = 2.0 * x0;                // the recurrence is carried as y = 2x (gs_point2: a shorter dependent chain)
             const int limit = L.n - 1;
             double old = pin[1];
             constexpr int kB = 8;
@@ -448,11 +484,11 @@ __device__ __forceinline__ double gauss_seidel(const MgDesc& D, Atom& A, int l, 
                 for (int q = 0; q < kB; ++q) { xp[q] = pin[i + q + 1]; sv[q] = S[i + q]; }
 #pragma unroll
                 for (int q = 0; q < kB; ++q) {
-                    const double x = gs_point(sv[q], xm, xp[q], dh);
+                    y = gs_point2(sv[q], y, xp[q], dh);
+                    const double x = 0.5 * y;
                     const double dif = old - x;
                     err2 += dif * dif;
                     xo[q] = x;
-                    xm = x;
                     old = xp[q];
                 }
 #pragma unroll
@@ -460,11 +496,11 @@ __device__ __forceinline__ double gauss_seidel(const MgDesc& D, Atom& A, int l, 
             }
             for (; i < limit; ++i) {
                 const double xp = pin[i + 1];
-                const double x = gs_point(S[i], xm, xp, dh);
+                y = gs_point2(S[i], y, xp, dh);
+                const double x = 0.5 * y;
                 const double dif = old - x;
                 err2 += dif * dif;
                 pout[i] = x;
-                xm = x;
                 old = xp;
             }
             pout[limit] = pin[limit];
@@ -622,6 +658,23 @@ __device__ __forceinline__ void gs_fused3(const MgDesc& D, Atom& A, int l, doubl
     e3 = sqrt((red[8] + red[9]) + (red[10] + red[11]));
 }
 
+// Copy C rows of 256 lanes between global memory and LDS (row strides in doubles).  The loads of up to 8 rows are issued
+// together: a row-by-row loop pays one memory round trip per row.
+template <typename Dst, typename Src>
+__device__ __forceinline__ void copy_rows(Dst* dst, int dstride, const Src* src, int sstride, int C)
+{
+    const int tid = threadIdx.x;
+    int k = 0;
+    for (; k + 8 <= C; k += 8) {
+        double v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = src[(k + q) * sstride + tid];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) dst[(k + q) * dstride + tid] = v[q];
+    }
+    for (; k < C; ++k) dst[k * dstride + tid] = src[k * sstride + tid];
+}
+
 // PoissonSolver::IterateGaussSeidel (PoissonSolver.cpp:66-77)
 __device__ __forceinline__ double iterate_gs(const MgDesc& D, Atom& A, int l, double errorMin, int iterno, double* red, long* nsweeps)
 {
@@ -636,10 +689,10 @@ __device__ __forceinline__ double iterate_gs(const MgDesc& D, Atom& A, int l, do
         }
         __syncthreads();                                      // rare: it stops early -- redo from the untouched input copy
     }
-    if (D.lv[l].stage) {
-        // Mid-size levels of workgroup 0: the level (current copy + source) is copied to LDS once, the sweeps of the visit
-        // ping-pong between two LDS copies (same interleaved layout, same arithmetic), the result goes back once.  A
-        // smoother step then costs LDS issue slots instead of the 12 vector-memory instructions that bound it in HBM/L2.
+    if (D.lv[l].stage == 1) {
+        // A level of one workgroup with <= 8193 nodes: the current copy and the source are copied to LDS once per visit
+        // (same interleaved layout), the sweeps of the visit run there in place, the result goes back once.  A smoother
+        // step then costs LDS issue slots instead of the 12 vector-memory instructions that bound it in HBM/L2.
         const Lvl L = D.lv[l];
         const double dh = L.d * 0.5;
         const int tid = threadIdx.x;
@@ -647,23 +700,25 @@ __device__ __forceinline__ double iterate_gs(const MgDesc& D, Atom& A, int l, do
         double* G0 = (c0 ? A.phi1 : A.phi0) + L.off;
         double* G1 = (c0 ? A.phi0 : A.phi1) + L.off;
         const double* Sg = A.src + L.off;
-        double* SA = A.stage + kStagePad;
-        double* SB = SA + kStageCap;
-        double* SS = SB + kStageCap;
-        for (int idx = tid; idx < L.n; idx += kThreads) { SA[idx] = G0[idx]; SS[idx] = Sg[idx]; }
+        double* PP = A.stage + kStagePad;
+        double* SS = PP + kStageArr;
+        const int C1 = 1 << L.logC;
+        copy_rows(PP, kThreads, G0, kThreads, C1);
+        copy_rows(SS, kThreads, Sg, kThreads, C1);
+        if (tid == 0) PP[L.n - 1] = G0[L.n - 1];
         __syncthreads();
+        const int lo_g = tid << L.logC;
         double err = 1E10;
         int done = 0;
         for (int i = 0; i < iterno; ++i) {
-            const double* pin = (done & 1) ? SB : SA;
-            double* pout = (done & 1) ? SA : SB;
             double err2;
             switch (L.logC) {
-                case 0:  err2 = gs_staged<0>(SS, pin, pout, tid, dh); break;
-                case 1:  err2 = gs_staged<1>(SS, pin, pout, tid, dh); break;
-                case 2:  err2 = gs_staged<2>(SS, pin, pout, tid, dh); break;
-                case 3:  err2 = gs_staged<3>(SS, pin, pout, tid, dh); break;
-                default: err2 = gs_staged<4>(SS, pin, pout, tid, dh); break;
+                case 0:  err2 = gs_lds<0, kThreads>(SS, PP, tid, lo_g, dh); break;
+                case 1:  err2 = gs_lds<1, kThreads>(SS, PP, tid, lo_g, dh); break;
+                case 2:  err2 = gs_lds<2, kThreads>(SS, PP, tid, lo_g, dh); break;
+                case 3:  err2 = gs_lds<3, kThreads>(SS, PP, tid, lo_g, dh); break;
+                case 4:  err2 = gs_lds<4, kThreads>(SS, PP, tid, lo_g, dh); break;
+                default: err2 = gs_lds<5, kThreads>(SS, PP, tid, lo_g, dh); break;
             }
             err = sqrt(block_sum(err2, red));
             ++done;
@@ -671,11 +726,84 @@ __device__ __forceinline__ double iterate_gs(const MgDesc& D, Atom& A, int l, do
             if (err < errorMin) break;
         }
         // after `done` sweeps the current copy is G1 for odd counts, G0 for even ones
-        const double* res = (done & 1) ? SB : SA;
         double* Gout = (done & 1) ? G1 : G0;
-        for (int idx = tid; idx < L.n; idx += kThreads) Gout[idx] = res[idx];
+        copy_rows(Gout, kThreads, PP, kThreads, C1);
+        if (tid == 0) Gout[L.n - 1] = PP[L.n - 1];
         if (done & 1) A.cur ^= (1u << l);
         __syncthreads();
+        return err;
+    }
+    if (D.lv[l].stage == 2) {
+        // A level shared by the G workgroups of the atom (lane ids run over the group: member g owns the columns
+        // g*256 .. g*256+255 of every row): each member stages its columns plus kStageH halo columns in front of them (the
+        // previous member's last lanes: the warm-up reads up to 96 nodes = 96/C lanes back) and Phi of the first node of
+        // the next member.  After every sweep the members exchange the new values of those boundary nodes through the
+        // level's other global copy (exactly where the unstaged sweep would have put them) around the group barrier that
+        // the error norm needs anyway; the last sweep of the visit writes the whole part out instead.
+        const Lvl L = D.lv[l];
+        const double dh = L.d * 0.5;
+        const int tid = threadIdx.x;
+        const int C = 1 << L.logC, logT = L.logT, g = A.g;
+        const int Hc = kWarm >> L.logC;                       // lanes in the halo that the warm-up touches
+        const unsigned c0 = (A.cur >> l) & 1u;
+        double* Gin = (c0 ? A.phi1 : A.phi0) + L.off;
+        double* Gout = (c0 ? A.phi0 : A.phi1) + L.off;
+        const double* Sg = A.src + L.off;
+        double* PP = A.stage + kStageH;
+        double* SS = PP + kStageArr;
+        const int col0 = g * kThreads;
+        const int end_g = (g == A.G - 1) ? (C << logT) : (col0 + kThreads);     // node behind this member's part
+        copy_rows(PP, kStageRS, Gin + col0, 1 << logT, C);
+        copy_rows(SS, kStageRS, Sg + col0, 1 << logT, C);
+        for (int idx = tid; idx < C * kStageH; idx += kThreads) {       // halo columns (member 0: in-bounds padding / the
+            const int k = idx / kStageH, c = idx % kStageH - kStageH;   // previous level's tail, never used)
+            PP[k * kStageRS + c] = Gin[(k << logT) + col0 + c];
+            SS[k * kStageRS + c] = Sg[(k << logT) + col0 + c];
+        }
+        if (tid == 0) PP[C * kStageRS] = Gin[end_g];
+        __syncthreads();
+        auto write_out = [&]() {
+            copy_rows(Gout + col0, 1 << logT, PP, kStageRS, C);
+            if (g == A.G - 1 && tid == 0) Gout[C << logT] = PP[C * kStageRS];
+        };
+        const int lo_g = (col0 + tid) << L.logC;
+        double err = 1E10;
+        int done = 0;
+        for (int i = 0; i < iterno; ++i) {
+            double err2;
+            switch (L.logC) {
+                case 3:  err2 = gs_lds<3, kStageRS>(SS, PP, tid, lo_g, dh); break;
+                case 4:  err2 = gs_lds<4, kStageRS>(SS, PP, tid, lo_g, dh); break;
+                default: err2 = gs_lds<5, kStageRS>(SS, PP, tid, lo_g, dh); break;
+            }
+            ++done;
+            ++*nsweeps;
+            const bool last = (i == iterno - 1);
+            __syncthreads();
+            if (last) write_out();
+            else {
+                if (tid < (Hc << L.logC)) {                    // the last Hc lanes' nodes: what the next member's warm-up reads
+                    const int k = tid & (C - 1), c = kThreads - Hc + (tid >> L.logC);
+                    Gout[(k << logT) + col0 + c] = PP[k * kStageRS + c];
+                }
+                if (tid == 0) Gout[col0] = PP[0];              // the first node: right neighbour of the previous member's last one
+            }
+            err = sqrt(group_sum(A, err2, red));
+            if (last) break;
+            if (err < errorMin) {                              // the reference stops here: publish everything, meet once more
+                write_out();
+                group_sync(A);
+                break;
+            }
+            if (g > 0 && tid < (Hc << L.logC)) {
+                const int k = tid & (C - 1), c = -Hc + (tid >> L.logC);
+                PP[k * kStageRS + c] = Gout[(k << logT) + col0 + c];
+            }
+            if (g < A.G - 1 && tid == 0) PP[C * kStageRS] = Gout[end_g];
+            { double* t = Gin; Gin = Gout; Gout = t; }
+            __syncthreads();
+        }
+        if (done & 1) A.cur ^= (1u << l);
         return err;
     }
     double err = 1E10;
@@ -904,7 +1032,7 @@ __global__ __launch_bounds__(kThreads) void k_poisson_solve(const MgDesc* __rest
 {
     __shared__ double red[12];
     __shared__ double seqmem[3 * kSeqCap];
-    __shared__ double stagemem[3 * kStageCap];
+    __shared__ double stagemem[2 * kStageArr];
     const MgDesc& D = *Dp;
     // consecutive blocks are the members of one group (they land on different XCDs, where the barrier is cheapest)
     const int a = blockIdx.x >> D.logG;
@@ -953,7 +1081,7 @@ __global__ __launch_bounds__(kThreads) void k_unit(const MgDesc* __restrict__ Dp
 {
     __shared__ double red[12];
     __shared__ double seqmem[3 * kSeqCap];
-    __shared__ double stagemem[3 * kStageCap];
+    __shared__ double stagemem[2 * kStageArr];
     const MgDesc& D = *Dp;
     Atom A;
     A.phi0 = phi0; A.phi1 = phi1; A.src = src; A.lds = seqmem;
@@ -1115,7 +1243,11 @@ int dfta_poisson_create(dfta_ctx* ctx, const dfta_grid* g, int batch, dfta_poiss
         if (n < kSeqBelow) { L.seq = 1; L.logT = 0; L.logC = lg; L.soff = soff; soff += n; }
         else {
             L.seq = 0; L.logT = std::min(lg, l < D.kcoop ? 8 + logG : 8); L.logC = lg - L.logT; L.soff = -1;
-            L.stage = (l >= D.kcoop && n <= kStageMaxN && L.logT == 8 && L.logC <= 4 && !getenv("DFTA_POISSON_NOSTAGE")) ? 1 : 0;
+            if (!getenv("DFTA_POISSON_NOSTAGE")) {
+                if (l >= D.kcoop && L.logT == 8 && L.logC <= kStageMaxLogC) L.stage = 1;
+                else if (l < D.kcoop && D.G > 1 && L.logT == 8 + logG && L.logC >= 3 && L.logC <= kStageMaxLogC &&
+                         !getenv("DFTA_POISSON_NOSTAGE_SHARED")) L.stage = 2;
+            }
         }
         off += n;
         n = (n + 1) / 2;

@@ -502,9 +502,10 @@ def test_iterate_gs_fused_equals_single_sweeps(ctx):
     e1 = b.gauss_seidel(0, 1)
     assert nsw == 1 and abs(err_1 - e1[0]) <= 1e-12 * e1[0]
     assert np.array_equal(a.get_level(0)[0], b.get_level(0)[0])
-    # levels 5..9 (4097 ... 257 nodes) are swept from a copy staged in LDS (result written back to the copy that is current
-    # after an odd / even number of sweeps); the sequential levels (129 ... 3 nodes) live in LDS for the whole solve
-    for lvl in (5, 6, 8, 9, 10, 11, 13, 15, 16):
+    # levels 1..9 (65537 ... 257 nodes) are swept in place from a copy staged in LDS -- 1..3 by the eight workgroups of the
+    # atom together, with a halo exchange per sweep -- and written back to the copy that is current after an odd / even
+    # number of sweeps; the sequential levels (129 ... 3 nodes) live in LDS for the whole solve
+    for lvl in (1, 2, 3, 4, 5, 6, 8, 9, 10, 11, 13, 15, 16):
         n = a.level_size(lvl)
         phi, src = rng.standard_normal(n), rng.standard_normal(n) * 1e-2
         for p in (a, b):
