@@ -33,8 +33,9 @@ constexpr int kThreads = 256;
 #define DFTA_KWARM 96
 #endif
 constexpr int kWarm = DFTA_KWARM;   // start-value error decays by <= 0.52^96 < 2^-90: chunked sweep == sequential sweep bit for bit
-constexpr int kSeqBelow = 257;   // levels with n < 257 nodes: one lane, sequential
-constexpr int kSeqCap = 272;     // LDS doubles per array for the sequential levels (129+65+33+17+9+5+3 = 261)
+constexpr int kSeqBelow = 129;   // levels with n < 129 nodes: one lane, sequential, LDS-resident
+constexpr int kWaveMaxN = 1025;  // staged levels up to this size are swept by the first wave alone (64 lanes: a quarter of the LDS traffic per warm-up step)
+constexpr int kSeqCap = 144;     // LDS doubles per array for the sequential levels (65+33+17+9+5+3 = 132)
 constexpr int kPF = 8;           // register prefetch depth of the chunked sweep
 constexpr int kFuseMinLogC = 9;  // fuse the three sweeps of a level visit when every lane owns >= 512 nodes
 constexpr int kStageMaxLogC = 5;   // chunked levels with <= 32 nodes per lane are swept from a copy in LDS (Phi, S)
@@ -325,7 +326,7 @@ __device__ __forceinline__ double gs_chunked(const Lvl& L, const double* __restr
     return err2;
 }
 
-// Chunked sweep, IN PLACE, of (a workgroup's part of) a level staged in LDS: 256 lanes, C = 2^LOGC nodes per lane; node
+// Chunked sweep, IN PLACE, of (a workgroup's part of) a level staged in LDS: NT lanes, C = 2^LOGC nodes per lane; node
 // t*C + k of the part lives at k*RS + t relative to SSbase / PPbase, lanes t < 0 (the 96 nodes in front of the part: the
 // previous lanes' columns for RS == 256, halo columns otherwise) included; Phi of the node behind the part at C*RS.  Same
 // arithmetic as gs_chunked.  A lone wave on a SIMD issues one instruction of any kind per ~4.5 cycles, so the step is
@@ -334,7 +335,8 @@ __device__ __forceinline__ double gs_chunked(const Lvl& L, const double* __restr
 // advances by 16/C per block) -- 2 reads + 6 flops per warm-up step, nothing else.  Everything a lane reads from other
 // lanes' nodes (warm-up, start values, right neighbour of its last node) is read before the barrier in the middle, the
 // owned nodes are overwritten after it.  lo_g = index of the lane's first node within the level.
-template <int LOGC, int RS>
+// NT = lanes that sweep (256: the workgroup; 64: its first wave alone -- the barrier is then a wave-level fence).
+template <int LOGC, int RS, int NT = kThreads>
 __device__ __forceinline__ double gs_lds(const double* __restrict__ SSbase, double* __restrict__ PPbase, const int tid,
                                          const int lo_g, const double dh)
 {
@@ -357,7 +359,7 @@ __device__ __forceinline__ double gs_lds(const double* __restrict__ SSbase, doub
         old = pp[(a1 & Cm1) * RS + (a1 >> LOGC)];
     }
     double y = 2.0 * xm;                        // the recurrence is carried as y = 2x (gs_point2)
-    const double xp_end = (tid == kThreads - 1) ? PPbase[C * RS] : pp[1];
+    const double xp_end = (tid == NT - 1) ? PPbase[C * RS] : pp[1];
     const double node0 = pp[0];
     const bool careful = __builtin_amdgcn_readfirstlane(lo_g) <= kWarm;
     lds_cf64* bs = ps - (kWarm >> LOGC);
@@ -411,7 +413,9 @@ __device__ __forceinline__ double gs_lds(const double* __restrict__ SSbase, doub
         for (int r = -kWarm; r < 0; r += BS) block(false_type{}, r);
     }
     if (lo_g >= 1) old = bx[kH - 1];            // Phi_old at the first owned node; the lane of node 0 keeps the value loaded above
-    __syncthreads();                            // all reads of other lanes' old values are done
+    // all reads of other lanes' old values are done
+    if constexpr (NT == kThreads) __syncthreads();
+    else { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); }
     double err2 = 0;
     auto own = [&](const double (&X)[kH], const double (&SV)[kH], int r0) {
 #pragma unroll
@@ -455,6 +459,49 @@ __device__ __forceinline__ double gs_lds(const double* __restrict__ SSbase, doub
     return err2;
 }
 
+// One sweep of an LDS-resident level by ONE thread, in the reference's order.  The loads of a batch (right neighbours,
+// sources) are independent of the recurrence: they are issued together ahead of it, so that the chain is not one LDS
+// round trip per node.  Returns sum dPhi^2.
+__device__ __forceinline__ double seq_sweep(const double* __restrict__ S, const double* __restrict__ pin, double* __restrict__ pout,
+                                            const int n, const double dh)
+{
+    double err2 = 0;
+    const double x0 = pin[0];
+    pout[0] = x0;
+    double y = 2.0 * x0;                // the recurrence is carried as y = 2x (gs_point2: a shorter dependent chain)
+    const int limit = n - 1;
+    double old = pin[1];
+    constexpr int kB = 8;
+    int i = 1;
+    for (; i + kB <= limit; i += kB) {
+        double xp[kB], sv[kB], xo[kB];
+#pragma unroll
+        for (int q = 0; q < kB; ++q) { xp[q] = pin[i + q + 1]; sv[q] = S[i + q]; }
+#pragma unroll
+        for (int q = 0; q < kB; ++q) {
+            y = gs_point2(sv[q], y, xp[q], dh);
+            const double x = 0.5 * y;
+            const double dif = old - x;
+            err2 += dif * dif;
+            xo[q] = x;
+            old = xp[q];
+        }
+#pragma unroll
+        for (int q = 0; q < kB; ++q) pout[i + q] = xo[q];
+    }
+    for (; i < limit; ++i) {
+        const double xp = pin[i + 1];
+        y = gs_point2(S[i], y, xp, dh);
+        const double x = 0.5 * y;
+        const double dif = old - x;
+        err2 += dif * dif;
+        pout[i] = x;
+        old = xp;
+    }
+    pout[limit] = pin[limit];
+    return err2;
+}
+
 // one lexicographic Gauss-Seidel sweep of level l: PoissonSolver::GaussSeidel (PoissonSolver.cpp:40-64).
 // returns ||dPhi||_2 (same value in every thread)
 __device__ __forceinline__ double gauss_seidel(const MgDesc& D, Atom& A, int l, double* red)
@@ -465,46 +512,7 @@ __device__ __forceinline__ double gauss_seidel(const MgDesc& D, Atom& A, int l, 
     const bool coop = l < D.kcoop;         // swept by the whole group: lane ids run over all members
     const int tid = coop ? A.lane() : static_cast<int>(threadIdx.x);
     if (L.seq) {
-        if (tid == 0) {
-            // one thread, level in LDS.  The loads of a batch (right neighbours, sources) are independent of the
-            // recurrence: they are issued together ahead of it, so that the chain is not one LDS round trip per node.
-            const double* __restrict__ S = A.src_of(L);
-            const double* __restrict__ pin = A.cur_phi(l, L);
-            double* __restrict__ pout = A.other_phi(l, L);
-            const double x0 = pin[0];
-            pout[0] = x0;
-            double y = 2.0 * x0;                // the recurrence is carried as y = 2x (gs_point2: a shorter dependent chain)
-            const int limit = L.n - 1;
-            double old = pin[1];
-            constexpr int kB = 8;
-            int i = 1;
-            for (; i + kB <= limit; i += kB) {
-                double xp[kB], sv[kB], xo[kB];
-#pragma unroll
-                for (int q = 0; q < kB; ++q) { xp[q] = pin[i + q + 1]; sv[q] = S[i + q]; }
-#pragma unroll
-                for (int q = 0; q < kB; ++q) {
-                    y = gs_point2(sv[q], y, xp[q], dh);
-                    const double x = 0.5 * y;
-                    const double dif = old - x;
-                    err2 += dif * dif;
-                    xo[q] = x;
-                    old = xp[q];
-                }
-#pragma unroll
-                for (int q = 0; q < kB; ++q) pout[i + q] = xo[q];
-            }
-            for (; i < limit; ++i) {
-                const double xp = pin[i + 1];
-                y = gs_point2(S[i], y, xp, dh);
-                const double x = 0.5 * y;
-                const double dif = old - x;
-                err2 += dif * dif;
-                pout[i] = x;
-                old = xp;
-            }
-            pout[limit] = pin[limit];
-        }
+        if (tid == 0) err2 = seq_sweep(A.src_of(L), A.cur_phi(l, L), A.other_phi(l, L), L.n, dh);
     } else {
         const double* S = A.src + L.off;
         const double* pin = (((A.cur >> l) & 1u) ? A.phi1 : A.phi0) + L.off;
@@ -688,6 +696,104 @@ __device__ __forceinline__ double iterate_gs(const MgDesc& D, Atom& A, int l, do
             return e3;
         }
         __syncthreads();                                      // rare: it stops early -- redo from the untouched input copy
+    }
+    if (D.lv[l].seq) {
+        // LDS-resident level: the sweeps of the visit by one thread, no workgroup barrier between them; the others wait
+        // for the result (the error norm of one thread's partial sums equals the workgroup sum: the others add zeros)
+        const Lvl L = D.lv[l];
+        if (threadIdx.x == 0) {
+            const double dh = L.d * 0.5;
+            unsigned cur = A.cur;
+            double err = 1E10;
+            int done = 0;
+            for (int i = 0; i < iterno; ++i) {
+                const unsigned c = (cur >> l) & 1u;
+                const double err2 = seq_sweep(A.lds + 2 * kSeqCap + L.soff, A.lds + c * kSeqCap + L.soff,
+                                              A.lds + (c ^ 1u) * kSeqCap + L.soff, L.n, dh);
+                cur ^= (1u << l);
+                err = sqrt(err2);
+                ++done;
+                if (err < errorMin) break;
+            }
+            red[16] = err;
+            red[17] = done;
+        }
+        __syncthreads();
+        const double err = red[16];
+        const int done = static_cast<int>(red[17]);
+        if (done & 1) A.cur ^= (1u << l);
+        *nsweeps += done;
+        __syncthreads();
+        return err;
+    }
+    if (D.lv[l].stage == 3) {
+        // A small level of one workgroup (129 ... 1025 nodes): staged like the others but laid out over 64 lanes and swept
+        // by the first wave alone -- a quarter of the LDS traffic per warm-up step, no workgroup barrier between the
+        // sweeps.  All four waves copy in and out.
+        const Lvl L = D.lv[l];
+        const double dh = L.d * 0.5;
+        const int tid = threadIdx.x;
+        const unsigned c0 = (A.cur >> l) & 1u;
+        double* G0 = (c0 ? A.phi1 : A.phi0) + L.off;
+        double* G1 = (c0 ? A.phi0 : A.phi1) + L.off;
+        const double* Sg = A.src + L.off;
+        double* PP = A.stage + kStagePad;
+        double* SS = PP + kStageArr;
+        const int lc = L.logC + L.logT - 6;                   // log2(nodes per lane) with 64 lanes
+        const int nm1 = L.n - 1;
+        const int Cg1 = (1 << L.logC) - 1;
+        // LDS index j = k*64 + t <-> node i = t*2^lc + k <-> global storage index (i & (C-1))*T + (i >> logC)
+        auto gidx = [&](int j) { const int i = ((j & 63) << lc) + (j >> 6); return ((i & Cg1) << L.logT) + (i >> L.logC); };
+        {
+            double a[4], b[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int j = tid + q * kThreads;
+                if (j < nm1) { const int gi = gidx(j); a[q] = G0[gi]; b[q] = Sg[gi]; }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int j = tid + q * kThreads;
+                if (j < nm1) { PP[j] = a[q]; SS[j] = b[q]; }
+            }
+            if (tid == 0) PP[nm1] = G0[nm1];
+        }
+        __syncthreads();
+        if (tid < 64) {
+            const int lo_g = tid << lc;
+            double err = 1E10;
+            int done = 0;
+            for (int i = 0; i < iterno; ++i) {
+                double err2;
+                switch (lc) {
+                    case 1:  err2 = gs_lds<1, 64, 64>(SS, PP, tid, lo_g, dh); break;
+                    case 2:  err2 = gs_lds<2, 64, 64>(SS, PP, tid, lo_g, dh); break;
+                    case 3:  err2 = gs_lds<3, 64, 64>(SS, PP, tid, lo_g, dh); break;
+                    default: err2 = gs_lds<4, 64, 64>(SS, PP, tid, lo_g, dh); break;
+                }
+                for (int off = 32; off > 0; off >>= 1) err2 += __shfl_xor(err2, off);
+                err = sqrt(err2);
+                ++done;
+                if (err < errorMin) break;
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+            if (tid == 0) { red[16] = err; red[17] = done; }
+        }
+        __syncthreads();
+        const double err = red[16];
+        const int done = static_cast<int>(red[17]);
+        *nsweeps += done;
+        double* Gout = (done & 1) ? G1 : G0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int j = tid + q * kThreads;
+            if (j < nm1) Gout[gidx(j)] = PP[j];
+        }
+        if (tid == 0) Gout[nm1] = PP[nm1];
+        if (done & 1) A.cur ^= (1u << l);
+        __syncthreads();
+        return err;
     }
     if (D.lv[l].stage == 1) {
         // A level of one workgroup with <= 8193 nodes: the current copy and the source are copied to LDS once per visit
@@ -983,6 +1089,16 @@ __device__ __forceinline__ double do_iterate(const MgDesc& D, Atom& A, int l, do
     return 1E10;
 }
 
+// -DDFTA_POISSON_PROF: time (s_memtime ticks of workgroup 0) per operation kind and level, printed when the solver is destroyed
+#ifdef DFTA_POISSON_PROF
+__device__ unsigned long long g_prof[3 * 24];
+#define PROF_T0() const long long prof_t0 = clock64()
+#define PROF_ADD(cat, lvl) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_prof[(cat) * 24 + (lvl)] += clock64() - prof_t0; } while (0)
+#else
+#define PROF_T0()
+#define PROF_ADD(cat, lvl)
+#endif
+
 __device__ __forceinline__ double run_cycles(const MgDesc& D, Atom& A, int first_step, int max_vcycles, double errorMin,
                                              double errorMinLast, double* red, Counters& c)
 {
@@ -1007,9 +1123,17 @@ __device__ __forceinline__ double run_cycles(const MgDesc& D, Atom& A, int first
         err = 1E10;
         if (!(dir < 0 && from == to)) {
             for (int lvl = (dir > 0) ? from : from - 1;; lvl += dir) {
-                if (dir > 0) { if (lvl > from) do_restrict(D, A, lvl); }
-                else do_prolong(D, A, lvl + 1);
-                err = do_iterate(D, A, lvl, emin, iterno, red, &c.sweeps);
+                {
+                    PROF_T0();
+                    if (dir > 0) { if (lvl > from) do_restrict(D, A, lvl); }
+                    else do_prolong(D, A, lvl + 1);
+                    PROF_ADD(dir > 0 ? 0 : 1, lvl);
+                }
+                {
+                    PROF_T0();
+                    err = do_iterate(D, A, lvl, emin, iterno, red, &c.sweeps);
+                    PROF_ADD(2, lvl);
+                }
                 if (lvl == to) break;
             }
         }
@@ -1030,7 +1154,7 @@ __global__ __launch_bounds__(kThreads) void k_poisson_solve(const MgDesc* __rest
                                                             unsigned long long* __restrict__ total_vcycles,
                                                             unsigned* __restrict__ group_ctr, double* __restrict__ group_part)
 {
-    __shared__ double red[12];
+    __shared__ double red[20];
     __shared__ double seqmem[3 * kSeqCap];
     __shared__ double stagemem[2 * kStageArr];
     const MgDesc& D = *Dp;
@@ -1079,7 +1203,7 @@ __global__ __launch_bounds__(kThreads) void k_poisson_solve(const MgDesc* __rest
 __global__ __launch_bounds__(kThreads) void k_unit(const MgDesc* __restrict__ Dp, double* phi0, double* phi1, double* src, int* cur, int op,
                                                    int lvl, int sweeps, double* out, unsigned* group_ctr, double* group_part)
 {
-    __shared__ double red[12];
+    __shared__ double red[20];
     __shared__ double seqmem[3 * kSeqCap];
     __shared__ double stagemem[2 * kStageArr];
     const MgDesc& D = *Dp;
@@ -1244,7 +1368,8 @@ int dfta_poisson_create(dfta_ctx* ctx, const dfta_grid* g, int batch, dfta_poiss
         else {
             L.seq = 0; L.logT = std::min(lg, l < D.kcoop ? 8 + logG : 8); L.logC = lg - L.logT; L.soff = -1;
             if (!getenv("DFTA_POISSON_NOSTAGE")) {
-                if (l >= D.kcoop && L.logT == 8 && L.logC <= kStageMaxLogC) L.stage = 1;
+                if (l >= D.kcoop && n <= kWaveMaxN && n >= 129 && !getenv("DFTA_POISSON_NOSTAGE_WAVE")) L.stage = 3;
+                else if (l >= D.kcoop && L.logT == 8 && L.logC <= kStageMaxLogC) L.stage = 1;
                 else if (l < D.kcoop && D.G > 1 && L.logT == 8 + logG && L.logC >= 3 && L.logC <= kStageMaxLogC &&
                          !getenv("DFTA_POISSON_NOSTAGE_SHARED")) L.stage = 2;
             }
@@ -1284,6 +1409,23 @@ int dfta_poisson_create(dfta_ctx* ctx, const dfta_grid* g, int batch, dfta_poiss
 void dfta_poisson_destroy(dfta_poisson* p)
 {
     if (!p) return;
+#ifdef DFTA_POISSON_PROF
+    {
+        unsigned long long h[3 * 24];
+        if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_prof), sizeof(h)) == hipSuccess) {
+            const char* names[3] = {"restrict", "prolong ", "iterate "};
+            unsigned long long tot = 0;
+            for (int c = 0; c < 3; ++c) {
+                fprintf(stderr, "[poisson prof] %s:", names[c]);
+                for (int l = 0; l < 18; ++l) { fprintf(stderr, " %llu", h[c * 24 + l]); tot += h[c * 24 + l]; }
+                fprintf(stderr, "\n");
+            }
+            fprintf(stderr, "[poisson prof] total ticks %llu\n", tot);
+            unsigned long long z[3 * 24] = {0};
+            (void)hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof(z));
+        }
+    }
+#endif
     void* ptrs[] = {p->d_phi0, p->d_phi1, p->d_src, p->d_cur, p->d_total_vcycles, p->d_desc, p->d_group_ctr, p->d_group_part};
     for (void* q : ptrs) if (q) (void)hipFree(q);
     delete p;
