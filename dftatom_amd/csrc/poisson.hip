@@ -40,9 +40,9 @@ constexpr int kPF = 8;           // register prefetch depth of the chunked sweep
 constexpr int kFuseMinLogC = 9;  // fuse the three sweeps of a level visit when every lane owns >= 512 nodes
 constexpr int kStageMaxLogC = 5;   // chunked levels with <= 32 nodes per lane are swept from a copy in LDS (Phi, S)
 constexpr int kStagePad = 128;     // one workgroup: doubles in front of each staged array (warm-up reads of the first lanes)
-constexpr int kStageH = 16;        // group members: halo columns in front of every staged row (>= 96/C lanes, C >= 8)
+constexpr int kStageH = 24;        // group members: halo columns in front of every staged row (>= 96/C lanes, C >= 4)
 constexpr int kStageRS = kThreads + kStageH;          // row stride of a member's staged part
-constexpr int kStageArr = 8736;    // doubles per staged array: >= kStagePad + 8193 and >= kStageH + 32*kStageRS + 1
+constexpr int kStageArr = 8992;    // doubles per staged array: >= kStagePad + 8193 and >= kStageH + 32*kStageRS + 1
 constexpr int kPad = 320;        // doubles of padding in front of every atom's level storage (warm-up reads of lane 0)
 
 struct Lvl {
@@ -342,7 +342,6 @@ __device__ __forceinline__ double gs_lds(const double* __restrict__ SSbase, doub
 {
     constexpr int C = 1 << LOGC, Cm1 = C - 1, kH = 8;
     auto uoff = [](int q) constexpr -> int { return (q & Cm1) * RS + (q >> LOGC); };    // q >= 0
-    const int one_minus_lo = 1 - lo_g;
     // explicit LDS pointers, each pinned in its own register: otherwise the compiler rebuilds every address from one
     // base plus a literal (the arrays are > 64 KB apart, beyond the instruction offset) -- one VALU add per access
     typedef __attribute__((address_space(3))) double lds_f64;
@@ -350,69 +349,68 @@ __device__ __forceinline__ double gs_lds(const double* __restrict__ SSbase, doub
     lds_cf64* ps = (lds_cf64*)(SSbase) + tid;
     lds_f64* pp = (lds_f64*)(PPbase) + tid;
     asm volatile("" : "+v"(ps), "+v"(pp));
-    // start values: first node of the run and its left neighbour (old values; the exact boundary value for node 0)
-    double xm, old;
-    {
-        const int j = ((lo_g - kWarm) > 1 ? (lo_g - kWarm) : 1) - lo_g;       // first node of the run relative to lo
-        const int a0 = j - 1, a1 = j;
-        xm = pp[(a0 & Cm1) * RS + (a0 >> LOGC)];
-        old = pp[(a1 & Cm1) * RS + (a1 >> LOGC)];
-    }
-    double y = 2.0 * xm;                        // the recurrence is carried as y = 2x (gs_point2)
+    // The warm-up covers the 95 nodes lo-95 .. lo-1, in blocks of BS = max(16, C) steps; step q of the block with base
+    // node lo + Rb (Rb = -96, -96+BS, ..: multiples of C) handles node lo + Rb + q + 1.  It starts from the old value of
+    // node lo-96.  Lanes whose run would begin below node 1 (the first 96/C lanes of the level) restart from the exact
+    // boundary value at node 1: with the blocks shifted by one node against the chunk rows that can only happen at steps
+    // with (q % C) == 0 -- one select per C steps instead of one per step.
+    const int neg_lo = -lo_g;
+    const double Y0 = 2.0 * PPbase[0];          // node 0 of the level (meaningful where a restart can happen at all)
+    double y = 2.0 * pp[-(kWarm >> LOGC)];      // the recurrence is carried as y = 2x (gs_point2)
     const double xp_end = (tid == NT - 1) ? PPbase[C * RS] : pp[1];
     const double node0 = pp[0];
-    const bool careful = __builtin_amdgcn_readfirstlane(lo_g) <= kWarm;
     lds_cf64* bs = ps - (kWarm >> LOGC);
     lds_cf64* bp = pp - (kWarm >> LOGC);
     double ax[kH], as[kH], bx[kH], bv[kH];
-    // the warm-up runs in blocks of BS = max(16, C) steps (whole chunk rows and whole A/B rounds); h = half block of 8
     constexpr int BS = C > 2 * kH ? C : 2 * kH;
     static_assert(kWarm % BS == 0, "warm-up must be a whole number of blocks");
+    static_assert(BS <= 4 * kH, "chunks of more than 32 nodes are not staged");
+    using std::integral_constant;
     auto load = [&](double (&X)[kH], double (&SV)[kH], auto HH) {
         constexpr int h = decltype(HH)::value;
 #pragma unroll
-        for (int q = 0; q < kH; ++q) { SV[q] = bs[uoff(h * kH + q)]; X[q] = bp[uoff(h * kH + q + 1)]; }
+        for (int q = 0; q < kH; ++q) { SV[q] = bs[uoff(h * kH + q + 1)]; X[q] = bp[uoff(h * kH + q + 2)]; }
     };
-    auto warm = [&](auto CAREFUL, const double (&X)[kH], const double (&SV)[kH], int rbase) {
+    auto load_own = [&](double (&X)[kH], double (&SV)[kH]) {     // rows 0 .. 7 of the own chunk (bs == ps, bp == pp by then)
 #pragma unroll
-        for (int q = 0; q < kH; ++q) {
-            const double yn = gs_point2(SV[q], y, X[q], dh);
-            if (decltype(CAREFUL)::value) y = (rbase + q >= one_minus_lo) ? yn : y;   // node index lo + r >= 1
-            else y = yn;
+        for (int q = 0; q < kH; ++q) { SV[q] = bs[uoff(q)]; X[q] = bp[uoff(q + 1)]; }
+    };
+    auto warm = [&](const double (&X)[kH], const double (&SV)[kH], int Rb, auto HH, auto NSTEPS) {
+        constexpr int h = decltype(HH)::value;
+#pragma unroll
+        for (int q = 0; q < decltype(NSTEPS)::value; ++q) {
+            if ((h * kH + q) % C == 0) y = (Rb + (h * kH + q) == neg_lo) ? Y0 : y;      // this step is node 1
+            y = gs_point2(SV[q], y, X[q], dh);
         }
     };
-    using std::integral_constant;
-    auto block = [&](auto CAREFUL, int r) {
-        // halves 0, 2, 4 .. in A, 1, 3, 5 .. in B; the reads stay a whole half block ahead of their use
+    auto block = [&](int Rb, auto LAST) {
+        // halves 0, 2 in A, 1, 3 in B; the reads stay a whole half block ahead of their use
+        constexpr bool last = decltype(LAST)::value;
         auto pair = [&](auto H0) {
             constexpr int h = decltype(H0)::value;
+            constexpr bool wraps = (h + 2) * kH >= BS;
             load(bx, bv, integral_constant<int, h + 1>{});
             __builtin_amdgcn_sched_barrier(0);
-            warm(CAREFUL, ax, as, r + h * kH);
-            if constexpr ((h + 2) * kH < BS) {
+            warm(ax, as, Rb, integral_constant<int, h>{}, integral_constant<int, kH>{});
+            if constexpr (!wraps) {
                 load(ax, as, integral_constant<int, h + 2>{});
             } else {
                 bs += BS >> LOGC;
                 bp += BS >> LOGC;
                 asm volatile("" : "+v"(bs), "+v"(bp));
-                load(ax, as, integral_constant<int, 0>{});      // the last one fetches the first owned nodes
+                if constexpr (last) load_own(ax, as);
+                else load(ax, as, integral_constant<int, 0>{});
             }
             __builtin_amdgcn_sched_barrier(0);
-            warm(CAREFUL, bx, bv, r + (h + 1) * kH);
+            warm(bx, bv, Rb, integral_constant<int, h + 1>{}, integral_constant<int, (last && wraps) ? kH - 1 : kH>{});
         };
         pair(integral_constant<int, 0>{});
         if constexpr (BS > 2 * kH) pair(integral_constant<int, 2>{});
-        static_assert(BS <= 4 * kH, "chunks of more than 32 nodes are not staged");
     };
-    using std::true_type;
-    using std::false_type;
     load(ax, as, integral_constant<int, 0>{});
-    if (careful) {
-        for (int r = -kWarm; r < 0; r += BS) block(true_type{}, r);
-    } else {
-        for (int r = -kWarm; r < 0; r += BS) block(false_type{}, r);
-    }
-    if (lo_g >= 1) old = bx[kH - 1];            // Phi_old at the first owned node; the lane of node 0 keeps the value loaded above
+    for (int Rb = -kWarm; Rb < -BS; Rb += BS) block(Rb, std::false_type{});
+    block(-BS, std::true_type{});
+    double old = bx[kH - 2];                    // Phi_old at the first owned node: the right neighbour of the last warm-up step
     // all reads of other lanes' old values are done
     if constexpr (NT == kThreads) __syncthreads();
     else { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); }
@@ -428,7 +426,7 @@ __device__ __forceinline__ double gs_lds(const double* __restrict__ SSbase, doub
             if (r == 0) {
                 const bool live = lo_g >= 1;    // node 0 is a boundary value, not an unknown
                 dif = live ? dif : 0.0;
-                y = live ? yn : y;
+                y = live ? yn : Y0;             // the lane of node 0 continues from the boundary value
             } else {
                 y = yn;
             }
@@ -878,6 +876,7 @@ __device__ __forceinline__ double iterate_gs(const MgDesc& D, Atom& A, int l, do
         for (int i = 0; i < iterno; ++i) {
             double err2;
             switch (L.logC) {
+                case 2:  err2 = gs_lds<2, kStageRS>(SS, PP, tid, lo_g, dh); break;
                 case 3:  err2 = gs_lds<3, kStageRS>(SS, PP, tid, lo_g, dh); break;
                 case 4:  err2 = gs_lds<4, kStageRS>(SS, PP, tid, lo_g, dh); break;
                 default: err2 = gs_lds<5, kStageRS>(SS, PP, tid, lo_g, dh); break;
@@ -960,7 +959,10 @@ __device__ __forceinline__ void restrict_to(const MgDesc& D, Atom& A, int lvl)
         if (coop) group_sync(A); else __syncthreads();
         return;
     }
-    for (int idx = coop ? A.lane() : static_cast<int>(threadIdx.x); idx < Lc.n; idx += coop ? kThreads * A.G : kThreads) {
+    // the fine level is shared but the coarse one is workgroup 0's (lvl == kcoop): the members compute it together all the
+    // same (their copy of the coarse level's `cur` bit dates from the last prolongation out of it and is still valid)
+    const bool share = coop || (lvl - 1 < D.kcoop && A.G > 1);
+    for (int idx = share ? A.lane() : static_cast<int>(threadIdx.x); idx < Lc.n; idx += share ? kThreads * A.G : kThreads) {
         const int i = node_of(Lc, idx);
         Pc[idx] = 0;
         double s = 0;
@@ -971,7 +973,7 @@ __device__ __forceinline__ void restrict_to(const MgDesc& D, Atom& A, int lvl)
         }
         Sc[idx] = s;
     }
-    if (coop) group_sync(A); else __syncthreads();
+    if (share) group_sync(A); else __syncthreads();
 }
 
 // PoissonSolver::Prolong (PoissonSolver.cpp:110-123): coarse = lvl -> fine = lvl-1 (additive)
@@ -1065,7 +1067,7 @@ __device__ __forceinline__ void initialize(const MgDesc& D, Atom& A, double lowB
 // alone (the other members skip them and meet workgroup 0 again at the barrier in front of the first shared operation).
 __device__ __forceinline__ void do_restrict(const MgDesc& D, Atom& A, int lvl)
 {
-    if (lvl < D.kcoop || A.g == 0) restrict_to(D, A, lvl);
+    if (lvl - 1 < D.kcoop || A.g == 0) restrict_to(D, A, lvl);
 }
 
 __device__ __forceinline__ void do_prolong(const MgDesc& D, Atom& A, int lvl)
@@ -1334,8 +1336,9 @@ int dfta_poisson_create(dfta_ctx* ctx, const dfta_grid* g, int batch, dfta_poiss
     D.levels = g->levels;
     // Workgroups per atom: a solve is bound by ONE compute unit's vector-memory path, so while the batch leaves compute
     // units idle the fine levels of every atom are shared by a group of G workgroups (all of them must be resident:
-    // batch * G <= 256 CUs).  A level is shared when every lane of the group still owns >= 8 nodes.
-    int logG = batch <= 32 ? 3 : (batch <= 64 ? 2 : (batch <= 128 ? 1 : 0));
+    // batch * G <= 256 CUs).  A level is shared when every lane of the group still owns >= 8 nodes (>= 4 for G = 16: the
+    // same four levels at 131073 nodes, with 32 nodes per lane on the finest one -- the most that is staged in LDS).
+    int logG = batch <= 16 ? 4 : (batch <= 32 ? 3 : (batch <= 64 ? 2 : (batch <= 128 ? 1 : 0)));
     if (const char* e = getenv("DFTA_POISSON_GROUP")) {      // measurements: force log2 of the group size
         const int v = atoi(e);
         if (v >= 0 && v <= 4 && (batch << v) <= 256) logG = v;
@@ -1350,7 +1353,7 @@ int dfta_poisson_create(dfta_ctx* ctx, const dfta_grid* g, int batch, dfta_poiss
     {
         int n = g->N;
         for (int l = 0; l < D.levels; ++l, n = (n + 1) / 2)
-            if (logG > 0 && (n - 1) >= (kThreads << logG) * 8) D.kcoop = l + 1;
+            if (logG > 0 && (n - 1) >= (kThreads << logG) * (logG >= 4 ? 4 : 8)) D.kcoop = l + 1;
     }
     if (D.kcoop == 0) logG = 0;
     D.logG = logG;
@@ -1370,7 +1373,7 @@ int dfta_poisson_create(dfta_ctx* ctx, const dfta_grid* g, int batch, dfta_poiss
             if (!getenv("DFTA_POISSON_NOSTAGE")) {
                 if (l >= D.kcoop && n <= kWaveMaxN && n >= 129 && !getenv("DFTA_POISSON_NOSTAGE_WAVE")) L.stage = 3;
                 else if (l >= D.kcoop && L.logT == 8 && L.logC <= kStageMaxLogC) L.stage = 1;
-                else if (l < D.kcoop && D.G > 1 && L.logT == 8 + logG && L.logC >= 3 && L.logC <= kStageMaxLogC &&
+                else if (l < D.kcoop && D.G > 1 && L.logT == 8 + logG && L.logC >= 2 && L.logC <= kStageMaxLogC &&
                          !getenv("DFTA_POISSON_NOSTAGE_SHARED")) L.stage = 2;
             }
         }
