@@ -9,10 +9,14 @@ int dfta_launch_build_tab(dfta_ctx* ctx, const dfta_grid* g, double2* tab, const
                           const int* d_slot_l, int nslots, double2* bounds /* nslots, may be null */);
 int dfta_launch_boundary(dfta_ctx* ctx, const dfta_grid* g, const double* dE, int ntrials, int* dStart, double* dUs,
                          double* dUs1);
+// flag in SweepArgs::istop (numerov.hip): the sweep left CountNodes because the count exceeded the limit
+constexpr int kStopOver = 0x40000000;
+
 int dfta_launch_sweep(dfta_ctx* ctx, const dfta_grid* g, int kind, const int* blk_kind, int nblocks, const double2* tab,
                       const int* blk_slot, const int* blk_first, const int* blk_cnt, const double* dE, const int* dLimit,
                       const int* dStart, const double* dUs, const double* dUs1, int* dCount, double* dU0, int* dTrip,
-                      unsigned long long* dTotalTrips, const double2* bounds /* per slot, may be null */);
+                      unsigned long long* dTotalTrips, const double2* bounds /* per slot, may be null */,
+                      double* dPhi = nullptr, int* dIstop = nullptr /* SweepArgs::phi / istop, may be null */);
 int dfta_launch_match(dfta_ctx* ctx, const dfta_grid* g, int ntrials, const double2* tab, const int* d_trial_slot,
                       const double* dE, const int* dStart, const double* dUs, const double* dUs1, const int* dL,
                       double* dPsi, double* dQ, int* dMatch, const double2* bounds /* per slot (dfta_bounds_stride), may be null */);

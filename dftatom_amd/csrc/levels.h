@@ -42,6 +42,14 @@ struct Job {
     int capz;                        // trials [0, capz) = probe + spine + tree, [capz, tpj) = scouts (0: all tpj)
     double se_lo, se_hi;
     int se_state, se_sl, se_stop;    // bracketed? / sign of u(0) at se_lo / no longer shrinking
+    // First bisection: every counted trial also reports where it stopped and how far the nearest zero of u was from that
+    // point (SweepArgs::phi / istop, numerov.hip) -- a smooth function of E that crosses 0 where the count changes.  The
+    // last sample on either side of the running bisection and the most recently replaced one give a secant estimate of
+    // the end point with an error bound from the second divided difference: the next round's spine follows it.
+    double sc_e[3], sc_phi[3];       // [0]: count <= nodes side (boe), [1]: count > nodes side (toe), [2]: replaced sample
+    int sc_is[3];                    // istop of the samples (-1: none)
+    double sc_lo, sc_hi;             // predicted bracket of the end point
+    int sc_ok;
 };
 
 struct LevelStats {
@@ -63,8 +71,8 @@ struct LevelSolver {
     Job* d_jobs = nullptr;
     int *d_chain_off = nullptr, *d_chain_off_b = nullptr, *d_v_off = nullptr, *d_slot_v = nullptr, *d_slot_l = nullptr;
     double2* d_tab = nullptr;
-    double *d_E = nullptr, *d_us = nullptr, *d_us1 = nullptr, *d_u0 = nullptr;
-    int *d_limit = nullptr, *d_start = nullptr, *d_count = nullptr;
+    double *d_E = nullptr, *d_us = nullptr, *d_us1 = nullptr, *d_u0 = nullptr, *d_phi = nullptr;
+    int *d_limit = nullptr, *d_start = nullptr, *d_count = nullptr, *d_istop = nullptr;
     int *d_wave_kind = nullptr, *d_wave_slot = nullptr, *d_wave_first = nullptr, *d_wave_cnt = nullptr;
     unsigned long long* d_counters = nullptr;   // [0] issued trials, [1] traversed points, [2] scratch
     double *d_Psi = nullptr, *d_Q = nullptr;     // njobs*N each

@@ -250,7 +250,13 @@ __device__ __forceinline__ void plan_round(dfta::Job& j, const dfta::Job* __rest
     // the last decisions before the predicted flip are left to the tree: at that scale (a few 1e-11) the counted nodes
     // and the sign of u(0) are not monotonic in the energy, and a miss on the spine costs the whole round
     constexpr double kGuard = 64 * kEnergyErr;
-    if (j.phase == PH_BOTTOM) {
+    bool secant = false;
+    if (j.phase == PH_TOP) {
+        if (j.sc_ok && j.miss < 2) {
+            predict_from_bracket(j, j.boe, j.toe, j.sc_lo - kGuard, j.sc_hi + kGuard, false);
+            secant = true;
+        }
+    } else if (j.phase == PH_BOTTOM) {
         if (j.nodes == 0) predict_from_bracket(j, j.boe, j.toe, -1e300, -1e300, false);   // "count < 0" never holds
         else if (j.sib >= 0) {
             const dfta::Job sb = jobs[j.sib];
@@ -274,14 +280,48 @@ __device__ __forceinline__ void plan_round(dfta::Job& j, const dfta::Job* __rest
     }
     // a long predicted spine needs the whole tree behind it to finish the bisection in this round: the scouts pause
     if (j.sp_len - j.phase_done >= 40) j.capz = tpj;
-    if (j.sp_len - j.phase_done > S) { S = j.sp_len - j.phase_done; j.use_sp = 1; }
+    // once a prediction has missed in this phase the predicted path and the real one have parted: plain trees from there,
+    // except for spines from the secant estimate, which is made afresh from this round's samples (until one of those misses)
+    if (j.miss && !secant) { S = 0; j.sp_len = 0; }
+    if (j.miss && secant) S = 0;
+    if (j.sp_len - j.phase_done > S) { S = j.sp_len - j.phase_done; j.use_sp = secant ? 2 : 1; }
     if (S > j.capz / 2 - 1) S = j.capz / 2 - 1;  // keep at least half of the trials for the tree
-    // once a prediction has missed in this phase the predicted path and the real one have parted: plain trees from there
-    if (j.miss) { S = 0; j.use_sp = 0; }
     j.spine = S > 0 ? S : 0;
 }
 
-__device__ void walk_job(dfta::Job& j, const int* __restrict__ count, const double* __restrict__ u0, int tpj, int base)
+// Secant estimate of the end point of the first bisection from the samples kept in the job (see levels.h).  With
+// F(E) = (stop index of the sample - stop index of the boe-side sample) + phi -- the distance of the nearest zero of u from
+// the point where CountNodes stops, in grid cells -- the count changes where F crosses 0.  The error bound is the
+// interpolation error of the secant with the second divided difference taken from the third sample (times 4).
+__device__ __forceinline__ void secant_predict(dfta::Job& j)
+{
+    j.sc_ok = 0;
+    const int ia = j.sc_is[0], ib = j.sc_is[1], ic = j.sc_is[2];
+    if (ia < 0 || ib < 0 || ic < 0 || (ia & kStopOver)) return;
+    auto F = [&](int k) { return static_cast<double>((j.sc_is[k] & ~kStopOver) - ia) + j.sc_phi[k]; };
+    // l > 0: the stop point (the inner turning point) moves with the energy too, by about a cell while the zero moves a
+    // few dozen: only samples that stopped at the same grid point are compared.  l == 0 always runs down to r = 0, and the
+    // grid is uniform there: the zero may be many cells away.
+    if (ia != 0 && ((ib & ~kStopOver) != ia || (ic & ~kStopOver) != ia)) return;
+    if (ia == 0 && ((!(ib & kStopOver) && ib != 0) || (!(ic & kStopOver) && ic != 0))) return;
+    const double a = j.sc_e[0], b = j.sc_e[1], c = j.sc_e[2];
+    const double fa = F(0), fb = F(1), fc = F(2);
+    if (!(fa < 0 && fb > 0) || !(fabs(fc) < 1e300) || !(b > a) || c == a || c == b) return;
+    const double w = b - a;
+    const double t = a + w * (fa / (fa - fb));
+    const double f1 = (fb - fa) / w;
+    const double f2 = ((fc - fb) / (c - b) - f1) / (c - a);
+    // 4 x |f2 / f1| (b - a)^2 / 4, plus the scale below which the count is no longer a monotonic function of the energy
+    // (round-off of the sweep: about 1e-11 of |E|)
+    const double e = fabs(f2 / f1) * w * w + 1e-10 * fabs(t);
+    if (!(e < w * 0.125)) return;
+    j.sc_lo = t - e;
+    j.sc_hi = t + e;
+    j.sc_ok = 1;
+}
+
+__device__ void walk_job(dfta::Job& j, const int* __restrict__ count, const double* __restrict__ u0, const double* __restrict__ phi,
+                         const int* __restrict__ istop, int tpj, int base)
 {
     Cursor c;
     c.init(j.spine, capz_of(j, tpj));
@@ -289,16 +329,22 @@ __device__ void walk_job(dfta::Job& j, const int* __restrict__ count, const doub
         double hi = j.toe, lo = j.boe;
         while (hi - lo > kEnergyErr) {
             const int h = c.node();
-            if (h < 0) { if (c.off) j.miss = 1; j.toe = hi; j.boe = lo; return; }
+            if (h < 0) { if (c.off) j.miss = (j.use_sp == 2) ? 2 : (j.miss > 1 ? j.miss : 1); j.toe = hi; j.boe = lo; secant_predict(j); return; }
             const double e = (hi + lo) / 2;
             const int cn = count[base + h];
             ++j.n_count;
             const bool bit = !(cn > j.nodes);                        // 1: boe = E
             if (bit) lo = e; else hi = e;
+            {
+                const int side = bit ? 0 : 1;
+                j.sc_e[2] = j.sc_e[side]; j.sc_phi[2] = j.sc_phi[side]; j.sc_is[2] = j.sc_is[side];
+                j.sc_e[side] = e; j.sc_phi[side] = phi[base + h]; j.sc_is[side] = istop[base + h];
+            }
             c.advance(bit, pred_bit(j, 0, j.phase_done));
             record_bit(j, 0, bit);
         }
         finish_phase(j, 0);
+        j.sc_ok = 0;
         j.top = hi;
         j.toe = hi;
         j.boe = j.bottom0;                                          // DFTAtom.cpp:587
@@ -411,7 +457,8 @@ __global__ __launch_bounds__(64) void k_scout(dfta::Job* __restrict__ jobs, int 
 }
 
 __global__ void k_walk(dfta::Job* __restrict__ jobs, const int* __restrict__ chain_off, int nchains, int tpj,
-                       const int* __restrict__ count, const double* __restrict__ u0, int* __restrict__ ndone)
+                       const int* __restrict__ count, const double* __restrict__ u0, const double* __restrict__ phi,
+                       const int* __restrict__ istop, int* __restrict__ ndone)
 {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= nchains) return;
@@ -431,10 +478,12 @@ __global__ void k_walk(dfta::Job* __restrict__ jobs, const int* __restrict__ cha
             j.capz = 0;
             j.se_state = 0;
             j.se_stop = 0;
+            j.sc_is[0] = j.sc_is[1] = j.sc_is[2] = -1;
+            j.sc_ok = 0;
             jobs[k] = j;
             break;                                                  // its trials are generated next round
         }
-        walk_job(j, count, u0, tpj, k * tpj);
+        walk_job(j, count, u0, phi, istop, tpj, k * tpj);
         jobs[k] = j;
         if (j.phase == PH_DONE) { ++done; continue; }
         break;
@@ -555,12 +604,12 @@ LevelSolver::~LevelSolver() { release(); }
 void LevelSolver::release()
 {
     void* ptrs[] = {d_jobs, d_chain_off, d_chain_off_b, d_v_off, d_slot_v, d_slot_l, d_tab, d_E, d_limit, d_start, d_us, d_us1, d_count,
-                    d_u0, d_wave_kind, d_wave_slot, d_wave_first, d_wave_cnt, d_counters, d_Psi, d_Q, d_jE, d_jslot, d_jl,
+                    d_u0, d_phi, d_istop, d_wave_kind, d_wave_slot, d_wave_first, d_wave_cnt, d_counters, d_Psi, d_Q, d_jE, d_jslot, d_jl,
                     d_jstart, d_jus, d_jus1, d_jmp, d_slot_min, d_bounds};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (hipEvent_t& e : ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
     d_jobs = nullptr; d_chain_off = nullptr; d_chain_off_b = nullptr; d_v_off = nullptr; d_slot_v = nullptr; d_slot_l = nullptr; d_tab = nullptr;
-    d_E = nullptr; d_limit = nullptr; d_start = nullptr; d_us = nullptr; d_us1 = nullptr; d_count = nullptr; d_u0 = nullptr;
+    d_E = nullptr; d_limit = nullptr; d_start = nullptr; d_us = nullptr; d_us1 = nullptr; d_count = nullptr; d_u0 = nullptr; d_phi = nullptr; d_istop = nullptr;
     d_wave_kind = nullptr; d_wave_slot = nullptr; d_wave_first = nullptr; d_wave_cnt = nullptr; d_counters = nullptr;
     d_Psi = nullptr; d_Q = nullptr; d_jE = nullptr; d_jslot = nullptr; d_jl = nullptr; d_jstart = nullptr; d_jus = nullptr;
     d_jus1 = nullptr; d_jmp = nullptr; d_slot_min = nullptr; d_bounds = nullptr;
@@ -633,7 +682,7 @@ int LevelSolver::setup(dfta_ctx* c, const dfta_grid* grid, int mode_, int tree_d
     ALLOC(d_slot_l, int, nslots); UPLOAD(d_slot_l, slot_l);
     ALLOC(d_tab, double2, (size_t)nslots * N);
     ALLOC(d_E, double, ntrials); ALLOC(d_limit, int, ntrials); ALLOC(d_start, int, ntrials);
-    ALLOC(d_us, double, ntrials); ALLOC(d_us1, double, ntrials); ALLOC(d_count, int, ntrials); ALLOC(d_u0, double, ntrials);
+    ALLOC(d_us, double, ntrials); ALLOC(d_us1, double, ntrials); ALLOC(d_count, int, ntrials); ALLOC(d_u0, double, ntrials); ALLOC(d_phi, double, ntrials); ALLOC(d_istop, int, ntrials);
     ALLOC(d_wave_kind, int, nwaves);
     ALLOC(d_wave_slot, int, nwaves); UPLOAD(d_wave_slot, wave_slot);
     ALLOC(d_wave_first, int, nwaves); UPLOAD(d_wave_first, wave_first);
@@ -690,6 +739,8 @@ int LevelSolver::run(const double* dV, const double* job_bottom, int run_mode, d
         j.se_state = 0;
         j.se_stop = 0;
         j.se_sl = 0;
+        j.sc_is[0] = j.sc_is[1] = j.sc_is[2] = -1;
+        j.sc_ok = 0;
         j.use_sp = 0;
         j.sp_len = 0;
         j.sp_bits = 0;
@@ -724,13 +775,13 @@ int LevelSolver::run(const double* dV, const double* job_bottom, int run_mode, d
         DFTA_CHECK_LAUNCH(ctx);
         if (stats) DFTA_HIP(ctx, hipEventRecord(ev[0], st));
         rc = dfta_launch_sweep(ctx, g, DFTA_SWEEP_COUNT, d_wave_kind, nwaves, d_tab, d_wave_slot, d_wave_first, d_wave_cnt, d_E,
-                               d_limit, d_start, d_us, d_us1, d_count, d_u0, nullptr, d_counters + 1, d_bounds);
+                               d_limit, d_start, d_us, d_us1, d_count, d_u0, nullptr, d_counters + 1, d_bounds, d_phi, d_istop);
         if (rc) return rc;
         if (stats) DFTA_HIP(ctx, hipEventRecord(ev[1], st));
         hipLaunchKernelGGL(k_scout, dim3(njobs), dim3(64), 0, st, d_jobs, tpj, d_E, d_start, d_u0);
         DFTA_CHECK_LAUNCH(ctx);
         DFTA_HIP(ctx, hipMemsetAsync(d_ndone, 0, sizeof(int), st));
-        hipLaunchKernelGGL(k_walk, dim3((run_chains + 63) / 64), dim3(64), 0, st, d_jobs, d_chains, run_chains, tpj, d_count, d_u0, d_ndone);
+        hipLaunchKernelGGL(k_walk, dim3((run_chains + 63) / 64), dim3(64), 0, st, d_jobs, d_chains, run_chains, tpj, d_count, d_u0, d_phi, d_istop, d_ndone);
         DFTA_CHECK_LAUNCH(ctx);
         hipLaunchKernelGGL(k_plan, dim3((njobs + 63) / 64), dim3(64), 0, st, d_jobs, njobs, tpj);
         DFTA_CHECK_LAUNCH(ctx);
@@ -750,6 +801,16 @@ int LevelSolver::run(const double* dV, const double* job_bottom, int run_mode, d
             for (int q = 0; q < njobs; ++q)
                 if (dbg[q].phase != PH_DONE) fprintf(stderr, " %d:%d/%d", q, dbg[q].phase, dbg[q].phase_done);
             fprintf(stderr, "\n");
+            if (atoi(getenv("DFTA_DEBUG_ROUNDS")) >= 2)
+                for (int q = 0; q < njobs; ++q) {
+                    const Job& J = dbg[q];
+                    if (J.phase != PH_TOP) continue;
+                    fprintf(stderr, "   job %2d l=%d w=%.3e ok=%d spine=%d use_sp=%d miss=%d | a: is=%d phi=%.4e  b: is=%s%d phi=%.4e  c: de=%.3e is=%s%d phi=%.4e | pred w/e=%.3e\n",
+                            q, J.l, J.toe - J.boe, J.sc_ok, J.spine, J.use_sp, J.miss, J.sc_is[0], J.sc_phi[0],
+                            (J.sc_is[1] >= 0 && (J.sc_is[1] & kStopOver)) ? "o" : "", J.sc_is[1] < 0 ? -1 : (J.sc_is[1] & ~kStopOver), J.sc_phi[1],
+                            J.sc_e[2] - J.sc_e[0], (J.sc_is[2] >= 0 && (J.sc_is[2] & kStopOver)) ? "o" : "", J.sc_is[2] < 0 ? -1 : (J.sc_is[2] & ~kStopOver), J.sc_phi[2],
+                            J.sc_ok ? (J.toe - J.boe) / (J.sc_hi - J.sc_lo) : 0.0);
+                }
         }
         if (ndone >= njobs) break;
     }

@@ -128,8 +128,11 @@ struct CountState {
     lanemask_t flag;      // firstClassicalReturnPoint
 };
 
-__device__ __forceinline__ void count_step(CountState& c, int& budget, const int lane, const double u, const double veff,
-                                           const double E, const lanemask_t started)
+// Returns the lanes that leave the loop at this point: bit set in .x because the classically allowed region ended
+// (Numerov.h:338), in .y because the count exceeded the limit (Numerov.h:330).
+struct CountExit { lanemask_t tp, over; };
+__device__ __forceinline__ CountExit count_step(CountState& c, int& budget, const int lane, const double u, const double veff,
+                                                 const double E, const lanemask_t started)
 {
     const lanemask_t m_inf = __ballot(fabs(u) == INFINITY);
     const lanemask_t m_pos = __ballot(u > 0);
@@ -147,6 +150,7 @@ __device__ __forceinline__ void count_step(CountState& c, int& budget, const int
     const lanemask_t tp = stay & c.flag & m_gt;            // left the classically allowed region again
     c.flag |= stay & m_le;
     c.live = (c.live & ~started) | (stay & ~tp);
+    return CountExit{tp, over};
 }
 
 struct SweepArgs {
@@ -167,6 +171,13 @@ struct SweepArgs {
     int* count;                // COUNT out
     double* u0;                // out (may be null for COUNT)
     int* trip;                 // out (may be null): loop iterations per trial (diagnostics)
+    // COUNT, optional (pipelined kernel; the fused one writes "unknown"): where the sweep stopped and how far the nearest
+    // zero of u is from that point.  istop = grid index of the last examined point (0: ran down to r = 0, -1: left for
+    // another reason); phi = u_stop / (u_stop - u_prev), the position of the zero of the line through the last two values
+    // in grid cells beyond the stop point -- a smooth, scale-free function of E that crosses 0 exactly where the counted
+    // number of nodes changes.  The level solver interpolates it to predict the end point of a bisection (speculation only).
+    double* phi;
+    int* istop;                // | kStopOver: left because the count exceeded the limit, at the sign change that did it
     unsigned long long* total_trips;   // optional global counter (points traversed)
 };
 
@@ -392,6 +403,8 @@ __device__ __forceinline__ void sweep_wave(const SweepArgs& a, const GridScalars
         if (KIND == DFTA_SWEEP_COUNT) a.count[t] = count;
         if (a.u0) a.u0[t] = u0;
         if (a.trip) a.trip[t] = trips;
+        if (KIND == DFTA_SWEEP_COUNT && a.phi) a.phi[t] = NAN;
+        if (KIND == DFTA_SWEEP_COUNT && a.istop) a.istop[t] = -1;
     }
     if (a.total_trips) {
         if (KIND == DFTA_SWEEP_ZERO) {
@@ -436,6 +449,7 @@ struct PipeShared {
     double prod[3][CH][2][64];   // f_i and the refined reciprocal r_i of d_i = 1 - f_i/12, per point and lane
     double u[2][CH][64];         // integrator -> counter
     double fin[64];              // u(0) of every lane at the end of a COUNT sweep
+    double fin1[64];             // and u at grid point 1
     int stop;                    // set by the counter when every lane has left CountNodes' loop
 };
 
@@ -688,6 +702,7 @@ __device__ __forceinline__ void sweep_pipe(const SweepArgs& a, const GridScalars
             }
         } else if (!stopped) {
             sh.fin[lane] = s.u * (2 + s.fprev) - s.prevSol;                          // Numerov.h:345
+            sh.fin1[lane] = s.u;
         }
     } else {
         // ---------------- counter
@@ -706,6 +721,8 @@ __device__ __forceinline__ void sweep_pipe(const SweepArgs& a, const GridScalars
         double2 mm_next = blkmm ? blkmm[max(nch - 1, 0)] : double2{0., 0.};
         lanemask_t last_le = 0;       // veff <= E at the last point that went through count_step
         bool poisoned = true;         // last_le unusable (nothing processed yet, or a NaN veff)
+        double phi = NAN, ucarry = NAN;   // see SweepArgs::phi; u at the last point of the previous chunk
+        int istop = -1;
         for (int it = 0; it < nit; ++it) {
             const int cc = it - 3;
             if (COUNT && cc >= 0 && cc < nch) {
@@ -753,7 +770,12 @@ __device__ __forceinline__ void sweep_pipe(const SweepArgs& a, const GridScalars
                             if (diag) trips += (int)((before >> lane) & 1ull);
                             wave_trips += __popcll(before);
                             const double veff = rows[k].x;
-                            count_step(c, budget, lane, u[k], veff, E, st);
+                            const CountExit ex = count_step(c, budget, lane, u[k], veff, E, st);
+                            if ((ex.tp | ex.over) != 0ull && (((ex.tp | ex.over) >> lane) & 1ull)) {
+                                const double up = (k == 0) ? ucarry : u[k > 0 ? k - 1 : 0];
+                                phi = u[k] / (u[k] - up);
+                                istop = ((ex.over >> lane) & 1ull) ? (i | kStopOver) : i;
+                            }
                             m_le = __ballot(veff <= E);
                             m_gt = __ballot(veff > E);
                         }
@@ -762,6 +784,7 @@ __device__ __forceinline__ void sweep_pipe(const SweepArgs& a, const GridScalars
                     poisoned = ((m_le | m_gt) != ~0ull);
                     if ((c.live & vmask) == 0ull && lane == 0) *stop = 1;
                 }
+                ucarry = u[CH - 1];
             }
             PIPE_BARRIER();
             if (COUNT && (it & 1) && *stop != 0) { stopped = true; break; }
@@ -775,11 +798,15 @@ __device__ __forceinline__ void sweep_pipe(const SweepArgs& a, const GridScalars
                 u0 = sh.fin[lane];
                 const bool oldSgn = (c.oldSgn >> lane) & 1ull;
                 if ((u0 > 0) != oldSgn) ++count;                                      // Numerov.h:346-347
+                phi = u0 / (u0 - sh.fin1[lane]);
+                istop = 0;
             }
             if (valid) {
                 a.count[t] = count;
                 if (a.u0) a.u0[t] = u0;
                 if (a.trip) a.trip[t] = trips;
+                if (a.phi) a.phi[t] = phi;
+                if (a.istop) a.istop[t] = istop;
             }
             if (a.total_trips && lane == 0) atomicAdd(a.total_trips, wave_trips);
         }
@@ -1084,9 +1111,10 @@ int dfta_launch_boundary(dfta_ctx* ctx, const dfta_grid* g, const double* dE, in
 int dfta_launch_sweep(dfta_ctx* ctx, const dfta_grid* g, int kind, const int* blk_kind, int nblocks, const double2* tab,
                       const int* blk_slot, const int* blk_first, const int* blk_cnt, const double* dE, const int* dLimit,
                       const int* dStart, const double* dUs, const double* dUs1, int* dCount, double* dU0, int* dTrip,
-                      unsigned long long* dTotalTrips, const double2* bounds)
+                      unsigned long long* dTotalTrips, const double2* bounds, double* dPhi, int* dIstop)
 {
     SweepArgs a;
+    a.phi = dPhi; a.istop = dIstop;
     a.kind = kind; a.blk_kind = blk_kind; a.bounds = bounds; a.bstride = dfta_bounds_stride(g);
     a.tab = tab; a.blk_slot = blk_slot; a.blk_first = blk_first; a.blk_cnt = blk_cnt; a.E = dE; a.limit = dLimit;
     a.start = dStart; a.us = dUs; a.us1 = dUs1; a.count = dCount; a.u0 = dU0; a.trip = dTrip; a.total_trips = dTotalTrips;
