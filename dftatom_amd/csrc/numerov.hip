@@ -877,24 +877,36 @@ __global__ void k_block_minmax(const double2* __restrict__ tab, int N, double2* 
 }
 
 // ---- match kernel (Numerov.h:403-504) --------------------------------------------------------------------
-// One wave per trial.  Lane 0 integrates inward from the cut-off until the outermost maximum (the match point), lane 1
-// integrates outward from the nucleus at the same time; they stop as soon as lane 0 has found the match point and lane
-// 1 has passed it.  The two recurrences are serial, but their per-point inputs are not: every kMB steps all 64 lanes
-// compute f_i and the refined reciprocal of 1 - f_i/12 for the next kMB points of BOTH streams (coalesced table loads,
-// ~30 instructions per batch) and park them in LDS; the serial loop then costs one 16-byte LDS read, the 8-instruction
-// recurrence and one store per step.  The remaining lanes finally join to rescale the outer part.
+// One workgroup of two waves per trial.  Lane 0 of the first wave integrates inward from the cut-off, lane 1 outward from
+// the nucleus, at the same time and BLINDLY: per step only the recurrence (11 instructions) and one LDS write of the new
+// value -- a lone wave issues one instruction of any kind per ~4.5 cycles, so everything else is moved off this path.
+// The second wave works one batch of kMB = 64 nodes ahead and one behind: it computes f_i, d_i = 1 - f_i/12 and the refined
+// reciprocal of d_i for the next batch of both streams (one node per lane, coalesced table loads), and it drains the
+// previous batch: coalesced stores of the 2 x 64 values, and the search for the match point -- the first node where the
+// inward solution turns down (the outermost maximum) or blows up (Numerov.h:463-467) -- as one compare per lane and a
+// ballot.  The integrator therefore overruns the match point by up to two batches; that is harmless: what it writes
+// below the match point is replaced by the outward values in the rescaling loop at the end.  A stream that has finished
+// is zeroed (its recurrence then stays 0).
 constexpr int kMB = 64;
 
-__global__ __launch_bounds__(64) void k_match(const double2* __restrict__ tab, const int* __restrict__ trial_slot,
-                                              const double* __restrict__ Earr, const int* __restrict__ startArr,
-                                              const double* __restrict__ usArr, const double* __restrict__ us1Arr,
-                                              const int* __restrict__ larr, double zero_l0, double zero_l1, double zero_l2,
-                                              double zero_l3, GridScalars gs, const double2* __restrict__ bounds, int bstride,
-                                              double* __restrict__ Psi, double* __restrict__ Q, int* __restrict__ matchPoint)
+struct MatchShared {
+    v2d fr[2][2][kMB];       // [batch parity][stream][step] = { f, r }
+    double dd[2][2][kMB];    // d
+    double uo[2][2][kMB];    // values computed by the integrator
+    int done0[2], done1[2], quit[2], mp;   // control, double-buffered by batch parity (written by the helper in iteration b, read after its barrier)
+};
+
+__global__ __launch_bounds__(128) void k_match(const double2* __restrict__ tab, const int* __restrict__ trial_slot,
+                                               const double* __restrict__ Earr, const int* __restrict__ startArr,
+                                               const double* __restrict__ usArr, const double* __restrict__ us1Arr,
+                                               const int* __restrict__ larr, double zero_l0, double zero_l1, double zero_l2,
+                                               double zero_l3, GridScalars gs, const double2* __restrict__ bounds, int bstride,
+                                               double* __restrict__ Psi, double* __restrict__ Q, int* __restrict__ matchPoint)
 {
-    __shared__ v2d stage[2][kMB];            // [stream][step] = { f, r }
+    __shared__ MatchShared sh;
     const int t = blockIdx.x;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // 0: integrator, 1: helper
     const int N = gs.N;
     const int slot = trial_slot[t];
     const double2* __restrict__ T = tab + (size_t)slot * N;
@@ -908,7 +920,7 @@ __global__ __launch_bounds__(64) void k_match(const double2* __restrict__ tab, c
     const double d2p4 = gs.delta2p4;
 
     // zero beyond the cut-off (Numerov.h:427-428)
-    for (int i = steps + 1 + lane; i < N; i += 64) P[i] = 0;
+    for (int i = steps + 1 + (int)threadIdx.x; i < N; i += 128) P[i] = 0;
 
     // may the division use the refined reciprocal?  (same range argument as in the sweeps: d in (0.5, 1.5) from the
     // slot bounds, |w| checked every 16 steps with 16 steps of margin)
@@ -917,120 +929,139 @@ __global__ __launch_bounds__(64) void k_match(const double2* __restrict__ tab, c
         const double2 bd = bounds[(size_t)slot * bstride];
         fast = (bd.x + fabs(E) * bd.y + d2p4 < 6.0);
     }
+    // batch b: inward nodes i0(b) - k, outward nodes j0(b) + k, k = 0 .. 63
+    const int i00 = steps - 2, j00 = 2;
+    auto produce = [&](int b) {
+        const int ii = max(i00 - b * kMB - lane, 1), jj = min(j00 + b * kMB + lane, N - 1);
+        const double2 ti = T[ii], tj = T[jj];
+        v2d oi, oj;
+        oi.x = (ti.x - E) * R2 * ti.y + d2p4;                                // Numerov.h:100
+        oj.x = (tj.x - E) * R2 * tj.y + d2p4;
+        const double di = 1. - kH2p12 * oi.x, dj = 1. - kH2p12 * oj.x;
+        oi.y = div_in_range(1.0, di);                                         // == the refined reciprocal (w = 1: q = r, rem ~ 0)
+        oj.y = div_in_range(1.0, dj);
+        sh.fr[b & 1][0][lane] = oi;
+        sh.fr[b & 1][1][lane] = oj;
+        sh.dd[b & 1][0][lane] = di;
+        sh.dd[b & 1][1][lane] = dj;
+    };
+    if (threadIdx.x == 0) { sh.done0[1] = (i00 < 1) ? 1 : 0; sh.done1[1] = 0; sh.quit[1] = 0; sh.mp = 2; }   // "iteration -1"; matchPoint default (Numerov.h:449)
+    if (role == 1) produce(0);
+    __syncthreads();
 
-    int mp = 2;              // matchPoint default (Numerov.h:449)
-    bool done = true;        // this lane's stream has stopped for good (lanes >= 2 own no stream)
-    int idx = 0;             // next node of this lane's stream
-    int found = 0;           // lane 0: the match point has been seen (sticky)
-    double w = 0, wprev = 0, u = 0, fprev = 0, unext = 0;
-    if (lane == 0) {
-        const double2 ts = T[steps];
-        const double2 t1 = T[steps - 1];
-        const double us = usArr[t];
-        u = us1Arr[t];
-        P[steps] = us;
-        P[steps - 1] = u;
-        fprev = f_of(ts.x, ts.y, E, gs);
-        wprev = (1 - kH2p12 * fprev) * us;
-        fprev = f_of(t1.x, t1.y, E, gs);
-        w = (1 - kH2p12 * fprev) * u;
-        unext = u;           // Psi[i+1]
-        idx = steps - 2;
-        done = idx < 1;
-    } else if (lane == 1) {
-        const double2 t1 = T[1];
-        u = zero1;           // Numerov.h:475
-        Qt[0] = 0;
-        Qt[1] = u;
-        fprev = f_of(t1.x, t1.y, E, gs);
-        wprev = 0;
-        w = (1 - kH2p12 * fprev) * u;
-        idx = 2;
-        done = false;
-    }
-
-    while (true) {
-        // state of the two streams at the start of the batch (wave-uniform)
-        const int i0 = __shfl(idx, 0), j0 = __shfl(idx, 1);
-        const bool d0 = __shfl((int)done, 0) != 0;
-        const int mp0 = __shfl(mp, 0);
-        // lane 1 needs the outward values up to and including the match point; while that is unknown, up to the node
-        // above lane 0's position (the match point can only lie below it)
-        const int jmax = min(steps, d0 ? mp0 : i0 + 1);
-        if (lane == 1 && idx > jmax) done = true;
-        if (__ballot(!done) == 0ull) break;
-
-        // per-point inputs of the next kMB nodes of both streams, one node per lane
-        {
-            const int ii = max(i0 - lane, 1), jj = min(j0 + lane, N - 1);
-            const double2 ti = T[ii], tj = T[jj];
-            v2d oi, oj;
-            oi.x = (ti.x - E) * R2 * ti.y + d2p4;                                // Numerov.h:100
-            oj.x = (tj.x - E) * R2 * tj.y + d2p4;
-            oi.y = div_in_range(1.0, 1. - kH2p12 * oi.x);                         // == the refined reciprocal (w = 1: q = r, rem ~ 0)
-            oj.y = div_in_range(1.0, 1. - kH2p12 * oj.x);
-            stage[0][lane] = oi;
-            stage[1][lane] = oj;
+    if (role == 0) {
+        // ---------------- integrator
+        double w = 0, wprev = 0, u = 0, fprev = 0;
+        if (lane == 0) {
+            const double2 ts = T[steps];
+            const double2 t1 = T[steps - 1];
+            const double us = usArr[t];
+            u = us1Arr[t];
+            P[steps] = us;
+            P[steps - 1] = u;
+            fprev = f_of(ts.x, ts.y, E, gs);
+            wprev = (1 - kH2p12 * fprev) * us;
+            fprev = f_of(t1.x, t1.y, E, gs);
+            w = (1 - kH2p12 * fprev) * u;
+        } else if (lane == 1) {
+            const double2 t1 = T[1];
+            u = zero1;           // Numerov.h:475
+            Qt[0] = 0;
+            Qt[1] = u;
+            fprev = f_of(t1.x, t1.y, E, gs);
+            wprev = 0;
+            w = (1 - kH2p12 * fprev) * u;
         }
-        __syncthreads();
-        if (lane < 2) {
-            const v2d* __restrict__ mine = &stage[lane][0];
-            const bool is0 = (lane == 0);
-            const int dir = is0 ? -1 : 1, is0i = is0 ? 1 : 0;
-            double* __restrict__ out = is0 ? P : Qt;
-            for (int k0 = 0; k0 < kMB; k0 += 16) {
-                // leave the reciprocal path for good when a value gets within 16 steps of the range edges
-                if (fast) {
-                    const double au = fabs(u);
-                    const bool ok = done || (au < 1e200 && (au > 1e-250 || u == 0.0));
-                    fast = (__ballot(ok) == 3ull);
-                }
-                if (__ballot(!done) == 0ull) break;
-                v2d in16[16];
-#pragma unroll
-                for (int q = 0; q < 16; ++q) in16[q] = mine[k0 + q];             // all 16 reads in flight before the chain starts
-                // the 16 nodes of this group lie in [idx - 15, idx] (lane 0) or [idx, idx + 15] (lane 1): the reciprocal
-                // path needs all of them inside the range of the division bounds (wave-uniform choice, straight-line code)
-                const bool grp_fast = fast && (__ballot(done || (is0 ? idx - 15 : idx) >= kBoundFrom) == 3ull);
-                // No exec masking inside a group (a mask that depends on the previous step's compare costs a VALU -> SGPR ->
-                // EXEC round trip per step): a lane that finishes inside the group keeps stepping to its end.  That is
-                // harmless -- lane 0 then only writes Psi below the match point, which the rescaling loop replaces by the
-                // outward values, and lane 1 writes scratch beyond the node it needed -- as long as the FIRST hit is kept.
-                auto step = [&](const v2d in, const bool use_r) {
-                    const double wnext = 2. * w - wprev + u * fprev;                // Numerov.h:311 (h2 == 1)
-                    wprev = w;
-                    w = wnext;
-                    const double f = in.x;
-                    const double d = 1. - kH2p12 * f;
-                    if (use_r) {
-                        const double qq = wnext * in.y;
-                        const double rem = __builtin_fma(-d, qq, wnext);
-                        u = __builtin_fma(rem, in.y, qq);
-                    } else {
-                        u = wnext / d;                                              // getU, Numerov.h:510-513
+        const int stream = lane == 1 ? 1 : 0;
+        for (int b = 0;; ++b) {
+            if (lane < 2) {
+                const bool mydone = (stream ? sh.done1[(b + 1) & 1] : sh.done0[(b + 1) & 1]) != 0;      // as of iteration b - 1
+                if (mydone) { w = 0; wprev = 0; u = 0; fprev = 0; }
+                const v2d* __restrict__ mine = &sh.fr[b & 1][stream][0];
+                const double* __restrict__ mined = &sh.dd[b & 1][stream][0];
+                double* __restrict__ outp = &sh.uo[b & 1][stream][0];
+                // first node of this lane's stream in the batch (for the range of the division bounds only)
+                const int node0 = stream ? j00 + b * kMB : i00 - b * kMB;
+                for (int k0 = 0; k0 < kMB; k0 += 16) {
+                    // leave the reciprocal path for good when a value gets within 16 steps of the range edges
+                    if (fast) {
+                        const double au = fabs(u);
+                        const bool ok = (au < 1e200 && (au > 1e-250 || u == 0.0));
+                        fast = (__ballot(ok) == 3ull);
                     }
-                    fprev = f;
-                    out[min(max(idx, 1), N - 1)] = u;                               // Psi (inward) / outward scratch
-                    // lane 0: the outermost maximum or a blow-up ends the inward sweep (Numerov.h:463-467)
-                    const int hit = is0i & ~found & (int)(idx >= 1) & ((int)(u < unext) | (int)(fabs(u) > 1E15));   // (not past node 1)
-                    unext = u;
-                    mp = hit ? idx : mp;
-                    found |= hit;
-                    idx += dir;
-                };
-                if (grp_fast) {
+                    v2d in16[16];
+                    double d16[16];
 #pragma unroll
-                    for (int q = 0; q < 16; ++q) step(in16[q], true);
-                } else {
+                    for (int q = 0; q < 16; ++q) { in16[q] = mine[k0 + q]; d16[q] = mined[k0 + q]; }   // all reads in flight before the chain starts
+                    // the 16 nodes of this group must lie inside the range of the division bounds for the reciprocal path
+                    const int lowest = stream ? node0 + k0 : node0 - k0 - 15;
+                    const bool grp_fast = fast && (__ballot(mydone || lowest >= kBoundFrom) == 3ull);
+                    auto step = [&](const v2d in, const double d, const int q, const bool use_r) {
+                        const double wnext = __builtin_fma(2., w, -wprev) + u * fprev;   // Numerov.h:311 (h2 == 1); 2w is exact
+                        wprev = w;
+                        w = wnext;
+                        if (use_r) {
+                            const double qq = wnext * in.y;
+                            const double rem = __builtin_fma(-d, qq, wnext);
+                            u = __builtin_fma(rem, in.y, qq);
+                        } else {
+                            u = wnext / d;                                              // getU, Numerov.h:510-513
+                        }
+                        fprev = in.x;
+                        outp[k0 + q] = u;
+                    };
+                    if (grp_fast) {
 #pragma unroll
-                    for (int q = 0; q < 16; ++q) step(in16[q], false);
+                        for (int q = 0; q < 16; ++q) step(in16[q], d16[q], q, true);
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) step(in16[q], d16[q], q, false);
+                    }
                 }
-                if (!done) done = found != 0 || (is0 ? idx < 1 : idx > jmax);
             }
+            __syncthreads();
+            if (sh.quit[b & 1]) break;
         }
-        __syncthreads();
+    } else {
+        // ---------------- helper: drains batch b - 1, produces batch b + 1 while the integrator works on batch b
+        double ulast = us1Arr[t];            // Psi at the node above the first one of the batch being drained
+        int found = (i00 < 1) ? 1 : 0, mp = 2;
+        bool d1 = false;
+        for (int b = 0;; ++b) {
+            if (b >= 1) {
+                const int bb = b - 1;
+                const int i = i00 - bb * kMB - lane, j = j00 + bb * kMB + lane;
+                const double ui = sh.uo[bb & 1][0][lane], uj = sh.uo[bb & 1][1][lane];
+                if (!found) {
+                    // lane 0: the outermost maximum or a blow-up ends the inward sweep (Numerov.h:463-467)
+                    double above = __shfl_up(ui, 1);
+                    if (lane == 0) above = ulast;
+                    const unsigned long long hits = __ballot(i >= 1 && ((ui < above) || (fabs(ui) > 1E15)));
+                    const int first = hits ? __ffsll((long long)hits) - 1 : kMB;
+                    if (i >= 1 && lane <= first) P[i] = ui;            // Psi down to the match point
+                    if (hits) { found = 1; mp = i00 - bb * kMB - first; }
+                    else if (i00 - b * kMB < 1) found = 1;              // ran down to node 1 without a hit: matchPoint stays 2
+                    ulast = __shfl(ui, 63);
+                }
+                if (!d1 && j <= steps) Qt[j] = uj;                     // outward scratch
+                // the outward stream is needed up to the match point; while that is unknown, up to the node above the
+                // inward stream's position (the match point can only lie below it)
+                const int jmax = min(steps, found ? mp : i00 - b * kMB + 1);
+                d1 = d1 || (j00 + b * kMB > jmax);
+            }
+            produce(b + 1);
+            if (lane == 0) {
+                sh.done0[b & 1] = found;
+                sh.done1[b & 1] = d1 ? 1 : 0;
+                sh.mp = mp;
+                sh.quit[b & 1] = (found && d1) ? 1 : 0;
+            }
+            __syncthreads();
+            if (found && d1) break;
+        }
     }
-    mp = __shfl(mp, 0);
+    int mp = sh.mp;
+    const int lane128 = threadIdx.x;
     __syncthreads();
 
     // Numerov.h:492-501: value of the outward solution at the match point, rescale the outer part
@@ -1048,14 +1079,14 @@ __global__ __launch_bounds__(64) void k_match(const double2* __restrict__ tab, c
     // already overwritten Psi[1] (Numerov.h:475) before the division at Numerov.h:497
     const double factor = sol / (mp >= 2 ? P[mp] : zero1);
     __syncthreads();
-    for (int k = lane; k <= steps; k += 64) {
+    for (int k = lane128; k <= steps; k += 128) {
         double v;
         if (k < mp) v = (k == 0) ? 0.0 : Qt[k];
         else if (k == mp) v = sol;
         else v = P[k] * factor;
         P[k] = v;
     }
-    if (lane == 0) matchPoint[t] = mp;
+    if (lane128 == 0) matchPoint[t] = mp;
 }
 
 GridScalars scalars_of(const dfta_grid* g)
@@ -1133,7 +1164,7 @@ int dfta_launch_match(dfta_ctx* ctx, const dfta_grid* g, int ntrials, const doub
                       const double* dE, const int* dStart, const double* dUs, const double* dUs1, const int* dL,
                       double* dPsi, double* dQ, int* dMatch, const double2* bounds)
 {
-    hipLaunchKernelGGL(k_match, dim3(ntrials), dim3(64), 0, ctx->stream, tab, d_trial_slot, dE, dStart, dUs, dUs1, dL,
+    hipLaunchKernelGGL(k_match, dim3(ntrials), dim3(128), 0, ctx->stream, tab, d_trial_slot, dE, dStart, dUs, dUs1, dL,
                        g->zero1[0], g->zero1[1], g->zero1[2], g->zero1[3], scalars_of(g), bounds, dfta_bounds_stride(g), dPsi, dQ,
                        dMatch);
     DFTA_CHECK_LAUNCH(ctx);
