@@ -931,9 +931,13 @@ __global__ __launch_bounds__(128) void k_match(const double2* __restrict__ tab, 
     }
     // batch b: inward nodes i0(b) - k, outward nodes j0(b) + k, k = 0 .. 63
     const int i00 = steps - 2, j00 = 2;
-    auto produce = [&](int b) {
+    // table rows of batch b (the helper fetches them two batches ahead: a round trip to L2 takes as long as a batch)
+    auto fetch = [&](int b, double2& ti, double2& tj) {
         const int ii = max(i00 - b * kMB - lane, 1), jj = min(j00 + b * kMB + lane, N - 1);
-        const double2 ti = T[ii], tj = T[jj];
+        ti = T[ii];
+        tj = T[jj];
+    };
+    auto produce = [&](int b, const double2 ti, const double2 tj) {
         v2d oi, oj;
         oi.x = (ti.x - E) * R2 * ti.y + d2p4;                                // Numerov.h:100
         oj.x = (tj.x - E) * R2 * tj.y + d2p4;
@@ -946,7 +950,13 @@ __global__ __launch_bounds__(128) void k_match(const double2* __restrict__ tab, 
         sh.dd[b & 1][1][lane] = dj;
     };
     if (threadIdx.x == 0) { sh.done0[1] = (i00 < 1) ? 1 : 0; sh.done1[1] = 0; sh.quit[1] = 0; sh.mp = 2; }   // "iteration -1"; matchPoint default (Numerov.h:449)
-    if (role == 1) produce(0);
+    double2 nti = {0., 0.}, ntj = {0., 0.};      // helper: rows of the batch after the next one
+    if (role == 1) {
+        double2 ti, tj;
+        fetch(0, ti, tj);
+        fetch(1, nti, ntj);
+        produce(0, ti, tj);
+    }
     __syncthreads();
 
     if (role == 0) {
@@ -982,44 +992,63 @@ __global__ __launch_bounds__(128) void k_match(const double2* __restrict__ tab, 
                 double* __restrict__ outp = &sh.uo[b & 1][stream][0];
                 // first node of this lane's stream in the batch (for the range of the division bounds only)
                 const int node0 = stream ? j00 + b * kMB : i00 - b * kMB;
-                for (int k0 = 0; k0 < kMB; k0 += 16) {
+                // groups of 16 steps; the LDS reads of the next group are issued before the chain of the current one starts
+                // (reads and writes of this wave queue up in the LDS pipeline: ~4 ns per 16-byte read, ~18 ns per 16-byte
+                // write instruction -- as long as a batch's arithmetic unless they overlap with it)
+                v2d inA[16], inB[16];
+                double dA[16], dB[16];
+                auto load16 = [&](v2d (&in)[16], double (&dv)[16], int k0) {
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) { in[q] = mine[k0 + q]; dv[q] = mined[k0 + q]; }
+                };
+                auto group = [&](const v2d (&in)[16], const double (&dv)[16], int k0) {
                     // leave the reciprocal path for good when a value gets within 16 steps of the range edges
                     if (fast) {
                         const double au = fabs(u);
                         const bool ok = (au < 1e200 && (au > 1e-250 || u == 0.0));
                         fast = (__ballot(ok) == 3ull);
                     }
-                    v2d in16[16];
-                    double d16[16];
-#pragma unroll
-                    for (int q = 0; q < 16; ++q) { in16[q] = mine[k0 + q]; d16[q] = mined[k0 + q]; }   // all reads in flight before the chain starts
                     // the 16 nodes of this group must lie inside the range of the division bounds for the reciprocal path
                     const int lowest = stream ? node0 + k0 : node0 - k0 - 15;
                     const bool grp_fast = fast && (__ballot(mydone || lowest >= kBoundFrom) == 3ull);
-                    auto step = [&](const v2d in, const double d, const int q, const bool use_r) {
+                    auto step = [&](const v2d in1, const double d, const int q, const bool use_r) {
                         const double wnext = __builtin_fma(2., w, -wprev) + u * fprev;   // Numerov.h:311 (h2 == 1); 2w is exact
                         wprev = w;
                         w = wnext;
                         if (use_r) {
-                            const double qq = wnext * in.y;
+                            const double qq = wnext * in1.y;
                             const double rem = __builtin_fma(-d, qq, wnext);
-                            u = __builtin_fma(rem, in.y, qq);
+                            u = __builtin_fma(rem, in1.y, qq);
                         } else {
                             u = wnext / d;                                              // getU, Numerov.h:510-513
                         }
-                        fprev = in.x;
+                        fprev = in1.x;
                         outp[k0 + q] = u;
                     };
                     if (grp_fast) {
 #pragma unroll
-                        for (int q = 0; q < 16; ++q) step(in16[q], d16[q], q, true);
+                        for (int q = 0; q < 16; ++q) step(in[q], dv[q], q, true);
                     } else {
 #pragma unroll
-                        for (int q = 0; q < 16; ++q) step(in16[q], d16[q], q, false);
+                        for (int q = 0; q < 16; ++q) step(in[q], dv[q], q, false);
                     }
-                }
+                };
+                load16(inA, dA, 0);
+                load16(inB, dB, 16);
+                __builtin_amdgcn_sched_barrier(0);
+                group(inA, dA, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                load16(inA, dA, 32);
+                __builtin_amdgcn_sched_barrier(0);
+                group(inB, dB, 16);
+                __builtin_amdgcn_sched_barrier(0);
+                load16(inB, dB, 48);
+                __builtin_amdgcn_sched_barrier(0);
+                group(inA, dA, 32);
+                __builtin_amdgcn_sched_barrier(0);
+                group(inB, dB, 48);
             }
-            __syncthreads();
+            PIPE_BARRIER();      // LDS only: the helper's stores to Psi / the scratch stay in flight
             if (sh.quit[b & 1]) break;
         }
     } else {
@@ -1028,6 +1057,8 @@ __global__ __launch_bounds__(128) void k_match(const double2* __restrict__ tab, 
         int found = (i00 < 1) ? 1 : 0, mp = 2;
         bool d1 = false;
         for (int b = 0;; ++b) {
+            const double2 cti = nti, ctj = ntj;      // rows of batch b + 1
+            fetch(b + 2, nti, ntj);
             if (b >= 1) {
                 const int bb = b - 1;
                 const int i = i00 - bb * kMB - lane, j = j00 + bb * kMB + lane;
@@ -1049,14 +1080,14 @@ __global__ __launch_bounds__(128) void k_match(const double2* __restrict__ tab, 
                 const int jmax = min(steps, found ? mp : i00 - b * kMB + 1);
                 d1 = d1 || (j00 + b * kMB > jmax);
             }
-            produce(b + 1);
+            produce(b + 1, cti, ctj);
             if (lane == 0) {
                 sh.done0[b & 1] = found;
                 sh.done1[b & 1] = d1 ? 1 : 0;
                 sh.mp = mp;
                 sh.quit[b & 1] = (found && d1) ? 1 : 0;
             }
-            __syncthreads();
+            PIPE_BARRIER();      // LDS only: the helper's stores to Psi / the scratch stay in flight
             if (found && d1) break;
         }
     }
