@@ -1338,7 +1338,9 @@ int dfta_poisson_create(dfta_ctx* ctx, const dfta_grid* g, int batch, dfta_poiss
     // units idle the fine levels of every atom are shared by a group of G workgroups (all of them must be resident:
     // batch * G <= 256 CUs).  A level is shared when every lane of the group still owns >= 8 nodes (>= 4 for G = 16: the
     // same four levels at 131073 nodes, with 32 nodes per lane on the finest one -- the most that is staged in LDS).
-    int logG = batch <= 16 ? 4 : (batch <= 32 ? 3 : (batch <= 64 ? 2 : (batch <= 128 ? 1 : 0)));
+    // (measured: G = 16 wins up to 4 atoms; beyond that the barriers of 16 members on a nearly full chip cost more than the
+    // shorter chunks save)
+    int logG = batch <= 4 ? 4 : (batch <= 32 ? 3 : (batch <= 64 ? 2 : (batch <= 128 ? 1 : 0)));
     if (const char* e = getenv("DFTA_POISSON_GROUP")) {      // measurements: force log2 of the group size
         const int v = atoi(e);
         if (v >= 0 && v <= 4 && (batch << v) <= 256) logG = v;
