@@ -171,7 +171,7 @@ struct SweepArgs {
     int* count;                // COUNT out
     double* u0;                // out (may be null for COUNT)
     int* trip;                 // out (may be null): loop iterations per trial (diagnostics)
-    // COUNT, optional (pipelined kernel; the fused one writes "unknown"): where the sweep stopped and how far the nearest
+    // COUNT, optional: where the sweep stopped and how far the nearest
     // zero of u is from that point.  istop = grid index of the last examined point (0: ran down to r = 0, -1: left for
     // another reason); phi = u_stop / (u_stop - u_prev), the position of the zero of the line through the last two values
     // in grid cells beyond the stop point -- a smooth, scale-free function of E that crosses 0 exactly where the counted
@@ -248,15 +248,22 @@ __device__ __forceinline__ void sweep_wave(const SweepArgs& a, const GridScalars
     ilo = __builtin_amdgcn_readfirstlane(ilo);   // from here down every valid lane has started
 
     // bookkeeping after a step; runs in wave-uniform control flow only, so that its lane masks stay in scalar registers
-#define SWEEP_COUNT_U(uval, veff, started)                                                             \
+    // (uprev = u at the point above, idx = grid index: for SweepArgs::phi / istop)
+    double phi = NAN;
+    int istop = -1;
+#define SWEEP_COUNT_U(uval, uprev, idx, veff, started)                                                 \
     if (KIND == DFTA_SWEEP_COUNT) {                                                                    \
         const lanemask_t before = c.live & (started);                                                  \
         if (diag) trips += (int)((before >> lane) & 1ull);                                             \
         wave_trips += __popcll(before);                                                                \
-        count_step(c, budget, lane, (uval), (veff), E, (started));                                     \
+        const CountExit ex_ = count_step(c, budget, lane, (uval), (veff), E, (started));               \
+        if ((ex_.tp | ex_.over) != 0ull && (((ex_.tp | ex_.over) >> lane) & 1ull)) {                   \
+            phi = (uval) / ((uval) - (uprev));                                                         \
+            istop = ((ex_.over >> lane) & 1ull) ? ((idx) | kStopOver) : (idx);                         \
+        }                                                                                              \
         poisoned = true;                                                                               \
     }
-#define SWEEP_COUNT(veff, started) SWEEP_COUNT_U(s.u, veff, started)
+#define SWEEP_COUNT(idx, veff, started) SWEEP_COUNT_U(s.u, s.prevSol, idx, veff, started)
     // Whole batches of the body are skipped by the bookkeeping when nothing can change in them (see the counter of the
     // pipelined kernel below: u keeps its sign and stays finite, veff stays on one side of E, for every live lane);
     // last_le = "veff <= E" at the last point that went through count_step, unusable while `poisoned`.
@@ -270,7 +277,7 @@ __device__ __forceinline__ void sweep_wave(const SweepArgs& a, const GridScalars
         const bool in = valid && i <= my_hi;
         const lanemask_t started = __ballot(in);
         if (in) numerov_step<false>(s, tv, E, R2, d2p4);
-        SWEEP_COUNT(tv.x, started)
+        SWEEP_COUNT(i, tv.x, started)
     }
     // body: all valid lanes step together, no exec masking on the arithmetic.
     // Lanes that have left the reference's loop keep integrating (harmless), only their bookkeeping is frozen.
@@ -306,6 +313,7 @@ __device__ __forceinline__ void sweep_wave(const SweepArgs& a, const GridScalars
                 for (int k = 0; k < CH; ++k) CUR[k] = T[i - 2 * CH - k];
             }
             double uu[CH];
+            const double ucarry = s.u;                                        // u at the point above this batch
 #pragma unroll
             for (int k = 0; k < CH; ++k) {
                 const double wnext = 2. * s.w - s.wprev + s.u * s.fprev;     // Numerov.h:311 (h2 == 1)
@@ -346,7 +354,7 @@ __device__ __forceinline__ void sweep_wave(const SweepArgs& a, const GridScalars
                     wave_trips += (unsigned long long)CH * __popcll(act);
                 } else {
 #pragma unroll
-                    for (int k = 0; k < CH; ++k) { SWEEP_COUNT_U(uu[k], veff[k], vmask) }
+                    for (int k = 0; k < CH; ++k) { SWEEP_COUNT_U(uu[k], (k == 0 ? ucarry : uu[k > 0 ? k - 1 : 0]), i - k, veff[k], vmask) }
                     const lanemask_t m_le = __ballot(veff[CH - 1] <= E), m_gt = __ballot(veff[CH - 1] > E);
                     last_le = m_le;
                     poisoned = ((m_le | m_gt) != ~0ull);
@@ -367,7 +375,7 @@ __device__ __forceinline__ void sweep_wave(const SweepArgs& a, const GridScalars
 #pragma unroll
                 for (int k = 0; k < CH; ++k) {
                     numerov_step<false>(s, OTH[k], E, R2, d2p4);
-                    SWEEP_COUNT(OTH[k].x, vmask)
+                    SWEEP_COUNT(i - k, OTH[k].x, vmask)
                 }
                 i -= CH;
                 return true;
@@ -383,7 +391,7 @@ __device__ __forceinline__ void sweep_wave(const SweepArgs& a, const GridScalars
     for (; i >= 1; --i) {
         const double2 tv = T[i];
         numerov_step<false>(s, tv, E, R2, d2p4);
-        SWEEP_COUNT(tv.x, vmask)
+        SWEEP_COUNT(i, tv.x, vmask)
     }
 #undef SWEEP_COUNT
 #undef SWEEP_COUNT_U
@@ -397,14 +405,16 @@ __device__ __forceinline__ void sweep_wave(const SweepArgs& a, const GridScalars
         if (KIND == DFTA_SWEEP_COUNT) {
             const bool oldSgn = (c.oldSgn >> lane) & 1ull;
             if ((u0 > 0) != oldSgn) ++count;                  // Numerov.h:346-347
+            phi = u0 / (u0 - s.u);
+            istop = 0;
         }
     }
     if (valid) {
         if (KIND == DFTA_SWEEP_COUNT) a.count[t] = count;
         if (a.u0) a.u0[t] = u0;
         if (a.trip) a.trip[t] = trips;
-        if (KIND == DFTA_SWEEP_COUNT && a.phi) a.phi[t] = NAN;
-        if (KIND == DFTA_SWEEP_COUNT && a.istop) a.istop[t] = -1;
+        if (KIND == DFTA_SWEEP_COUNT && a.phi) a.phi[t] = phi;
+        if (KIND == DFTA_SWEEP_COUNT && a.istop) a.istop[t] = istop;
     }
     if (a.total_trips) {
         if (KIND == DFTA_SWEEP_ZERO) {
