@@ -93,6 +93,8 @@ struct Atom {
     unsigned* ctr;          // monotonic arrival counter of the group (zeroed before the launch)
     unsigned bar;           // barriers passed so far
     double* part;           // [2][3][G] partial sums of the members (double-buffered by barrier parity) + [1] published `cur`
+    double* fslot;          // [3][G] slots of the fast sum (group_sum_fast), sentinel-filled before the launch
+    unsigned fseq;          // fast sums taken so far
     __device__ __forceinline__ int lane() const { return g * kThreads + static_cast<int>(threadIdx.x); }
     // pointer to storage element 0 of the level (generic address space: LDS for sequential levels, global otherwise)
     __device__ __forceinline__ double* cur_phi(int l, const Lvl& L) const
@@ -156,6 +158,58 @@ __device__ __forceinline__ double group_sum(Atom& A, double v, double* red)
     double tot = 0;
     for (int m = 0; m < A.G; ++m) tot += slot[m];
     return tot;
+}
+
+// -DDFTA_POISSON_PROF: time (s_memtime ticks of workgroup 0) per operation kind and level, printed when the solver is destroyed
+#ifdef DFTA_POISSON_PROF
+__device__ unsigned long long g_prof[6 * 24];
+#define PROF_T0() const long long prof_t0 = clock64()
+#define PROF_ADD(cat, lvl) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_prof[(cat) * 24 + (lvl)] += clock64() - prof_t0; } while (0)
+#else
+#define PROF_T0()
+#define PROF_ADD(cat, lvl)
+#endif
+
+// Sum over the group for the sweeps in the middle of a staged visit, where the members exchange only a few values: no
+// cache maintenance at all.  Everything exchanged (the boundary nodes before the call, the partial sums here) is written
+// and read with agent-scope atomic accesses, which go to the coherent level directly; the barrier is implicit -- every
+// member publishes its partial sum into its slot of a buffer that holds a sentinel (a NaN with a payload no arithmetic
+// produces) and polls the others' slots until none holds the sentinel: one round trip instead of three (arrival counter,
+// poll, read of the sums) plus an L2 write-back and an invalidate.  Three buffers rotate: after the sum of sweep s is
+// complete everybody has finished reading sweep s-1's buffer (they have all published sweep s), so each member resets its
+// slot of that one; it is used again in sweep s+2, a whole sweep later.  Sums are added in member order, as in group_sum.
+constexpr unsigned long long kFastSentinel = 0x7FF8DEAD7FF8DEADull;
+__device__ __forceinline__ double group_sum_fast(Atom& A, double v, double* red)
+{
+    const double mine = block_sum(v, red);      // its barriers wait for every store of this member issued so far
+    if (A.G == 1) return mine;
+    const unsigned s = A.fseq++;
+    double* cur = A.fslot + (s % 3u) * A.G;
+    if (threadIdx.x < 64) {
+        if (threadIdx.x == 0) __hip_atomic_store(cur + A.g, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        double x = 0;
+        if (static_cast<int>(threadIdx.x) < A.G) {
+            int spins = 0;
+            while (true) {
+                x = __hip_atomic_load(cur + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (static_cast<unsigned long long>(__double_as_longlong(x)) != kFastSentinel) break;
+                if (++spins > (1 << 22)) {      // a lost member must not hang the GPU: raise the group's abort flag
+                    __hip_atomic_fetch_or(A.ctr, 0x80000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+        }
+        double tot = 0;
+        for (int m = 0; m < A.G; ++m) tot += __shfl(x, m);
+        if (threadIdx.x == 0) {
+            red[18] = tot;
+            __hip_atomic_store(A.fslot + ((s + 2u) % 3u) * A.G + A.g, __longlong_as_double(static_cast<long long>(kFastSentinel)),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    __syncthreads();
+    return red[18];
 }
 
 __device__ __forceinline__ double gs_point(double s, double xm, double xp, double dh)
@@ -875,25 +929,29 @@ __device__ __forceinline__ double iterate_gs(const MgDesc& D, Atom& A, int l, do
         int done = 0;
         for (int i = 0; i < iterno; ++i) {
             double err2;
+            { PROF_T0();
             switch (L.logC) {
                 case 2:  err2 = gs_lds<2, kStageRS>(SS, PP, tid, lo_g, dh); break;
                 case 3:  err2 = gs_lds<3, kStageRS>(SS, PP, tid, lo_g, dh); break;
                 case 4:  err2 = gs_lds<4, kStageRS>(SS, PP, tid, lo_g, dh); break;
                 default: err2 = gs_lds<5, kStageRS>(SS, PP, tid, lo_g, dh); break;
             }
+            PROF_ADD(4, l); }
             ++done;
             ++*nsweeps;
             const bool last = (i == iterno - 1);
             __syncthreads();
             if (last) write_out();
             else {
+                // agent-scope atomic stores / loads: coherent without cache maintenance (group_sum_fast)
                 if (tid < (Hc << L.logC)) {                    // the last Hc lanes' nodes: what the next member's warm-up reads
                     const int k = tid & (C - 1), c = kThreads - Hc + (tid >> L.logC);
-                    Gout[(k << logT) + col0 + c] = PP[k * kStageRS + c];
+                    __hip_atomic_store(&Gout[(k << logT) + col0 + c], PP[k * kStageRS + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
-                if (tid == 0) Gout[col0] = PP[0];              // the first node: right neighbour of the previous member's last one
+                if (tid == 0)                                  // the first node: right neighbour of the previous member's last one
+                    __hip_atomic_store(&Gout[col0], PP[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            err = sqrt(group_sum(A, err2, red));
+            { PROF_T0(); err = sqrt(last ? group_sum(A, err2, red) : group_sum_fast(A, err2, red)); PROF_ADD(3, l); }
             if (last) break;
             if (err < errorMin) {                              // the reference stops here: publish everything, meet once more
                 write_out();
@@ -902,9 +960,9 @@ __device__ __forceinline__ double iterate_gs(const MgDesc& D, Atom& A, int l, do
             }
             if (g > 0 && tid < (Hc << L.logC)) {
                 const int k = tid & (C - 1), c = -Hc + (tid >> L.logC);
-                PP[k * kStageRS + c] = Gout[(k << logT) + col0 + c];
+                PP[k * kStageRS + c] = __hip_atomic_load(&Gout[(k << logT) + col0 + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            if (g < A.G - 1 && tid == 0) PP[C * kStageRS] = Gout[end_g];
+            if (g < A.G - 1 && tid == 0) PP[C * kStageRS] = __hip_atomic_load(&Gout[end_g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             { double* t = Gin; Gin = Gout; Gout = t; }
             __syncthreads();
         }
@@ -1091,16 +1149,6 @@ __device__ __forceinline__ double do_iterate(const MgDesc& D, Atom& A, int l, do
     return 1E10;
 }
 
-// -DDFTA_POISSON_PROF: time (s_memtime ticks of workgroup 0) per operation kind and level, printed when the solver is destroyed
-#ifdef DFTA_POISSON_PROF
-__device__ unsigned long long g_prof[3 * 24];
-#define PROF_T0() const long long prof_t0 = clock64()
-#define PROF_ADD(cat, lvl) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_prof[(cat) * 24 + (lvl)] += clock64() - prof_t0; } while (0)
-#else
-#define PROF_T0()
-#define PROF_ADD(cat, lvl)
-#endif
-
 __device__ __forceinline__ double run_cycles(const MgDesc& D, Atom& A, int first_step, int max_vcycles, double errorMin,
                                              double errorMinLast, double* red, Counters& c)
 {
@@ -1173,7 +1221,9 @@ __global__ __launch_bounds__(kThreads) void k_poisson_solve(const MgDesc* __rest
     A.g = blockIdx.x & (D.G - 1);
     A.ctr = group_ctr + a;
     A.bar = 0;
-    A.part = group_part + (size_t)a * (6 * D.G + 2);
+    A.part = group_part + (size_t)a * (9 * D.G + 2);
+    A.fslot = A.part + 6 * D.G + 2;
+    A.fseq = 0;
     const Lvl L0 = D.lv[0];
     const int N = L0.n;
     const double* rho = density + (size_t)a * N;
@@ -1217,6 +1267,8 @@ __global__ __launch_bounds__(kThreads) void k_unit(const MgDesc* __restrict__ Dp
     A.ctr = group_ctr;
     A.bar = 0;
     A.part = group_part;
+    A.fslot = A.part + 6 * D.G + 2;
+    A.fseq = 0;
     A.cur = 0;
     for (int l = 0; l < D.levels; ++l) A.cur |= (cur[l] ? 1u : 0u) << l;
     // sequential levels: global -> LDS (the solve kernel initialises them itself); they are workgroup 0's
@@ -1290,6 +1342,7 @@ int dfta_poisson_solve_launch(dfta_poisson* p, const int* dZ, const double* dDen
 {
     dfta_ctx* ctx = p->ctx;
     DFTA_HIP(ctx, hipMemsetAsync(p->d_group_ctr, 0, sizeof(unsigned) * p->batch, ctx->stream));
+    DFTA_HIP(ctx, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(p->d_group_part), 0x7FF8DEAD, (size_t)p->batch * (9 * p->D.G + 2) * 2, ctx->stream));   // group_sum_fast's sentinel
     hipLaunchKernelGGL(k_poisson_solve, dim3(p->batch * p->D.G), dim3(kThreads), 0, ctx->stream, p->d_desc, p->d_phi0, p->d_phi1,
                        p->d_src, dZ, dDensity, p->g->d_r, p->g->d_psrc, dU, dVcycles, dErr, p->d_total_vcycles, p->d_group_ctr,
                        p->d_group_part);
@@ -1394,7 +1447,7 @@ int dfta_poisson_create(dfta_ctx* ctx, const dfta_grid* g, int batch, dfta_poiss
     if (e == hipSuccess) e = hipMemcpyAsync(p->d_desc, &p->D, sizeof(MgDesc), hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->d_total_vcycles), sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->d_group_ctr), sizeof(unsigned) * batch);
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->d_group_part), sizeof(double) * (size_t)batch * (6 * D.G + 2));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->d_group_part), sizeof(double) * (size_t)batch * (9 * D.G + 2));
     if (e == hipSuccess) e = hipMemsetAsync(p->d_phi0, 0, tot * sizeof(double), ctx->stream);
     if (e == hipSuccess) e = hipMemsetAsync(p->d_phi1, 0, tot * sizeof(double), ctx->stream);
     if (e == hipSuccess) e = hipMemsetAsync(p->d_src, 0, tot * sizeof(double), ctx->stream);
@@ -1416,17 +1469,17 @@ void dfta_poisson_destroy(dfta_poisson* p)
     if (!p) return;
 #ifdef DFTA_POISSON_PROF
     {
-        unsigned long long h[3 * 24];
+        unsigned long long h[6 * 24];
         if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_prof), sizeof(h)) == hipSuccess) {
-            const char* names[3] = {"restrict", "prolong ", "iterate "};
+            const char* names[6] = {"restrict", "prolong ", "iterate ", "grp_sum ", "gs_lds  ", "other   "};
             unsigned long long tot = 0;
-            for (int c = 0; c < 3; ++c) {
+            for (int c = 0; c < 6; ++c) {
                 fprintf(stderr, "[poisson prof] %s:", names[c]);
                 for (int l = 0; l < 18; ++l) { fprintf(stderr, " %llu", h[c * 24 + l]); tot += h[c * 24 + l]; }
                 fprintf(stderr, "\n");
             }
             fprintf(stderr, "[poisson prof] total ticks %llu\n", tot);
-            unsigned long long z[3 * 24] = {0};
+            unsigned long long z[6 * 24] = {0};
             (void)hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof(z));
         }
     }
@@ -1526,6 +1579,7 @@ static int unit_op(dfta_poisson* p, int op, int lvl, int sweeps, double* out_hos
     DFTA_HIP(ctx, dOut.alloc(std::max(nout, 1)));
     DFTA_HIP(ctx, hipMemcpyAsync(p->d_cur, p->h_cur.data(), sizeof(int) * kMaxLevels, hipMemcpyHostToDevice, st));
     DFTA_HIP(ctx, hipMemsetAsync(p->d_group_ctr, 0, sizeof(unsigned), st));
+    DFTA_HIP(ctx, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(p->d_group_part), 0x7FF8DEAD, (size_t)(9 * p->D.G + 2) * 2, st));
     hipLaunchKernelGGL(k_unit, dim3(p->D.G), dim3(kThreads), 0, st, p->d_desc, p->d_phi0, p->d_phi1, p->d_src, p->d_cur, op, lvl, sweeps, dOut.p,
                        p->d_group_ctr, p->d_group_part);
     DFTA_CHECK_LAUNCH(ctx);
@@ -1552,6 +1606,7 @@ int dfta_poisson_iterate_gs(dfta_poisson* p, int lvl, double errorMin, int itern
     DFTA_HIP(ctx, hipMemcpyAsync(dOut.p, &errorMin, sizeof(double), hipMemcpyHostToDevice, st));
     DFTA_HIP(ctx, hipMemcpyAsync(p->d_cur, p->h_cur.data(), sizeof(int) * kMaxLevels, hipMemcpyHostToDevice, st));
     DFTA_HIP(ctx, hipMemsetAsync(p->d_group_ctr, 0, sizeof(unsigned), st));
+    DFTA_HIP(ctx, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(p->d_group_part), 0x7FF8DEAD, (size_t)(9 * p->D.G + 2) * 2, st));
     hipLaunchKernelGGL(k_unit, dim3(p->D.G), dim3(kThreads), 0, st, p->d_desc, p->d_phi0, p->d_phi1, p->d_src, p->d_cur, 4, lvl, iterno, dOut.p,
                        p->d_group_ctr, p->d_group_part);
     DFTA_CHECK_LAUNCH(ctx);
