@@ -170,12 +170,13 @@ __device__ unsigned long long g_prof[6 * 24];
 #define PROF_ADD(cat, lvl)
 #endif
 
-// Sum over the group for the sweeps in the middle of a staged visit, where the members exchange only a few values: no
-// cache maintenance at all.  Everything exchanged (the boundary nodes before the call, the partial sums here) is written
-// and read with agent-scope atomic accesses, which go to the coherent level directly; the barrier is implicit -- every
+// Sum over the group for the sweeps in the middle of a staged visit, where the members exchange only a few values.
+// Everything exchanged (the boundary nodes before the call, the partial sums here) is written and read with agent-scope
+// atomic accesses, one release before the sum is published and one acquire after the last one has arrived order them, and
+// the barrier is implicit -- every
 // member publishes its partial sum into its slot of a buffer that holds a sentinel (a NaN with a payload no arithmetic
 // produces) and polls the others' slots until none holds the sentinel: one round trip instead of three (arrival counter,
-// poll, read of the sums) plus an L2 write-back and an invalidate.  Three buffers rotate: after the sum of sweep s is
+// poll, read of the sums).  Three buffers rotate: after the sum of sweep s is
 // complete everybody has finished reading sweep s-1's buffer (they have all published sweep s), so each member resets its
 // slot of that one; it is used again in sweep s+2, a whole sweep later.  Sums are added in member order, as in group_sum.
 constexpr unsigned long long kFastSentinel = 0x7FF8DEAD7FF8DEADull;
@@ -186,7 +187,12 @@ __device__ __forceinline__ double group_sum_fast(Atom& A, double v, double* red)
     const unsigned s = A.fseq++;
     double* cur = A.fslot + (s % 3u) * A.G;
     if (threadIdx.x < 64) {
-        if (threadIdx.x == 0) __hip_atomic_store(cur + A.g, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (threadIdx.x == 0) {
+            // the boundary nodes published before this call must be visible wherever this sum is (measured: without the
+            // release an agent-scope store can overtake earlier ones on its way to the other XCDs)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            __hip_atomic_store(cur + A.g, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         double x = 0;
         if (static_cast<int>(threadIdx.x) < A.G) {
             int spins = 0;
@@ -203,6 +209,7 @@ __device__ __forceinline__ double group_sum_fast(Atom& A, double v, double* red)
         double tot = 0;
         for (int m = 0; m < A.G; ++m) tot += __shfl(x, m);
         if (threadIdx.x == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             red[18] = tot;
             __hip_atomic_store(A.fslot + ((s + 2u) % 3u) * A.G + A.g, __longlong_as_double(static_cast<long long>(kFastSentinel)),
                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
