@@ -60,6 +60,7 @@ struct MgDesc {
     int levels;
     int G;           // workgroups per atom (power of two); 1: the whole solve runs in one workgroup
     int logG;
+    int nofold;   // DFTA_POISSON_NOFOLD: prolongation as a separate pass even where it could be folded into a staged copy-in
     int kcoop;       // levels 0 .. kcoop-1 are swept by all G workgroups together (256 G lanes), the others by workgroup 0
     long per_atom;   // doubles per atom and per array (sum of n)
     Lvl lv[kMaxLevels];
@@ -95,6 +96,7 @@ struct Atom {
     double* part;           // [2][3][G] partial sums of the members (double-buffered by barrier parity) + [1] published `cur`
     double* fslot;          // [3][G] slots of the fast sum (group_sum_fast), sentinel-filled before the launch
     unsigned fseq;          // fast sums taken so far
+    int pend;               // > 0: the prolongation from this level is folded into the staged copy-in of the level below it
     __device__ __forceinline__ int lane() const { return g * kThreads + static_cast<int>(threadIdx.x); }
     // pointer to storage element 0 of the level (generic address space: LDS for sequential levels, global otherwise)
     __device__ __forceinline__ double* cur_phi(int l, const Lvl& L) const
@@ -472,6 +474,8 @@ __device__ __forceinline__ double gs_lds(const double* __restrict__ SSbase, doub
     for (int Rb = -kWarm; Rb < -BS; Rb += BS) block(Rb, std::false_type{});
     block(-BS, std::true_type{});
     double old = bx[kH - 2];                    // Phi_old at the first owned node: the right neighbour of the last warm-up step
+    // node 1 as a lane's FIRST node (C == 1, lane 1): its restart falls on the step that the warm-up leaves to the owned part
+    if constexpr (C == 1) y = (lo_g == 1) ? Y0 : y;
     // all reads of other lanes' old values are done
     if constexpr (NT == kThreads) __syncthreads();
     else { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); }
@@ -918,14 +922,58 @@ __device__ __forceinline__ double iterate_gs(const MgDesc& D, Atom& A, int l, do
         double* SS = PP + kStageArr;
         const int col0 = g * kThreads;
         const int end_g = (g == A.G - 1) ? (C << logT) : (col0 + kThreads);     // node behind this member's part
-        copy_rows(PP, kStageRS, Gin + col0, 1 << logT, C);
-        copy_rows(SS, kStageRS, Sg + col0, 1 << logT, C);
-        for (int idx = tid; idx < C * kStageH; idx += kThreads) {       // halo columns (member 0: in-bounds padding / the
-            const int k = idx / kStageH, c = idx % kStageH - kStageH;   // previous level's tail, never used)
-            PP[k * kStageRS + c] = Gin[(k << logT) + col0 + c];
-            SS[k * kStageRS + c] = Sg[(k << logT) + col0 + c];
+        const bool fold = (A.pend == l + 1);
+        A.pend = 0;
+        if (!fold) {
+            copy_rows(PP, kStageRS, Gin + col0, 1 << logT, C);
+            copy_rows(SS, kStageRS, Sg + col0, 1 << logT, C);
+            for (int idx = tid; idx < C * kStageH; idx += kThreads) {       // halo columns (member 0: in-bounds padding / the
+                const int k = idx / kStageH, c = idx % kStageH - kStageH;   // previous level's tail, never used)
+                PP[k * kStageRS + c] = Gin[(k << logT) + col0 + c];
+                SS[k * kStageRS + c] = Sg[(k << logT) + col0 + c];
+            }
+            if (tid == 0) PP[C * kStageRS] = Gin[end_g];
+        } else {
+            // PoissonSolver::Prolong (PoissonSolver.cpp:110-123) from level l+1 folded into the copy: every member adds the
+            // correction to what it stages -- its own columns, the halo columns and the node behind its part -- from the
+            // coarse level, which is complete and visible since that level's last barrier.  The separate pass over the fine
+            // level and the group barrier after it are gone; the level's global copy is brought up to date by the write-out
+            // at the end of this visit.
+            const Lvl Lc = D.lv[l + 1];
+            const double* __restrict__ Pc = (((A.cur >> (l + 1)) & 1u) ? A.phi1 : A.phi0) + Lc.off;
+            auto corr = [&](int i, bool odd) -> double {               // fine node i (odd-ness known to the caller)
+                if (!odd) return Pc[addr(Lc, i >> 1)];                  // fine(2j) += coarse(j)
+                return 0.5 * (Pc[addr(Lc, (i - 1) >> 1)] + Pc[addr(Lc, (i + 1) >> 1)]);   // fine(2j-1) += 0.5 (coarse(j-1) + coarse(j))
+            };
+            const int lane0 = col0 + tid;
+            for (int k0 = 0; k0 < C; k0 += 4) {                         // C >= 4, a multiple of 4
+                double a[4], b[4], cadd[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int k = k0 + q, gi = (k << logT) + lane0;
+                    a[q] = Gin[gi];
+                    b[q] = Sg[gi];
+                    cadd[q] = corr((lane0 << L.logC) + k, (q & 1) != 0);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    PP[(k0 + q) * kStageRS + tid] = a[q] + cadd[q];
+                    SS[(k0 + q) * kStageRS + tid] = b[q];
+                }
+            }
+            for (int idx = tid; idx < C * kStageH; idx += kThreads) {
+                const int k = idx / kStageH, c = idx % kStageH - kStageH;
+                const int lanec = col0 + c, gi = (k << logT) + lanec;
+                double v = Gin[gi];
+                if (lanec >= 0) v += corr((lanec << L.logC) + k, (k & 1) != 0);
+                PP[k * kStageRS + c] = v;
+                SS[k * kStageRS + c] = Sg[gi];
+            }
+            if (tid == 0) {
+                const int i_end = (g == A.G - 1) ? (L.n - 1) : ((col0 + kThreads) << L.logC);
+                PP[C * kStageRS] = Gin[end_g] + corr(i_end, false);    // even node in both cases
+            }
         }
-        if (tid == 0) PP[C * kStageRS] = Gin[end_g];
         __syncthreads();
         auto write_out = [&]() {
             copy_rows(Gout + col0, 1 << logT, PP, kStageRS, C);
@@ -1135,7 +1183,9 @@ __device__ __forceinline__ void do_restrict(const MgDesc& D, Atom& A, int lvl)
     if (lvl - 1 < D.kcoop || A.g == 0) restrict_to(D, A, lvl);
 }
 
-__device__ __forceinline__ void do_prolong(const MgDesc& D, Atom& A, int lvl)
+// may_fold: the caller visits level lvl-1 next (the V-cycle driver); a staged shared level then takes the correction in
+// while it is copied to LDS (iterate_gs) and the pass below is skipped
+__device__ __forceinline__ void do_prolong(const MgDesc& D, Atom& A, int lvl, bool may_fold = false)
 {
     if (lvl - 1 < D.kcoop) {
         if (lvl >= D.kcoop && A.G > 1) {
@@ -1146,6 +1196,7 @@ __device__ __forceinline__ void do_prolong(const MgDesc& D, Atom& A, int lvl)
             const unsigned shared = (1u << D.kcoop) - 1u;
             A.cur = (A.cur & shared) | (*pub & ~shared);
         }
+        if (may_fold && D.lv[lvl - 1].stage == 2 && !D.nofold) { A.pend = lvl; return; }
         prolong_from(D, A, lvl);
     } else if (A.g == 0) prolong_from(D, A, lvl);
 }
@@ -1183,7 +1234,7 @@ __device__ __forceinline__ double run_cycles(const MgDesc& D, Atom& A, int first
                 {
                     PROF_T0();
                     if (dir > 0) { if (lvl > from) do_restrict(D, A, lvl); }
-                    else do_prolong(D, A, lvl + 1);
+                    else do_prolong(D, A, lvl + 1, true);
                     PROF_ADD(dir > 0 ? 0 : 1, lvl);
                 }
                 {
@@ -1231,6 +1282,7 @@ __global__ __launch_bounds__(kThreads) void k_poisson_solve(const MgDesc* __rest
     A.part = group_part + (size_t)a * (9 * D.G + 2);
     A.fslot = A.part + 6 * D.G + 2;
     A.fseq = 0;
+    A.pend = 0;
     const Lvl L0 = D.lv[0];
     const int N = L0.n;
     const double* rho = density + (size_t)a * N;
@@ -1276,6 +1328,7 @@ __global__ __launch_bounds__(kThreads) void k_unit(const MgDesc* __restrict__ Dp
     A.part = group_part;
     A.fslot = A.part + 6 * D.G + 2;
     A.fseq = 0;
+    A.pend = 0;
     A.cur = 0;
     for (int l = 0; l < D.levels; ++l) A.cur |= (cur[l] ? 1u : 0u) << l;
     // sequential levels: global -> LDS (the solve kernel initialises them itself); they are workgroup 0's
@@ -1419,6 +1472,7 @@ int dfta_poisson_create(dfta_ctx* ctx, const dfta_grid* g, int batch, dfta_poiss
     }
     if (D.kcoop == 0) logG = 0;
     D.logG = logG;
+    D.nofold = getenv("DFTA_POISSON_NOFOLD") ? 1 : 0;
     D.G = 1 << logG;
     long off = kPad, soff = 0;
     double d = g->delta;                       // PoissonSolver.cpp:21-26

@@ -230,28 +230,37 @@ def test_poisson_solve_vs_golden(ctx, golden, tag, Z):
 
 
 def test_poisson_workgroup_groups_are_bit_identical(ctx, grid17):
-    """131073 nodes: the solve with 1, 2, 4 and 8 cooperating workgroups per atom returns the same bits (same arithmetic
-    per node; only the order of the error-norm sums differs, which never reaches the result), for a batch of two atoms"""
+    """131073 nodes: the solve with 1, 2, 4, 8 and 16 cooperating workgroups per atom returns the same bits (same arithmetic
+    per node; only the order of the error-norm sums differs, which never reaches the result), for a batch of two atoms --
+    and so do the solves with the LDS staging of the sweeps, its flavours and the folded prolongation switched off"""
     rr = grid17.r()
     rho = np.stack([86 * np.exp(-2 * rr) / np.pi, 18 * np.exp(-1.3 * rr) * 1.3 ** 3 / (8 * np.pi)])
     ref = None
-    old = os.environ.get("DFTA_POISSON_GROUP")
+    knobs = ("DFTA_POISSON_GROUP", "DFTA_POISSON_NOSTAGE", "DFTA_POISSON_NOSTAGE_SHARED", "DFTA_POISSON_NOSTAGE_WAVE",
+             "DFTA_POISSON_NOFOLD")
+    old = {k: os.environ.get(k) for k in knobs}
+    variants = [{"DFTA_POISSON_GROUP": str(g)} for g in (0, 1, 2, 3, 4)]
+    variants += [{"DFTA_POISSON_NOSTAGE": "1"}, {"DFTA_POISSON_NOSTAGE_SHARED": "1"}, {"DFTA_POISSON_NOSTAGE_WAVE": "1"},
+                 {"DFTA_POISSON_NOFOLD": "1"}, {"DFTA_POISSON_GROUP": "3", "DFTA_POISSON_NOFOLD": "1"}]
     try:
-        for logG in (0, 1, 2, 3):
-            os.environ["DFTA_POISSON_GROUP"] = str(logG)            # read by dfta_poisson_create
+        for var in variants:
+            for k in knobs:
+                os.environ.pop(k, None)
+            os.environ.update(var)                                  # read by dfta_poisson_create
             ps = D.Poisson(ctx, grid17, 2)
             U, vc, err = ps.solve([86, 18], rho)
             ps.close()
             if ref is None:
                 ref = (U.copy(), vc.copy())
             else:
-                assert np.array_equal(U.view(np.int64), ref[0].view(np.int64)), logG
-                assert np.array_equal(vc, ref[1])
+                assert np.array_equal(U.view(np.int64), ref[0].view(np.int64)), var
+                assert np.array_equal(vc, ref[1]), var
     finally:
-        if old is None:
-            os.environ.pop("DFTA_POISSON_GROUP", None)
-        else:
-            os.environ["DFTA_POISSON_GROUP"] = old
+        for k in knobs:
+            if old[k] is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = old[k]
 
 
 def test_vwn_vs_golden(ctx, golden):
