@@ -60,7 +60,7 @@ struct MgDesc {
     int levels;
     int G;           // workgroups per atom (power of two); 1: the whole solve runs in one workgroup
     int logG;
-    int nofold;   // DFTA_POISSON_NOFOLD: prolongation as a separate pass even where it could be folded into a staged copy-in
+    int nofold;   // DFTA_POISSON_NOFOLD: restriction / prolongation as separate passes even where they could be folded into a staged copy-in
     int kcoop;       // levels 0 .. kcoop-1 are swept by all G workgroups together (256 G lanes), the others by workgroup 0
     long per_atom;   // doubles per atom and per array (sum of n)
     Lvl lv[kMaxLevels];
@@ -97,6 +97,7 @@ struct Atom {
     double* fslot;          // [3][G] slots of the fast sum (group_sum_fast), sentinel-filled before the launch
     unsigned fseq;          // fast sums taken so far
     int pend;               // > 0: the prolongation from this level is folded into the staged copy-in of the level below it
+    int pend_r;             // > 0: the restriction TO this level is folded into its staged copy-in
     __device__ __forceinline__ int lane() const { return g * kThreads + static_cast<int>(threadIdx.x); }
     // pointer to storage element 0 of the level (generic address space: LDS for sequential levels, global otherwise)
     __device__ __forceinline__ double* cur_phi(int l, const Lvl& L) const
@@ -923,8 +924,49 @@ __device__ __forceinline__ double iterate_gs(const MgDesc& D, Atom& A, int l, do
         const int col0 = g * kThreads;
         const int end_g = (g == A.G - 1) ? (C << logT) : (col0 + kThreads);     // node behind this member's part
         const bool fold = (A.pend == l + 1);
+        const bool fold_r = (l > 0 && A.pend_r == l);
         A.pend = 0;
-        if (!fold) {
+        A.pend_r = 0;
+        if (fold_r) {
+            // PoissonSolver::Restrict (PoissonSolver.cpp:126-157) from level l-1 folded into the copy: the source of every
+            // staged node -- own columns and halo columns -- comes straight from the fine level (complete and visible since
+            // its last barrier), Phi starts from 0.  The own columns of the source also go to the level's global array, where
+            // the later visits of this V-cycle and the next restriction read them (after this visit's barriers).
+            const Lvl Lf = D.lv[l - 1];
+            const double* __restrict__ Pf = (((A.cur >> (l - 1)) & 1u) ? A.phi1 : A.phi0) + Lf.off;
+            const double* __restrict__ Sf = A.src + Lf.off;
+            double* __restrict__ Sgw = A.src + L.off;
+            const int lim = L.n - 1;
+            const double dc = L.d;
+            auto src_of_node = [&](int i) -> double {
+                if (i <= 0 || i >= lim) return 0.0;
+                const int twoi = 2 * i;
+                const double pm = Pf[addr(Lf, twoi - 1)], p0 = Pf[addr(Lf, twoi)], pp = Pf[addr(Lf, twoi + 1)];
+                return 4. * (Sf[addr(Lf, twoi)] + pm - 2. * p0 + pp) - dc * (pp - pm);
+            };
+            const int lane0 = col0 + tid;
+            for (int k0 = 0; k0 < C; k0 += 4) {
+                double b[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) b[q] = src_of_node((lane0 << L.logC) + k0 + q);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    PP[(k0 + q) * kStageRS + tid] = 0;
+                    SS[(k0 + q) * kStageRS + tid] = b[q];
+                    Sgw[((k0 + q) << logT) + lane0] = b[q];
+                }
+            }
+            for (int idx = tid; idx < C * kStageH; idx += kThreads) {
+                const int k = idx / kStageH, c = idx % kStageH - kStageH;
+                const int lanec = col0 + c;
+                PP[k * kStageRS + c] = 0;
+                SS[k * kStageRS + c] = lanec >= 0 ? src_of_node((lanec << L.logC) + k) : 0.0;
+            }
+            if (tid == 0) {
+                PP[C * kStageRS] = 0;
+                if (g == A.G - 1) Sgw[C << logT] = 0;          // source of node n-1
+            }
+        } else if (!fold) {
             copy_rows(PP, kStageRS, Gin + col0, 1 << logT, C);
             copy_rows(SS, kStageRS, Sg + col0, 1 << logT, C);
             for (int idx = tid; idx < C * kStageH; idx += kThreads) {       // halo columns (member 0: in-bounds padding / the
@@ -1178,8 +1220,11 @@ __device__ __forceinline__ void initialize(const MgDesc& D, Atom& A, double lowB
 // Descend(from,to): { Prolong(from); GS(from-1); ... ; GS(to) }                  (PoissonSolver.cpp:173-186)
 // The operations as the members of a group execute them: levels below kcoop by everybody, the others by workgroup 0
 // alone (the other members skip them and meet workgroup 0 again at the barrier in front of the first shared operation).
-__device__ __forceinline__ void do_restrict(const MgDesc& D, Atom& A, int lvl)
+// may_fold: the caller visits level lvl next (the V-cycle driver); a staged shared level then computes its source -- own
+// columns and halo -- while it is copied to LDS (iterate_gs), and the pass and the group barrier below are skipped
+__device__ __forceinline__ void do_restrict(const MgDesc& D, Atom& A, int lvl, bool may_fold = false)
 {
+    if (may_fold && lvl < D.kcoop && D.lv[lvl].stage == 2 && !D.nofold) { A.pend_r = lvl; return; }
     if (lvl - 1 < D.kcoop || A.g == 0) restrict_to(D, A, lvl);
 }
 
@@ -1233,7 +1278,7 @@ __device__ __forceinline__ double run_cycles(const MgDesc& D, Atom& A, int first
             for (int lvl = (dir > 0) ? from : from - 1;; lvl += dir) {
                 {
                     PROF_T0();
-                    if (dir > 0) { if (lvl > from) do_restrict(D, A, lvl); }
+                    if (dir > 0) { if (lvl > from) do_restrict(D, A, lvl, true); }
                     else do_prolong(D, A, lvl + 1, true);
                     PROF_ADD(dir > 0 ? 0 : 1, lvl);
                 }
@@ -1283,6 +1328,7 @@ __global__ __launch_bounds__(kThreads) void k_poisson_solve(const MgDesc* __rest
     A.fslot = A.part + 6 * D.G + 2;
     A.fseq = 0;
     A.pend = 0;
+    A.pend_r = 0;
     const Lvl L0 = D.lv[0];
     const int N = L0.n;
     const double* rho = density + (size_t)a * N;
@@ -1329,6 +1375,7 @@ __global__ __launch_bounds__(kThreads) void k_unit(const MgDesc* __restrict__ Dp
     A.fslot = A.part + 6 * D.G + 2;
     A.fseq = 0;
     A.pend = 0;
+    A.pend_r = 0;
     A.cur = 0;
     for (int l = 0; l < D.levels; ++l) A.cur |= (cur[l] ? 1u : 0u) << l;
     // sequential levels: global -> LDS (the solve kernel initialises them itself); they are workgroup 0's
