@@ -20,15 +20,23 @@ __device__ __forceinline__ void wave_ordered_sums(const double* __restrict__ v, 
                                                   const int (&cls)[P], double (&acc)[3], double* lds)
 {
     const int lane = threadIdx.x & 63;
-    for (long base = 0; base < count; base += kTile) {
-        const int nt = (count - base) < kTile ? static_cast<int>(count - base) : kTile;
-        // coalesced tile load (stride 1) or strided gather
+    // the next tile's loads (coalesced for stride 1, a strided gather otherwise) are in flight while the chain of the
+    // current one runs: a round trip to memory takes about as long as the 768 dependent adds of a tile
+    double nxt[kTile / 64];
+    auto fetch = [&](long base) {
 #pragma unroll
         for (int k = 0; k < kTile / 64; ++k) {
-            const int j = k * 64 + lane;
-            if (j < nt) lds[j] = v[first + (base + j) * stride];
+            const long j = base + k * 64 + lane;
+            nxt[k] = j < count ? v[first + j * stride] : 0.0;
         }
-        __builtin_amdgcn_s_waitcnt(0);          // vmcnt(0) lgkmcnt(0): tile is in LDS
+    };
+    fetch(0);
+    for (long base = 0; base < count; base += kTile) {
+        const int nt = (count - base) < kTile ? static_cast<int>(count - base) : kTile;
+#pragma unroll
+        for (int k = 0; k < kTile / 64; ++k) lds[k * 64 + lane] = nxt[k];
+        if (base + kTile < count) fetch(base + kTile);
+        __builtin_amdgcn_s_waitcnt(0xc07f);     // lgkmcnt(0) only: the tile is in LDS, the next one stays in flight
         __builtin_amdgcn_wave_barrier();
         // sequential chain; base is a multiple of kTile and kTile % P == 0, so the class pattern restarts per tile.
         // Blocks of kBlk elements are read back with 16-byte broadcasts that are all in flight before the first add:
