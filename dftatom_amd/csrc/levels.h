@@ -50,6 +50,14 @@ struct Job {
     int sc_is[3];                    // istop of the samples (-1: none)
     double sc_lo, sc_hi;             // predicted bracket of the end point
     int sc_ok;
+    // History: the end points of the three bisections in the previous SCF step (top, bottom, E) and how far each had moved
+    // against the step before.  The potential changes by about half as much every step (mixing), so this step's end
+    // point lies within a few times that distance of the last one: the spine follows the bisection while its midpoints
+    // stay outside that bracket.  (Replaces the bit-prefix rule -- "as many leading decisions as matched last time" --
+    // once two steps of history exist: a level close to a coarse bisection boundary flips an early decision now and then,
+    // and a miss on the spine forfeits the round's tree.)
+    double hist_T[3], hist_d[3];
+    int hist_ok;                     // 0: none, 1: end points only, 2: end points and distances
 };
 
 struct LevelStats {

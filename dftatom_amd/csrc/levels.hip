@@ -245,8 +245,21 @@ __device__ __forceinline__ void plan_round(dfta::Job& j, const dfta::Job* __rest
     int S = j.trust[ph] - 1 - j.phase_done;
     const int avail = j.pred_len[ph] - j.phase_done;
     if (S > avail) S = avail;
+    if (j.hist_ok == 2) S = 0;                 // two steps of history: the bracket below replaces the bit-prefix rule
     j.use_sp = 0;
     j.sp_len = 0;
+    // history bracket (levels.h): this step's end point within kHistSafety x the last movement of the previous one
+    constexpr double kHistSafety = 2.0;
+    unsigned long long hbits = 0;
+    int hlen = 0;
+    if (j.hist_ok == 2 && !j.miss && j.hist_d[ph] >= 0) {
+        const double T = j.hist_T[ph];
+        const double m = kHistSafety * j.hist_d[ph] + 1e-10 * fabs(T) + 64 * kEnergyErr;
+        predict_from_bracket(j, j.boe, j.toe, T - m, T + m, j.phase == PH_ZERO);
+        hbits = j.sp_bits;
+        hlen = j.sp_len;
+        j.sp_len = 0;
+    }
     // the last decisions before the predicted flip are left to the tree: at that scale (a few 1e-11) the counted nodes
     // and the sign of u(0) are not monotonic in the energy, and a miss on the spine costs the whole round
     constexpr double kGuard = 64 * kEnergyErr;
@@ -273,6 +286,7 @@ __device__ __forceinline__ void plan_round(dfta::Job& j, const dfta::Job* __rest
     // scouts for the third bisection of l > 0 (whole blocks of their own kind: tpj >= 128)
     j.capz = tpj;
     if (j.l > 0 && tpj >= 128 && (j.phase == PH_TOP || j.phase == PH_BOTTOM) && !j.se_stop &&
+        !(j.phase == PH_TOP && j.phase_done == 0) &&
         !(j.se_state == 1 && j.se_hi - j.se_lo <= kEnergyErr)) {
         double blo, bhi;
         band_of(j, jobs, blo, bhi);
@@ -280,6 +294,8 @@ __device__ __forceinline__ void plan_round(dfta::Job& j, const dfta::Job* __rest
     }
     // a long predicted spine needs the whole tree behind it to finish the bisection in this round: the scouts pause
     if (j.sp_len - j.phase_done >= 40) j.capz = tpj;
+    // the history bracket where nothing better (sibling, top rule, scouts, secant) reaches further
+    if (hlen > j.sp_len) { j.sp_bits = hbits; j.sp_len = hlen; secant = false; }
     // once a prediction has missed in this phase the predicted path and the real one have parted: plain trees from there,
     // except for spines from the secant estimate, which is made afresh from this round's samples (until one of those misses)
     if (j.miss && !secant) { S = 0; j.sp_len = 0; }
@@ -733,6 +749,15 @@ int LevelSolver::run(const double* dV, const double* job_bottom, int run_mode, d
                 // (no spine from it: a miss forfeits the whole tree of a round, three predicted bits are not worth that)
                 if (h_last[k].pred_len[ph] == 0) j.trust[ph] = 0;
             }
+            const Job& h = h_last[k];
+            const double T[3] = {h.top, h.bottom, h.E};
+            for (int ph = 0; ph < 3; ++ph) {
+                j.hist_T[ph] = T[ph];
+                j.hist_d[ph] = h.hist_ok >= 1 ? fabs(T[ph] - h.hist_T[ph]) : -1.0;
+            }
+            j.hist_ok = h.hist_ok >= 1 ? 2 : 1;
+        } else {
+            j.hist_ok = 0;
         }
         j.miss = 0;
         j.capz = 0;
@@ -747,12 +772,8 @@ int LevelSolver::run(const double* dV, const double* job_bottom, int run_mode, d
         j.sib = -1;
         for (int q = 0; q < njobs; ++q)
             if (jobs[q].v == j.v && jobs[q].l == j.l && jobs[q].nodes == j.nodes - 1) j.sib = q;
-        if (j.phase == PH_TOP) {
-            int S = j.trust[0] - 1;
-            if (S > j.pred_len[0]) S = j.pred_len[0];
-            if (S > tpj / 2 - 1) S = tpj / 2 - 1;
-            j.spine = S > 0 ? S : 0;
-        }
+        j.spine = 0;           // planned on the device (k_plan below), after the bottoms have been clamped
+        j.phase_done = 0;
     }
     DFTA_HIP(ctx, hipMemcpyAsync(d_jobs, jobs.data(), sizeof(Job) * njobs, hipMemcpyHostToDevice, st));
     DFTA_HIP(ctx, hipMemsetAsync(d_counters, 0, sizeof(unsigned long long) * 4, st));
@@ -765,6 +786,8 @@ int LevelSolver::run(const double* dV, const double* job_bottom, int run_mode, d
         DFTA_CHECK_LAUNCH(ctx);
     }
 
+    hipLaunchKernelGGL(k_plan, dim3((njobs + 63) / 64), dim3(64), 0, st, d_jobs, njobs, tpj);     // spines of the first round
+    DFTA_CHECK_LAUNCH(ctx);
     int* d_ndone = reinterpret_cast<int*>(d_counters + 2);
     int rounds = 0;
     float ms_sweep = 0;
