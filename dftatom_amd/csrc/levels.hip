@@ -365,6 +365,25 @@ __device__ void walk_job(dfta::Job& j, const int* __restrict__ count, const doub
         j.toe = hi;
         j.boe = j.bottom0;                                          // DFTAtom.cpp:587
         j.phase = PH_BOTTOM;
+        if (j.nodes == 0) {
+            // A level without nodes: the second bisection asks "count < 0", which CountNodes can never answer with yes
+            // (Numerov.h:272-349 counts up from 0).  Its whole path -- toe = E at every step (DFTAtom.cpp:589-601) -- is
+            // therefore known without a single sweep: it is taken here, in the round that ended the first bisection, and
+            // only counted in n_count (the reference does integrate those ~52 trials).
+            double hi2 = j.toe, lo2 = j.boe;
+            while (hi2 - lo2 > kEnergyErr) {
+                hi2 = (hi2 + lo2) / 2;
+                ++j.n_count;
+                record_bit(j, 1, false);
+            }
+            finish_phase(j, 1);
+            j.bottom = hi2;                                         // BottomEnergy = toe
+            j.toe = j.top;
+            j.boe = hi2;
+            j.haveSgn = 0;
+            j.iter3 = 0;
+            j.phase = PH_ZERO;
+        }
         return;
     }
     if (j.phase == PH_BOTTOM) {                                     // DFTAtom.cpp:587-603
