@@ -309,27 +309,38 @@ __device__ __forceinline__ void plan_round(dfta::Job& j, const dfta::Job* __rest
 // F(E) = (stop index of the sample - stop index of the boe-side sample) + phi -- the distance of the nearest zero of u from
 // the point where CountNodes stops, in grid cells -- the count changes where F crosses 0.  The error bound is the
 // interpolation error of the secant with the second divided difference taken from the third sample (times 4).
-__device__ __forceinline__ void secant_predict(dfta::Job& j)
+__device__ __forceinline__ void secant_predict(dfta::Job& j, const double2* __restrict__ veff /* table rows of the job's slot */)
 {
     j.sc_ok = 0;
     const int ia = j.sc_is[0], ib = j.sc_is[1], ic = j.sc_is[2];
     if (ia < 0 || ib < 0 || ic < 0 || (ia & kStopOver)) return;
-    auto F = [&](int k) { return static_cast<double>((j.sc_is[k] & ~kStopOver) - ia) + j.sc_phi[k]; };
-    // l > 0: the stop point (the inner turning point) moves with the energy too, by about a cell while the zero moves a
-    // few dozen: only samples that stopped at the same grid point are compared.  l == 0 always runs down to r = 0, and the
-    // grid is uniform there: the zero may be many cells away.
-    if (ia != 0 && ((ib & ~kStopOver) != ia || (ic & ~kStopOver) != ia)) return;
-    if (ia == 0 && ((!(ib & kStopOver) && ib != 0) || (!(ic & kStopOver) && ic != 0))) return;
+    // x0(E) = stop index + phi = position of the zero of u next to the stop point, in grid cells (absolute): smooth in E
+    // whatever made the sweep stop.  The count changes where x0(E) reaches the point at which CountNodes stops for THAT
+    // energy: s(E) = 0 for l == 0, the inner turning point -- the largest i below the well with veff_i > E -- otherwise,
+    // a step function that comes down as E goes up (by about a cell while the zero moves a few dozen).
+    auto X = [&](int k) { return static_cast<double>(j.sc_is[k] & ~kStopOver) + j.sc_phi[k]; };
     const double a = j.sc_e[0], b = j.sc_e[1], c = j.sc_e[2];
-    const double fa = F(0), fb = F(1), fc = F(2);
-    if (!(fa < 0 && fb > 0) || !(fabs(fc) < 1e300) || !(b > a) || c == a || c == b) return;
+    const double xa = X(0), xb = X(1), xc = X(2);
+    if (!(b > a) || c == a || c == b || !(xb > xa) || !(fabs(xc) < 1e300) || !(xa < ia)) return;
     const double w = b - a;
-    const double t = a + w * (fa / (fa - fb));
-    const double f1 = (fb - fa) / w;
-    const double f2 = ((fc - fb) / (c - b) - f1) / (c - a);
-    // 4 x |f2 / f1| (b - a)^2 / 4, plus the scale below which the count is no longer a monotonic function of the energy
-    // (round-off of the sweep: about 1e-11 of |E|)
-    const double e = fabs(f2 / f1) * w * w + 1e-10 * fabs(t);
+    const double f1 = (xb - xa) / w;
+    const double f2 = ((xc - xb) / (c - b) - f1) / (c - a);
+    double t = 0;
+    bool found = false, at_step = false;
+    int s = ia;                                       // stop index at E = a (the boe-side sample ran to its turning point)
+    for (int it = 0; it < 16 && !found; ++it) {
+        // the stop index stays s while E < veff_s (l == 0: for ever)
+        const double Ej = (ia != 0 && s >= 1) ? veff[s].x : 1e300;
+        const double tl = a + (static_cast<double>(s) - xa) / f1;        // the zero reaches s here
+        if (tl < Ej) { t = tl; found = true; }
+        else if (xa + (Ej - a) * f1 >= static_cast<double>(s - 1)) { t = Ej; found = true; at_step = true; }   // the stop point
+        else --s;                                                                 // steps over the zero at E = veff_s
+        if (s < 1 && ia != 0) break;
+    }
+    if (!found || !(t > a && t < b)) return;
+    // 4 x |f2 / f1| (b - a)^2 / 4 for the secant, plus the scale below which the count is no longer a monotonic function of
+    // the energy (round-off of the sweep: about 1e-11 of |E|)
+    const double e = (at_step ? 0.0 : fabs(f2 / f1) * w * w) + 1e-10 * fabs(t);
     if (!(e < w * 0.125)) return;
     j.sc_lo = t - e;
     j.sc_hi = t + e;
@@ -337,7 +348,7 @@ __device__ __forceinline__ void secant_predict(dfta::Job& j)
 }
 
 __device__ void walk_job(dfta::Job& j, const int* __restrict__ count, const double* __restrict__ u0, const double* __restrict__ phi,
-                         const int* __restrict__ istop, int tpj, int base)
+                         const int* __restrict__ istop, int tpj, int base, const double2* __restrict__ veff)
 {
     Cursor c;
     c.init(j.spine, capz_of(j, tpj));
@@ -345,7 +356,7 @@ __device__ void walk_job(dfta::Job& j, const int* __restrict__ count, const doub
         double hi = j.toe, lo = j.boe;
         while (hi - lo > kEnergyErr) {
             const int h = c.node();
-            if (h < 0) { if (c.off) j.miss = (j.use_sp == 2) ? 2 : (j.miss > 1 ? j.miss : 1); j.toe = hi; j.boe = lo; secant_predict(j); return; }
+            if (h < 0) { if (c.off) j.miss = (j.use_sp == 2) ? 2 : (j.miss > 1 ? j.miss : 1); j.toe = hi; j.boe = lo; secant_predict(j, veff); return; }
             const double e = (hi + lo) / 2;
             const int cn = count[base + h];
             ++j.n_count;
@@ -493,7 +504,7 @@ __global__ __launch_bounds__(64) void k_scout(dfta::Job* __restrict__ jobs, int 
 
 __global__ void k_walk(dfta::Job* __restrict__ jobs, const int* __restrict__ chain_off, int nchains, int tpj,
                        const int* __restrict__ count, const double* __restrict__ u0, const double* __restrict__ phi,
-                       const int* __restrict__ istop, int* __restrict__ ndone)
+                       const int* __restrict__ istop, const double2* __restrict__ tab, int N, int* __restrict__ ndone)
 {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= nchains) return;
@@ -518,7 +529,7 @@ __global__ void k_walk(dfta::Job* __restrict__ jobs, const int* __restrict__ cha
             jobs[k] = j;
             break;                                                  // its trials are generated next round
         }
-        walk_job(j, count, u0, phi, istop, tpj, k * tpj);
+        walk_job(j, count, u0, phi, istop, tpj, k * tpj, tab + (size_t)j.slot * N);
         jobs[k] = j;
         if (j.phase == PH_DONE) { ++done; continue; }
         break;
@@ -823,7 +834,7 @@ int LevelSolver::run(const double* dV, const double* job_bottom, int run_mode, d
         hipLaunchKernelGGL(k_scout, dim3(njobs), dim3(64), 0, st, d_jobs, tpj, d_E, d_start, d_u0);
         DFTA_CHECK_LAUNCH(ctx);
         DFTA_HIP(ctx, hipMemsetAsync(d_ndone, 0, sizeof(int), st));
-        hipLaunchKernelGGL(k_walk, dim3((run_chains + 63) / 64), dim3(64), 0, st, d_jobs, d_chains, run_chains, tpj, d_count, d_u0, d_phi, d_istop, d_ndone);
+        hipLaunchKernelGGL(k_walk, dim3((run_chains + 63) / 64), dim3(64), 0, st, d_jobs, d_chains, run_chains, tpj, d_count, d_u0, d_phi, d_istop, d_tab, N, d_ndone);
         DFTA_CHECK_LAUNCH(ctx);
         hipLaunchKernelGGL(k_plan, dim3((njobs + 63) / 64), dim3(64), 0, st, d_jobs, njobs, tpj);
         DFTA_CHECK_LAUNCH(ctx);
