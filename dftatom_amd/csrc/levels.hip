@@ -263,6 +263,7 @@ __device__ __forceinline__ void plan_round(dfta::Job& j, const dfta::Job* __rest
     // the last decisions before the predicted flip are left to the tree: at that scale (a few 1e-11) the counted nodes
     // and the sign of u(0) are not monotonic in the energy, and a miss on the spine costs the whole round
     constexpr double kGuard = 64 * kEnergyErr;
+    constexpr double kNoise = 2e-11;
     bool secant = false;
     if (j.phase == PH_TOP) {
         if (j.sc_ok && j.miss < 2) {
@@ -273,8 +274,12 @@ __device__ __forceinline__ void plan_round(dfta::Job& j, const dfta::Job* __rest
         if (j.nodes == 0) predict_from_bracket(j, j.boe, j.toe, -1e300, -1e300, false);   // "count < 0" never holds
         else if (j.sib >= 0) {
             const dfta::Job sb = jobs[j.sib];
-            if (sb.phase == PH_BOTTOM || sb.phase == PH_ZERO || sb.phase == PH_DONE)
-                predict_from_bracket(j, j.boe, j.toe, sb.top - kGuard, sb.top + kGuard, false);
+            if (sb.phase == PH_BOTTOM || sb.phase == PH_ZERO || sb.phase == PH_DONE) {
+                // the spine stops where the count stops being a monotonic function of the energy (round-off of the sweep,
+                // about 1e-11 |E|): a spine that runs into that band misses and forfeits the round's tree
+                const double gd = kGuard + kNoise * fabs(sb.top);
+                predict_from_bracket(j, j.boe, j.toe, sb.top - gd, sb.top + gd, false);
+            }
             else if (sb.phase == PH_TOP)
                 predict_from_bracket(j, j.boe, j.toe, sb.boe - kGuard, sb.toe + kGuard, false);
         }
@@ -309,6 +314,7 @@ __device__ __forceinline__ void plan_round(dfta::Job& j, const dfta::Job* __rest
 // F(E) = (stop index of the sample - stop index of the boe-side sample) + phi -- the distance of the nearest zero of u from
 // the point where CountNodes stops, in grid cells -- the count changes where F crosses 0.  The error bound is the
 // interpolation error of the secant with the second divided difference taken from the third sample (times 4).
+constexpr double kSecantNoise = 3e-11;
 __device__ __forceinline__ void secant_predict(dfta::Job& j, const double2* __restrict__ veff /* table rows of the job's slot */)
 {
     j.sc_ok = 0;
@@ -340,7 +346,7 @@ __device__ __forceinline__ void secant_predict(dfta::Job& j, const double2* __re
     if (!found || !(t > a && t < b)) return;
     // 4 x |f2 / f1| (b - a)^2 / 4 for the secant, plus the scale below which the count is no longer a monotonic function of
     // the energy (round-off of the sweep: about 1e-11 of |E|)
-    const double e = (at_step ? 0.0 : fabs(f2 / f1) * w * w) + 1e-10 * fabs(t);
+    const double e = (at_step ? 0.0 : fabs(f2 / f1) * w * w) + kSecantNoise * fabs(t);
     if (!(e < w * 0.125)) return;
     j.sc_lo = t - e;
     j.sc_hi = t + e;
