@@ -42,6 +42,9 @@ struct Job {
     int capz;                        // trials [0, capz) = probe + spine + tree, [capz, tpj) = scouts (0: all tpj)
     double se_lo, se_hi;
     int se_state, se_sl, se_stop;    // bracketed? / sign of u(0) at se_lo / no longer shrinking
+    double se_plo, se_phi;           // u(0) at se_lo / se_hi (NaN: unknown)
+    double se_tlo, se_thi;           // secant estimate of the sign change inside the bracket, with its error bound
+    int se_tok;
     // First bisection: every counted trial also reports where it stopped and how far the nearest zero of u was from that
     // point (SweepArgs::phi / istop, numerov.hip) -- a smooth function of E that crosses 0 where the count changes.  The
     // last sample on either side of the running bisection and the most recently replaced one give a secant estimate of

@@ -286,6 +286,7 @@ __device__ __forceinline__ void plan_round(dfta::Job& j, const dfta::Job* __rest
     } else if (j.phase == PH_ZERO) {
         // l == 0: no inner turning point, the count changes exactly where u(0) changes sign -- at the upper end
         if (j.l == 0) predict_from_bracket(j, j.boe, j.toe, j.top - kGuard, j.top + kGuard, true);
+        else if (j.se_state == 1 && j.se_tok && !j.miss) predict_from_bracket(j, j.boe, j.toe, j.se_tlo - kGuard, j.se_thi + kGuard, true);
         else if (j.se_state == 1) predict_from_bracket(j, j.boe, j.toe, j.se_lo - kGuard, j.se_hi + kGuard, true);
     }
     // scouts for the third bisection of l > 0 (whole blocks of their own kind: tpj >= 128)
@@ -492,20 +493,47 @@ __global__ __launch_bounds__(64) void k_scout(dfta::Job* __restrict__ jobs, int 
     all_active = __ballot(all_active) == ~0ull;
     if (lane != 0 || !all_active) return;
     const double* Es = E + base + capz;
+    // u(0) itself is the smooth function here: every sweep starts from the analytic decaying solution, so its scale does
+    // not depend on where the sweep starts
+    const double* Ps = u0 + base + capz;
+    double nlo, nhi, plo, phi_hi;
     if (!bracketed) {
-        if (first < n) {                     // first >= 1 here
-            jobs[job].se_lo = Es[first - 1];
-            jobs[job].se_hi = Es[first];
-            jobs[job].se_sl = u0[base + capz + first - 1] > 0 ? 1 : 0;
-            jobs[job].se_state = 1;
-        }
+        if (first >= n) return;              // first >= 1 here
+        nlo = Es[first - 1]; plo = Ps[first - 1];
+        nhi = Es[first]; phi_hi = Ps[first];
+        jobs[job].se_sl = u0[base + capz + first - 1] > 0 ? 1 : 0;
+        jobs[job].se_state = 1;
     } else {
-        const double nlo = first < n ? (first > 0 ? Es[first - 1] : j.se_lo) : Es[n - 1];
-        const double nhi = first < n ? Es[first] : j.se_hi;
+        nlo = first < n ? (first > 0 ? Es[first - 1] : j.se_lo) : Es[n - 1];
+        plo = first < n ? (first > 0 ? Ps[first - 1] : j.se_plo) : Ps[n - 1];
+        nhi = first < n ? Es[first] : j.se_hi;
+        phi_hi = first < n ? Ps[first] : j.se_phi;
         if (!((nhi - nlo) * 2 < j.se_hi - j.se_lo)) jobs[job].se_stop = 1;
-        jobs[job].se_lo = nlo;
-        jobs[job].se_hi = nhi;
     }
+    jobs[job].se_lo = nlo;
+    jobs[job].se_hi = nhi;
+    jobs[job].se_plo = plo;
+    jobs[job].se_phi = phi_hi;
+    // secant estimate of the sign change from phi at the two ends, error bound from a third sample (the next one outside
+    // the bracket on either side); speculation only: it predicts the third bisection (plan_round)
+    int tok = 0;
+    double tlo = 0, thi = 0;
+    {
+        double c = 0, pc = NAN;
+        if (first < n && first + 1 < n) { c = Es[first + 1]; pc = Ps[first + 1]; }
+        else if (first < n && first >= 2) { c = Es[first - 2]; pc = Ps[first - 2]; }
+        const double w = nhi - nlo;
+        if (w > 0 && plo * phi_hi < 0 && fabs(pc) < 1e300 && c != nlo && c != nhi) {
+            const double f1 = (phi_hi - plo) / w;
+            const double f2 = ((pc - phi_hi) / (c - nhi) - f1) / (c - nlo);
+            const double t = nlo + w * (plo / (plo - phi_hi));
+            const double e = fabs(f2 / f1) * w * w + kSecantNoise * fabs(t);
+            if (e < w * 0.125) { tok = 1; tlo = t - e; thi = t + e; }
+        }
+    }
+    jobs[job].se_tok = tok;
+    jobs[job].se_tlo = tlo;
+    jobs[job].se_thi = thi;
 }
 
 __global__ void k_walk(dfta::Job* __restrict__ jobs, const int* __restrict__ chain_off, int nchains, int tpj,
@@ -530,6 +558,7 @@ __global__ void k_walk(dfta::Job* __restrict__ jobs, const int* __restrict__ cha
             j.capz = 0;
             j.se_state = 0;
             j.se_stop = 0;
+            j.se_tok = 0;
             j.sc_is[0] = j.sc_is[1] = j.sc_is[2] = -1;
             j.sc_ok = 0;
             jobs[k] = j;
@@ -800,6 +829,8 @@ int LevelSolver::run(const double* dV, const double* job_bottom, int run_mode, d
         j.se_state = 0;
         j.se_stop = 0;
         j.se_sl = 0;
+        j.se_tok = 0;
+        j.se_plo = j.se_phi = NAN;
         j.sc_is[0] = j.sc_is[1] = j.sc_is[2] = -1;
         j.sc_ok = 0;
         j.use_sp = 0;
