@@ -573,13 +573,14 @@ __global__ void k_walk(dfta::Job* __restrict__ jobs, const int* __restrict__ cha
 }
 
 // spines of the next round, after every walk of this one (a job reads its sibling's first-bisection result)
-__global__ void k_plan(dfta::Job* __restrict__ jobs, int njobs, int tpj)
+__global__ void k_plan(dfta::Job* __restrict__ jobs, int njobs, int tpj, int nopredict)
 {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= njobs) return;
     dfta::Job j = jobs[k];
     if (j.phase != PH_TOP && j.phase != PH_BOTTOM && j.phase != PH_ZERO) return;
     plan_round(j, jobs, tpj);
+    if (nopredict) { j.spine = 0; j.capz = tpj; j.use_sp = 0; j.sp_len = 0; j.sp_bits = 0; }     // plain trees only (DFTA_LEVELS_NOPREDICT)
     jobs[k].spine = j.spine;
     jobs[k].capz = j.capz;
     jobs[k].use_sp = j.use_sp;
@@ -797,6 +798,7 @@ int LevelSolver::run(const double* dV, const double* job_bottom, int run_mode, d
     const bool chained = (run_mode == DFTA_LEVELS_CHAINED);
     const int* d_chains = chained ? d_chain_off : d_chain_off_b;
     const int run_chains = chained ? nchains_chained : njobs;
+    use_prediction = getenv("DFTA_LEVELS_NOPREDICT") == nullptr;   // measurements / tests: every spine and scout off
     std::vector<Job> jobs = h_jobs_template;
     for (int k = 0; k < njobs; ++k) {
         Job& j = jobs[k];
@@ -853,7 +855,7 @@ int LevelSolver::run(const double* dV, const double* job_bottom, int run_mode, d
         DFTA_CHECK_LAUNCH(ctx);
     }
 
-    hipLaunchKernelGGL(k_plan, dim3((njobs + 63) / 64), dim3(64), 0, st, d_jobs, njobs, tpj);     // spines of the first round
+    hipLaunchKernelGGL(k_plan, dim3((njobs + 63) / 64), dim3(64), 0, st, d_jobs, njobs, tpj, use_prediction ? 0 : 1);     // spines of the first round
     DFTA_CHECK_LAUNCH(ctx);
     int* d_ndone = reinterpret_cast<int*>(d_counters + 2);
     int rounds = 0;
@@ -873,7 +875,7 @@ int LevelSolver::run(const double* dV, const double* job_bottom, int run_mode, d
         DFTA_HIP(ctx, hipMemsetAsync(d_ndone, 0, sizeof(int), st));
         hipLaunchKernelGGL(k_walk, dim3((run_chains + 63) / 64), dim3(64), 0, st, d_jobs, d_chains, run_chains, tpj, d_count, d_u0, d_phi, d_istop, d_tab, N, d_ndone);
         DFTA_CHECK_LAUNCH(ctx);
-        hipLaunchKernelGGL(k_plan, dim3((njobs + 63) / 64), dim3(64), 0, st, d_jobs, njobs, tpj);
+        hipLaunchKernelGGL(k_plan, dim3((njobs + 63) / 64), dim3(64), 0, st, d_jobs, njobs, tpj, use_prediction ? 0 : 1);
         DFTA_CHECK_LAUNCH(ctx);
         int ndone = 0;
         DFTA_HIP(ctx, hipMemcpyAsync(&ndone, d_ndone, sizeof(int), hipMemcpyDeviceToHost, st));

@@ -329,6 +329,39 @@ def test_scf_batch_of_atoms_matches_single(ctx, grid14):
     batch.close()
 
 
+def test_predictions_never_change_results(ctx, grid14):
+    """The level solver's speculation (spines from history, sibling, top rule, scouts, secants) only selects which of the
+    reference's midpoints are integrated early: with all of it switched off (plain bisection trees) every SCF step gives
+    the same bits -- energies, eigenvalues and the reference-equivalent sweep counts"""
+    def run(nopredict):
+        old = os.environ.get("DFTA_LEVELS_NOPREDICT")
+        try:
+            if nopredict:
+                os.environ["DFTA_LEVELS_NOPREDICT"] = "1"
+            else:
+                os.environ.pop("DFTA_LEVELS_NOPREDICT", None)
+            scf = D.Scf(ctx, grid14, [36], lsda=False)               # Kr: s, p and d levels
+            out = []
+            for _ in range(5):
+                st = scf.step()
+                en, _ = scf.energies()
+                lv = scf.levels(0, 0)
+                out.append((en[0].as_list(), lv["E"].copy(), int(st.sweeps_reference), int(st.rounds)))
+            scf.close()
+            return out
+        finally:
+            if old is None:
+                os.environ.pop("DFTA_LEVELS_NOPREDICT", None)
+            else:
+                os.environ["DFTA_LEVELS_NOPREDICT"] = old
+    a, b = run(False), run(True)
+    for k, (x, y) in enumerate(zip(a, b)):
+        assert x[0] == y[0], k
+        assert np.array_equal(x[1].view(np.int64), y[1].view(np.int64)), k
+        assert x[2] == y[2], k                                        # the reference's path length
+    assert sum(x[3] for x in a) < sum(y[3] for y in b)                # ... in fewer rounds
+
+
 def test_scf_odd_batches_are_uniform(ctx, grid14):
     """batches whose job count is not a multiple of 4 (64-trial trees: the trial array is not a multiple of the expand
     kernel's block) and that use 8 / 4 / 2 workgroups per atom in the Poisson solver: every copy of the atom gets the
