@@ -63,6 +63,11 @@ struct MgDesc {
     int nofold;   // DFTA_POISSON_NOFOLD: restriction / prolongation as separate passes even where they could be folded into a staged copy-in
     int kcoop;       // levels 0 .. kcoop-1 are swept by all G workgroups together (256 G lanes), the others by workgroup 0
     long per_atom;   // doubles per atom and per array (sum of n)
+    // Coarse section (coarse_section below): levels cs_top .. levels-1 of a V-cycle are handled by the first wave of
+    // workgroup 0 alone, entirely in LDS.  -1: off.  cs_phi / cs_src: offsets of a level's arrays inside the staging memory
+    // (doubles), cs_lc: log2(nodes per lane) of its 64-lane interleaved layout, or -1 for natural order.
+    int cs_top;
+    int cs_phi[kMaxLevels], cs_src[kMaxLevels], cs_lc[kMaxLevels];
     Lvl lv[kMaxLevels];
 };
 
@@ -1252,12 +1257,191 @@ __device__ __forceinline__ double do_iterate(const MgDesc& D, Atom& A, int l, do
     return 1E10;
 }
 
+// ---- coarse section -----------------------------------------------------------------------------------------------
+// The levels with <= 1025 nodes cost a V-cycle more in waiting than in arithmetic: every visit pays a copy-in from global
+// memory, workgroup barriers and a copy-out for ~1 us of sweeps.  From the first V-cycle on, the part of a cycle below
+// level cs_top -- restrict .. iterate down to the coarsest level and prolong .. iterate back up -- therefore runs in the
+// first wave of workgroup 0 alone, on copies that stay in LDS (the staging memory is idle meanwhile): no barrier, no
+// global round trip until the wave hands level cs_top back.  Same operations in the same order on the same values as the
+// level-by-level code (the error norms are summed in a different order, as everywhere).  Nothing on these levels
+// carries over from one V-cycle to the next: the restriction rewrites the sources and zeroes Phi on the way down.
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// index of node i inside the LDS copy of a level (n nodes, lc as in MgDesc::cs_lc)
+__device__ __forceinline__ int cs_idx(int n, int lc, int i)
+{
+    if (lc < 0 || i == n - 1) return i;
+    return ((i & ((1 << lc) - 1)) << 6) + (i >> lc);
+}
+
+// One in-place sweep of a level in natural order by ONE thread (PoissonSolver.cpp:40-64); returns sum dPhi^2.  Explicit LDS
+// pointers; the loads of a batch are issued together ahead of the recurrence (the right neighbours are read before the
+// batch overwrites them).
+__device__ __forceinline__ double seq_sweep_inplace(const double* __restrict__ Sg, double* __restrict__ Pg, const int n, const double dh)
+{
+    typedef __attribute__((address_space(3))) double lds_f64;
+    typedef __attribute__((address_space(3))) const double lds_cf64;
+    lds_cf64* S = (lds_cf64*)(Sg);
+    lds_f64* P = (lds_f64*)(Pg);
+    double err2 = 0;
+    double y = 2.0 * P[0];
+    const int limit = n - 1;
+    double old = P[1];
+    constexpr int kB = 8;
+    int i = 1;
+    for (; i + kB <= limit; i += kB) {
+        double xp[kB], sv[kB], xo[kB];
+#pragma unroll
+        for (int q = 0; q < kB; ++q) { xp[q] = P[i + q + 1]; sv[q] = S[i + q]; }
+#pragma unroll
+        for (int q = 0; q < kB; ++q) {
+            y = gs_point2(sv[q], y, xp[q], dh);
+            const double x = 0.5 * y;
+            const double dif = old - x;
+            err2 += dif * dif;
+            xo[q] = x;
+            old = xp[q];
+        }
+#pragma unroll
+        for (int q = 0; q < kB; ++q) P[i + q] = xo[q];
+    }
+    for (; i < limit; ++i) {
+        const double xp = P[i + 1];
+        y = gs_point2(S[i], y, xp, dh);
+        const double x = 0.5 * y;
+        const double dif = old - x;
+        err2 += dif * dif;
+        P[i] = x;
+        old = xp;
+    }
+    return err2;
+}
+
+// IterateGaussSeidel on the LDS copy of level l; all 64 lanes of the wave call
+__device__ __forceinline__ double cs_iterate(const MgDesc& D, Atom& A, int l, double errorMin, int iterno, long* nsweeps)
+{
+    const Lvl L = D.lv[l];
+    const double dh = L.d * 0.5;
+    const int lane = threadIdx.x;
+    double* P = A.stage + D.cs_phi[l];
+    const double* S = A.stage + D.cs_src[l];
+    const int lc = D.cs_lc[l];
+    double err = 1E10;
+    for (int i = 0; i < iterno; ++i) {
+        double err2 = 0;
+        if (lc >= 0) {
+            switch (lc) {
+                case 1:  err2 = gs_lds<1, 64, 64>(S, P, lane, lane << lc, dh); break;
+                case 2:  err2 = gs_lds<2, 64, 64>(S, P, lane, lane << lc, dh); break;
+                case 3:  err2 = gs_lds<3, 64, 64>(S, P, lane, lane << lc, dh); break;
+                default: err2 = gs_lds<4, 64, 64>(S, P, lane, lane << lc, dh); break;
+            }
+            for (int off = 32; off > 0; off >>= 1) err2 += __shfl_xor(err2, off);
+        } else {
+            if (lane == 0) err2 = seq_sweep_inplace(S, P, L.n, dh);
+            err2 = __shfl(err2, 0);
+        }
+        err = sqrt(err2);
+        ++*nsweeps;
+        wave_sync();
+        if (err < errorMin) break;
+    }
+    return err;
+}
+
+// PoissonSolver::Restrict into the LDS copy of level lc; the fine level is read through `fine(i)` / `fsrc(i)` (node index)
+template <int NT, typename FP, typename FS>
+__device__ __forceinline__ void cs_restrict(const MgDesc& D, Atom& A, int lvl, FP fine, FS fsrc)
+{
+    const Lvl Lc = D.lv[lvl];
+    double* P = A.stage + D.cs_phi[lvl];
+    double* S = A.stage + D.cs_src[lvl];
+    const int lc = D.cs_lc[lvl], lim = Lc.n - 1;
+    // four nodes per thread and pass, all their loads in flight together
+    for (int i0 = threadIdx.x; i0 < Lc.n; i0 += 4 * NT) {
+        double pm[4], p0[4], pp[4], s0[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = i0 + q * NT;
+            if (i > 0 && i < lim) { pm[q] = fine(2 * i - 1); p0[q] = fine(2 * i); pp[q] = fine(2 * i + 1); s0[q] = fsrc(2 * i); }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = i0 + q * NT;
+            if (i < Lc.n) {
+                double sv = 0;
+                if (i > 0 && i < lim) sv = 4. * (s0[q] + pm[q] - 2. * p0[q] + pp[q]) - Lc.d * (pp[q] - pm[q]);
+                const int idx = cs_idx(Lc.n, lc, i);
+                S[idx] = sv;
+                P[idx] = 0;
+            }
+        }
+    }
+    if (NT == 64) wave_sync();
+}
+
+// The whole part of a V-cycle below level cs_top (first wave of workgroup 0; the level above it, cs_top-1, is current in
+// global memory on entry, and level cs_top is current in global memory on return).
+// entry, by the whole workgroup: the restriction from level cs_top-1 (global) into the LDS copy of level cs_top
+__device__ __forceinline__ void coarse_section_enter(const MgDesc& D, Atom& A)
+{
+    const int top = D.cs_top;
+    const Lvl Lf = D.lv[top - 1];
+    const double* __restrict__ Pf = (((A.cur >> (top - 1)) & 1u) ? A.phi1 : A.phi0) + Lf.off;
+    const double* __restrict__ Sf = A.src + Lf.off;
+    cs_restrict<kThreads>(D, A, top, [&](int i) { return Pf[addr(Lf, i)]; }, [&](int i) { return Sf[addr(Lf, i)]; });
+}
+
+// exit, by the whole workgroup: level cs_top goes back to its current global copy
+__device__ __forceinline__ void coarse_section_leave(const MgDesc& D, Atom& A)
+{
+    const int top = D.cs_top;
+    const Lvl L = D.lv[top];
+    double* __restrict__ G = (((A.cur >> top) & 1u) ? A.phi1 : A.phi0) + L.off;
+    const double* P = A.stage + D.cs_phi[top];
+    const int lc = D.cs_lc[top];
+    for (int i = threadIdx.x; i < L.n; i += kThreads) G[addr(L, i)] = P[cs_idx(L.n, lc, i)];
+}
+
+__device__ __forceinline__ void coarse_section(const MgDesc& D, Atom& A, double errorMin, int iterno, long* nsweeps)
+{
+    const int top = D.cs_top, last = D.levels - 1;
+    // down: iterate, then restrict / iterate
+    cs_iterate(D, A, top, errorMin, iterno, nsweeps);
+    for (int l = top + 1; l <= last; ++l) {
+        const int nf = D.lv[l - 1].n, lcf = D.cs_lc[l - 1];
+        const double* Pf = A.stage + D.cs_phi[l - 1];
+        const double* Sf = A.stage + D.cs_src[l - 1];
+        cs_restrict<64>(D, A, l, [&](int i) { return Pf[cs_idx(nf, lcf, i)]; }, [&](int i) { return Sf[cs_idx(nf, lcf, i)]; });
+        cs_iterate(D, A, l, errorMin, iterno, nsweeps);
+    }
+    // up: prolong (PoissonSolver.cpp:110-123), iterate
+    for (int l = last - 1; l >= top; --l) {
+        const int nc = D.lv[l + 1].n, lcc = D.cs_lc[l + 1], nf = D.lv[l].n, lcf = D.cs_lc[l];
+        const double* Pc = A.stage + D.cs_phi[l + 1];
+        double* Pf = A.stage + D.cs_phi[l];
+        for (int i = threadIdx.x; i < nc; i += 64) {
+            const double c = Pc[cs_idx(nc, lcc, i)];
+            Pf[cs_idx(nf, lcf, 2 * i)] += c;
+            if (i > 0) Pf[cs_idx(nf, lcf, 2 * i - 1)] += 0.5 * (Pc[cs_idx(nc, lcc, i - 1)] + c);
+        }
+        wave_sync();
+        cs_iterate(D, A, l, errorMin, iterno, nsweeps);
+    }
+}
+
+template <bool CS>
 __device__ __forceinline__ double run_cycles(const MgDesc& D, Atom& A, int first_step, int max_vcycles, double errorMin,
                                              double errorMinLast, double* red, Counters& c)
 {
     const int last = D.levels - 1;
     const int nramp = D.levels - 2 > 0 ? D.levels - 2 : 0;
     double err = 0;
+    bool cs_skip = false;
     for (int step = first_step;; ++step) {
         int from, to, iterno = 3;
         double emin = errorMin;
@@ -1275,7 +1459,25 @@ __device__ __forceinline__ double run_cycles(const MgDesc& D, Atom& A, int first
         const int dir = (from > to) ? -1 : 1;
         err = 1E10;
         if (!(dir < 0 && from == to)) {
-            for (int lvl = (dir > 0) ? from : from - 1;; lvl += dir) {
+            int first_lvl = (dir > 0) ? from : from - 1;
+            if (CS && cs_skip) { first_lvl = D.cs_top - 1; cs_skip = false; }       // the section has done last .. cs_top
+            for (int lvl = first_lvl;; lvl += dir) {
+                if (CS && D.cs_top > 0 && dir > 0 && lvl == D.cs_top && lvl > from && to == last && step > 2 * nramp + 1) {
+                    // the rest of this leg and the beginning of the next one (coarse_section)
+                    if (A.g == 0) {
+                        long nsw = 0;
+                        coarse_section_enter(D, A);
+                        __syncthreads();
+                        if (threadIdx.x < 64) coarse_section(D, A, emin, iterno, &nsw);
+                        if (threadIdx.x == 0) red[17] = static_cast<double>(nsw);
+                        __syncthreads();
+                        c.sweeps += static_cast<long>(red[17]);
+                        coarse_section_leave(D, A);
+                        __syncthreads();
+                    }
+                    cs_skip = true;
+                    break;
+                }
                 {
                     PROF_T0();
                     if (dir > 0) { if (lvl > from) do_restrict(D, A, lvl, true); }
@@ -1344,7 +1546,7 @@ __global__ __launch_bounds__(kThreads) void k_poisson_solve(const MgDesc* __rest
     __syncthreads();
     Counters c{0, 0};
     initialize(D, A, 0.0, (double)Z[a]);
-    const double err = run_cycles(D, A, 0, 100, 1E-3, 1E-14, red, c);      // FullCycle(1E-3, 1E-14), PoissonSolver.h:78
+    const double err = run_cycles<true>(D, A, 0, 100, 1E-3, 1E-14, red, c);      // FullCycle(1E-3, 1E-14), PoissonSolver.h:78
     const double* __restrict__ P = A.cur_phi(0, L0);
     if (coop0 || A.g == 0)
         for (int i = coop0 ? A.lane() : static_cast<int>(threadIdx.x); i < N; i += coop0 ? kThreads * A.G : kThreads)
@@ -1407,7 +1609,7 @@ __global__ __launch_bounds__(kThreads) void k_unit(const MgDesc* __restrict__ Dp
     }
     else if (op == 3) {
         const int nramp = D.levels - 2 > 0 ? D.levels - 2 : 0;
-        const double e = run_cycles(D, A, 2 * nramp + 2, 1, 1E-14, 1E-14, red, c);   // one VCycle(last, 1E-14, 3)
+        const double e = run_cycles<false>(D, A, 2 * nramp + 2, 1, 1E-14, 1E-14, red, c);   // one VCycle(last, 1E-14, 3)
         if (threadIdx.x == 0 && lead) out[0] = e;
     }
     __syncthreads();
@@ -1545,6 +1747,31 @@ int dfta_poisson_create(dfta_ctx* ctx, const dfta_grid* g, int batch, dfta_poiss
         d *= 2;
     }
     D.per_atom = off;
+    // coarse section: from the first one-wave level down, if everything below is one-wave or sequential and fits the staging memory
+    D.cs_top = -1;
+    if (!getenv("DFTA_POISSON_NOCOARSE")) {
+        int top = -1;
+        for (int l = 1; l < D.levels; ++l)
+            if (D.lv[l].stage == 3) { top = l; break; }
+        bool ok = top >= 1 && top >= D.kcoop + 1 && top <= D.levels - 2;
+        int at = 0;
+        for (int l = top; ok && l < D.levels; ++l) {
+            const Lvl& L = D.lv[l];
+            if (L.stage == 3) {
+                int lc = 0;
+                while ((64 << lc) < L.n - 1) ++lc;                 // n - 1 == 64 * 2^lc
+                if (lc < 1 || lc > 4) { ok = false; break; }
+                D.cs_lc[l] = lc;
+                D.cs_phi[l] = at + kStagePad; at += kStagePad + L.n + 8;
+                D.cs_src[l] = at + kStagePad; at += kStagePad + L.n + 8;
+            } else if (L.seq) {
+                D.cs_lc[l] = -1;
+                D.cs_phi[l] = at; at += L.n + 1;
+                D.cs_src[l] = at; at += L.n + 1;
+            } else ok = false;
+        }
+        if (ok && at <= 2 * kStageArr) D.cs_top = top;
+    }
     if (soff > kSeqCap) { delete p; snprintf(ctx->err, sizeof(ctx->err), "sequential levels exceed LDS budget"); return DFTA_ERR_INVALID; }
     const size_t tot = (size_t)off * batch;
     hipError_t e = hipMalloc(reinterpret_cast<void**>(&p->d_phi0), tot * sizeof(double));

@@ -232,16 +232,18 @@ def test_poisson_solve_vs_golden(ctx, golden, tag, Z):
 def test_poisson_workgroup_groups_are_bit_identical(ctx, grid17):
     """131073 nodes: the solve with 1, 2, 4, 8 and 16 cooperating workgroups per atom returns the same bits (same arithmetic
     per node; only the order of the error-norm sums differs, which never reaches the result), for a batch of two atoms --
-    and so do the solves with the LDS staging of the sweeps, its flavours and the folded prolongation switched off"""
+    and so do the solves with the LDS staging of the sweeps, its flavours, the folded transfers and the one-wave coarse
+    section switched off"""
     rr = grid17.r()
     rho = np.stack([86 * np.exp(-2 * rr) / np.pi, 18 * np.exp(-1.3 * rr) * 1.3 ** 3 / (8 * np.pi)])
     ref = None
     knobs = ("DFTA_POISSON_GROUP", "DFTA_POISSON_NOSTAGE", "DFTA_POISSON_NOSTAGE_SHARED", "DFTA_POISSON_NOSTAGE_WAVE",
-             "DFTA_POISSON_NOFOLD")
+             "DFTA_POISSON_NOFOLD", "DFTA_POISSON_NOCOARSE")
     old = {k: os.environ.get(k) for k in knobs}
     variants = [{"DFTA_POISSON_GROUP": str(g)} for g in (0, 1, 2, 3, 4)]
     variants += [{"DFTA_POISSON_NOSTAGE": "1"}, {"DFTA_POISSON_NOSTAGE_SHARED": "1"}, {"DFTA_POISSON_NOSTAGE_WAVE": "1"},
-                 {"DFTA_POISSON_NOFOLD": "1"}, {"DFTA_POISSON_GROUP": "3", "DFTA_POISSON_NOFOLD": "1"}]
+                 {"DFTA_POISSON_NOFOLD": "1"}, {"DFTA_POISSON_GROUP": "3", "DFTA_POISSON_NOFOLD": "1"},
+                 {"DFTA_POISSON_NOCOARSE": "1"}, {"DFTA_POISSON_GROUP": "0", "DFTA_POISSON_NOCOARSE": "1"}]
     try:
         for var in variants:
             for k in knobs:
