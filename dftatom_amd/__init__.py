@@ -79,6 +79,8 @@ SIGNATURES = {
     "dfta_poisson_destroy": (None, [vp]),
     "dfta_poisson_solve": (C.c_int, [vp, c_ip, c_dp, c_dp, c_ip, c_dp]),
     "dfta_poisson_solve_dev": (C.c_int, [vp, vp, vp, vp]),
+    "dfta_poisson_group_info": (C.c_int, [vp, c_ip, c_ip, c_ip]),
+    "dfta_scf_poisson_info": (C.c_int, [vp, c_ip, c_ip, c_ip]),
     "dfta_poisson_level_size": (C.c_int, [vp, C.c_int]),
     "dfta_poisson_set_level": (C.c_int, [vp, C.c_int, c_dp, c_dp]),
     "dfta_poisson_get_level": (C.c_int, [vp, C.c_int, c_dp, c_dp]),
@@ -291,6 +293,12 @@ class Poisson:
         self.ctx.check(self.ctx.lib.dfta_poisson_solve(self.h, _ip(Z), _dp(rho), _dp(U), _ip(vc), _dp(err)))
         return U, vc, err
 
+    def group_info(self):
+        """(workgroups per atom, degraded to one workgroup per atom?, solves that had to be repeated)"""
+        g, d, a = C.c_int(), C.c_int(), C.c_int()
+        self.ctx.check(self.ctx.lib.dfta_poisson_group_info(self.h, C.byref(g), C.byref(d), C.byref(a)))
+        return g.value, bool(d.value), a.value
+
     def level_size(self, lvl):
         return self.ctx.lib.dfta_poisson_level_size(self.h, lvl)
 
@@ -386,6 +394,11 @@ class Scf:
         out = np.zeros(self.grid.N)
         self.ctx.check(self.ctx.lib.dfta_scf_get_array(self.h, atom, which, _dp(out)))
         return out
+
+    def poisson_info(self):
+        g, d, a = C.c_int(), C.c_int(), C.c_int()
+        self.ctx.check(self.ctx.lib.dfta_scf_poisson_info(self.h, C.byref(g), C.byref(d), C.byref(a)))
+        return g.value, bool(d.value), a.value
 
     def records_into(self, device_ptr):
         self.ctx.check(self.ctx.lib.dfta_scf_get_records_dev(self.h, vp(device_ptr)))

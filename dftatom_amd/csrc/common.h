@@ -32,6 +32,15 @@ struct dfta_ctx {
         }                                                                                       \
     } while (0)
 
+// every C-ABI entry point makes the context's device current first: the caller (or another library in the process)
+// may have changed it since dfta_ctx_create
+static inline int dfta_use(dfta_ctx* ctx)
+{
+    if (!ctx) return DFTA_ERR_INVALID;
+    DFTA_HIP(ctx, hipSetDevice(ctx->device));
+    return DFTA_OK;
+}
+
 #define DFTA_CHECK_LAUNCH(ctx) DFTA_HIP(ctx, hipGetLastError())
 
 #define DFTA_REQUIRE(ctx, cond, msg)                                               \

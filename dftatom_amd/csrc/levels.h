@@ -61,6 +61,7 @@ struct Job {
     // and a miss on the spine forfeits the round's tree.)
     double hist_T[3], hist_d[3];
     int hist_ok;                     // 0: none, 1: end points only, 2: end points and distances
+    int frozen;                      // the job's atom has finished its SCF: the result of its last solve stands, nothing is integrated
 };
 
 struct LevelStats {
@@ -79,6 +80,7 @@ struct LevelSolver {
     std::vector<Job> h_jobs_template;
     std::vector<Job> h_last;       // job records of the previous solve (source of the path predictions)
     bool use_prediction = true;
+    int debug_rounds = 0;          // $DFTA_DEBUG_ROUNDS, read once in setup()
     Job* d_jobs = nullptr;
     int *d_chain_off = nullptr, *d_chain_off_b = nullptr, *d_v_off = nullptr, *d_slot_v = nullptr, *d_slot_l = nullptr;
     double2* d_tab = nullptr;
@@ -99,7 +101,9 @@ struct LevelSolver {
     ~LevelSolver();
     void release();
     int setup(dfta_ctx* c, const dfta_grid* grid, int mode, int tree_depth, int nV, const std::vector<JobSpec>& specs);
-    int run(const double* dV, const double* job_bottom, int run_mode, double* dNewDensity, LevelStats* stats);
+    // frozen (host, njobs, may be null): jobs whose result of the previous run() stands (finished atoms of an SCF batch)
+    int run(const double* dV, const double* job_bottom, int run_mode, double* dNewDensity, LevelStats* stats,
+            const unsigned char* frozen = nullptr);
     int fetch_jobs(std::vector<Job>& out);
 };
 

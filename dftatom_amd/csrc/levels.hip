@@ -591,10 +591,12 @@ __global__ void k_plan(dfta::Job* __restrict__ jobs, int njobs, int tpj, int nop
 // ---- normalise (DFTAtom.cpp:36-56) ------------------------------------------------------------------------------
 // one 256-thread block per job; wave 0 performs the Simpson 3/8 sum in the reference's order
 __global__ __launch_bounds__(256) void k_normalize(double* __restrict__ Psi, double* __restrict__ G, int N,
-                                                   const double* __restrict__ eh, const double* __restrict__ cnst)
+                                                   const double* __restrict__ eh, const double* __restrict__ cnst,
+                                                   const int* __restrict__ jstart)
 {
     __shared__ __attribute__((aligned(16))) double lds[dfta::kTile];
     __shared__ double s_unorm;
+    if (jstart && jstart[blockIdx.x] < 0) return;     // frozen job: its normalised Psi stands
     double* P = Psi + (size_t)blockIdx.x * N;
     double* g = G + (size_t)blockIdx.x * N;
     for (int i = threadIdx.x; i < N; i += 256) {
@@ -674,7 +676,14 @@ __global__ void k_job_energies(const dfta::Job* __restrict__ jobs, int njobs, do
 __global__ void k_store_match(dfta::Job* __restrict__ jobs, int njobs, const int* __restrict__ mp)
 {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k < njobs) jobs[k].matchPoint = mp[k];
+    if (k < njobs && !jobs[k].frozen) jobs[k].matchPoint = mp[k];
+}
+
+// frozen jobs are skipped by the match / normalise kernels: their cut-off index is replaced by -1
+__global__ void k_mask_frozen(const dfta::Job* __restrict__ jobs, int njobs, int* __restrict__ jstart)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < njobs && jobs[k].frozen) jstart[k] = -1;
 }
 
 }  // namespace
@@ -702,6 +711,8 @@ int LevelSolver::setup(dfta_ctx* c, const dfta_grid* grid, int mode_, int tree_d
 {
     release();
     ctx = c; g = grid; mode = mode_; nV = nV_;
+    use_prediction = getenv("DFTA_LEVELS_NOPREDICT") == nullptr;   // measurements / tests: every spine and scout off
+    debug_rounds = getenv("DFTA_DEBUG_ROUNDS") ? atoi(getenv("DFTA_DEBUG_ROUNDS")) : 0;
     njobs = static_cast<int>(specs.size());
     if (njobs == 0) return DFTA_OK;
     const int N = g->N;
@@ -790,7 +801,8 @@ int LevelSolver::setup(dfta_ctx* c, const dfta_grid* grid, int mode_, int tree_d
 //   job_bottom (host, njobs): BottomEnergy at entry of LocateInterval for every job.  CHAINED uses only the entry
 //   of the first job of each potential (-Z^2-1, DFTAtom.cpp:407) and hands E-3 from level to level (DFTAtom.cpp:541);
 //   BATCHED starts every level from its own entry (the caller's hint: E_{k-1} of the previous SCF step - 3).
-int LevelSolver::run(const double* dV, const double* job_bottom, int run_mode, double* dNewDensity, LevelStats* stats)
+int LevelSolver::run(const double* dV, const double* job_bottom, int run_mode, double* dNewDensity, LevelStats* stats,
+                     const unsigned char* frozen)
 {
     if (njobs == 0) return DFTA_OK;
     const int N = g->N;
@@ -798,10 +810,20 @@ int LevelSolver::run(const double* dV, const double* job_bottom, int run_mode, d
     const bool chained = (run_mode == DFTA_LEVELS_CHAINED);
     const int* d_chains = chained ? d_chain_off : d_chain_off_b;
     const int run_chains = chained ? nchains_chained : njobs;
-    use_prediction = getenv("DFTA_LEVELS_NOPREDICT") == nullptr;   // measurements / tests: every spine and scout off
     std::vector<Job> jobs = h_jobs_template;
+    int nfrozen = 0;
     for (int k = 0; k < njobs; ++k) {
         Job& j = jobs[k];
+        if (frozen && frozen[k] && h_last.size() == jobs.size()) {
+            j = h_last[k];             // E, interval, convergence flag, match point, history: as the last solve left them
+            j.phase = PH_DONE;
+            j.frozen = 1;
+            j.spine = 0;
+            j.capz = 0;
+            ++nfrozen;
+            continue;
+        }
+        j.frozen = 0;
         j.bottom0 = job_bottom[k];
         const bool first = (k == 0 || jobs[k].v != jobs[k - 1].v);
         if (!chained || first) { j.phase = PH_TOP; j.toe = 50; j.boe = j.bottom0; }   // DFTAtom.cpp:499
@@ -846,6 +868,11 @@ int LevelSolver::run(const double* dV, const double* job_bottom, int run_mode, d
     }
     DFTA_HIP(ctx, hipMemcpyAsync(d_jobs, jobs.data(), sizeof(Job) * njobs, hipMemcpyHostToDevice, st));
     DFTA_HIP(ctx, hipMemsetAsync(d_counters, 0, sizeof(unsigned long long) * 4, st));
+    if (nfrozen == njobs) {            // nothing to solve: Psi, density contributions and job records stand
+        DFTA_HIP(ctx, hipStreamSynchronize(st));      // `jobs` is the source of the copy above
+        if (stats) *stats = LevelStats();
+        return DFTA_OK;
+    }
     int rc = dfta_launch_build_tab(ctx, g, d_tab, dV, d_slot_v, d_slot_l, nslots, d_bounds);
     if (rc) return rc;
     if (!chained && clamp_bottoms) {
@@ -886,14 +913,14 @@ int LevelSolver::run(const double* dV, const double* job_bottom, int run_mode, d
             ms_sweep += ms;
         }
         ++rounds;
-        if (getenv("DFTA_DEBUG_ROUNDS")) {      // per-round census of the jobs (phase/decisions taken), stderr
+        if (debug_rounds) {      // per-round census of the jobs (phase/decisions taken), stderr
             std::vector<Job> dbg(njobs);
             DFTA_HIP(ctx, hipMemcpy(dbg.data(), d_jobs, sizeof(Job) * njobs, hipMemcpyDeviceToHost));
             fprintf(stderr, "round %2d |", rounds);
             for (int q = 0; q < njobs; ++q)
                 if (dbg[q].phase != PH_DONE) fprintf(stderr, " %d:%d/%d", q, dbg[q].phase, dbg[q].phase_done);
             fprintf(stderr, "\n");
-            if (atoi(getenv("DFTA_DEBUG_ROUNDS")) >= 2)
+            if (debug_rounds >= 2)
                 for (int q = 0; q < njobs; ++q) {
                     const Job& J = dbg[q];
                     if (J.phase != PH_TOP) continue;
@@ -913,11 +940,15 @@ int LevelSolver::run(const double* dV, const double* job_bottom, int run_mode, d
     DFTA_CHECK_LAUNCH(ctx);
     rc = dfta_launch_boundary(ctx, g, d_jE, njobs, d_jstart, d_jus, d_jus1);
     if (rc) return rc;
+    if (nfrozen) {
+        hipLaunchKernelGGL(k_mask_frozen, dim3((njobs + 63) / 64), dim3(64), 0, st, d_jobs, njobs, d_jstart);
+        DFTA_CHECK_LAUNCH(ctx);
+    }
     rc = dfta_launch_match(ctx, g, njobs, d_tab, d_jslot, d_jE, d_jstart, d_jus, d_jus1, d_jl, d_Psi, d_Q, d_jmp, d_bounds);
     if (rc) return rc;
     hipLaunchKernelGGL(k_store_match, dim3((njobs + 63) / 64), dim3(64), 0, st, d_jobs, njobs, d_jmp);
     DFTA_CHECK_LAUNCH(ctx);
-    hipLaunchKernelGGL(k_normalize, dim3(njobs), dim3(256), 0, st, d_Psi, d_Q, N, g->d_eh, g->d_cnst);
+    hipLaunchKernelGGL(k_normalize, dim3(njobs), dim3(256), 0, st, d_Psi, d_Q, N, g->d_eh, g->d_cnst, nfrozen ? d_jstart : nullptr);
     DFTA_CHECK_LAUNCH(ctx);
     if (dNewDensity) {
         hipLaunchKernelGGL(k_accumulate_density, dim3(std::min(256, (N + 255) / 256), nV), dim3(256), 0, st, d_Psi, d_jobs, d_v_off,
@@ -929,7 +960,7 @@ int LevelSolver::run(const double* dV, const double* job_bottom, int run_mode, d
         DFTA_HIP(ctx, hipMemcpyAsync(cnt, d_counters, sizeof(cnt), hipMemcpyDeviceToHost, st));
         DFTA_HIP(ctx, hipStreamSynchronize(st));
         stats->rounds = rounds;
-        stats->sweeps_issued = static_cast<long>(cnt[0]) + 2L * njobs;    // + inward/outward halves of the match solve
+        stats->sweeps_issued = static_cast<long>(cnt[0]) + 2L * (njobs - nfrozen);    // + inward/outward halves of the match solve
         stats->points_traversed = static_cast<long>(cnt[1]);
         stats->ms_sweep = ms_sweep;
     }
@@ -955,6 +986,7 @@ extern "C" int dfta_solve_levels(dfta_ctx* ctx, const dfta_grid* g, int mode, in
                                  long* issued_sweeps)
 {
     if (!ctx || !g) return DFTA_ERR_INVALID;
+    if (int rc_ = dfta_use(ctx)) return rc_;
     DFTA_REQUIRE(ctx, V && bottom0 && n && l && occ && results && nV > 0 && nlevels > 0, "null input");
     DFTA_REQUIRE(ctx, mode == DFTA_LEVELS_CHAINED || mode == DFTA_LEVELS_BATCHED, "mode");
     const int N = g->N;

@@ -24,6 +24,7 @@
 #include <vector>
 
 #include "internal.h"
+#include "xc.h"
 
 namespace {
 
@@ -62,6 +63,7 @@ struct MgDesc {
     int logG;
     int nofold;   // DFTA_POISSON_NOFOLD: restriction / prolongation as separate passes even where they could be folded into a staged copy-in
     int kcoop;       // levels 0 .. kcoop-1 are swept by all G workgroups together (256 G lanes), the others by workgroup 0
+    int spin_max;    // bound of the group barriers' spin loops (Atom::spin_max)
     long per_atom;   // doubles per atom and per array (sum of n)
     // Coarse section (coarse_section below): levels cs_top .. levels-1 of a V-cycle are handled by the first wave of
     // workgroup 0 alone, entirely in LDS.  -1: off.  cs_phi / cs_src: offsets of a level's arrays inside the staging memory
@@ -103,6 +105,8 @@ struct Atom {
     unsigned fseq;          // fast sums taken so far
     int pend;               // > 0: the prolongation from this level is folded into the staged copy-in of the level below it
     int pend_r;             // > 0: the restriction TO this level is folded into its staged copy-in
+    int spin_max;           // polls of a group barrier before the waiting member gives up and raises the abort flag
+    bool gave_up;           // this thread has timed out on a slot of group_sum_fast: it does not wait for that member again
     __device__ __forceinline__ int lane() const { return g * kThreads + static_cast<int>(threadIdx.x); }
     // pointer to storage element 0 of the level (generic address space: LDS for sequential levels, global otherwise)
     __device__ __forceinline__ double* cur_phi(int l, const Lvl& L) const
@@ -137,7 +141,7 @@ __device__ __forceinline__ void group_sync(Atom& A)
         unsigned seen;
         while ((seen = __hip_atomic_load(A.ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < target) {
             __builtin_amdgcn_s_sleep(1);
-            if (++spins > (1 << 23)) { __hip_atomic_fetch_or(A.ctr, 0x80000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            if (++spins > A.spin_max) { __hip_atomic_fetch_or(A.ctr, 0x80000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
@@ -203,12 +207,13 @@ __device__ __forceinline__ double group_sum_fast(Atom& A, double v, double* red)
         }
         double x = 0;
         if (static_cast<int>(threadIdx.x) < A.G) {
-            int spins = 0;
+            int spins = A.gave_up ? A.spin_max : 0;
             while (true) {
                 x = __hip_atomic_load(cur + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (static_cast<unsigned long long>(__double_as_longlong(x)) != kFastSentinel) break;
-                if (++spins > (1 << 22)) {      // a lost member must not hang the GPU: raise the group's abort flag
+                if (++spins > A.spin_max) {      // a lost member must not hang the GPU: raise the group's abort flag
                     __hip_atomic_fetch_or(A.ctr, 0x80000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    A.gave_up = true;
                     break;
                 }
                 __builtin_amdgcn_s_sleep(1);
@@ -1507,7 +1512,8 @@ __global__ __launch_bounds__(kThreads) void k_poisson_solve(const MgDesc* __rest
                                                             const double* __restrict__ psrc, double* __restrict__ U,
                                                             int* __restrict__ vcycles, double* __restrict__ errs,
                                                             unsigned long long* __restrict__ total_vcycles,
-                                                            unsigned* __restrict__ group_ctr, double* __restrict__ group_part)
+                                                            unsigned* __restrict__ group_ctr, double* __restrict__ group_part,
+                                                            const int* __restrict__ skip, int fault)
 {
     __shared__ double red[20];
     __shared__ double seqmem[3 * kSeqCap];
@@ -1515,6 +1521,8 @@ __global__ __launch_bounds__(kThreads) void k_poisson_solve(const MgDesc* __rest
     const MgDesc& D = *Dp;
     // consecutive blocks are the members of one group (they land on different XCDs, where the barrier is cheapest)
     const int a = blockIdx.x >> D.logG;
+    if (skip && skip[a]) return;                                  // a frozen atom of the batch (finished SCF): U stays as it is
+    if (fault && D.G > 1 && (blockIdx.x & (D.G - 1)) == D.G - 1) return;   // fault injection (tests): this member never arrives
     Atom A;
     A.phi0 = phi0 + (size_t)a * D.per_atom;
     A.phi1 = phi1 + (size_t)a * D.per_atom;
@@ -1531,6 +1539,8 @@ __global__ __launch_bounds__(kThreads) void k_poisson_solve(const MgDesc* __rest
     A.fseq = 0;
     A.pend = 0;
     A.pend_r = 0;
+    A.spin_max = D.spin_max;
+    A.gave_up = false;
     const Lvl L0 = D.lv[0];
     const int N = L0.n;
     const double* rho = density + (size_t)a * N;
@@ -1578,6 +1588,8 @@ __global__ __launch_bounds__(kThreads) void k_unit(const MgDesc* __restrict__ Dp
     A.fseq = 0;
     A.pend = 0;
     A.pend_r = 0;
+    A.spin_max = D.spin_max;
+    A.gave_up = false;
     A.cur = 0;
     for (int l = 0; l < D.levels; ++l) A.cur |= (cur[l] ? 1u : 0u) << l;
     // sequential levels: global -> LDS (the solve kernel initialises them itself); they are workgroup 0's
@@ -1639,7 +1651,18 @@ struct dfta_poisson {
     unsigned long long* d_total_vcycles = nullptr;
     unsigned* d_group_ctr = nullptr;    // per atom: arrival counter of its group of workgroups (zeroed before every launch)
     double* d_group_part = nullptr;     // per atom: 6 G + 2 doubles (partial sums of the members, published state)
+    // Groups of workgroups wait for each other, so every workgroup of a launch has to be resident: the launch is a
+    // COOPERATIVE one (the runtime refuses it when the grid cannot be co-resident), the barriers' spins are bounded, and
+    // dfta_poisson_finish() inspects the abort flag after every solve.  If a launch is refused or a group gives up, the
+    // solve is repeated by `fallback` -- the same solver with one workgroup per atom (no cross-workgroup waits, results
+    // bit-identical) -- and this solver stays degraded to it.
+    dfta_poisson* fallback = nullptr;
+    bool degraded = false;
+    int aborts = 0;                 // solves that had to be repeated
+    int fault = 0;                  // $DFTA_FAULT_POISSON_MEMBER (tests): the last member of every group never arrives
 };
+
+static int poisson_create_impl(dfta_ctx* ctx, const dfta_grid* g, int batch, int force_logG, dfta_poisson** out);
 
 static long host_addr(const Lvl& L, int i)
 {
@@ -1647,15 +1670,46 @@ static long host_addr(const Lvl& L, int i)
     return L.off + ((long)(i & ((1 << L.logC) - 1)) << L.logT) + (i >> L.logC);
 }
 
-int dfta_poisson_solve_launch(dfta_poisson* p, const int* dZ, const double* dDensity, double* dU, int* dVcycles, double* dErr)
+static int degrade(dfta_poisson* p)
+{
+    if (!p->fallback) {
+        int rc = poisson_create_impl(p->ctx, p->g, p->batch, 0, &p->fallback);
+        if (rc) return rc;
+    }
+    p->degraded = true;
+    return DFTA_OK;
+}
+
+// dSkip (device, per atom, may be null): atoms with a non-zero entry are left untouched (frozen atoms of an SCF batch)
+int dfta_poisson_solve_launch(dfta_poisson* p, const int* dZ, const double* dDensity, double* dU, int* dVcycles, double* dErr,
+                              const int* dSkip)
 {
     dfta_ctx* ctx = p->ctx;
+    if (p->degraded) return dfta_poisson_solve_launch(p->fallback, dZ, dDensity, dU, dVcycles, dErr, dSkip);
     DFTA_HIP(ctx, hipMemsetAsync(p->d_group_ctr, 0, sizeof(unsigned) * p->batch, ctx->stream));
     DFTA_HIP(ctx, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(p->d_group_part), 0x7FF8DEAD, (size_t)p->batch * (9 * p->D.G + 2) * 2, ctx->stream));   // group_sum_fast's sentinel
-    hipLaunchKernelGGL(k_poisson_solve, dim3(p->batch * p->D.G), dim3(kThreads), 0, ctx->stream, p->d_desc, p->d_phi0, p->d_phi1,
-                       p->d_src, dZ, dDensity, p->g->d_r, p->g->d_psrc, dU, dVcycles, dErr, p->d_total_vcycles, p->d_group_ctr,
-                       p->d_group_part);
-    DFTA_CHECK_LAUNCH(ctx);
+    if (p->D.G == 1) {
+        hipLaunchKernelGGL(k_poisson_solve, dim3(p->batch), dim3(kThreads), 0, ctx->stream, p->d_desc, p->d_phi0, p->d_phi1, p->d_src, dZ,
+                           dDensity, p->g->d_r, p->g->d_psrc, dU, dVcycles, dErr, p->d_total_vcycles, p->d_group_ctr, p->d_group_part,
+                           dSkip, 0);
+        DFTA_CHECK_LAUNCH(ctx);
+        return DFTA_OK;
+    }
+    const MgDesc* a0 = p->d_desc;
+    const double *a_r = p->g->d_r, *a_psrc = p->g->d_psrc;
+    int fault = p->fault;
+    void* args[] = {&a0, &p->d_phi0, &p->d_phi1, &p->d_src, &dZ, &dDensity, &a_r, &a_psrc, &dU, &dVcycles, &dErr, &p->d_total_vcycles,
+                    &p->d_group_ctr, &p->d_group_part, &dSkip, &fault};
+    const hipError_t e = hipLaunchCooperativeKernel(reinterpret_cast<const void*>(k_poisson_solve), dim3(p->batch * p->D.G), dim3(kThreads),
+                                                    args, 0, ctx->stream);
+    if (e != hipSuccess) {
+        // the grid cannot be co-resident right now (or cooperative launches are unavailable): one workgroup per atom instead
+        (void)hipGetLastError();
+        int rc = degrade(p);
+        if (rc) return rc;
+        ++p->aborts;
+        return dfta_poisson_solve_launch(p->fallback, dZ, dDensity, dU, dVcycles, dErr, dSkip);
+    }
     return DFTA_OK;
 }
 
@@ -1663,26 +1717,56 @@ int dfta_poisson_solve_launch(dfta_poisson* p, const int* dZ, const double* dDen
 static int check_groups(dfta_poisson* p)
 {
     dfta_ctx* ctx = p->ctx;
-    if (p->D.G == 1) return DFTA_OK;
+    if (p->D.G == 1 || p->degraded) return DFTA_OK;
     std::vector<unsigned> h(p->batch);
     DFTA_HIP(ctx, hipMemcpyAsync(h.data(), p->d_group_ctr, sizeof(unsigned) * p->batch, hipMemcpyDeviceToHost, ctx->stream));
     DFTA_HIP(ctx, hipStreamSynchronize(ctx->stream));
     for (unsigned v : h)
         if (v & 0x80000000u) {
             snprintf(ctx->err, sizeof(ctx->err), "poisson: a group of %d workgroups lost a member at a barrier (the %d workgroups of "
-                     "the launch were not all resident); set DFTA_POISSON_GROUP=0", p->D.G, p->batch * p->D.G);
+                     "the launch were not all resident)", p->D.G, p->batch * p->D.G);
             return DFTA_ERR_HIP;
         }
+    return DFTA_OK;
+}
+
+// Completes the solve launched last (synchronises the stream).  If a group of workgroups gave up, the solve is repeated
+// with one workgroup per atom, in this process and on the same stream, and every later solve of `p` takes that path.
+int dfta_poisson_finish(dfta_poisson* p, const int* dZ, const double* dDensity, double* dU, int* dVcycles, double* dErr,
+                        const int* dSkip)
+{
+    dfta_ctx* ctx = p->ctx;
+    if (p->D.G == 1 || p->degraded) { DFTA_HIP(ctx, hipStreamSynchronize(ctx->stream)); return DFTA_OK; }
+    if (check_groups(p) == DFTA_OK) return DFTA_OK;
+    ++p->aborts;
+    DFTA_HIP(ctx, hipMemsetAsync(p->d_total_vcycles, 0, sizeof(unsigned long long), ctx->stream));   // the aborted solve's count
+    int rc = degrade(p);
+    if (rc) return rc;
+    rc = dfta_poisson_solve_launch(p->fallback, dZ, dDensity, dU, dVcycles, dErr, dSkip);
+    if (rc) return rc;
+    DFTA_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return DFTA_OK;
 }
 
 int dfta_poisson_take_vcycles(dfta_poisson* p, unsigned long long* out)   // reads and clears the V-cycle counter
 {
     dfta_ctx* ctx = p->ctx;
-    DFTA_HIP(ctx, hipMemcpyAsync(out, p->d_total_vcycles, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+    unsigned long long a = 0, b = 0;
+    DFTA_HIP(ctx, hipMemcpyAsync(&a, p->d_total_vcycles, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+    if (p->fallback) DFTA_HIP(ctx, hipMemcpyAsync(&b, p->fallback->d_total_vcycles, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
     DFTA_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (int rc = check_groups(p)) return rc;
     DFTA_HIP(ctx, hipMemsetAsync(p->d_total_vcycles, 0, sizeof(unsigned long long), ctx->stream));
+    if (p->fallback) DFTA_HIP(ctx, hipMemsetAsync(p->fallback->d_total_vcycles, 0, sizeof(unsigned long long), ctx->stream));
+    *out = a + b;
+    return DFTA_OK;
+}
+
+int dfta_poisson_group_state(const dfta_poisson* p, int* G, int* degraded, int* aborts)
+{
+    if (!p) return DFTA_ERR_INVALID;
+    if (G) *G = p->D.G;
+    if (degraded) *degraded = p->degraded ? 1 : 0;
+    if (aborts) *aborts = p->aborts;
     return DFTA_OK;
 }
 
@@ -1691,6 +1775,15 @@ extern "C" {
 int dfta_poisson_create(dfta_ctx* ctx, const dfta_grid* g, int batch, dfta_poisson** out)
 {
     if (!ctx || !g || !out) return DFTA_ERR_INVALID;
+    if (int rc = dfta_use(ctx)) return rc;
+    return poisson_create_impl(ctx, g, batch, -1, out);
+}
+
+}  // extern "C"
+
+// force_logG >= 0: that many doublings of the workgroups per atom (0: one workgroup per atom); -1: chosen from the batch size
+static int poisson_create_impl(dfta_ctx* ctx, const dfta_grid* g, int batch, int force_logG, dfta_poisson** out)
+{
     DFTA_REQUIRE(ctx, batch >= 1 && g->levels <= kMaxLevels, "poisson batch/levels");
     dfta_poisson* p = new dfta_poisson();
     p->ctx = ctx; p->g = g; p->batch = batch;
@@ -1707,6 +1800,9 @@ int dfta_poisson_create(dfta_ctx* ctx, const dfta_grid* g, int batch, dfta_poiss
         const int v = atoi(e);
         if (v >= 0 && v <= 4 && (batch << v) <= 256) logG = v;
     }
+    if (force_logG >= 0) logG = force_logG;
+    if (const char* e = getenv("DFTA_FAULT_POISSON_MEMBER")) p->fault = atoi(e) != 0;
+    D.spin_max = p->fault ? (1 << 12) : (1 << 23);
     {
         // every workgroup of the launch must be resident at once (the members wait for each other)
         int per_cu = 0;
@@ -1799,9 +1895,12 @@ int dfta_poisson_create(dfta_ctx* ctx, const dfta_grid* g, int batch, dfta_poiss
     return DFTA_OK;
 }
 
+extern "C" {
+
 void dfta_poisson_destroy(dfta_poisson* p)
 {
     if (!p) return;
+    if (p->fallback) dfta_poisson_destroy(p->fallback);
 #ifdef DFTA_POISSON_PROF
     {
         unsigned long long h[6 * 24];
@@ -1828,6 +1927,7 @@ int dfta_poisson_solve(dfta_poisson* p, const int* Z, const double* density, dou
 {
     if (!p) return DFTA_ERR_INVALID;
     dfta_ctx* ctx = p->ctx;
+    if (int rc_ = dfta_use(ctx)) return rc_;
     DFTA_REQUIRE(ctx, Z && density && U, "null input");
     const int N = p->g->N, B = p->batch;
     hipStream_t st = ctx->stream;
@@ -1838,22 +1938,34 @@ int dfta_poisson_solve(dfta_poisson* p, const int* Z, const double* density, dou
     DFTA_HIP(ctx, hipMemcpyAsync(dZ.p, Z, sizeof(int) * B, hipMemcpyHostToDevice, st));
     DFTA_HIP(ctx, hipMemcpyAsync(dRho.p, density, sizeof(double) * (size_t)B * N, hipMemcpyHostToDevice, st));
     DFTA_HIP(ctx, hipEventRecord(ctx->ev[0], st));
-    int rc = dfta_poisson_solve_launch(p, dZ.p, dRho.p, dU.p, dVc.p, dErr.p);
+    int rc = dfta_poisson_solve_launch(p, dZ.p, dRho.p, dU.p, dVc.p, dErr.p, nullptr);
     if (rc) return rc;
     DFTA_HIP(ctx, hipEventRecord(ctx->ev[1], st));
     ctx->have_kernel_time = true;
+    rc = dfta_poisson_finish(p, dZ.p, dRho.p, dU.p, dVc.p, dErr.p, nullptr);
+    if (rc) return rc;
     DFTA_HIP(ctx, hipMemcpyAsync(U, dU.p, sizeof(double) * (size_t)B * N, hipMemcpyDeviceToHost, st));
     if (vcycles_out) DFTA_HIP(ctx, hipMemcpyAsync(vcycles_out, dVc.p, sizeof(int) * B, hipMemcpyDeviceToHost, st));
     if (err_out) DFTA_HIP(ctx, hipMemcpyAsync(err_out, dErr.p, sizeof(double) * B, hipMemcpyDeviceToHost, st));
     DFTA_HIP(ctx, hipStreamSynchronize(st));
-    return check_groups(p);
+    return DFTA_OK;
 }
 
 int dfta_poisson_solve_dev(dfta_poisson* p, const int* dZ, const double* dDensity, double* dU)
 {
     if (!p) return DFTA_ERR_INVALID;
     DFTA_REQUIRE(p->ctx, dZ && dDensity && dU, "null input");
-    return dfta_poisson_solve_launch(p, dZ, dDensity, dU, nullptr, nullptr);
+    if (int rc = dfta_use(p->ctx)) return rc;
+    // synchronises: the group barriers' abort flag is inspected after every solve (and the solve repeated with one
+    // workgroup per atom if it was raised), so a DFTA_OK always means a completed solve
+    int rc = dfta_poisson_solve_launch(p, dZ, dDensity, dU, nullptr, nullptr, nullptr);
+    if (rc) return rc;
+    return dfta_poisson_finish(p, dZ, dDensity, dU, nullptr, nullptr, nullptr);
+}
+
+int dfta_poisson_group_info(const dfta_poisson* p, int* G, int* degraded, int* aborts)
+{
+    return dfta_poisson_group_state(p, G, degraded, aborts);
 }
 
 int dfta_poisson_level_size(const dfta_poisson* p, int lvl)
@@ -1866,6 +1978,7 @@ int dfta_poisson_set_level(dfta_poisson* p, int lvl, const double* Phi, const do
 {
     if (!p) return DFTA_ERR_INVALID;
     dfta_ctx* ctx = p->ctx;
+    if (int rc_ = dfta_use(ctx)) return rc_;
     DFTA_REQUIRE(ctx, lvl >= 0 && lvl < p->D.levels, "level");
     const Lvl& L = p->D.lv[lvl];
     std::vector<double> tmp(L.n);
@@ -1888,6 +2001,7 @@ int dfta_poisson_get_level(dfta_poisson* p, int lvl, double* Phi, double* Src)
 {
     if (!p) return DFTA_ERR_INVALID;
     dfta_ctx* ctx = p->ctx;
+    if (int rc_ = dfta_use(ctx)) return rc_;
     DFTA_REQUIRE(ctx, lvl >= 0 && lvl < p->D.levels, "level");
     const Lvl& L = p->D.lv[lvl];
     std::vector<double> tmp(L.n);
@@ -1906,18 +2020,33 @@ int dfta_poisson_get_level(dfta_poisson* p, int lvl, double* Phi, double* Src)
     return DFTA_OK;
 }
 
+// the unit hooks run on atom 0 with the solver's own group of G workgroups (cooperative launch, like the solve)
+static int launch_unit(dfta_poisson* p, int op, int lvl, int sweeps, double* dOut)
+{
+    dfta_ctx* ctx = p->ctx;
+    if (p->D.G == 1) {
+        hipLaunchKernelGGL(k_unit, dim3(1), dim3(kThreads), 0, ctx->stream, p->d_desc, p->d_phi0, p->d_phi1, p->d_src, p->d_cur, op, lvl, sweeps,
+                           dOut, p->d_group_ctr, p->d_group_part);
+        DFTA_CHECK_LAUNCH(ctx);
+        return DFTA_OK;
+    }
+    const MgDesc* a0 = p->d_desc;
+    void* args[] = {&a0, &p->d_phi0, &p->d_phi1, &p->d_src, &p->d_cur, &op, &lvl, &sweeps, &dOut, &p->d_group_ctr, &p->d_group_part};
+    DFTA_HIP(ctx, hipLaunchCooperativeKernel(reinterpret_cast<const void*>(k_unit), dim3(p->D.G), dim3(kThreads), args, 0, ctx->stream));
+    return DFTA_OK;
+}
+
 static int unit_op(dfta_poisson* p, int op, int lvl, int sweeps, double* out_host, int nout)
 {
     dfta_ctx* ctx = p->ctx;
+    if (int rc_ = dfta_use(ctx)) return rc_;
     hipStream_t st = ctx->stream;
     DevBuf<double> dOut;
     DFTA_HIP(ctx, dOut.alloc(std::max(nout, 1)));
     DFTA_HIP(ctx, hipMemcpyAsync(p->d_cur, p->h_cur.data(), sizeof(int) * kMaxLevels, hipMemcpyHostToDevice, st));
     DFTA_HIP(ctx, hipMemsetAsync(p->d_group_ctr, 0, sizeof(unsigned), st));
     DFTA_HIP(ctx, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(p->d_group_part), 0x7FF8DEAD, (size_t)(9 * p->D.G + 2) * 2, st));
-    hipLaunchKernelGGL(k_unit, dim3(p->D.G), dim3(kThreads), 0, st, p->d_desc, p->d_phi0, p->d_phi1, p->d_src, p->d_cur, op, lvl, sweeps, dOut.p,
-                       p->d_group_ctr, p->d_group_part);
-    DFTA_CHECK_LAUNCH(ctx);
+    if (int rc = launch_unit(p, op, lvl, sweeps, dOut.p)) return rc;
     DFTA_HIP(ctx, hipMemcpyAsync(p->h_cur.data(), p->d_cur, sizeof(int) * kMaxLevels, hipMemcpyDeviceToHost, st));
     if (out_host && nout > 0) DFTA_HIP(ctx, hipMemcpyAsync(out_host, dOut.p, sizeof(double) * nout, hipMemcpyDeviceToHost, st));
     DFTA_HIP(ctx, hipStreamSynchronize(st));
@@ -1934,6 +2063,7 @@ int dfta_poisson_iterate_gs(dfta_poisson* p, int lvl, double errorMin, int itern
 {
     if (!p) return DFTA_ERR_INVALID;
     dfta_ctx* ctx = p->ctx;
+    if (int rc_ = dfta_use(ctx)) return rc_;
     DFTA_REQUIRE(ctx, lvl >= 0 && lvl < p->D.levels && iterno >= 1 && iterno <= 1024, "level/iterno");
     hipStream_t st = ctx->stream;
     DevBuf<double> dOut;
@@ -1942,9 +2072,7 @@ int dfta_poisson_iterate_gs(dfta_poisson* p, int lvl, double errorMin, int itern
     DFTA_HIP(ctx, hipMemcpyAsync(p->d_cur, p->h_cur.data(), sizeof(int) * kMaxLevels, hipMemcpyHostToDevice, st));
     DFTA_HIP(ctx, hipMemsetAsync(p->d_group_ctr, 0, sizeof(unsigned), st));
     DFTA_HIP(ctx, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(p->d_group_part), 0x7FF8DEAD, (size_t)(9 * p->D.G + 2) * 2, st));
-    hipLaunchKernelGGL(k_unit, dim3(p->D.G), dim3(kThreads), 0, st, p->d_desc, p->d_phi0, p->d_phi1, p->d_src, p->d_cur, 4, lvl, iterno, dOut.p,
-                       p->d_group_ctr, p->d_group_part);
-    DFTA_CHECK_LAUNCH(ctx);
+    if (int rc = launch_unit(p, 4, lvl, iterno, dOut.p)) return rc;
     double out[2] = {0, 0};
     DFTA_HIP(ctx, hipMemcpyAsync(p->h_cur.data(), p->d_cur, sizeof(int) * kMaxLevels, hipMemcpyDeviceToHost, st));
     DFTA_HIP(ctx, hipMemcpyAsync(out, dOut.p, sizeof(out), hipMemcpyDeviceToHost, st));

@@ -105,6 +105,7 @@ int dfta_launch_simpson38_ordered(dfta_ctx* ctx, const double* dVals, int n, int
 extern "C" int dfta_integrate(dfta_ctx* ctx, int rule, double delta, const double* values, int sz, double* result)
 {
     if (!ctx) return DFTA_ERR_INVALID;
+    if (int rc_ = dfta_use(ctx)) return rc_;
     DFTA_REQUIRE(ctx, values && result && sz >= 3 && rule >= 0 && rule <= DFTA_INT_ROMBERG, "integrate arguments");
     // the reference asserts these shapes (Integral.h:13,27-28,52-53,77-78,110)
     if (rule == DFTA_INT_SIMPSON13 || rule == DFTA_INT_SIMPSON38) DFTA_REQUIRE(ctx, sz >= 5 && sz % 2 == 1, "size");

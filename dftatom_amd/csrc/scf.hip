@@ -73,9 +73,11 @@ __global__ void k_potential(const AtomState* __restrict__ atoms, int lsda, int N
 
 // newDensity /= 4 pi r^2; density = alpha density + (1-alpha) newDensity (DFTAtom.cpp:332-342); LSDA total (DFTAtom.cpp:933-934)
 __global__ void k_mix(int lsda, int N, double alpha, double oneMinusAlpha, const double* __restrict__ fpr2,
-                      double* __restrict__ newDensity, double* __restrict__ density, double* __restrict__ dA, double* __restrict__ dB)
+                      double* __restrict__ newDensity, double* __restrict__ density, double* __restrict__ dA, double* __restrict__ dB,
+                      const int* __restrict__ fin)
 {
     const int a = blockIdx.y;
+    if (fin[a]) return;        // a finished atom is frozen (the reference leaves its loop: DFTAtom.cpp:474-479)
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) {
         if (i == 0) continue;
         const size_t o = (size_t)a * N + i;
@@ -108,6 +110,7 @@ __global__ void k_tail(const AtomState* __restrict__ atoms, int lsda, int N, con
                        double* __restrict__ V, double* __restrict__ integrands)
 {
     const int a = blockIdx.y;
+    if (atoms[a].finished) return;
     const int Z = atoms[a].Z;
     double* nuclear = integrands + ((size_t)a * 5 + 0) * N;
     double* exccor = integrands + ((size_t)a * 5 + 1) * N;
@@ -156,11 +159,12 @@ __global__ void k_tail(const AtomState* __restrict__ atoms, int lsda, int N, con
 
 // energy assembly and the reference's stop test (DFTAtom.cpp:459-481 / 985-1006); one thread per atom
 __global__ void k_energies(AtomState* __restrict__ atoms, int natoms, const dfta::Job* __restrict__ jobs,
-                           const double* __restrict__ integrals, double* __restrict__ records)
+                           const double* __restrict__ integrals, double* __restrict__ records, int* __restrict__ fin)
 {
     const int a = blockIdx.x * blockDim.x + threadIdx.x;
     if (a >= natoms) return;
     AtomState s = atoms[a];
+    if (s.finished) return;     // energies, eigenvalues, step count and record stay those of the finishing step
     double Eelectronic = 0;
     bool conv = true;
     for (int k = s.job_off; k < s.job_end; ++k) {
@@ -182,6 +186,7 @@ __global__ void k_energies(AtomState* __restrict__ atoms, int natoms, const dfta
     if (fabs((s.Eold - Etotal) / Etotal) < kTotalEnergyErr && conv && s.lastTimeConverged) s.finished = 1;
     else { s.Eold = Etotal; s.lastTimeConverged = conv ? 1 : 0; }
     atoms[a] = s;
+    fin[a] = s.finished;
     if (records) {
         double* R = records + (size_t)a * DFTA_RECORD_DOUBLES;
         R[0] = s.Z; R[1] = Etotal; R[2] = Ekinetic; R[3] = -Ehartree; R[4] = Enuclear; R[5] = Exc; R[6] = s.finished;
@@ -205,6 +210,9 @@ struct dfta_scf {
     std::vector<double> h_bottom0;        // per potential: -Z^2-1 (DFTAtom.cpp:407)
     std::vector<double> h_job_bottom;     // per job: bracket start of the next level solve
     std::vector<dfta::Job> h_jobs;        // job results of the last step
+    std::vector<unsigned char> h_frozen;  // per job: its atom has finished
+    int* d_fin = nullptr;                 // per atom: finished (device copy for the kernels that skip frozen atoms)
+    bool debug_levels = false;            // $DFTA_DEBUG_LEVELS
     int levels_mode = DFTA_LEVELS_BATCHED;
     int steps_done = 0;
     std::vector<int> spin_nlev[2];      // per atom number of levels per spin
@@ -228,7 +236,7 @@ extern "C" {
 void dfta_scf_destroy(dfta_scf* s)
 {
     if (!s) return;
-    void* ptrs[] = {s->d_atoms, s->d_Z, s->d_density, s->d_dA, s->d_dB, s->d_V, s->d_U, s->d_Vexc, s->d_va, s->d_vb, s->d_eexc,
+    void* ptrs[] = {s->d_fin, s->d_atoms, s->d_Z, s->d_density, s->d_dA, s->d_dB, s->d_V, s->d_U, s->d_Vexc, s->d_va, s->d_vb, s->d_eexc,
                     s->d_newDensity, s->d_integrands, s->d_integrals, s->d_records};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (hipEvent_t e : s->ev) if (e) (void)hipEventDestroy(e);
@@ -240,6 +248,7 @@ int dfta_scf_create(dfta_ctx* ctx, const dfta_grid* g, int lsda, int natoms, con
                     int tree_depth, dfta_scf** out)
 {
     if (!ctx || !g || !out) return DFTA_ERR_INVALID;
+    if (int rc_ = dfta_use(ctx)) return rc_;
     DFTA_REQUIRE(ctx, natoms >= 1 && Z && alpha >= 0 && alpha <= 1, "scf arguments");
     dfta_scf* s = new dfta_scf();
     s->ctx = ctx; s->g = g; s->lsda = lsda ? 1 : 0; s->natoms = natoms; s->nspin = lsda ? 2 : 1; s->nV = natoms * s->nspin;
@@ -291,6 +300,8 @@ int dfta_scf_create(dfta_ctx* ctx, const dfta_grid* g, int lsda, int natoms, con
     al(&s->d_integrals, (size_t)natoms * 5); al(&s->d_records, (size_t)natoms * DFTA_RECORD_DOUBLES);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&s->d_atoms), sizeof(AtomState) * natoms);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&s->d_Z), sizeof(int) * natoms);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&s->d_fin), sizeof(int) * natoms);
+    if (e == hipSuccess) e = hipMemsetAsync(s->d_fin, 0, sizeof(int) * natoms, st);
     for (auto& ev : s->ev) if (e == hipSuccess) e = hipEventCreate(&ev);
     if (e == hipSuccess) e = hipMemcpyAsync(s->d_atoms, s->h_atoms.data(), sizeof(AtomState) * natoms, hipMemcpyHostToDevice, st);
     if (e == hipSuccess) e = hipMemcpyAsync(s->d_Z, Z, sizeof(int) * natoms, hipMemcpyHostToDevice, st);
@@ -303,7 +314,8 @@ int dfta_scf_create(dfta_ctx* ctx, const dfta_grid* g, int lsda, int natoms, con
     // DFTAtom.cpp:371-392 / 874-904: flat density, Poisson, v_xc, start potential
     const dim3 grid(std::min(64, (N + 255) / 256), natoms), block(256);
     hipLaunchKernelGGL(k_init_density, grid, block, 0, st, s->d_atoms, s->lsda, N, g->Rmax, s->d_density, s->d_dA, s->d_dB);
-    rc = dfta_poisson_solve_launch(s->poisson, s->d_Z, s->d_density, s->d_U, nullptr, nullptr);
+    rc = dfta_poisson_solve_launch(s->poisson, s->d_Z, s->d_density, s->d_U, nullptr, nullptr, nullptr);
+    if (!rc) rc = dfta_poisson_finish(s->poisson, s->d_Z, s->d_density, s->d_U, nullptr, nullptr, nullptr);
     if (!rc) rc = scf_xc(s);
     if (rc) { dfta_scf_destroy(s); return rc; }
     hipLaunchKernelGGL(k_potential, grid, block, 0, st, s->d_atoms, s->lsda, N, g->d_r, s->d_U, s->d_Vexc, s->d_va, s->d_vb, s->d_V);
@@ -315,7 +327,10 @@ int dfta_scf_create(dfta_ctx* ctx, const dfta_grid* g, int lsda, int natoms, con
         return DFTA_ERR_HIP;
     }
     unsigned long long dummy;
-    (void)dfta_poisson_take_vcycles(s->poisson, &dummy);
+    rc = dfta_poisson_take_vcycles(s->poisson, &dummy);
+    if (rc) { dfta_scf_destroy(s); return rc; }
+    s->debug_levels = getenv("DFTA_DEBUG_LEVELS") != nullptr;
+    s->h_frozen.assign(specs.size(), 0);
     *out = s;
     return DFTA_OK;
 }
@@ -324,6 +339,7 @@ int dfta_scf_step(dfta_scf* s, dfta_step_stats* stats)
 {
     if (!s) return DFTA_ERR_INVALID;
     dfta_ctx* ctx = s->ctx;
+    if (int rc_ = dfta_use(ctx)) return rc_;
     const dfta_grid* g = s->g;
     const int N = g->N, natoms = s->natoms;
     hipStream_t st = ctx->stream;
@@ -335,7 +351,16 @@ int dfta_scf_step(dfta_scf* s, dfta_step_stats* stats)
     // bracket starts: CHAINED hands E-3 from level to level exactly as DFTAtom.cpp:541 (levels one after the other);
     // BATCHED starts every level concurrently from max(-Z^2-1, min Veff_l) (LevelSolver::clamp_bottoms)
     const int run_mode = s->levels_mode;
-    int rc = s->solver.run(s->d_V, s->h_job_bottom.data(), run_mode, s->d_newDensity, stats ? &ls : nullptr);
+    // atoms that have met the reference's stop test (DFTAtom.cpp:474-479) are frozen: no level search, no mixing, no
+    // Poisson solve, no new energies -- every atom of a batch ends in the state of its own last step
+    bool any_frozen = false;
+    for (int a = 0; a < natoms; ++a) {
+        const AtomState& as = s->h_atoms[a];
+        for (int k = as.job_off; k < as.job_end; ++k) s->h_frozen[k] = as.finished ? 1 : 0;
+        any_frozen = any_frozen || as.finished;
+    }
+    int rc = s->solver.run(s->d_V, s->h_job_bottom.data(), run_mode, s->d_newDensity, stats ? &ls : nullptr,
+                           any_frozen ? s->h_frozen.data() : nullptr);
     if (rc) return rc;
     {
         std::vector<dfta::Job>& jobs = s->h_jobs;
@@ -345,7 +370,7 @@ int dfta_scf_step(dfta_scf* s, dfta_step_stats* stats)
             s->h_job_bottom[k] = s->h_bottom0[jobs[k].v];
         }
         s->steps_done++;
-        if (getenv("DFTA_DEBUG_LEVELS")) {
+        if (s->debug_levels) {
             for (size_t k = 0; k < jobs.size(); ++k)
                 fprintf(stderr, "step %d job %zu n%d l%d: trust %d %d %d  len %d %d %d  pred_len %d %d %d  sweeps %d %d\n", s->steps_done, k, jobs[k].n,
                         jobs[k].l, jobs[k].trust[0], jobs[k].trust[1], jobs[k].trust[2], jobs[k].cur_len[0], jobs[k].cur_len[1],
@@ -353,12 +378,16 @@ int dfta_scf_step(dfta_scf* s, dfta_step_stats* stats)
         }
     }
     hipLaunchKernelGGL(k_mix, grid, block, 0, st, s->lsda, N, s->alpha, 1. - s->alpha, g->d_fpr2, s->d_newDensity, s->d_density,
-                       s->d_dA, s->d_dB);
+                       s->d_dA, s->d_dB, s->d_fin);
     DFTA_CHECK_LAUNCH(ctx);
     DFTA_HIP(ctx, hipEventRecord(s->ev[1], st));
-    rc = dfta_poisson_solve_launch(s->poisson, s->d_Z, s->d_density, s->d_U, nullptr, nullptr);
+    rc = dfta_poisson_solve_launch(s->poisson, s->d_Z, s->d_density, s->d_U, nullptr, nullptr, s->d_fin);
     if (rc) return rc;
     DFTA_HIP(ctx, hipEventRecord(s->ev[2], st));   // ev[1]..ev[2] brackets exactly the persistent multigrid kernel
+    // synchronises and inspects the group barriers' abort flag on EVERY step; an aborted solve is repeated with one
+    // workgroup per atom before anything reads U
+    rc = dfta_poisson_finish(s->poisson, s->d_Z, s->d_density, s->d_U, nullptr, nullptr, s->d_fin);
+    if (rc) return rc;
     rc = scf_xc(s);
     if (rc) return rc;
     hipLaunchKernelGGL(k_tail, grid, block, 0, st, s->d_atoms, s->lsda, N, g->d_r, g->d_cnst, s->d_density, s->d_dA, s->d_dB, s->d_U,
@@ -367,9 +396,12 @@ int dfta_scf_step(dfta_scf* s, dfta_step_stats* stats)
     rc = dfta_launch_simpson38_ordered(ctx, s->d_integrands, N, natoms * 5, (size_t)N, s->d_integrals);
     if (rc) return rc;
     hipLaunchKernelGGL(k_energies, dim3((natoms + 63) / 64), dim3(64), 0, st, s->d_atoms, natoms, s->solver.d_jobs, s->d_integrals,
-                       s->d_records);
+                       s->d_records, s->d_fin);
     DFTA_CHECK_LAUNCH(ctx);
     DFTA_HIP(ctx, hipEventRecord(s->ev[3], st));
+    // the step ends synchronised with the atoms' state on the host: the next step freezes what has finished
+    DFTA_HIP(ctx, hipMemcpyAsync(s->h_atoms.data(), s->d_atoms, sizeof(AtomState) * natoms, hipMemcpyDeviceToHost, st));
+    DFTA_HIP(ctx, hipStreamSynchronize(st));
     if (stats) {
         DFTA_HIP(ctx, hipEventSynchronize(s->ev[3]));
         memset(stats, 0, sizeof(*stats));
@@ -382,7 +414,7 @@ int dfta_scf_step(dfta_scf* s, dfta_step_stats* stats)
         stats->sweeps_issued = ls.sweeps_issued;
         stats->points_traversed = ls.points_traversed;
         long ref = 0;
-        for (const auto& j : s->h_jobs) ref += j.n_count + j.n_zero + 1;   // + the matched solve of each level
+        for (const auto& j : s->h_jobs) if (!j.frozen) ref += j.n_count + j.n_zero + 1;   // + the matched solve of each level
         stats->sweeps_reference = ref;
         unsigned long long vc = 0;
         rc = dfta_poisson_take_vcycles(s->poisson, &vc);
@@ -396,9 +428,8 @@ int dfta_scf_get_energies(dfta_scf* s, dfta_energies* e, int* finished)
 {
     if (!s) return DFTA_ERR_INVALID;
     dfta_ctx* ctx = s->ctx;
-    DFTA_HIP(ctx, hipMemcpyAsync(s->h_atoms.data(), s->d_atoms, sizeof(AtomState) * s->natoms, hipMemcpyDeviceToHost, ctx->stream));
-    DFTA_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    for (int a = 0; a < s->natoms; ++a) {
+    if (int rc_ = dfta_use(ctx)) return rc_;
+    for (int a = 0; a < s->natoms; ++a) {      // h_atoms is current: every step ends with its copy
         if (e) e[a] = s->h_atoms[a].e;
         if (finished) finished[a] = s->h_atoms[a].finished;
     }
@@ -414,6 +445,12 @@ int dfta_scf_info(const dfta_scf* s, int* tree_depth, int* njobs, long* trials_p
     return DFTA_OK;
 }
 
+int dfta_scf_poisson_info(const dfta_scf* s, int* G, int* degraded, int* aborts)
+{
+    if (!s) return DFTA_ERR_INVALID;
+    return dfta_poisson_group_state(s->poisson, G, degraded, aborts);
+}
+
 int dfta_scf_num_levels(const dfta_scf* s, int atom, int spin)
 {
     if (!s || atom < 0 || atom >= s->natoms || spin < 0 || spin > 1) return -1;
@@ -424,6 +461,7 @@ int dfta_scf_get_levels(dfta_scf* s, int atom, int spin, int* n, int* l, int* oc
 {
     if (!s) return DFTA_ERR_INVALID;
     dfta_ctx* ctx = s->ctx;
+    if (int rc_ = dfta_use(ctx)) return rc_;
     DFTA_REQUIRE(ctx, atom >= 0 && atom < s->natoms && spin >= 0 && spin < s->nspin, "atom/spin");
     const std::vector<dfta::Job>& jobs = s->h_jobs;
     DFTA_REQUIRE(ctx, !jobs.empty(), "no SCF step has run yet");
@@ -444,6 +482,7 @@ int dfta_scf_get_array(dfta_scf* s, int atom, int which, double* out)
 {
     if (!s) return DFTA_ERR_INVALID;
     dfta_ctx* ctx = s->ctx;
+    if (int rc_ = dfta_use(ctx)) return rc_;
     DFTA_REQUIRE(ctx, atom >= 0 && atom < s->natoms && out, "atom/out");
     const int N = s->g->N;
     const double* src = nullptr;
@@ -465,6 +504,7 @@ int dfta_scf_get_records_dev(dfta_scf* s, double* dRecords)
 {
     if (!s || !dRecords) return DFTA_ERR_INVALID;
     dfta_ctx* ctx = s->ctx;
+    if (int rc_ = dfta_use(ctx)) return rc_;
     DFTA_HIP(ctx, hipMemcpyAsync(dRecords, s->d_records, sizeof(double) * (size_t)s->natoms * DFTA_RECORD_DOUBLES,
                                  hipMemcpyDeviceToDevice, ctx->stream));
     return DFTA_OK;

@@ -155,7 +155,15 @@ void dfta_poisson_destroy(dfta_poisson* p);
  * vcycles_out/err_out (optional, per atom): V-cycles executed (<=100) and last ||dPhi||_2. */
 int  dfta_poisson_solve(dfta_poisson* p, const int* Z, const double* density, double* U,
                         int* vcycles_out, double* err_out);
+/* device-pointer form; SYNCHRONISES: see dfta_poisson_group_info */
 int  dfta_poisson_solve_dev(dfta_poisson* p, const int* dZ, const double* dDensity, double* dU);
+/* While the batch leaves compute units idle, the fine levels of an atom are swept by a group of G workgroups that wait
+ * for each other: the solve is launched cooperatively (the runtime refuses a grid that cannot be co-resident), the
+ * barriers' spins are bounded, and after EVERY solve (dfta_poisson_solve, _solve_dev, dfta_scf_create, dfta_scf_step)
+ * the groups' abort flag is inspected.  A refused launch or an aborted solve is repeated in the same process with one
+ * workgroup per atom (bit-identical results), and the solver stays `degraded` to that path; `aborts` counts the solves
+ * that had to be repeated.  $DFTA_FAULT_POISSON_MEMBER=1 (tests) makes the last member of every group return at once. */
+int  dfta_poisson_group_info(const dfta_poisson* p, int* G, int* degraded, int* aborts);
 /* unit-parity hooks on level storage of atom 0 (GaussSeidel / Restrict / Prolong / VCycle,
  * PoissonSolver.cpp:40-64, 110-157; PoissonSolver.h:155-159) */
 int  dfta_poisson_level_size(const dfta_poisson* p, int lvl);
@@ -207,10 +215,14 @@ int  dfta_scf_create(dfta_ctx* ctx, const dfta_grid* g, int lsda, int natoms, co
                      double alpha, int levels_mode, int tree_depth, dfta_scf** out);   /* DFTAtom.cpp:351-394 / 852-906 */
 void dfta_scf_destroy(dfta_scf* s);
 int  dfta_scf_step(dfta_scf* s, dfta_step_stats* stats);                               /* DFTAtom.cpp:396-484 / 908-1009 */
-/* results of the last step (host copies): per atom energies; finished flag (the reference's Finished! test) */
+/* An atom that has met the reference's stop test (DFTAtom.cpp:474-479: |dE/E| < 1e-11 and all levels converged in two
+ * consecutive steps) is FROZEN: later steps of the batch leave its density, potential, eigenvalues, energies, step count
+ * and record untouched, exactly as if it had been run alone, and cost nothing for it.
+ * results of the last step (host copies): per atom energies; finished flag (the reference's Finished! test) */
 int  dfta_scf_get_energies(dfta_scf* s, dfta_energies* e /* natoms */, int* finished /* natoms */);
 /* geometry of the level search: bisection-tree depth, number of (atom,spin,n,l) jobs, trial lanes per round */
 int  dfta_scf_info(const dfta_scf* s, int* tree_depth, int* njobs, long* trials_per_round);
+int  dfta_scf_poisson_info(const dfta_scf* s, int* G, int* degraded, int* aborts);   /* dfta_poisson_group_info of the SCF's solver */
 int  dfta_scf_num_levels(const dfta_scf* s, int atom, int spin);
 int  dfta_scf_get_levels(dfta_scf* s, int atom, int spin, int* n, int* l, int* occ, double* E, int* converged);
 int  dfta_scf_get_array(dfta_scf* s, int atom, int which, double* out /* N */);  /* 0 density,1 densityA,2 densityB,3 potA,4 potB,5 U */

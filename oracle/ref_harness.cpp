@@ -37,6 +37,7 @@
 #undef protected
 
 using NumerovNU = DFT::Numerov<DFT::NumerovFunctionNonUniformGrid>;
+using NumerovU = DFT::Numerov<DFT::NumerovFunctionRegularGrid>;
 
 namespace {
 struct CoutSilencer {
@@ -57,9 +58,73 @@ struct RefNumerov {
     }
     ~RefNumerov() { delete num; }
 };
+
+struct RefNumerovU {        // uniform grid: r_i = i * MaxR / (N - 1)
+    DFT::Potential pot;
+    NumerovU* num;
+    int N;
+    double MaxR;
+    RefNumerovU(const double* V, int n, double Rmax) : N(n), MaxR(Rmax)
+    {
+        pot.m_potentialValues.assign(V, V + n);
+        num = new NumerovU(pot, 0, Rmax, static_cast<size_t>(n));
+    }
+    ~RefNumerovU() { delete num; }
+};
 }
 
 extern "C" {
+
+// ---- Numerov, uniform grid (Numerov.h:16-70 functor; DFTAtom.cpp:213-325 driver) -----------------
+void* ref_unumerov_create(const double* V, int N, double Rmax) { return new RefNumerovU(V, N, Rmax); }
+void ref_unumerov_destroy(void* h) { delete static_cast<RefNumerovU*>(h); }
+int ref_ucount_nodes(void* h, unsigned l, double E, long nodesLimit)
+{
+    RefNumerovU* r = static_cast<RefNumerovU*>(h);
+    int cnt = -1;
+    r->num->SolveSchrodingerCountNodes(r->MaxR, l, E, r->N - 1, nodesLimit, cnt);
+    return cnt;
+}
+double ref_usolution_in_zero(void* h, unsigned l, double E)
+{
+    RefNumerovU* r = static_cast<RefNumerovU*>(h);
+    return r->num->SolveSchrodingerSolutionInZero(r->MaxR, l, E, r->N - 1);
+}
+long ref_umatch(void* h, unsigned l, double E, double* Psi)
+{
+    RefNumerovU* r = static_cast<RefNumerovU*>(h);
+    long mp = -1;
+    std::vector<double> res = r->num->SolveSchrodingerMatchSolutionCompletely(r->MaxR, l, E, r->N - 1, mp);
+    std::memcpy(Psi, res.data(), sizeof(double) * res.size());
+    return mp;
+}
+int ref_uloop_over_levels(void* h, int nlevels, const int* n, const int* l, const int* occ, double* Eout,
+                          double* newDensity, double* Eelectronic, double* BottomEnergy)
+{
+    RefNumerovU* r = static_cast<RefNumerovU*>(h);
+    std::vector<DFT::Subshell> levels;
+    for (int i = 0; i < nlevels; ++i) levels.emplace_back(DFT::Subshell(n[i], l[i], occ[i]));
+    std::vector<double> nd(newDensity, newDensity + r->N);
+    bool reallyConverged = true;
+    CoutSilencer quiet;
+    DFT::DFTAtom::LoopOverLevels(*r->num, levels, nd, *Eelectronic, *BottomEnergy, r->N - 1, r->MaxR,
+                                 r->MaxR / (r->N - 1), reallyConverged, 1E-12);
+    std::memcpy(newDensity, nd.data(), sizeof(double) * nd.size());
+    for (int i = 0; i < nlevels; ++i) Eout[i] = levels[i].E;
+    return reallyConverged ? 1 : 0;
+}
+void ref_normalize_uniform(double* Psi, int N, double h)
+{
+    std::vector<double> v(Psi, Psi + N);
+    DFT::DFTAtom::NormalizeUniform(v, h);
+    std::memcpy(Psi, v.data(), sizeof(double) * v.size());
+}
+void ref_solve_poisson_uniform(void* p, int Z, double maxRadius, const double* density, int N, double* U)
+{
+    std::vector<double> d(density, density + N);
+    std::vector<double> u = static_cast<DFT::PoissonSolver*>(p)->SolvePoissonUniform(Z, maxRadius, d);
+    std::memcpy(U, u.data(), sizeof(double) * u.size());
+}
 
 // ---- Numerov --------------------------------------------------------------------------------
 void* ref_numerov_create(const double* V, int N, double delta, double Rmax)
@@ -251,7 +316,8 @@ long ref_calculate(int mode, int Z, int levels, double alpha, double MaxR, doubl
     return n;
 }
 
-// same, from the high-precision build of the same sources (ref_hp.cpp)
+// same, from the high-precision build of the same sources (ref_hp.cpp); _steps: first max_steps SCF steps only, modes 0..3
 long ref_calculate_hp(int mode, int Z, int levels, double alpha, double MaxR, double delta, char* out, long cap);
+long ref_calculate_hp_steps(int mode, int Z, int levels, double alpha, double MaxR, double delta, int max_steps, char* out, long cap);
 
 }  // extern "C"

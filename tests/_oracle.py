@@ -177,6 +177,16 @@ def ref():
         "ref_initialize_levels": (None, [C.c_int, c_ip, c_ip, c_ip, c_ip, c_ip, c_ip, c_ip, c_ip, c_ip, c_ip]),
         "ref_calculate": (C.c_long, [C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_char_p, C.c_long]),
         "ref_calculate_hp": (C.c_long, [C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_char_p, C.c_long]),
+        "ref_calculate_hp_steps": (C.c_long, [C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int,
+                                              C.c_char_p, C.c_long]),
+        "ref_unumerov_create": (vp, [c_dp, C.c_int, C.c_double]),
+        "ref_unumerov_destroy": (None, [vp]),
+        "ref_ucount_nodes": (C.c_int, [vp, C.c_uint, C.c_double, C.c_long]),
+        "ref_usolution_in_zero": (C.c_double, [vp, C.c_uint, C.c_double]),
+        "ref_umatch": (C.c_long, [vp, C.c_uint, C.c_double, c_dp]),
+        "ref_uloop_over_levels": (C.c_int, [vp, C.c_int, c_ip, c_ip, c_ip, c_dp, c_dp, c_dp, c_dp]),
+        "ref_normalize_uniform": (None, [c_dp, C.c_int, C.c_double]),
+        "ref_solve_poisson_uniform": (None, [vp, C.c_int, C.c_double, c_dp, C.c_int, c_dp]),
     }
     for name, (res, args) in sig.items():
         f = getattr(L, name)

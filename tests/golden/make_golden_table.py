@@ -1,0 +1,120 @@
+#!/usr/bin/env python3
+"""Golden values for the BASELINE configs that round 1 left without fixtures, from the COMPILED REFERENCE
+(oracle/_ref/libdfta_ref.so, built by `make -C oracle ref` from /root/reference where it lies).
+
+    python tests/golden/make_golden_table.py table [--jobs 6]    -> periodic_table_L17.json  (config 4)
+    python tests/golden/make_golden_table.py l20                 -> l20.npz + l20_meta.json   (config 5)
+
+table: DFT::DFTAtom::CalculateNonUniformLDA(Z, 17, 0.5, 50, 1e-4) for Z = 1..86, run to the reference's own stop
+       (17-digit console protocol of oracle/ref_hp.cpp); stored per atom: number of steps, Finished flag, the
+       first two steps and the last one (eigenvalues + the five printed energies).  About 3 CPU-hours, spread
+       over a process pool.
+l20  : 1 048 577-node grid (20 levels, delta = 1.25e-5, Rmax = 50): CountNodes / u(0) / matchPoint rows on a screened
+       Rn-like potential, one SolvePoissonNonUniform, and the first two SCF steps of Rn LSDA (the capture buffer stops
+       the run when "Step: 2" is printed).
+
+Fixtures are data (inputs are regenerated deterministically by the tests; outputs are stored here).
+"""
+import ctypes as C
+import json
+import multiprocessing as mp
+import os
+import sys
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+import _oracle as O  # noqa: E402
+from make_golden import parse_run, screened_potential  # noqa: E402
+
+
+def run_ref(mode, Z, L, alpha, R, d, max_steps=-1):
+    r = O.ref()
+    buf = C.create_string_buffer(1 << 23)
+    r.ref_calculate_hp_steps(mode, Z, L, alpha, R, d, max_steps, buf, len(buf))
+    return buf.value.decode()
+
+
+def one_atom(Z):
+    t0 = time.time()
+    txt = run_ref(0, Z, 17, 0.5, 50.0, 1e-4)
+    steps = parse_run(txt)
+    rec = {"Z": Z, "nsteps": len(steps), "finished": "Finished!" in txt, "first": steps[0], "second": steps[1],
+           "last": steps[-1], "etotal_all": [s["energies"][0] for s in steps],
+           "config": txt.strip().splitlines()[-1], "seconds": round(time.time() - t0, 1)}
+    return rec
+
+
+def table(jobs):
+    path = os.path.join(HERE, "periodic_table_L17.json")
+    done = {}
+    if os.path.exists(path):
+        with open(path) as f:
+            done = json.load(f)
+    todo = [Z for Z in range(86, 0, -1) if str(Z) not in done]      # heavy atoms first: better packing
+    with mp.Pool(jobs) as pool:
+        for rec in pool.imap_unordered(one_atom, todo):
+            done[str(rec["Z"])] = rec
+            with open(path + ".tmp", "w") as f:
+                json.dump(done, f, indent=0, sort_keys=True)
+            os.replace(path + ".tmp", path)
+            print("Z=%d: %d steps, finished=%s, Etotal=%.9f (%.0f s)" % (rec["Z"], rec["nsteps"], rec["finished"],
+                                                                       rec["last"]["energies"][0], rec["seconds"]), flush=True)
+
+
+def l20():
+    r = O.ref()
+    L, d, R = 20, 1.25e-5, 50.0
+    g = O.make_grid(L, d, R)
+    N = g.N
+    rr = O.grid_r(g)
+    V = screened_potential(rr, 86.0)
+    out, meta = {}, {"grid": {"L": L, "delta": d, "Rmax": R, "N": N}}
+    rng = np.random.default_rng(20261002)
+    h = r.ref_numerov_create(O.dp(V), N, d, R)
+    rows = []
+    Es = np.concatenate([-rng.uniform(1e-2, 86.0 ** 2 + 1, 10), [-3204.75, -0.29, -86.0 ** 2 / 2, 0.5, 50.0]])
+    for l in range(4):
+        for E in Es:
+            cnt = r.ref_count_nodes(h, l, float(E), 3)
+            u0 = r.ref_solution_in_zero(h, l, float(E))
+            cut = r.ref_max_radius_index(h, float(E))
+            rows.append([l, E, 3, cnt, u0, cut])
+    out["sweeps"] = np.array(rows)
+    P = np.zeros(N)
+    ms = []
+    for l, E in ((0, -3000.0), (1, -500.0), (3, -8.0)):
+        mp_ = r.ref_match(h, l, E, O.dp(P))
+        ms.append(np.concatenate([[l, E, mp_, np.nansum(P), np.nansum(np.abs(P))], P[:: N // 64][:64]]))
+    out["match"] = np.array(ms)
+    r.ref_numerov_destroy(h)
+    print("sweeps done", flush=True)
+    # one Poisson solve: Rn-like density 86 * exp(-2 r) / pi scaled to 86 electrons
+    rho = 86.0 * np.exp(-2 * rr) / np.pi
+    q = r.ref_poisson_create(L, d)
+    U = np.zeros(N)
+    t0 = time.time()
+    r.ref_solve_poisson_nonuniform(q, 86, R, O.dp(rho), N, O.dp(U))
+    r.ref_poisson_destroy(q)
+    out["poisson_U_sample"] = U[:: 64].copy()          # every 64th node: 16385 values
+    out["poisson_U_checksum"] = np.array([U.sum(), np.abs(U).sum(), U[1], U[N // 2], U[N - 2]])
+    print("poisson done %.0f s" % (time.time() - t0), flush=True)
+    np.savez_compressed(os.path.join(HERE, "l20.npz"), **out)
+    t0 = time.time()
+    txt = run_ref(1, 86, L, 0.5, R, d, max_steps=2)
+    steps = parse_run(txt)
+    meta["Rn_LSDA_L20"] = {"steps": steps[:2]}
+    print("scf done %.0f s" % (time.time() - t0), flush=True)
+    with open(os.path.join(HERE, "l20_meta.json"), "w") as f:
+        json.dump(meta, f, indent=1)
+
+
+if __name__ == "__main__":
+    what = sys.argv[1] if len(sys.argv) > 1 else "table"
+    jobs = int(sys.argv[sys.argv.index("--jobs") + 1]) if "--jobs" in sys.argv else 6
+    if what == "table":
+        table(jobs)
+    else:
+        l20()

@@ -1,0 +1,128 @@
+"""GPU suite (-m gpu): batch semantics and failure handling of the SCF driver.
+
+  * an atom that has met the reference's stop test (DFTAtom.cpp:474-479) is frozen: every atom of a batch ends in the
+    state of ITS OWN last step -- energies, eigenvalues, step count -- bit for bit what a run of that atom alone gives;
+  * the Poisson solver's groups of workgroups: a lost member (fault injection) is detected after the solve, the solve
+    is repeated with one workgroup per atom in the same process and returns the same bits.
+"""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import dftatom_amd as D                 # noqa: E402
+from golden.make_golden import GRIDS    # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = D.Context(0)
+    yield c
+    c.close()
+
+
+def _run_to_end(scf, cap=100):
+    steps = 0
+    while steps < cap:
+        scf.step(want_stats=False)
+        steps += 1
+        _, fin = scf.energies()
+        if fin.all():
+            break
+    return steps
+
+
+def test_finished_atoms_are_frozen(ctx):
+    """He, Ne, Ar on a 4097-node grid, run as one batch until ALL have finished (they stop at different steps) ==
+    each run alone until ITS stop: same energies, eigenvalues, densities and step counts, bit for bit."""
+    L, d, R = 12, 2e-3, 25.0
+    grid = D.Grid(ctx, L, d, R)
+    Zs = [2, 10, 18]
+    batch = D.Scf(ctx, grid, Zs, lsda=False)
+    nb = _run_to_end(batch)
+    eb, finb = batch.energies()
+    assert finb.all()
+    steps_alone = []
+    for k, Z in enumerate(Zs):
+        one = D.Scf(ctx, grid, [Z], lsda=False)
+        n1 = _run_to_end(one)
+        steps_alone.append(n1)
+        e1, fin1 = one.energies()
+        assert fin1[0]
+        assert eb[k].as_list() == e1[0].as_list(), Z
+        assert np.array_equal(batch.levels(k, 0)["E"].view(np.int64), one.levels(0, 0)["E"].view(np.int64)), Z
+        assert np.array_equal(batch.array(0, k).view(np.int64), one.array(0, 0).view(np.int64)), Z     # density
+        assert np.array_equal(batch.array(3, k).view(np.int64), one.array(3, 0).view(np.int64)), Z     # potential
+        one.close()
+    assert nb == max(steps_alone) and len(set(steps_alone)) > 1, steps_alone     # they really stop at different steps
+    # further steps of a finished batch change nothing
+    before = [e.as_list() for e in eb]
+    batch.step(want_stats=False)
+    after = [e.as_list() for e in batch.energies()[0]]
+    assert before == after
+    batch.close()
+    grid.close()
+
+
+def test_records_hold_each_atoms_own_stop_state(ctx):
+    import torch
+    L, d, R = 12, 2e-3, 25.0
+    grid = D.Grid(ctx, L, d, R)
+    from dftatom_amd import sweep
+    Zs = [1, 2, 4]
+    batch = D.Scf(ctx, grid, Zs, lsda=False)
+    _run_to_end(batch)
+    block = torch.zeros((len(Zs), D.RECORD_DOUBLES), dtype=torch.float64, device="cuda")
+    batch.records_into(block.data_ptr())
+    ctx.synchronize()
+    rows = block.cpu().numpy()
+    for k, Z in enumerate(Zs):
+        one = D.Scf(ctx, grid, [Z], lsda=False)
+        n1 = _run_to_end(one)
+        f = sweep.record_fields(rows[k])
+        assert f["Z"] == Z and f["finished"] and f["steps"] == n1
+        assert f["Etotal"] == one.energies()[0][0].Etotal
+        one.close()
+    batch.close()
+    grid.close()
+
+
+def test_lost_group_member_is_detected_and_solve_repeated(ctx):
+    """$DFTA_FAULT_POISSON_MEMBER=1: the last workgroup of every group returns at once, so the others time out at their
+    first barrier and raise the abort flag.  Every entry point that solves (dfta_poisson_solve, dfta_scf_create,
+    dfta_scf_step with stats == NULL) must notice, repeat the solve with one workgroup per atom and return the bits of an
+    undisturbed solve."""
+    L, d, R = GRIDS["L17"]
+    grid = D.Grid(ctx, L, d, R)
+    rr = grid.r()
+    rho = 86 * np.exp(-2 * rr) / np.pi
+    good = D.Poisson(ctx, grid, 1)
+    G, degraded, aborts = good.group_info()
+    assert G > 1 and not degraded and aborts == 0
+    U0, vc0, _ = good.solve([86], rho)
+    assert good.group_info() == (G, False, 0)
+    good.close()
+    os.environ["DFTA_FAULT_POISSON_MEMBER"] = "1"
+    try:
+        bad = D.Poisson(ctx, grid, 1)
+        U1, vc1, _ = bad.solve([86], rho)
+        assert bad.group_info() == (G, True, 1)
+        assert np.array_equal(U0.view(np.int64), U1.view(np.int64)) and np.array_equal(vc0, vc1)
+        U2, _, _ = bad.solve([86], rho)                       # stays on the one-workgroup path: no second abort
+        assert bad.group_info() == (G, True, 1) and np.array_equal(U0.view(np.int64), U2.view(np.int64))
+        bad.close()
+        scf_bad = D.Scf(ctx, grid, [18], lsda=False)          # the start potential's solve already trips it
+        assert scf_bad.poisson_info()[1:] == (True, 1)
+        scf_bad.step(want_stats=False)
+        e_bad = scf_bad.energies()[0][0].as_list()
+        scf_bad.close()
+    finally:
+        os.environ.pop("DFTA_FAULT_POISSON_MEMBER", None)
+    scf_ok = D.Scf(ctx, grid, [18], lsda=False)
+    assert scf_ok.poisson_info()[1:] == (False, 0)
+    scf_ok.step(want_stats=False)
+    assert scf_ok.energies()[0][0].as_list() == e_bad
+    scf_ok.close()
+    grid.close()
