@@ -21,6 +21,8 @@ SWEEP_KERNEL_AUTO, SWEEP_KERNEL_FUSED, SWEEP_KERNEL_PIPELINED = 0, 1, 2
 BOUNDARY_DEVICE, BOUNDARY_HOST = 0, 1
 LEVELS_CHAINED, LEVELS_BATCHED = 0, 1
 INT_TRAPEZOID, INT_SIMPSON13, INT_SIMPSON38, INT_BOOLE, INT_ROMBERG = range(5)
+XC_VWN, XC_CHACHIYO, XC_CHACHIYO_IMPROVED = range(3)
+AUFBAU_REFERENCE, AUFBAU_TRANSITION_METALS = range(2)
 RECORD_DOUBLES = 64
 
 c_dp = C.POINTER(C.c_double)
@@ -46,6 +48,10 @@ class Energies(C.Structure):
         return [self.Etotal, self.Ekinetic, self.Ecoul, self.Enuclear, self.Exc]
 
 
+class ScfOptions(C.Structure):
+    _fields_ = [("integrator", C.c_int), ("functional", C.c_int), ("aufbau", C.c_int)]
+
+
 class StepStats(C.Structure):
     _fields_ = [("sweeps_issued", C.c_long), ("sweeps_reference", C.c_long), ("points_traversed", C.c_long),
                 ("vcycles", C.c_long), ("rounds", C.c_int), ("ms_levels", C.c_float), ("ms_poisson", C.c_float),
@@ -63,6 +69,8 @@ SIGNATURES = {
     "dfta_ctx_last_kernel_ms": (C.c_int, [vp, C.POINTER(C.c_float)]),
     "dfta_ctx_set_sweep_kernel": (C.c_int, [vp, C.c_int]),
     "dfta_grid_create": (C.c_int, [vp, C.c_int, C.c_double, C.c_double, C.POINTER(vp)]),
+    "dfta_grid_create_uniform": (C.c_int, [vp, C.c_int, C.c_double, C.POINTER(vp)]),
+    "dfta_grid_is_uniform": (C.c_int, [vp]),
     "dfta_grid_destroy": (None, [vp]),
     "dfta_grid_num_nodes": (C.c_int, [vp]),
     "dfta_grid_rp": (C.c_double, [vp]),
@@ -89,10 +97,13 @@ SIGNATURES = {
     "dfta_poisson_restrict": (C.c_int, [vp, C.c_int]),
     "dfta_poisson_prolong": (C.c_int, [vp, C.c_int]),
     "dfta_poisson_vcycle": (C.c_int, [vp, c_dp]),
+    "dfta_poisson_full_cycle": (C.c_int, [vp, C.c_double, C.c_double, C.c_double, C.c_double, c_dp, c_ip]),
+    "dfta_scf_set_integrator": (C.c_int, [vp, C.c_int]),
     "dfta_vwn_lda": (C.c_int, [vp, c_dp, C.c_size_t, c_dp, c_dp]),
     "dfta_vwn_lsda": (C.c_int, [vp, c_dp, c_dp, C.c_size_t, c_dp, c_dp, c_dp, c_dp]),
     "dfta_integrate": (C.c_int, [vp, C.c_int, C.c_double, c_dp, C.c_int, C.POINTER(C.c_double)]),
     "dfta_scf_create": (C.c_int, [vp, vp, C.c_int, C.c_int, c_ip, C.c_double, C.c_int, C.c_int, C.POINTER(vp)]),
+    "dfta_scf_create_ex": (C.c_int, [vp, vp, C.c_int, C.c_int, c_ip, C.c_double, C.c_int, C.c_int, vp, C.POINTER(vp)]),
     "dfta_scf_destroy": (None, [vp]),
     "dfta_scf_step": (C.c_int, [vp, C.POINTER(StepStats)]),
     "dfta_scf_get_energies": (C.c_int, [vp, C.POINTER(Energies), c_ip]),
@@ -102,6 +113,9 @@ SIGNATURES = {
     "dfta_scf_get_array": (C.c_int, [vp, C.c_int, C.c_int, c_dp]),
     "dfta_scf_get_records_dev": (C.c_int, [vp, vp]),
     "dfta_get_subshells": (C.c_int, [C.c_int, c_ip, c_ip, c_ip, C.c_int]),
+    "dfta_get_subshells_ex": (C.c_int, [C.c_int, C.c_int, c_ip, c_ip, c_ip, C.c_int]),
+    "dfta_split_spin_ex": (C.c_int, [C.c_int, C.c_int, c_ip, c_ip, c_ip, c_ip, c_ip, c_ip, c_ip, c_ip, C.c_int]),
+    "dfta_chachiyo_lda": (C.c_int, [vp, C.c_int, c_dp, C.c_size_t, c_dp, c_dp]),
     "dfta_split_spin": (C.c_int, [C.c_int, c_ip, c_ip, c_ip, c_ip, c_ip, c_ip, c_ip, c_ip, C.c_int]),
 }
 
@@ -182,12 +196,18 @@ class Context:
 
 
 class Grid:
+    """Logarithmic grid r_i = Rp (exp(i delta) - 1), or -- delta = None / 0 -- the uniform grid r_i = i Rmax / (N - 1)."""
+
     def __init__(self, ctx, mg_levels, delta, Rmax):
         self.ctx = ctx
         h = vp()
-        ctx.check(ctx.lib.dfta_grid_create(ctx.h, mg_levels, delta, Rmax, C.byref(h)))
+        self.uniform = not delta
+        if self.uniform:
+            ctx.check(ctx.lib.dfta_grid_create_uniform(ctx.h, mg_levels, Rmax, C.byref(h)))
+        else:
+            ctx.check(ctx.lib.dfta_grid_create(ctx.h, mg_levels, delta, Rmax, C.byref(h)))
         self.h = h
-        self.levels, self.delta, self.Rmax = mg_levels, delta, Rmax
+        self.levels, self.delta, self.Rmax = mg_levels, (delta or 0.0), Rmax
         self.N = ctx.lib.dfta_grid_num_nodes(h)
         self.Rp = ctx.lib.dfta_grid_rp(h)
 
@@ -232,10 +252,10 @@ def numerov_match(ctx, grid, V, l, E, vidx=None, boundary=BOUNDARY_HOST):
     return psi, mp
 
 
-def get_subshells(Z):
+def get_subshells(Z, aufbau=AUFBAU_REFERENCE):
     lib = load()
     n, l, occ = (np.zeros(32, np.int32) for _ in range(3))
-    c = lib.dfta_get_subshells(Z, _ip(n), _ip(l), _ip(occ), 32)
+    c = lib.dfta_get_subshells_ex(Z, aufbau, _ip(n), _ip(l), _ip(occ), 32)
     if c < 0:
         raise DftaError("dfta_get_subshells(%d) failed" % Z)
     return [(int(n[i]), int(l[i]), int(occ[i])) for i in range(c)]
@@ -335,6 +355,12 @@ class Poisson:
         self.ctx.check(self.ctx.lib.dfta_poisson_vcycle(self.h, _dp(err)))
         return err[0]
 
+    def full_cycle(self, low, high, error_min=1e-3, error_min_last=1e-14):
+        """SetBoundaries + FullCycle on the source left by the last solve: returns (err, V-cycles)."""
+        err, vc = C.c_double(), C.c_int()
+        self.ctx.check(self.ctx.lib.dfta_poisson_full_cycle(self.h, low, high, error_min, error_min_last, C.byref(err), C.byref(vc)))
+        return err.value, vc.value
+
     def close(self):
         if self.h:
             self.ctx.lib.dfta_poisson_destroy(self.h)
@@ -348,6 +374,13 @@ def vwn_lda(ctx, n):
     return v, e
 
 
+def chachiyo_lda(ctx, n, improved=True):
+    n = _f64(n)
+    v, e = np.zeros_like(n), np.zeros_like(n)
+    ctx.check(ctx.lib.dfta_chachiyo_lda(ctx.h, int(improved), _dp(n), n.size, _dp(v), _dp(e)))
+    return v, e
+
+
 def vwn_lsda(ctx, na, nb):
     na, nb = _f64(na), _f64(nb)
     r, va, vb, e = (np.zeros_like(na) for _ in range(4))
@@ -358,14 +391,16 @@ def vwn_lsda(ctx, na, nb):
 class Scf:
     """Device-resident SCF state of a batch of atoms (dfta_scf): the body of CalculateNonUniformLDA/LSDA."""
 
-    def __init__(self, ctx, grid, Z, lsda=False, alpha=0.5, levels_mode=LEVELS_BATCHED, tree_depth=0):
+    def __init__(self, ctx, grid, Z, lsda=False, alpha=0.5, levels_mode=LEVELS_BATCHED, tree_depth=0, integrator=INT_SIMPSON38,
+                 functional=XC_VWN, aufbau=AUFBAU_REFERENCE):
         self.ctx, self.grid = ctx, grid
         self.Z = _i32(np.atleast_1d(Z))
         self.natoms = len(self.Z)
         self.lsda = bool(lsda)
         h = vp()
-        ctx.check(ctx.lib.dfta_scf_create(ctx.h, grid.h, int(self.lsda), self.natoms, _ip(self.Z), alpha, levels_mode,
-                                          tree_depth, C.byref(h)))
+        opt = ScfOptions(integrator, functional, aufbau)
+        ctx.check(ctx.lib.dfta_scf_create_ex(ctx.h, grid.h, int(self.lsda), self.natoms, _ip(self.Z), alpha, levels_mode,
+                                             tree_depth, C.cast(C.byref(opt), vp), C.byref(h)))
         self.h = h
         d, nj, tr = C.c_int(), C.c_int(), C.c_long()
         ctx.check(ctx.lib.dfta_scf_info(h, C.byref(d), C.byref(nj), C.byref(tr)))
@@ -394,6 +429,10 @@ class Scf:
         out = np.zeros(self.grid.N)
         self.ctx.check(self.ctx.lib.dfta_scf_get_array(self.h, atom, which, _dp(out)))
         return out
+
+    def set_integrator(self, rule):
+        """INT_TRAPEZOID .. INT_ROMBERG: quadrature of the energy integrals and of the orbitals' normalisation."""
+        self.ctx.check(self.ctx.lib.dfta_scf_set_integrator(self.h, int(rule)))
 
     def poisson_info(self):
         g, d, a = C.c_int(), C.c_int(), C.c_int()

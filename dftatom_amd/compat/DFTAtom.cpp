@@ -12,6 +12,7 @@ namespace DFT {
 
 const char DFTAtom::orb[] = {'s', 'p', 'd', 'f'};
 int DFTAtom::levelsMode = DFTA_LEVELS_BATCHED;
+int DFTAtom::integrator = DFTA_INT_SIMPSON38;
 
 namespace {
 struct LevelLine { int n, l, occ; double E; };
@@ -36,21 +37,29 @@ void print_configuration(std::vector<LevelLine> levels)
 }
 }  // namespace
 
-void DFTAtom::Run(bool lsda, int Z, int MultigridLevels, double alpha, double MaxR, double deltaGrid)
+void DFTAtom::Run(bool lsda, bool uniform, int Z, int MultigridLevels, double alpha, double MaxR, double deltaGrid)
 {
     auto& rt = dfta_compat::Runtime::instance();
-    dfta_grid* grid = rt.grid(MultigridLevels, deltaGrid, MaxR);
-    std::cout << "Computing atom with Z=" << Z << (lsda ? " using LSDA with non-uniform grid" : " using LSD with non-uniform grid") << std::endl;
+    dfta_grid* grid = uniform ? rt.uniform_grid(MultigridLevels, MaxR) : rt.grid(MultigridLevels, deltaGrid, MaxR);
+    // banners of DFTAtom.cpp:70,358,658,857 (the non-uniform LDA one does say "LSD")
+    std::cout << "Computing atom with Z=" << Z
+              << (uniform ? (lsda ? " using LSDA with uniform grid" : " using LDA with uniform grid")
+                          : (lsda ? " using LSDA with non-uniform grid" : " using LSD with non-uniform grid")) << std::endl;
 
     dfta_scf* scf = nullptr;
     dfta_compat::check(dfta_scf_create(rt.ctx(), grid, lsda ? 1 : 0, 1, &Z, alpha, levelsMode, 0, &scf), rt.ctx(), "dfta_scf_create");
+    dfta_compat::check(dfta_scf_set_integrator(scf, integrator), rt.ctx(), "dfta_scf_set_integrator");
     const int maxSteps = lsda ? 150 : 100;                                  // DFTAtom.cpp:396 / 908
     for (int sp = 0; sp < maxSteps; ++sp) {
         std::cout << "Step: " << sp << std::endl;
         dfta_compat::check(dfta_scf_step(scf, nullptr), rt.ctx(), "dfta_scf_step");
         for (int spin = 0; spin < (lsda ? 2 : 1); ++spin)
-            for (const auto& lv : fetch_levels(scf, spin))                 // DFTAtom.cpp:548-556 (the alpha/beta tag is lost on this path)
-                std::cout << "Energy " << lv.n + 1 << orb[lv.l] << ": " << std::fixed << std::setprecision(6) << lv.E << " Num nodes: " << lv.n - lv.l << std::endl;
+            for (const auto& lv : fetch_levels(scf, spin)) {
+                // DFTAtom.cpp:548-556: the non-uniform path loses the alpha/beta tag, the uniform one prints it (DFTAtom.cpp:266-273,698,717)
+                std::cout << "Energy ";
+                if (lsda && uniform) std::cout << (spin == 0 ? "alpha " : "beta ");
+                std::cout << lv.n + 1 << orb[lv.l] << ": " << std::fixed << std::setprecision(6) << lv.E << " Num nodes: " << lv.n - lv.l << std::endl;
+            }
         dfta_energies e;
         int finished = 0;
         dfta_compat::check(dfta_scf_get_energies(scf, &e, &finished), rt.ctx(), "dfta_scf_get_energies");
@@ -72,12 +81,10 @@ void DFTAtom::Run(bool lsda, int Z, int MultigridLevels, double alpha, double Ma
     dfta_scf_destroy(scf);
 }
 
-void DFTAtom::CalculateNonUniformLDA(int Z, int MultigridLevels, double alpha, double MaxR, double deltaGrid) { Run(false, Z, MultigridLevels, alpha, MaxR, deltaGrid); }
-void DFTAtom::CalculateNonUniformLSDA(int Z, int MultigridLevels, double alpha, double MaxR, double deltaGrid) { Run(true, Z, MultigridLevels, alpha, MaxR, deltaGrid); }
-
-// the uniform-grid entry points are unreachable from the reference's GUI (DFTAtomFrame.cpp:191,194 are commented out) and
-// outside the accelerated hot path
-void DFTAtom::CalculateUniformLDA(int, int, double, double) { throw std::runtime_error("CalculateUniformLDA: uniform grid is not part of the HIP hot path"); }
-void DFTAtom::CalculateUniformLSDA(int, int, double, double) { throw std::runtime_error("CalculateUniformLSDA: uniform grid is not part of the HIP hot path"); }
+void DFTAtom::CalculateNonUniformLDA(int Z, int MultigridLevels, double alpha, double MaxR, double deltaGrid) { Run(false, false, Z, MultigridLevels, alpha, MaxR, deltaGrid); }
+void DFTAtom::CalculateNonUniformLSDA(int Z, int MultigridLevels, double alpha, double MaxR, double deltaGrid) { Run(true, false, Z, MultigridLevels, alpha, MaxR, deltaGrid); }
+// DFTAtom.cpp:60-210, 646-844: the same SCF on r_i = i h (unreachable from the reference's GUI, DFTAtomFrame.cpp:191,194, but part of its surface)
+void DFTAtom::CalculateUniformLDA(int Z, int MultigridLevels, double alpha, double MaxR) { Run(false, true, Z, MultigridLevels, alpha, MaxR, 0); }
+void DFTAtom::CalculateUniformLSDA(int Z, int MultigridLevels, double alpha, double MaxR) { Run(true, true, Z, MultigridLevels, alpha, MaxR, 0); }
 
 }  // namespace DFT

@@ -1,13 +1,19 @@
-// Numerov.h -- DFT::Potential, DFT::NumerovFunctionNonUniformGrid and DFT::Numerov<> with the reference's surface
-// (reference Numerov.h:7-13, 73-196, 199-518), executed by the batched HIP sweep kernels through the C ABI.
+// Numerov.h -- DFT::Potential, the two grid functors and DFT::Numerov<> with the reference's surface
+// (reference Numerov.h:7-13, 16-70, 73-196, 199-518), executed by the batched HIP sweep kernels through the C ABI.
 //
 // Semantics kept from the reference: Numerov stores a REFERENCE to the caller's Potential and re-reads it on every
-// call (Numerov.h:69,186); `startPoint`/`steps` are accepted and, as in the reference's non-uniform path, only the
-// grid size matters (Numerov.h:283-291).  Boundary values are evaluated on the host with libm exactly as the
-// reference does (DFTA_BOUNDARY_HOST), so node counts, u(0) and Psi are bit-identical to the reference's.
+// call (Numerov.h:69,186).  `startPoint`/`steps` must describe the whole grid, which is how DFTAtom.cpp always calls
+// (N-1 / N-1 on the logarithmic grid, MaxR / N-1 on the uniform one); the cut-off is then derived per trial as in
+// Numerov.h:274-291.  Boundary values are evaluated on the host with libm exactly as the reference does
+// (DFTA_BOUNDARY_HOST), so node counts, u(0) and Psi are bit-identical to the reference's.
+// The functors' own public methods (f(i), boundary values, cut-off) are kept for callers that use them directly; the
+// kernels evaluate the same expressions from tables and never call back into them.
 // Extension (not in the reference): the *Batch methods integrate many (l, E) trials in one launch.
 #pragma once
 
+#include <math.h>
+
+#include <algorithm>
 #include <vector>
 
 #include "dfta_runtime.h"
@@ -20,15 +26,75 @@ public:
     std::vector<double> m_potentialValues;
 };
 
-// carries the grid parameters; f(i), boundary values and the cut-off index are evaluated inside the kernels
+// r_i = i h (reference Numerov.h:16-70); the grid handle carries h = Rmax / (numPoints - 1)
+class NumerovFunctionRegularGrid {
+public:
+    NumerovFunctionRegularGrid(const Potential& pot, double /*delta*/, double Rmax, size_t numPoints) : m_pot(pot), m_numPoints(numPoints)
+    {
+        m_grid = dfta_compat::Runtime::instance().uniform_grid(dfta_compat::Runtime::levels_for_nodes(numPoints), Rmax);
+    }
+    inline double GetEffectivePotential(unsigned int l, double position, size_t posIndex) const { return m_pot(posIndex) + l * (l + 1.) / (position * position) * 0.5; }
+    inline double operator()(unsigned int l, double E, double position, size_t posIndex) const { return 2. * (GetEffectivePotential(l, position, posIndex) - E); }
+    inline static double GetBoundaryValueFar(double position, double E) { return exp(-position * sqrt(2. * fabs(E))); }
+    inline static double GetBoundaryValueZero(double position, unsigned int l) { return pow(position, static_cast<double>(l) + 1.); }
+    inline static double GetMaxRadius(double E, size_t /*maxIndex*/) { return 200. / sqrt(2. * fabs(E)); }
+    inline static double GetMaxRadiusIndex(double E, size_t maxIndex, double stepSize) { return std::min(GetMaxRadius(E, maxIndex) / stepSize, static_cast<double>(maxIndex)); }
+    inline static double GetDerivativeStep(int /*posIndex*/, double h) { return h; }
+    inline static double GetWavefunctionValue(size_t /*posIndex*/, double value) { return value; }
+    inline static bool IsUniform() { return true; }
+    const Potential& potential() const { return m_pot; }
+    dfta_grid* grid() const { return m_grid; }
+    size_t numPoints() const { return m_numPoints; }
+
+protected:
+    const Potential& m_pot;
+    const size_t m_numPoints;
+    dfta_grid* m_grid = nullptr;
+};
+
+// r_i = Rp (exp(i delta) - 1) (reference Numerov.h:73-196)
 class NumerovFunctionNonUniformGrid {
 public:
     NumerovFunctionNonUniformGrid(const Potential& pot, double delta, double Rmax, size_t numPoints)
         : m_pot(pot), m_delta(delta), m_Rmax(Rmax), m_numPoints(numPoints)
     {
         m_grid = dfta_compat::Runtime::instance().grid(dfta_compat::Runtime::levels_for_nodes(numPoints), delta, Rmax);
+        Rp = dfta_grid_rp(m_grid);
     }
-    inline double GetRp() const { return dfta_grid_rp(m_grid); }
+    inline double GetEffectivePotential(unsigned int l, double /*position*/, size_t posIndex) const
+    {
+        const double position = GetPosition(posIndex);
+        return m_pot(posIndex) + l * (l + 1.) / (position * position) * 0.5;
+    }
+    inline double operator()(unsigned int l, double E, double position, size_t posIndex) const
+    {
+        return 2. * (GetEffectivePotential(l, position, posIndex) - E) * (Rp * Rp * (m_delta * m_delta)) * exp(posIndex * (2. * m_delta)) + m_delta * m_delta * 0.25;
+    }
+    inline double GetBoundaryValueFar(double position, double E) const
+    {
+        return exp(-GetPosition(static_cast<int>(position)) * sqrt(2. * fabs(E)) - position * m_delta * 0.5);
+    }
+    inline double GetBoundaryValueZero(double position, unsigned int l) const
+    {
+        return pow(GetPosition(static_cast<int>(position)), static_cast<double>(l) + 1) * exp(-position * m_delta * 0.5);
+    }
+    inline double GetMaxRadiusIndex(double E, size_t maxIndex, double /*stepSize*/) const
+    {
+        size_t minIndex = 1;
+        while (maxIndex - minIndex > 1) {
+            const size_t midIndex = (maxIndex + minIndex) / 2;
+            if (GetBoundaryValueFar(static_cast<double>(midIndex), E) < 1E-200) maxIndex = midIndex; else minIndex = midIndex;
+        }
+        return static_cast<double>(maxIndex);
+    }
+    inline double GetMaxRadius(double E, size_t maxIndex) const
+    {
+        if (GetBoundaryValueFar(static_cast<double>(maxIndex), E) > 1E-200) return GetPosition(maxIndex);
+        return GetPosition(static_cast<size_t>(GetMaxRadiusIndex(E, maxIndex, 1)));
+    }
+    inline double GetDerivativeStep(int posIndex, double /*h*/) const { return Rp * exp(posIndex * m_delta) * (1. - exp(-m_delta)); }
+    inline double GetWavefunctionValue(size_t posIndex, double value) const { return exp(static_cast<double>(posIndex) * m_delta * 0.5) * value; }
+    inline double GetRp() const { return Rp; }
     inline double GetDelta() const { return m_delta; }
     inline static bool IsUniform() { return false; }
     const Potential& potential() const { return m_pot; }
@@ -36,9 +102,11 @@ public:
     size_t numPoints() const { return m_numPoints; }
 
 private:
+    inline double GetPosition(size_t posIndex) const { return Rp * (exp(static_cast<double>(posIndex) * m_delta) - 1.); }
     const Potential& m_pot;
     const double m_delta, m_Rmax;
     const size_t m_numPoints;
+    double Rp = 0;
     dfta_grid* m_grid = nullptr;
 };
 
@@ -47,22 +115,25 @@ public:
     Numerov(const Potential& pot, double delta = 0, double Rmax = 0, size_t numPoints = 0) : function(pot, delta, Rmax, numPoints) {}
 
     // reference Numerov.h:272-349
-    inline void SolveSchrodingerCountNodes(double /*startPoint*/, unsigned int l, double E, long int /*steps*/, long int nodesLimit, int& nodesCount)
+    inline void SolveSchrodingerCountNodes(double /*startPoint*/, unsigned int l, double E, long int steps, long int nodesLimit, int& nodesCount)
     {
+        whole_grid(steps);
         const int li = static_cast<int>(l), lim = static_cast<int>(nodesLimit);
         run(DFTA_SWEEP_COUNT, 1, &li, &E, &lim, &nodesCount, nullptr);
     }
     // reference Numerov.h:351-401
-    inline double SolveSchrodingerSolutionInZero(double /*startPoint*/, unsigned int l, double E, long int /*steps*/)
+    inline double SolveSchrodingerSolutionInZero(double /*startPoint*/, unsigned int l, double E, long int steps)
     {
+        whole_grid(steps);
         const int li = static_cast<int>(l);
         double u0 = 0;
         run(DFTA_SWEEP_ZERO, 1, &li, &E, nullptr, nullptr, &u0);
         return u0;
     }
     // reference Numerov.h:403-504
-    inline std::vector<double> SolveSchrodingerMatchSolutionCompletely(double /*startPoint*/, unsigned int l, double E, long int /*steps*/, long int& matchPoint)
+    inline std::vector<double> SolveSchrodingerMatchSolutionCompletely(double /*startPoint*/, unsigned int l, double E, long int steps, long int& matchPoint)
     {
+        whole_grid(steps);
         auto& rt = dfta_compat::Runtime::instance();
         const std::vector<double>& V = function.potential().m_potentialValues;
         std::vector<double> Psi(V.size());
@@ -89,6 +160,10 @@ public:
     NumerovFunction function;
 
 private:
+    void whole_grid(long int steps) const
+    {
+        if (static_cast<size_t>(steps) + 1 != function.numPoints()) throw std::runtime_error("Numerov: steps must be numPoints - 1 (the whole grid)");
+    }
     void run(int kind, int n, const int* l, const double* E, const int* limit, int* counts, double* u0)
     {
         auto& rt = dfta_compat::Runtime::instance();

@@ -39,6 +39,16 @@ public:
         m_grids[key] = g;
         return g;
     }
+    dfta_grid* uniform_grid(int levels, double Rmax)
+    {
+        const auto key = std::make_tuple(levels, 0.0, Rmax);     // delta == 0 marks the uniform grid (as PoissonSolver's dGrid does)
+        auto it = m_grids.find(key);
+        if (it != m_grids.end()) return it->second;
+        dfta_grid* g = nullptr;
+        check(dfta_grid_create_uniform(m_ctx, levels, Rmax, &g), m_ctx, "dfta_grid_create_uniform");
+        m_grids[key] = g;
+        return g;
+    }
     // multigrid levels for a node count 2^L + 1 (PoissonSolver.h:127-135 inverted)
     static int levels_for_nodes(size_t numPoints)
     {

@@ -59,6 +59,10 @@ struct dfta_grid {
     int levels = 0;
     int N = 0;
     double delta = 0, Rmax = 0, Rp = 0, twodelta = 0, Rp2delta2 = 0, delta2p4 = 0;
+    // uniform grid r_i = i h (NumerovFunctionRegularGrid, Numerov.h:16-70): delta = 0, h = Rmax / (N - 1); the tables
+    // keep their meaning with exp(...) == 1 (d_eh, d_cnst are all ones), so the SCF kernels need no second flavour
+    int uniform = 0;
+    double h = 1, h2 = 1, h2p12 = 1. / 12.;   // step of the Numerov recurrence (1 on the logarithmic grid, Numerov.h:285-287)
     double far_arg_threshold = 0;   // exp(a) < 1e-200  <=>  a < far_arg_threshold (host libm, monotone)
     double zero1[4] = {0, 0, 0, 0};  // GetBoundaryValueZero(1, l), l = 0..3 (Numerov.h:110-116)
     // host copies
@@ -72,6 +76,7 @@ struct dfta_grid {
     double* d_cnst = nullptr;   // (Rp delta) exp(delta i)            (DFTAtom.cpp:47,442)
     double* d_psrc = nullptr;   // (4 pi Rp^2 delta^2) exp(i 2delta)  (PoissonSolver.h:66-74)
     double* d_fpr2 = nullptr;   // (4 pi r_i) r_i                     (DFTAtom.cpp:340)
+    double* d_rsrc = nullptr;   // the r factor of the Poisson source: d_r, or FillR's (Rmax i) / (N-1) on a uniform grid (PoissonSolver.cpp:200-210)
 };
 
 template <typename T>

@@ -167,6 +167,66 @@ int dfta_grid_create(dfta_ctx* ctx, int mg_levels, double delta, double Rmax, df
         }
     }
     DFTA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    g->d_rsrc = g->d_r;
+    *out = g;
+    return DFTA_OK;
+}
+
+// Uniform grid r_i = i h, h = MaxR / NumSteps (DFTAtom.cpp:66-68, NumerovFunctionRegularGrid Numerov.h:16-70).
+int dfta_grid_create_uniform(dfta_ctx* ctx, int mg_levels, double Rmax, dfta_grid** out)
+{
+    if (!ctx || !out) return DFTA_ERR_INVALID;
+    if (int rc_ = dfta_use(ctx)) return rc_;
+    DFTA_REQUIRE(ctx, mg_levels >= 3 && mg_levels <= 24 && Rmax > 0, "grid parameters");
+    dfta_grid* g = new dfta_grid();
+    g->ctx = ctx;
+    g->levels = mg_levels;
+    const int N = dfta_num_nodes(mg_levels);
+    g->N = N;
+    g->uniform = 1;
+    g->delta = 0;
+    g->Rmax = Rmax;
+    g->Rp = 0;
+    const long steps = N - 1;
+    g->h = Rmax / steps;                         // Numerov.h:276 (h = startPoint / steps), DFTAtom.cpp:68
+    g->h2 = g->h * g->h;
+    g->h2p12 = g->h2 / 12.;
+    g->Rp2delta2 = 1; g->delta2p4 = 0; g->twodelta = 0;
+    g->far_arg_threshold = far_threshold();
+    std::vector<double>&r = g->h_r, &e1 = g->h_e1, &e2 = g->h_e2, &eh = g->h_eh;
+    r.resize(N); e1.assign(N, 1.0); e2.assign(N, 1.0); eh.assign(N, 1.0);
+    std::vector<double> cl(static_cast<size_t>(4) * N, 0.0), cnst(N, 1.0), psrc(N), fpr2(N), rsrc(N);
+    const double fourM_PI = 4. * M_PI;
+    {
+        // PoissonSolver::FillR(Source, 0, maxRadius) (PoissonSolver.cpp:200-210) and the factor of PoissonSolver.h:26-40
+        const size_t Nn = static_cast<size_t>(N) - 1;
+        for (size_t i = 0; i < static_cast<size_t>(N); ++i) rsrc[i] = (0.0 * (Nn - i) + Rmax * i) / Nn;
+        const double dl = rsrc[1] - rsrc[0];
+        const double delta2fourM_PI = (dl * dl) * fourM_PI;
+        for (int i = 0; i < N; ++i) psrc[i] = delta2fourM_PI;
+    }
+    for (int i = 0; i < N; ++i) {
+        r[i] = g->h * i;                                           // Numerov.h:313 (position = h * i), DFTAtom.cpp:102,126
+        fpr2[i] = fourM_PI * r[i] * r[i];                          // DFTAtom.cpp:132
+        if (i > 0)
+            for (unsigned l = 1; l < 4; ++l)
+                cl[static_cast<size_t>(l) * N + i] = l * (l + 1.) / (r[i] * r[i]) * 0.5;   // Numerov.h:23
+    }
+    for (unsigned l = 0; l < 4; ++l) g->zero1[l] = pow(g->h, static_cast<double>(l) + 1.);   // Numerov.h:38-41 at position = h (sweeps keep h; the match solve re-derives it)
+    struct Up { double** d; const double* h; size_t n; } ups[] = {
+        {&g->d_r, r.data(), (size_t)N}, {&g->d_e1, e1.data(), (size_t)N}, {&g->d_e2, e2.data(), (size_t)N},
+        {&g->d_eh, eh.data(), (size_t)N}, {&g->d_cl, cl.data(), (size_t)4 * N}, {&g->d_cnst, cnst.data(), (size_t)N},
+        {&g->d_psrc, psrc.data(), (size_t)N}, {&g->d_fpr2, fpr2.data(), (size_t)N}, {&g->d_rsrc, rsrc.data(), (size_t)N}};
+    for (auto& u : ups) {
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(u.d), u.n * sizeof(double));
+        if (e == hipSuccess) e = hipMemcpyAsync(*u.d, u.h, u.n * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+        if (e != hipSuccess) {
+            snprintf(ctx->err, sizeof(ctx->err), "grid upload: %s", hipGetErrorString(e));
+            dfta_grid_destroy(g);
+            return DFTA_ERR_HIP;
+        }
+    }
+    DFTA_HIP(ctx, hipStreamSynchronize(ctx->stream));
     *out = g;
     return DFTA_OK;
 }
@@ -174,10 +234,13 @@ int dfta_grid_create(dfta_ctx* ctx, int mg_levels, double delta, double Rmax, df
 void dfta_grid_destroy(dfta_grid* g)
 {
     if (!g) return;
-    double* ptrs[] = {g->d_r, g->d_e1, g->d_e2, g->d_eh, g->d_cl, g->d_cnst, g->d_psrc, g->d_fpr2};
+    if (g->d_rsrc == g->d_r) g->d_rsrc = nullptr;
+    double* ptrs[] = {g->d_r, g->d_e1, g->d_e2, g->d_eh, g->d_cl, g->d_cnst, g->d_psrc, g->d_fpr2, g->d_rsrc};
     for (double* p : ptrs) if (p) (void)hipFree(p);
     delete g;
 }
+
+int dfta_grid_is_uniform(const dfta_grid* g) { return g ? g->uniform : 0; }
 
 int dfta_grid_num_nodes(const dfta_grid* g) { return g ? g->N : 0; }
 double dfta_grid_rp(const dfta_grid* g) { return g ? g->Rp : 0.0; }
@@ -200,7 +263,22 @@ static void adjust_f_block(int& nrElectrons, int Z, int N, int L)
     } else if (Z == 103 && N == 5 && L == 2) nrElectrons = 0;              // Lr
 }
 
-int dfta_get_subshells(int Z, int* n, int* l, int* occ, int cap)
+// AufbauPrinciple.h:78-99,119-127: the s shell under a d shell that the Madelung rule leaves one (Pd: two) short hands
+// the electron(s) over.  The reference defines this adjustment but never calls it (Cr comes out as 3d4 4s2); here it is an
+// option, applied once, after the clamp to the electrons that are left (an s shell is never clamped, so once is enough).
+static void adjust_transition_metal(int& nrElectrons, int Z, int N, int L)
+{
+    if (L != 0) return;
+    const bool one = (Z == 24 || Z == 29 || Z == 41 || Z == 42 || Z == 44 || Z == 45 || Z == 47 || Z == 78 || Z == 79);
+    if (one) {
+        const int outer_s = Z <= 29 ? 3 : (Z <= 47 ? 4 : 5);              // 4s, 5s, 6s
+        if (N == outer_s) --nrElectrons;
+    } else if (Z == 46 && N == 4) nrElectrons -= 2;                        // Pd: 4d10 5s0
+}
+
+int dfta_get_subshells(int Z, int* n, int* l, int* occ, int cap) { return dfta_get_subshells_ex(Z, DFTA_AUFBAU_REFERENCE, n, l, occ, cap); }
+
+int dfta_get_subshells_ex(int Z, int aufbau, int* n, int* l, int* occ, int cap)
 {
     if (Z < 1 || !n || !l || !occ) return -1;
     struct S { int n, l, occ; };
@@ -215,6 +293,7 @@ int dfta_get_subshells(int Z, int* n, int* l, int* occ, int cap)
             adjust_f_block(e, Z, N, L);
             if (Z - electronCount < e) e = Z - electronCount;
             adjust_f_block(e, Z, N, L);
+            if (aufbau == DFTA_AUFBAU_TRANSITION_METALS) adjust_transition_metal(e, Z, N, L);
             if (e > 0) { electronCount += e; lv.push_back({N, L, e}); }
             if (electronCount == Z) { stop = true; break; }
         }
@@ -226,8 +305,13 @@ int dfta_get_subshells(int Z, int* n, int* l, int* occ, int cap)
 
 int dfta_split_spin(int Z, int* nA, int* nB, int* an, int* al, int* aocc, int* bn, int* bl, int* bocc, int cap)
 {
+    return dfta_split_spin_ex(Z, DFTA_AUFBAU_REFERENCE, nA, nB, an, al, aocc, bn, bl, bocc, cap);
+}
+
+int dfta_split_spin_ex(int Z, int aufbau, int* nA, int* nB, int* an, int* al, int* aocc, int* bn, int* bl, int* bocc, int cap)
+{
     if (!nA || !nB) return DFTA_ERR_INVALID;
-    const int cnt = dfta_get_subshells(Z, an, al, aocc, cap);
+    const int cnt = dfta_get_subshells_ex(Z, aufbau, an, al, aocc, cap);
     if (cnt < 0) return DFTA_ERR_INVALID;
     int m = 0;
     for (int i = 0; i < cnt; ++i) {

@@ -7,8 +7,10 @@
 int dfta_bounds_stride(const dfta_grid* g);
 int dfta_launch_build_tab(dfta_ctx* ctx, const dfta_grid* g, double2* tab, const double* dV, const int* d_slot_v,
                           const int* d_slot_l, int nslots, double2* bounds /* nslots, may be null */);
+// for_match / dL / dUz: uniform grid only -- the match solve re-derives its step from the truncated step count, so its
+// second start value differs from a sweep's, and it needs GetBoundaryValueZero(h', l) per trial (Numerov.h:430,475)
 int dfta_launch_boundary(dfta_ctx* ctx, const dfta_grid* g, const double* dE, int ntrials, int* dStart, double* dUs,
-                         double* dUs1);
+                         double* dUs1, int for_match = 0, const int* dL = nullptr, double* dUz = nullptr);
 // flag in SweepArgs::istop (numerov.hip): the sweep left CountNodes because the count exceeded the limit
 constexpr int kStopOver = 0x40000000;
 
@@ -16,11 +18,15 @@ int dfta_launch_sweep(dfta_ctx* ctx, const dfta_grid* g, int kind, const int* bl
                       const int* blk_slot, const int* blk_first, const int* blk_cnt, const double* dE, const int* dLimit,
                       const int* dStart, const double* dUs, const double* dUs1, int* dCount, double* dU0, int* dTrip,
                       unsigned long long* dTotalTrips, const double2* bounds /* per slot, may be null */,
-                      double* dPhi = nullptr, int* dIstop = nullptr /* SweepArgs::phi / istop, may be null */);
+                      double* dPhi = nullptr, int* dIstop = nullptr /* SweepArgs::phi / istop, may be null */,
+                      const int* d_slot_l = nullptr /* uniform grid: l per table slot */);
 int dfta_launch_match(dfta_ctx* ctx, const dfta_grid* g, int ntrials, const double2* tab, const int* d_trial_slot,
                       const double* dE, const int* dStart, const double* dUs, const double* dUs1, const int* dL,
-                      double* dPsi, double* dQ, int* dMatch, const double2* bounds /* per slot (dfta_bounds_stride), may be null */);
+                      double* dPsi, double* dQ, int* dMatch, const double2* bounds /* per slot (dfta_bounds_stride), may be null */,
+                      const double* dUz = nullptr /* uniform grid: start value at the first node per trial */);
 
-// reduce.hip: Integral::Simpson38 (Integral.h:50-73) with the reference's sequential summation order, one wave
-// per vector: out[k] = Simpson38(1, vals + k*stride) for k < nvec
-int dfta_launch_simpson38_ordered(dfta_ctx* ctx, const double* dVals, int n, int nvec, size_t stride, double* dOut);
+// reduce.hip: Integral::{Trapezoid,SimpsonOneThird,Simpson38,Boole,Romberg} (Integral.h:11-155) with the reference's
+// sequential summation order, one wave per vector: out[k] = rule(delta, vals + k*stride) for k < nvec
+int dfta_launch_integrate_ordered(dfta_ctx* ctx, int rule /* DFTA_INT_* */, double delta, const double* dVals, int n, int nvec,
+                                  size_t stride, double* dOut);
+int dfta_integral_shape_ok(int rule, int sz);

@@ -81,6 +81,7 @@ struct LevelSolver {
     std::vector<Job> h_last;       // job records of the previous solve (source of the path predictions)
     bool use_prediction = true;
     int debug_rounds = 0;          // $DFTA_DEBUG_ROUNDS, read once in setup()
+    int integ_rule = DFTA_INT_SIMPSON38;   // quadrature of the normalisation integral (the reference calls Simpson38: DFTAtom.cpp:27,51)
     Job* d_jobs = nullptr;
     int *d_chain_off = nullptr, *d_chain_off_b = nullptr, *d_v_off = nullptr, *d_slot_v = nullptr, *d_slot_l = nullptr;
     double2* d_tab = nullptr;

@@ -75,7 +75,7 @@ __global__ __launch_bounds__(256) void k_expand(const dfta::Job* __restrict__ jo
                                                 int N, double delta, double far_thr, double* __restrict__ E,
                                                 int* __restrict__ limit, int* __restrict__ start, double* __restrict__ us,
                                                 double* __restrict__ us1, int* __restrict__ wave_kind,
-                                                unsigned long long* __restrict__ issued)
+                                                unsigned long long* __restrict__ issued, int uniform, double Rmax, double hstep)
 {
     const int gt = blockIdx.x * blockDim.x + threadIdx.x;
     if (gt >= ntrials) return;       // ntrials is a multiple of 64: whole waves leave
@@ -151,7 +151,15 @@ __global__ __launch_bounds__(256) void k_expand(const dfta::Job* __restrict__ jo
     E[gt] = e;
     limit[gt] = j.nodes;
     int st = 0;
-    if (active) {
+    if (active && uniform) {
+        // uniform grid (Numerov.h:32-35,43-56,274-296): start at min(Rmax, 200 / sqrt(2|E|)), index (long)(startPoint / h)
+        const double s = sqrt(2. * fabs(e));
+        const double mr = 200. / s;
+        const double sp = mr < Rmax ? mr : Rmax;
+        st = static_cast<int>(static_cast<long>(sp / hstep));
+        us[gt] = exp(-sp * s);
+        us1[gt] = exp(-(sp - hstep) * s);
+    } else if (active) {
         // GetMaxRadiusIndex (Numerov.h:119-136); exp(arg) < 1e-200 <=> arg < far_thr
         const double s = sqrt(2. * fabs(e));
         int maxIndex = N - 1, minIndex = 1;
@@ -592,9 +600,10 @@ __global__ void k_plan(dfta::Job* __restrict__ jobs, int njobs, int tpj, int nop
 // one 256-thread block per job; wave 0 performs the Simpson 3/8 sum in the reference's order
 __global__ __launch_bounds__(256) void k_normalize(double* __restrict__ Psi, double* __restrict__ G, int N,
                                                    const double* __restrict__ eh, const double* __restrict__ cnst,
-                                                   const int* __restrict__ jstart)
+                                                   const int* __restrict__ jstart, double step, int rule)
 {
     __shared__ __attribute__((aligned(16))) double lds[dfta::kTile];
+    __shared__ double rtab[64];
     __shared__ double s_unorm;
     if (jstart && jstart[blockIdx.x] < 0) return;     // frozen job: its normalised Psi stands
     double* P = Psi + (size_t)blockIdx.x * N;
@@ -608,7 +617,7 @@ __global__ __launch_bounds__(256) void k_normalize(double* __restrict__ Psi, dou
     }
     __syncthreads();
     if (threadIdx.x < 64) {
-        const double integral = dfta::wave_simpson38(g, N, 1.0, lds);
+        const double integral = dfta::wave_integrate(rule, g, N, step, lds, rtab);   // Simpson38(1, .) on the logarithmic grid, Simpson38(h, .) on the uniform one (DFTAtom.cpp:27,51)
         if (threadIdx.x == 0) s_unorm = 1. / sqrt(integral);
     }
     __syncthreads();
@@ -890,11 +899,12 @@ int LevelSolver::run(const double* dV, const double* job_bottom, int run_mode, d
     const int max_rounds = 4096;
     while (rounds < max_rounds) {
         hipLaunchKernelGGL(k_expand, dim3((unsigned)((ntrials + 255) / 256)), dim3(256), 0, st, d_jobs, tpj, (int)ntrials, g->d_r, N, g->delta,
-                           g->far_arg_threshold, d_E, d_limit, d_start, d_us, d_us1, d_wave_kind, d_counters);
+                           g->far_arg_threshold, d_E, d_limit, d_start, d_us, d_us1, d_wave_kind, d_counters, g->uniform, g->Rmax, g->h);
         DFTA_CHECK_LAUNCH(ctx);
         if (stats) DFTA_HIP(ctx, hipEventRecord(ev[0], st));
         rc = dfta_launch_sweep(ctx, g, DFTA_SWEEP_COUNT, d_wave_kind, nwaves, d_tab, d_wave_slot, d_wave_first, d_wave_cnt, d_E,
-                               d_limit, d_start, d_us, d_us1, d_count, d_u0, nullptr, d_counters + 1, d_bounds, d_phi, d_istop);
+                               d_limit, d_start, d_us, d_us1, d_count, d_u0, nullptr, d_counters + 1, g->uniform ? nullptr : d_bounds, d_phi,
+                               d_istop, d_slot_l);
         if (rc) return rc;
         if (stats) DFTA_HIP(ctx, hipEventRecord(ev[1], st));
         hipLaunchKernelGGL(k_scout, dim3(njobs), dim3(64), 0, st, d_jobs, tpj, d_E, d_start, d_u0);
@@ -938,17 +948,18 @@ int LevelSolver::run(const double* dV, const double* job_bottom, int run_mode, d
     // wavefunctions: match, normalise, accumulate
     hipLaunchKernelGGL(k_job_energies, dim3((njobs + 63) / 64), dim3(64), 0, st, d_jobs, njobs, d_jE, d_jslot, d_jl);
     DFTA_CHECK_LAUNCH(ctx);
-    rc = dfta_launch_boundary(ctx, g, d_jE, njobs, d_jstart, d_jus, d_jus1);
+    rc = dfta_launch_boundary(ctx, g, d_jE, njobs, d_jstart, d_jus, d_jus1, 1, d_jl, d_Q /* uniform: start value at the first node, one per job */);
     if (rc) return rc;
     if (nfrozen) {
         hipLaunchKernelGGL(k_mask_frozen, dim3((njobs + 63) / 64), dim3(64), 0, st, d_jobs, njobs, d_jstart);
         DFTA_CHECK_LAUNCH(ctx);
     }
-    rc = dfta_launch_match(ctx, g, njobs, d_tab, d_jslot, d_jE, d_jstart, d_jus, d_jus1, d_jl, d_Psi, d_Q, d_jmp, d_bounds);
+    rc = dfta_launch_match(ctx, g, njobs, d_tab, d_jslot, d_jE, d_jstart, d_jus, d_jus1, d_jl, d_Psi, d_Q, d_jmp, g->uniform ? nullptr : d_bounds,
+                           d_Q);
     if (rc) return rc;
     hipLaunchKernelGGL(k_store_match, dim3((njobs + 63) / 64), dim3(64), 0, st, d_jobs, njobs, d_jmp);
     DFTA_CHECK_LAUNCH(ctx);
-    hipLaunchKernelGGL(k_normalize, dim3(njobs), dim3(256), 0, st, d_Psi, d_Q, N, g->d_eh, g->d_cnst, nfrozen ? d_jstart : nullptr);
+    hipLaunchKernelGGL(k_normalize, dim3(njobs), dim3(256), 0, st, d_Psi, d_Q, N, g->d_eh, g->d_cnst, nfrozen ? d_jstart : nullptr, g->uniform ? g->h : 1.0, integ_rule);
     DFTA_CHECK_LAUNCH(ctx);
     if (dNewDensity) {
         hipLaunchKernelGGL(k_accumulate_density, dim3(std::min(256, (N + 255) / 256), nV), dim3(256), 0, st, d_Psi, d_jobs, d_v_off,

@@ -32,6 +32,8 @@ constexpr double kH2p12 = 1. / 12.;   // Numerov.h:287
 struct GridScalars {
     int N;
     double delta, Rp2delta2, delta2p4, far_thr;
+    int uniform;                  // NumerovFunctionRegularGrid (Numerov.h:16-70)
+    double Rmax, h, h2, h2p12;    // uniform: step of the grid and of the recurrence (Numerov.h:276-278)
 };
 
 __device__ __forceinline__ double f_of(double veff, double e2, double E, const GridScalars& gs)
@@ -42,15 +44,18 @@ __device__ __forceinline__ double f_of(double veff, double e2, double E, const G
 
 // ---- table of wave-uniform per-point inputs -----------------------------------------------------------
 // tab[(slot)*N + i] = { V[v][i] + cl[l][i], e2[i] }   (Numerov.h:93: V + l(l+1)/(r r) * 0.5)
+// uniform grid: .y carries V_i itself (f needs no exp factor there, and the first two points of a sweep and the whole
+// match solve evaluate the centrifugal term at positions that are not i h: Numerov.h:289-296, 430-458)
 __global__ void k_build_tab(double2* __restrict__ tab, const double* __restrict__ V, const double* __restrict__ cl,
-                            const double* __restrict__ e2, const int* __restrict__ slot_v, const int* __restrict__ slot_l, int N)
+                            const double* __restrict__ e2, const int* __restrict__ slot_v, const int* __restrict__ slot_l, int N,
+                            int uniform)
 {
     const int slot = blockIdx.y;
     const int v = slot_v[slot], l = slot_l[slot];
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) {
         double2 t;
         t.x = V[(size_t)v * N + i] + cl[(size_t)l * N + i];
-        t.y = e2[i];
+        t.y = uniform ? V[(size_t)v * N + i] : e2[i];
         tab[(size_t)slot * N + i] = t;
     }
 }
@@ -76,6 +81,31 @@ __global__ void k_boundary(const double* __restrict__ r, const double* __restric
     start[t] = maxIndex;
     us[t] = exp(far_arg(r, maxIndex, s, gs.delta));
     us1[t] = exp(far_arg(r, maxIndex - 1, s, gs.delta));
+}
+
+// Uniform grid (Numerov.h:43-58, 274-296): the sweep starts at startPoint = min(Rmax, 200 / sqrt(2|E|)), at index
+// (long)(startPoint / h); the two start values are exp(-position sqrt(2|E|)) at startPoint and startPoint - h.
+__device__ __forceinline__ double uniform_start_point(double E, double Rmax)
+{
+    const double mr = 200. / sqrt(2. * fabs(E));      // GetMaxRadius, Numerov.h:53-56
+    return mr < Rmax ? mr : Rmax;                      // std::min(startPoint, GetMaxRadius)
+}
+
+__global__ void k_boundary_uniform(const double* __restrict__ E, int ntrials, GridScalars gs, int* __restrict__ start,
+                                   double* __restrict__ us, double* __restrict__ us1, int for_match,
+                                   const int* __restrict__ l, double* __restrict__ uz)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= ntrials) return;
+    const double s = sqrt(2. * fabs(E[t]));
+    const double sp = uniform_start_point(E[t], gs.Rmax);
+    const long steps = static_cast<long>(sp / gs.h);
+    // the match solve re-derives the step from the truncated count (Numerov.h:430) before it steps back once
+    const double hh = for_match ? sp / steps : gs.h;
+    start[t] = static_cast<int>(steps);
+    us[t] = exp(-sp * s);
+    us1[t] = exp(-(sp - hh) * s);
+    if (uz) uz[t] = pow(hh, static_cast<double>(l[t]) + 1.);       // GetBoundaryValueZero(h, l), Numerov.h:38-41
 }
 
 // ---- the sweep --------------------------------------------------------------------------------------------------
@@ -179,6 +209,7 @@ struct SweepArgs {
     double* phi;
     int* istop;                // | kStopOver: left because the count exceeded the limit, at the sign change that did it
     unsigned long long* total_trips;   // optional global counter (points traversed)
+    const int* slot_l;         // uniform grid: l of every table slot
 };
 
 // Every wave owns up to 64 trials that share one table slot (potential, l).  The grid index loop is wave-uniform;
@@ -1131,11 +1162,245 @@ __global__ __launch_bounds__(128) void k_match(const double2* __restrict__ tab, 
     if (lane128 == 0) matchPoint[t] = mp;
 }
 
+// ---- uniform grid (Numerov.h:16-70 and the IsUniform() branches of Numerov.h:272-504) -------------------------------------
+// The reference's uniform-grid path is not reachable from its front end (DFTAtomFrame.cpp:191,194) and not part of any
+// BASELINE configuration; it is served by plain kernels: one lane per trial, the wave marches the grid index together, table
+// rows staged through LDS 64 at a time with the next 64 in flight.  Arithmetic in the reference's order:
+//     f_i = 2 (V_i + l(l+1)/(r_i r_i)/2 - E),   w_i = 2 w_{i+1} - w_{i+2} + h^2 u_{i+1} f_{i+1},   u_i = w_i / (1 - h^2/12 f_i)
+template <int KIND>
+__device__ __forceinline__ void usweep_wave(const SweepArgs& a, const GridScalars& gs, const int b, const int lane, double2* rows)
+{
+    const int cnt = a.blk_cnt[b];
+    const int t = a.blk_first[b] + (lane < cnt ? lane : 0);
+    const bool valid = (lane < cnt) && (a.start[t] >= 2);
+    if (__ballot(valid) == 0ull) return;
+    const int slot = a.blk_slot[b];
+    const double2* __restrict__ T = a.tab + (size_t)slot * gs.N;
+    const unsigned l = static_cast<unsigned>(a.slot_l[slot]);
+    const double E = a.E[t];
+    const int start = valid ? a.start[t] : 2;
+    const int limit = (KIND == DFTA_SWEEP_COUNT) ? a.limit[t] : 0;
+    const double h = gs.h, h2 = gs.h2, h2p12 = gs.h2p12;
+    // prologue (Numerov.h:289-301): the first two points sit at startPoint and startPoint - h, not at i h
+    double u, w, wprev, fprev, prevSol;
+    {
+        const double sp = uniform_start_point(E, gs.Rmax);
+        const double p1 = sp - h;
+        const double us = a.us[t];
+        u = a.us1[t];
+        const double fs = 2. * ((T[start].y + l * (l + 1.) / (sp * sp) * 0.5) - E);           // Numerov.h:21-30
+        wprev = (1 - h2p12 * fs) * us;
+        fprev = 2. * ((T[start - 1].y + l * (l + 1.) / (p1 * p1) * 0.5) - E);
+        w = (1 - h2p12 * fprev) * u;
+        prevSol = us;
+    }
+    bool oldSgn = (u > 0), live = valid, exited = false, flag = false;
+    int count = 0, trips = 0;
+    const int my_hi = valid ? start - 2 : 0;
+    int ihi = my_hi;
+    for (int off = 32; off > 0; off >>= 1) ihi = max(ihi, __shfl_xor(ihi, off));
+    ihi = __builtin_amdgcn_readfirstlane(ihi);
+    double2 nxt = T[max(ihi - lane, 1)];
+    for (int top = ihi; top >= 1; top -= 64) {
+        __syncthreads();
+        rows[lane] = nxt;
+        nxt = T[max(top - 64 - lane, 1)];
+        __syncthreads();
+        const int nk = top < 64 ? top : 64;
+        for (int k = 0; k < nk; ++k) {
+            const int i = top - k;
+            const double2 tv = rows[k];
+            if (live && i <= my_hi) {
+                const double wnext = 2. * w - wprev + h2 * u * fprev;          // Numerov.h:311
+                wprev = w;
+                w = wnext;
+                const double f = 2. * (tv.x - E);                               // Numerov.h:28-30 at position = h i
+                prevSol = u;
+                u = w / (1. - h2p12 * f);                                       // getU, Numerov.h:510-513
+                fprev = f;
+                ++trips;
+                if (KIND == DFTA_SWEEP_COUNT) {                                 // Numerov.h:323-340
+                    if (fabs(u) == INFINITY) { live = false; exited = true; }
+                    else {
+                        const bool newSgn = (u > 0);
+                        if (newSgn != oldSgn) {
+                            ++count;
+                            if (count > limit) { live = false; exited = true; }
+                            oldSgn = newSgn;
+                        }
+                        if (live) {
+                            if (tv.x <= E) flag = true;
+                            else if (flag && tv.x > E) { live = false; exited = true; }
+                        }
+                    }
+                }
+            }
+        }
+        if (KIND == DFTA_SWEEP_COUNT && __ballot(live) == 0ull) break;
+    }
+    double u0 = NAN;
+    if (valid && (KIND == DFTA_SWEEP_ZERO || !exited)) {
+        u0 = u * (2 + h2 * fprev) - prevSol;                                    // Numerov.h:345 / 398
+        if (KIND == DFTA_SWEEP_COUNT && (u0 > 0) != oldSgn) ++count;            // Numerov.h:346-347
+    }
+    if (valid) {
+        if (KIND == DFTA_SWEEP_COUNT) a.count[t] = count;
+        if (a.u0) a.u0[t] = u0;
+        if (a.trip) a.trip[t] = trips;
+        if (KIND == DFTA_SWEEP_COUNT && a.phi) a.phi[t] = NAN;                   // no secant samples on this path
+        if (KIND == DFTA_SWEEP_COUNT && a.istop) a.istop[t] = -1;
+    }
+    if (a.total_trips) {
+        int sum = valid ? trips : 0;
+        for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+        if (lane == 0) atomicAdd(a.total_trips, (unsigned long long)sum);
+    }
+}
+
+__global__ __launch_bounds__(64) void k_usweep(SweepArgs a, GridScalars gs, int nwaves)
+{
+    __shared__ double2 rows[64];
+    const int lane = threadIdx.x;
+    const int b = blockIdx.x;
+    if (b >= nwaves) return;
+    const int kind = a.blk_kind ? __builtin_amdgcn_readfirstlane(a.blk_kind[b]) : a.kind;
+    if (kind == DFTA_SWEEP_COUNT) usweep_wave<DFTA_SWEEP_COUNT>(a, gs, b, lane, rows);
+    else                          usweep_wave<DFTA_SWEEP_ZERO>(a, gs, b, lane, rows);
+}
+
+// SolveSchrodingerMatchSolutionCompletely on the uniform grid (Numerov.h:403-504 with IsUniform()): one 64-thread block
+// per trial; thread 0 integrates (inward to the match point, then outward), the block stages table rows and stores Psi.
+// The step is re-derived from the truncated step count (Numerov.h:430), so positions are h' i with a per-trial h'.
+__global__ __launch_bounds__(64) void k_umatch(const double2* __restrict__ tab, const int* __restrict__ trial_slot,
+                                               const double* __restrict__ Earr, const int* __restrict__ startArr,
+                                               const double* __restrict__ usArr, const double* __restrict__ us1Arr,
+                                               const double* __restrict__ uzArr, const int* __restrict__ larr, GridScalars gs,
+                                               double* __restrict__ Psi, int* __restrict__ matchPoint)
+{
+    __shared__ double2 rows[64];
+    __shared__ double outv[64];
+    __shared__ int s_n, s_stop, s_mp;
+    __shared__ double s_factor;
+    const int t = blockIdx.x, tid = threadIdx.x;
+    const int steps = startArr[t];
+    if (steps < 0) return;                      // frozen job (levels.hip)
+    const int N = gs.N;
+    const double2* __restrict__ T = tab + (size_t)trial_slot[t] * N;
+    double* __restrict__ P = Psi + (size_t)t * N;
+    const double E = Earr[t];
+    const unsigned l = static_cast<unsigned>(larr[t]);
+    for (int i = steps + 1 + tid; i < N; i += 64) P[i] = 0;                     // Numerov.h:427-428
+    const double sp = uniform_start_point(E, gs.Rmax);
+    const double h = sp / steps, h2 = h * h, h2p12 = h2 / 12.;                   // Numerov.h:430-432
+    const double ll = l * (l + 1.);
+    auto func = [&](double V, double position) { return 2. * ((V + ll / (position * position) * 0.5) - E); };   // Numerov.h:21-30
+    double sol = 0, w = 0, wprev = 0, f = 0, above = 0;
+    if (tid == 0) {
+        sol = usArr[t];
+        P[steps] = sol;
+        f = func(T[steps].y, sp);
+        wprev = (1 - h2p12 * f) * sol;
+        sol = us1Arr[t];
+        P[steps - 1] = sol;
+        f = func(T[steps - 1].y, sp - h);
+        w = (1 - h2p12 * f) * sol;
+        above = sol;
+        s_stop = 0;
+        s_mp = 2;                                                                // Numerov.h:449
+    }
+    __syncthreads();
+    for (int top = steps - 2; top >= 1; top -= 64) {                             // inward, Numerov.h:450-470
+        const int idx = top - tid;
+        if (idx >= 1) rows[tid] = T[idx];
+        __syncthreads();
+        if (tid == 0) {
+            int n = 0;
+            for (int k = 0; k < 64 && top - k >= 1; ++k) {
+                const int i = top - k;
+                const double wnext = 2. * w - wprev + h2 * sol * f;
+                wprev = w;
+                w = wnext;
+                f = func(rows[k].y, h * i);
+                sol = w / (1. - h2p12 * f);
+                outv[k] = sol;
+                n = k + 1;
+                if (sol < above || fabs(sol) > 1E15) { s_mp = i; s_stop = 1; break; }
+                above = sol;
+            }
+            s_n = n;
+        }
+        __syncthreads();
+        if (tid < s_n) P[top - tid] = outv[tid];
+        const int stop = s_stop;
+        __syncthreads();
+        if (stop) break;
+    }
+    const int mp = s_mp;
+    __syncthreads();
+    if (tid == 0) {                                                              // outward, Numerov.h:472-480
+        P[0] = 0;
+        wprev = 0;
+        sol = uzArr[t];
+        P[1] = sol;
+        f = func(T[1].y, h);
+        w = (1 - h2p12 * f) * sol;
+    }
+    for (int base = 2; base < mp; base += 64) {                                  // Numerov.h:482-492
+        const int idx = base + tid;
+        if (idx < mp) rows[tid] = T[idx];
+        __syncthreads();
+        if (tid == 0) {
+            int n = 0;
+            for (int k = 0; k < 64 && base + k < mp; ++k) {
+                const int i = base + k;
+                const double wnext = 2. * w - wprev + h2 * sol * f;
+                wprev = w;
+                w = wnext;
+                f = func(rows[k].y, h * i);
+                sol = w / (1. - h2p12 * f);
+                outv[k] = sol;
+                n = k + 1;
+            }
+            s_n = n;
+        }
+        __syncthreads();
+        if (tid < s_n) P[base + tid] = outv[tid];
+        __syncthreads();
+    }
+    if (tid == 0) {                                                              // Numerov.h:494-499
+        w = 2. * w - wprev + h2 * sol * f;
+        f = func(T[mp].y, h * mp);
+        sol = w / (1. - h2p12 * f);
+        __threadfence_block();
+        s_factor = sol / P[mp];
+        P[mp] = sol;
+        matchPoint[t] = mp;
+    }
+    __syncthreads();
+    const double factor = s_factor;
+    for (int i = mp + 1 + tid; i <= steps; i += 64) P[i] *= factor;              // Numerov.h:500-501
+}
+
 GridScalars scalars_of(const dfta_grid* g)
 {
     GridScalars gs;
     gs.N = g->N; gs.delta = g->delta; gs.Rp2delta2 = g->Rp2delta2; gs.delta2p4 = g->delta2p4; gs.far_thr = g->far_arg_threshold;
+    gs.uniform = g->uniform; gs.Rmax = g->Rmax; gs.h = g->h; gs.h2 = g->h2; gs.h2p12 = g->h2p12;
     return gs;
+}
+
+// uniform grid, host side: cut-off and start values exactly as the reference evaluates them (libm), Numerov.h:32-41,274-296
+void host_boundary_uniform(const dfta_grid* g, double E, unsigned l, bool for_match, int* start, double* us, double* us1, double* uz)
+{
+    const double s = sqrt(2. * fabs(E));
+    const double mr = 200. / s;
+    const double sp = mr < g->Rmax ? mr : g->Rmax;
+    const long steps = static_cast<long>(sp / g->h);
+    const double hh = for_match ? sp / steps : g->h;
+    *start = static_cast<int>(steps);
+    *us = exp(-sp * s);
+    *us1 = exp(-(sp - hh) * s);
+    if (uz) *uz = pow(hh, static_cast<double>(l) + 1.);
 }
 
 // host-side boundary values exactly as the reference evaluates them (libm exp)
@@ -1162,9 +1427,9 @@ int dfta_launch_build_tab(dfta_ctx* ctx, const dfta_grid* g, double2* tab, const
                           const int* d_slot_l, int nslots, double2* bounds)
 {
     dim3 grid((g->N + 255) / 256 > 64 ? 64 : (g->N + 255) / 256, nslots);
-    hipLaunchKernelGGL(k_build_tab, grid, dim3(256), 0, ctx->stream, tab, dV, g->d_cl, g->d_e2, d_slot_v, d_slot_l, g->N);
+    hipLaunchKernelGGL(k_build_tab, grid, dim3(256), 0, ctx->stream, tab, dV, g->d_cl, g->d_e2, d_slot_v, d_slot_l, g->N, g->uniform);
     DFTA_CHECK_LAUNCH(ctx);
-    if (bounds) {
+    if (bounds && !g->uniform) {
         const int bstride = dfta_bounds_stride(g);
         hipLaunchKernelGGL(k_slot_bounds, dim3(nslots), dim3(256), 0, ctx->stream, tab, g->N, 2. * g->Rp2delta2, bounds, bstride);
         hipLaunchKernelGGL(k_block_minmax, dim3((bstride + 254) / 256, nslots), dim3(256), 0, ctx->stream, tab, g->N, bounds, bstride);
@@ -1173,8 +1438,15 @@ int dfta_launch_build_tab(dfta_ctx* ctx, const dfta_grid* g, double2* tab, const
     return DFTA_OK;
 }
 
-int dfta_launch_boundary(dfta_ctx* ctx, const dfta_grid* g, const double* dE, int ntrials, int* dStart, double* dUs, double* dUs1)
+int dfta_launch_boundary(dfta_ctx* ctx, const dfta_grid* g, const double* dE, int ntrials, int* dStart, double* dUs, double* dUs1,
+                         int for_match, const int* dL, double* dUz)
 {
+    if (g->uniform) {
+        hipLaunchKernelGGL(k_boundary_uniform, dim3((ntrials + 255) / 256), dim3(256), 0, ctx->stream, dE, ntrials, scalars_of(g), dStart,
+                           dUs, dUs1, for_match, dL, dL ? dUz : nullptr);
+        DFTA_CHECK_LAUNCH(ctx);
+        return DFTA_OK;
+    }
     hipLaunchKernelGGL(k_boundary, dim3((ntrials + 255) / 256), dim3(256), 0, ctx->stream, g->d_r, dE, ntrials,
                        scalars_of(g), dStart, dUs, dUs1);
     DFTA_CHECK_LAUNCH(ctx);
@@ -1184,15 +1456,19 @@ int dfta_launch_boundary(dfta_ctx* ctx, const dfta_grid* g, const double* dE, in
 int dfta_launch_sweep(dfta_ctx* ctx, const dfta_grid* g, int kind, const int* blk_kind, int nblocks, const double2* tab,
                       const int* blk_slot, const int* blk_first, const int* blk_cnt, const double* dE, const int* dLimit,
                       const int* dStart, const double* dUs, const double* dUs1, int* dCount, double* dU0, int* dTrip,
-                      unsigned long long* dTotalTrips, const double2* bounds, double* dPhi, int* dIstop)
+                      unsigned long long* dTotalTrips, const double2* bounds, double* dPhi, int* dIstop, const int* d_slot_l)
 {
     SweepArgs a;
+    a.slot_l = d_slot_l;
     a.phi = dPhi; a.istop = dIstop;
     a.kind = kind; a.blk_kind = blk_kind; a.bounds = bounds; a.bstride = dfta_bounds_stride(g);
     a.tab = tab; a.blk_slot = blk_slot; a.blk_first = blk_first; a.blk_cnt = blk_cnt; a.E = dE; a.limit = dLimit;
     a.start = dStart; a.us = dUs; a.us1 = dUs1; a.count = dCount; a.u0 = dU0; a.trip = dTrip; a.total_trips = dTotalTrips;
     const bool pipe = ctx->sweep_kernel == DFTA_SWEEP_AUTO ? nblocks <= kPipeMaxBlocks : ctx->sweep_kernel == DFTA_SWEEP_PIPELINED;
-    if (pipe) {
+    if (g->uniform) {
+        if (!d_slot_l) { snprintf(ctx->err, sizeof(ctx->err), "uniform sweeps need the slots' l"); return DFTA_ERR_INVALID; }
+        hipLaunchKernelGGL(k_usweep, dim3(nblocks), dim3(64), 0, ctx->stream, a, scalars_of(g), nblocks);
+    } else if (pipe) {
         hipLaunchKernelGGL((k_sweep_pipe<kPipeChunk>), dim3(nblocks), dim3(kPipeThreads), 0, ctx->stream, a, scalars_of(g), nblocks);
     } else {
         const dim3 grid((nblocks + 3) / 4), block(256);
@@ -1204,8 +1480,15 @@ int dfta_launch_sweep(dfta_ctx* ctx, const dfta_grid* g, int kind, const int* bl
 
 int dfta_launch_match(dfta_ctx* ctx, const dfta_grid* g, int ntrials, const double2* tab, const int* d_trial_slot,
                       const double* dE, const int* dStart, const double* dUs, const double* dUs1, const int* dL,
-                      double* dPsi, double* dQ, int* dMatch, const double2* bounds)
+                      double* dPsi, double* dQ, int* dMatch, const double2* bounds, const double* dUz)
 {
+    if (g->uniform) {
+        if (!dUz) { snprintf(ctx->err, sizeof(ctx->err), "uniform match needs the start values at the origin"); return DFTA_ERR_INVALID; }
+        hipLaunchKernelGGL(k_umatch, dim3(ntrials), dim3(64), 0, ctx->stream, tab, d_trial_slot, dE, dStart, dUs, dUs1, dUz, dL, scalars_of(g),
+                           dPsi, dMatch);
+        DFTA_CHECK_LAUNCH(ctx);
+        return DFTA_OK;
+    }
     hipLaunchKernelGGL(k_match, dim3(ntrials), dim3(128), 0, ctx->stream, tab, d_trial_slot, dE, dStart, dUs, dUs1, dL,
                        g->zero1[0], g->zero1[1], g->zero1[2], g->zero1[3], scalars_of(g), bounds, dfta_bounds_stride(g), dPsi, dQ,
                        dMatch);
@@ -1289,7 +1572,10 @@ extern "C" int dfta_numerov_sweeps(dfta_ctx* ctx, const dfta_grid* g, int kind, 
         const int t = G.order[s];
         sE[s] = E[t];
         if (nodesLimit) sLim[s] = nodesLimit[t];
-        if (boundary == DFTA_BOUNDARY_HOST) host_boundary(g, E[t], &sStart[s], &sUs[s], &sUs1[s]);
+        if (boundary == DFTA_BOUNDARY_HOST) {
+            if (g->uniform) host_boundary_uniform(g, E[t], static_cast<unsigned>(l[t]), false, &sStart[s], &sUs[s], &sUs1[s], nullptr);
+            else host_boundary(g, E[t], &sStart[s], &sUs[s], &sUs1[s]);
+        }
     }
     DevBuf<double> dV, dE, dUs, dUs1, dU0;
     DevBuf<int> dLim, dStart, dCount, dTrip, dSlotV, dSlotL, dBs, dBf, dBc;
@@ -1325,7 +1611,7 @@ extern "C" int dfta_numerov_sweeps(dfta_ctx* ctx, const dfta_grid* g, int kind, 
     if (rc) return rc;
     DFTA_HIP(ctx, hipEventRecord(ctx->ev[0], st));
     rc = dfta_launch_sweep(ctx, g, kind, nullptr, (int)G.blk_slot.size(), dTab.p, dBs.p, dBf.p, dBc.p, dE.p, dLim.p, dStart.p,
-                           dUs.p, dUs1.p, dCount.p, dU0.p, dTrip.p, nullptr, dBounds.p);
+                           dUs.p, dUs1.p, dCount.p, dU0.p, dTrip.p, nullptr, dBounds.p, nullptr, nullptr, dSlotL.p);
     if (rc) return rc;
     DFTA_HIP(ctx, hipEventRecord(ctx->ev[1], st));
     ctx->have_kernel_time = true;
@@ -1388,7 +1674,7 @@ extern "C" int dfta_numerov_sweeps_dev(dfta_ctx* ctx, const dfta_grid* g, int ki
     int rc = dfta_launch_build_tab(ctx, g, dTab.p, dV, dSlotV.p, dSlotL.p, ngroups, dBounds.p);
     if (rc) return rc;
     rc = dfta_launch_sweep(ctx, g, kind, nullptr, (int)bs.size(), dTab.p, dBs.p, dBf.p, dBc.p, dE, dLimit, pStart, pUs, pUs1, dCount,
-                           dU0, dTrip, nullptr, dBounds.p);
+                           dU0, dTrip, nullptr, dBounds.p, nullptr, nullptr, dSlotL.p);
     if (rc) return rc;
     if (dStartOut) DFTA_HIP(ctx, hipMemcpyAsync(dStartOut, pStart, ntrials * sizeof(int), hipMemcpyDeviceToDevice, st));
     DFTA_HIP(ctx, hipStreamSynchronize(st));   // scratch buffers die with this scope
@@ -1405,16 +1691,19 @@ extern "C" int dfta_numerov_match(dfta_ctx* ctx, const dfta_grid* g, int boundar
     const int N = g->N;
     Grouping G;
     if (make_grouping(ntrials, vidx, l, nV, G) != DFTA_OK) { snprintf(ctx->err, sizeof(ctx->err), "invalid vidx/l"); return DFTA_ERR_INVALID; }
-    std::vector<double> sE(ntrials), sUs(ntrials), sUs1(ntrials);
+    std::vector<double> sE(ntrials), sUs(ntrials), sUs1(ntrials), sUz(ntrials, 0.0);
     std::vector<int> sStart(ntrials), sL(ntrials);
     for (int s = 0; s < ntrials; ++s) {
         const int t = G.order[s];
         sE[s] = E[t];
         sL[s] = l[t];
-        if (boundary == DFTA_BOUNDARY_HOST) host_boundary(g, E[t], &sStart[s], &sUs[s], &sUs1[s]);
+        if (boundary == DFTA_BOUNDARY_HOST) {
+            if (g->uniform) host_boundary_uniform(g, E[t], static_cast<unsigned>(l[t]), true, &sStart[s], &sUs[s], &sUs1[s], &sUz[s]);
+            else host_boundary(g, E[t], &sStart[s], &sUs[s], &sUs1[s]);
+        }
     }
     hipStream_t st = ctx->stream;
-    DevBuf<double> dV, dE, dUs, dUs1, dPsi, dQ;
+    DevBuf<double> dV, dE, dUs, dUs1, dPsi, dQ, dUz;
     DevBuf<int> dStart, dSlotV, dSlotL, dTs, dL, dMp;
     DevBuf<double2> dTab;
     DFTA_HIP(ctx, dV.alloc((size_t)nV * N));
@@ -1432,18 +1721,21 @@ extern "C" int dfta_numerov_match(dfta_ctx* ctx, const dfta_grid* g, int boundar
         DFTA_HIP(ctx, upload(dStart, sStart, st));
         DFTA_HIP(ctx, upload(dUs, sUs, st));
         DFTA_HIP(ctx, upload(dUs1, sUs1, st));
+        DFTA_HIP(ctx, upload(dUz, sUz, st));
     } else {
         DFTA_HIP(ctx, dStart.alloc(ntrials));
         DFTA_HIP(ctx, dUs.alloc(ntrials));
         DFTA_HIP(ctx, dUs1.alloc(ntrials));
-        int rc = dfta_launch_boundary(ctx, g, dE.p, ntrials, dStart.p, dUs.p, dUs1.p);
+        DFTA_HIP(ctx, dUz.alloc(ntrials));
+        int rc = dfta_launch_boundary(ctx, g, dE.p, ntrials, dStart.p, dUs.p, dUs1.p, 1, dL.p, dUz.p);
         if (rc) return rc;
     }
     DevBuf<double2> dBounds;
     DFTA_HIP(ctx, dBounds.alloc(G.slot_v.size() * (size_t)dfta_bounds_stride(g)));
     int rc = dfta_launch_build_tab(ctx, g, dTab.p, dV.p, dSlotV.p, dSlotL.p, (int)G.slot_v.size(), dBounds.p);
     if (rc) return rc;
-    rc = dfta_launch_match(ctx, g, ntrials, dTab.p, dTs.p, dE.p, dStart.p, dUs.p, dUs1.p, dL.p, dPsi.p, dQ.p, dMp.p, dBounds.p);
+    rc = dfta_launch_match(ctx, g, ntrials, dTab.p, dTs.p, dE.p, dStart.p, dUs.p, dUs1.p, dL.p, dPsi.p, dQ.p, dMp.p, g->uniform ? nullptr : dBounds.p,
+                           dUz.p);
     if (rc) return rc;
     std::vector<double> hPsi((size_t)ntrials * N);
     std::vector<int> hMp(ntrials);

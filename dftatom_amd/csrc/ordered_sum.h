@@ -89,4 +89,82 @@ __device__ __forceinline__ double wave_simpson38(const double* __restrict__ v, i
     return sum * delta * coef;
 }
 
+// Integral::Romberg(delta, values, 1E-18, 3) (Integral.h:106-155): the trapezoid refinement of level i adds
+// values[n], values[n + oldStep], ... (n = numPoints >> i, oldStep = numPoints >> (i-1)) in that order; the extrapolation
+// table is filled exactly as the reference does.  rtab: 2 * 32 doubles of LDS private to the wave.  All 64 lanes call
+// and return the same value.
+__device__ __forceinline__ double wave_romberg(const double* __restrict__ v, int sz, double delta, double* lds, double* rtab)
+{
+    const int numPoints = sz - 1;
+    int cnt = 0;
+    for (int n = numPoints; n; n >>= 1) ++cnt;
+    double* Rprev = rtab;
+    double* Rcur = rtab + 32;
+    const int lane = threadIdx.x & 63;
+    if (lane < 32) { Rprev[lane] = 0; Rcur[lane] = 0; }
+    __builtin_amdgcn_wave_barrier();
+    double h = delta * numPoints;
+    if (lane == 0) Rprev[0] = 0.5 * h * (v[0] + v[numPoints]);
+    double result = 0;
+    bool done = false;
+    for (int i = 1; i < cnt && !done; ++i) {
+        const long n = numPoints >> i;
+        const long oldStep = numPoints >> (i - 1);
+        double acc[3] = {0, 0, 0};
+        const int cls[1] = {0};
+        if (n > 0) wave_ordered_sums<1>(v, n, oldStep, (numPoints - 1 - n) / oldStep + 1, cls, acc, lds);
+        h *= 0.5;
+        int stop = 0;
+        if (lane == 0) {
+            Rcur[0] = 0.5 * Rprev[0] + h * acc[0];
+            double nk = 1;
+            for (int m = 1; m <= i; ++m) {
+                nk *= 4;
+                Rcur[m] = Rcur[m - 1] + (Rcur[m - 1] - Rprev[m - 1]) / (nk - 1);
+            }
+            if (i >= 3 && fabs(Rcur[i] - Rprev[i - 1]) < 1E-18) stop = 1;
+        }
+        stop = __shfl(stop, 0);
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        if (stop) { result = Rcur[i]; done = true; }
+        double* t = Rcur; Rcur = Rprev; Rprev = t;
+    }
+    if (!done) result = Rprev[cnt - 1];
+    return result;
+}
+
+// Integral::{Trapezoid, SimpsonOneThird, Simpson38, Boole, Romberg}(delta, values) (Integral.h:11-155) by one wave;
+// rule = DFTA_INT_* (include/dftatom_hip.h).  lds: kTile doubles, rtab: 64 doubles (Romberg only).
+__device__ __forceinline__ double wave_integrate(int rule, const double* __restrict__ v, int sz, double delta, double* lds, double* rtab)
+{
+    const long cnt = static_cast<long>(sz) - 2;   // interior points i = 1 .. sz-2
+    if (rule == 0) {                                            // Trapezoid, Integral.h:11-23
+        double acc[3] = {0.5 * (v[0] + v[sz - 1]), 0, 0};       // the running sum starts from the end terms
+        const int cls[1] = {0};
+        wave_ordered_sums<1>(v, 1, 1, cnt, cls, acc, lds);
+        return acc[0] * delta;
+    }
+    if (rule == 1) {                                            // SimpsonOneThird, Integral.h:25-48
+        double acc[3] = {0, 0, 0};                              // acc0 = sum4 (odd i), acc1 = sum2 (even i)
+        const int cls[2] = {0, 1};
+        wave_ordered_sums<2>(v, 1, 1, cnt, cls, acc, lds);
+        double sum = v[0] + v[sz - 1];
+        sum += 4. * acc[0] + 2. * acc[1];
+        constexpr double coef = 1. / 3.;
+        return sum * delta * coef;
+    }
+    if (rule == 2) return wave_simpson38(v, sz, delta, lds);
+    if (rule == 3) {                                            // Boole, Integral.h:75-104
+        double acc[3] = {0, 0, 0};                              // acc0 = sum32 (odd i), acc1 = sum12 (i%4==2), acc2 = sum14 (i%4==0)
+        const int cls[4] = {0, 1, 0, 2};
+        wave_ordered_sums<4>(v, 1, 1, cnt, cls, acc, lds);
+        double sum = 7. * (v[0] + v[sz - 1]);
+        sum += 32. * acc[0] + 12. * acc[1] + 14. * acc[2];
+        constexpr double coef = 2. / 45.;
+        return sum * delta * coef;
+    }
+    return wave_romberg(v, sz, delta, lds, rtab);
+}
+
 }  // namespace dfta

@@ -1513,7 +1513,7 @@ __global__ __launch_bounds__(kThreads) void k_poisson_solve(const MgDesc* __rest
                                                             int* __restrict__ vcycles, double* __restrict__ errs,
                                                             unsigned long long* __restrict__ total_vcycles,
                                                             unsigned* __restrict__ group_ctr, double* __restrict__ group_part,
-                                                            const int* __restrict__ skip, int fault)
+                                                            const int* __restrict__ skip, int fault, int src_all)
 {
     __shared__ double red[20];
     __shared__ double seqmem[3 * kSeqCap];
@@ -1550,7 +1550,7 @@ __global__ __launch_bounds__(kThreads) void k_poisson_solve(const MgDesc* __rest
     for (int idx = coop0 ? A.lane() : static_cast<int>(threadIdx.x); idx < N; idx += coop0 ? kThreads * A.G : kThreads) {
         const int i = node_of(L0, idx);
         double s = r[i];
-        if (i > 0 && i < N - 1) s *= psrc[i] * rho[i];
+        if (src_all || (i > 0 && i < N - 1)) s *= psrc[i] * rho[i];      // PoissonSolver.h:72-74; uniform grid: every node (PoissonSolver.h:39-40)
         A.src[L0.off + idx] = s;   // level 0 is never sequential: plain global storage
     }
     __syncthreads();
@@ -1618,6 +1618,13 @@ __global__ __launch_bounds__(kThreads) void k_unit(const MgDesc* __restrict__ Dp
         group_sync(A);                                    // everybody has read out[0]
         const double e = do_iterate(D, A, lvl, emin, sweeps, red, &c.sweeps);
         if (threadIdx.x == 0 && lead) { out[0] = e; out[1] = (double)c.sweeps; }
+    }
+    else if (op == 5) {                                   // FullCycle(errorMin = out[0], errorMinLast = out[1]) with boundaries out[2], out[3]
+        const double e1 = out[0], e2 = out[1], lowB = out[2], highB = out[3];
+        group_sync(A);                                    // everybody has read out[]
+        initialize(D, A, lowB, highB);
+        const double e = run_cycles<true>(D, A, 0, 100, e1, e2, red, c);
+        if (threadIdx.x == 0 && lead) { out[0] = e; out[1] = (double)c.vcycles; }
     }
     else if (op == 3) {
         const int nramp = D.levels - 2 > 0 ? D.levels - 2 : 0;
@@ -1690,16 +1697,16 @@ int dfta_poisson_solve_launch(dfta_poisson* p, const int* dZ, const double* dDen
     DFTA_HIP(ctx, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(p->d_group_part), 0x7FF8DEAD, (size_t)p->batch * (9 * p->D.G + 2) * 2, ctx->stream));   // group_sum_fast's sentinel
     if (p->D.G == 1) {
         hipLaunchKernelGGL(k_poisson_solve, dim3(p->batch), dim3(kThreads), 0, ctx->stream, p->d_desc, p->d_phi0, p->d_phi1, p->d_src, dZ,
-                           dDensity, p->g->d_r, p->g->d_psrc, dU, dVcycles, dErr, p->d_total_vcycles, p->d_group_ctr, p->d_group_part,
-                           dSkip, 0);
+                           dDensity, p->g->d_rsrc, p->g->d_psrc, dU, dVcycles, dErr, p->d_total_vcycles, p->d_group_ctr, p->d_group_part,
+                           dSkip, 0, p->g->uniform);
         DFTA_CHECK_LAUNCH(ctx);
         return DFTA_OK;
     }
     const MgDesc* a0 = p->d_desc;
-    const double *a_r = p->g->d_r, *a_psrc = p->g->d_psrc;
-    int fault = p->fault;
+    const double *a_r = p->g->d_rsrc, *a_psrc = p->g->d_psrc;
+    int fault = p->fault, src_all = p->g->uniform;
     void* args[] = {&a0, &p->d_phi0, &p->d_phi1, &p->d_src, &dZ, &dDensity, &a_r, &a_psrc, &dU, &dVcycles, &dErr, &p->d_total_vcycles,
-                    &p->d_group_ctr, &p->d_group_part, &dSkip, &fault};
+                    &p->d_group_ctr, &p->d_group_part, &dSkip, &fault, &src_all};
     const hipError_t e = hipLaunchCooperativeKernel(reinterpret_cast<const void*>(k_poisson_solve), dim3(p->batch * p->D.G), dim3(kThreads),
                                                     args, 0, ctx->stream);
     if (e != hipSuccess) {
@@ -1820,7 +1827,7 @@ static int poisson_create_impl(dfta_ctx* ctx, const dfta_grid* g, int batch, int
     D.nofold = getenv("DFTA_POISSON_NOFOLD") ? 1 : 0;
     D.G = 1 << logG;
     long off = kPad, soff = 0;
-    double d = g->delta;                       // PoissonSolver.cpp:21-26
+    double d = g->delta;                       // PoissonSolver.cpp:21-26 (0 on a uniform grid: PoissonSolver(levels), DFTAtom.cpp:89)
     int n = g->N;                              // finest level first
     for (int l = 0; l < D.levels; ++l) {
         Lvl& L = D.lv[l];
@@ -2081,6 +2088,32 @@ int dfta_poisson_iterate_gs(dfta_poisson* p, int lvl, double errorMin, int itern
     if (sweeps_out) *sweeps_out = (int)out[1];
     return DFTA_OK;
 }
+// PoissonSolver::FullCycle (PoissonSolver.h:89-124) on atom 0's level storage: Initialize from the level-0 source that
+// the last solve (or dfta_poisson_set_level) left there and from the boundary values, FMG ramp, up to 100 V-cycles
+int dfta_poisson_full_cycle(dfta_poisson* p, double lowBoundary, double highBoundary, double errorMin, double errorMinLast,
+                            double* err_out, int* vcycles_out)
+{
+    if (!p) return DFTA_ERR_INVALID;
+    dfta_ctx* ctx = p->ctx;
+    if (int rc_ = dfta_use(ctx)) return rc_;
+    hipStream_t st = ctx->stream;
+    DevBuf<double> dOut;
+    DFTA_HIP(ctx, dOut.alloc(4));
+    double io[4] = {errorMin, errorMinLast, lowBoundary, highBoundary};
+    DFTA_HIP(ctx, hipMemcpyAsync(dOut.p, io, sizeof(io), hipMemcpyHostToDevice, st));
+    std::fill(p->h_cur.begin(), p->h_cur.end(), 0);       // Initialize starts from copy 0 of every level
+    DFTA_HIP(ctx, hipMemcpyAsync(p->d_cur, p->h_cur.data(), sizeof(int) * kMaxLevels, hipMemcpyHostToDevice, st));
+    DFTA_HIP(ctx, hipMemsetAsync(p->d_group_ctr, 0, sizeof(unsigned), st));
+    DFTA_HIP(ctx, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(p->d_group_part), 0x7FF8DEAD, (size_t)(9 * p->D.G + 2) * 2, st));
+    if (int rc = launch_unit(p, 5, 0, 0, dOut.p)) return rc;
+    DFTA_HIP(ctx, hipMemcpyAsync(p->h_cur.data(), p->d_cur, sizeof(int) * kMaxLevels, hipMemcpyDeviceToHost, st));
+    DFTA_HIP(ctx, hipMemcpyAsync(io, dOut.p, sizeof(double) * 2, hipMemcpyDeviceToHost, st));
+    DFTA_HIP(ctx, hipStreamSynchronize(st));
+    if (err_out) *err_out = io[0];
+    if (vcycles_out) *vcycles_out = (int)io[1];
+    return DFTA_OK;
+}
+
 int dfta_poisson_restrict(dfta_poisson* p, int lvl)
 {
     if (!p) return DFTA_ERR_INVALID;

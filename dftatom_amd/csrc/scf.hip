@@ -107,7 +107,7 @@ __global__ void k_tail(const AtomState* __restrict__ atoms, int lsda, int N, con
                        const double* __restrict__ cnst, const double* __restrict__ density, const double* __restrict__ dA,
                        const double* __restrict__ dB, const double* __restrict__ U, const double* __restrict__ Vexc,
                        const double* __restrict__ va, const double* __restrict__ vb, const double* __restrict__ eexc,
-                       double* __restrict__ V, double* __restrict__ integrands)
+                       double* __restrict__ V, double* __restrict__ integrands, int uniform)
 {
     const int a = blockIdx.y;
     if (atoms[a].finished) return;
@@ -152,7 +152,8 @@ __global__ void k_tail(const AtomState* __restrict__ atoms, int lsda, int N, con
             exccor[i] = position2density * Vexc[o];
             eexcD[i] = position2density * eexc[o];
             hartree[i] = positiondensity * U[o];
-            potentiale[i] = p2a * pa + p2b * pb;
+            // DFTAtom.cpp:981 on the logarithmic grid; the uniform-grid loop groups the product differently (DFTAtom.cpp:799)
+            potentiale[i] = uniform ? (position * position) * (dA[o] * pa + dB[o] * pb) : p2a * pa + p2b * pb;
         }
     }
 }
@@ -213,6 +214,8 @@ struct dfta_scf {
     std::vector<unsigned char> h_frozen;  // per job: its atom has finished
     int* d_fin = nullptr;                 // per atom: finished (device copy for the kernels that skip frozen atoms)
     bool debug_levels = false;            // $DFTA_DEBUG_LEVELS
+    int integ_rule = DFTA_INT_SIMPSON38;  // dfta_scf_set_integrator
+    int functional = DFTA_XC_VWN;         // dfta_scf_options::functional
     int levels_mode = DFTA_LEVELS_BATCHED;
     int steps_done = 0;
     std::vector<int> spin_nlev[2];      // per atom number of levels per spin
@@ -227,6 +230,8 @@ struct dfta_scf {
 static int scf_xc(dfta_scf* s)
 {
     const size_t sz = (size_t)s->natoms * s->g->N;
+    if (!s->lsda && s->functional != DFTA_XC_VWN)
+        return dfta_launch_chachiyo_lda(s->ctx, s->functional == DFTA_XC_CHACHIYO_IMPROVED, s->d_density, sz, s->d_Vexc, s->d_eexc);
     if (!s->lsda) return dfta_launch_vwn_lda(s->ctx, s->d_density, sz, s->d_Vexc, s->d_eexc);
     return dfta_launch_vwn_lsda(s->ctx, s->d_dA, s->d_dB, sz, s->d_Vexc, s->d_va, s->d_vb, s->d_eexc);
 }
@@ -247,10 +252,25 @@ void dfta_scf_destroy(dfta_scf* s)
 int dfta_scf_create(dfta_ctx* ctx, const dfta_grid* g, int lsda, int natoms, const int* Z, double alpha, int levels_mode,
                     int tree_depth, dfta_scf** out)
 {
+    return dfta_scf_create_ex(ctx, g, lsda, natoms, Z, alpha, levels_mode, tree_depth, nullptr, out);
+}
+
+int dfta_scf_create_ex(dfta_ctx* ctx, const dfta_grid* g, int lsda, int natoms, const int* Z, double alpha, int levels_mode,
+                       int tree_depth, const dfta_scf_options* options, dfta_scf** out)
+{
     if (!ctx || !g || !out) return DFTA_ERR_INVALID;
     if (int rc_ = dfta_use(ctx)) return rc_;
     DFTA_REQUIRE(ctx, natoms >= 1 && Z && alpha >= 0 && alpha <= 1, "scf arguments");
+    dfta_scf_options opt = {DFTA_INT_SIMPSON38, DFTA_XC_VWN, DFTA_AUFBAU_REFERENCE};
+    if (options) opt = *options;
+    DFTA_REQUIRE(ctx, dfta_integral_shape_ok(opt.integrator, g->N), "integration rule / grid size");
+    DFTA_REQUIRE(ctx, opt.functional >= DFTA_XC_VWN && opt.functional <= DFTA_XC_CHACHIYO_IMPROVED, "functional");
+    DFTA_REQUIRE(ctx, opt.functional == DFTA_XC_VWN || !lsda, "the Chachiyo functional is LDA only (ExcCor.h)");
+    DFTA_REQUIRE(ctx, opt.aufbau == DFTA_AUFBAU_REFERENCE || opt.aufbau == DFTA_AUFBAU_TRANSITION_METALS, "aufbau");
     dfta_scf* s = new dfta_scf();
+    s->integ_rule = opt.integrator;
+    s->solver.integ_rule = opt.integrator;
+    s->functional = opt.functional;
     s->ctx = ctx; s->g = g; s->lsda = lsda ? 1 : 0; s->natoms = natoms; s->nspin = lsda ? 2 : 1; s->nV = natoms * s->nspin;
     s->alpha = alpha;
     const int N = g->N;
@@ -266,12 +286,12 @@ int dfta_scf_create(dfta_ctx* ctx, const dfta_grid* g, int lsda, int natoms, con
         st.job_off = (int)specs.size();
         int an[32], al[32], ao[32], bn[32], bl[32], bo[32], nA = 0, nB = 0;
         if (!lsda) {
-            nA = dfta_get_subshells(Z[a], an, al, ao, 32);
+            nA = dfta_get_subshells_ex(Z[a], opt.aufbau, an, al, ao, 32);
             if (nA < 0) { dfta_scf_destroy(s); return DFTA_ERR_INVALID; }
             for (int k = 0; k < nA; ++k) specs.push_back({a, an[k], al[k], ao[k]});
             s->h_bottom0[a] = -double(Z[a]) * Z[a] - 1.;                                   // DFTAtom.cpp:407
         } else {
-            if (dfta_split_spin(Z[a], &nA, &nB, an, al, ao, bn, bl, bo, 32) != DFTA_OK) { dfta_scf_destroy(s); return DFTA_ERR_INVALID; }
+            if (dfta_split_spin_ex(Z[a], opt.aufbau, &nA, &nB, an, al, ao, bn, bl, bo, 32) != DFTA_OK) { dfta_scf_destroy(s); return DFTA_ERR_INVALID; }
             int ne = 0;
             for (int k = 0; k < nA; ++k) { specs.push_back({2 * a, an[k], al[k], ao[k]}); ne += ao[k]; }
             for (int k = 0; k < nB; ++k) specs.push_back({2 * a + 1, bn[k], bl[k], bo[k]});
@@ -391,9 +411,10 @@ int dfta_scf_step(dfta_scf* s, dfta_step_stats* stats)
     rc = scf_xc(s);
     if (rc) return rc;
     hipLaunchKernelGGL(k_tail, grid, block, 0, st, s->d_atoms, s->lsda, N, g->d_r, g->d_cnst, s->d_density, s->d_dA, s->d_dB, s->d_U,
-                       s->d_Vexc, s->d_va, s->d_vb, s->d_eexc, s->d_V, s->d_integrands);
+                       s->d_Vexc, s->d_va, s->d_vb, s->d_eexc, s->d_V, s->d_integrands, g->uniform);
     DFTA_CHECK_LAUNCH(ctx);
-    rc = dfta_launch_simpson38_ordered(ctx, s->d_integrands, N, natoms * 5, (size_t)N, s->d_integrals);
+    // Simpson38(1, .) on the logarithmic grid (DFTAtom.cpp:459-467), Simpson38(h, .) on the uniform one (DFTAtom.cpp:167-177)
+    rc = dfta_launch_integrate_ordered(ctx, s->integ_rule, g->uniform ? g->h : 1.0, s->d_integrands, N, natoms * 5, (size_t)N, s->d_integrals);
     if (rc) return rc;
     hipLaunchKernelGGL(k_energies, dim3((natoms + 63) / 64), dim3(64), 0, st, s->d_atoms, natoms, s->solver.d_jobs, s->d_integrals,
                        s->d_records, s->d_fin);
@@ -442,6 +463,15 @@ int dfta_scf_info(const dfta_scf* s, int* tree_depth, int* njobs, long* trials_p
     if (tree_depth) *tree_depth = s->solver.depth;
     if (njobs) *njobs = s->solver.njobs;
     if (trials_per_round) *trials_per_round = s->solver.ntrials;
+    return DFTA_OK;
+}
+
+int dfta_scf_set_integrator(dfta_scf* s, int rule)
+{
+    if (!s) return DFTA_ERR_INVALID;
+    DFTA_REQUIRE(s->ctx, dfta_integral_shape_ok(rule, s->g->N), "integration rule / grid size");
+    s->integ_rule = rule;
+    s->solver.integ_rule = rule;
     return DFTA_OK;
 }
 

@@ -5,6 +5,7 @@
 int dfta_launch_vwn_lda(dfta_ctx* ctx, const double* dN, size_t sz, double* dVexc, double* dEexc);
 int dfta_launch_vwn_lsda(dfta_ctx* ctx, const double* dNa, const double* dNb, size_t sz, double* dRes, double* dVa, double* dVb,
                          double* dEexc);
+int dfta_launch_chachiyo_lda(dfta_ctx* ctx, int improved, const double* dN, size_t sz, double* dVexc, double* dEexc);
 // poisson.hip: launch (asynchronous) / finish (synchronises, inspects the group barriers' abort flag and repeats the solve with
 // one workgroup per atom if it was raised).  dSkip: per atom, non-zero = leave this atom alone (may be null).
 int dfta_poisson_solve_launch(dfta_poisson* p, const int* dZ, const double* dDensity, double* dU, int* dVcycles, double* dErr,

@@ -7,6 +7,7 @@
 // HBM-bound by construction: LDA reads 8 B and writes 16 B per point, LSDA reads 16 B and writes 32 B.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 
 #include "internal.h"
@@ -15,135 +16,138 @@
 namespace {
 
 constexpr double kPi = 3.14159265358979323846;
-constexpr double fourM_PI = 4. * kPi;
-constexpr double aThird = 1. / 3.;                                  // ExcCorBase.h:12
-// VWNExcCor.h:23-41
-constexpr double AP = 0.0310907, y0P = -0.10498, bP = 3.72744, cP = 12.93532;
-constexpr double Y0P = y0P * y0P + bP * y0P + cP;
-constexpr double AF = 0.01554535, y0F = -0.325, bF = 7.06042, cF = 18.0578;
-constexpr double Y0F = y0F * y0F + bF * y0F + cF;
-constexpr double Aalpha = -1. / (6. * kPi * kPi);
-constexpr double y0alpha = -0.0047584, balpha = 1.13107, calpha = 13.0045;
-constexpr double Y0alpha = y0alpha * y0alpha + balpha * y0alpha + calpha;
+constexpr double kFourPi = 4. * kPi;
+constexpr double kThird = 1. / 3.;                                  // ExcCorBase.h:12
 
-__device__ __forceinline__ double vwnF(double y, double dify, double A, double y0, double b, double c, double Y0, double Y)
-{   // VWNExcCor.h:43-50 (B.5)
-    const double Q = sqrt(4 * c - b * b);
-    const double twoyb = 2. * y + b;
-    const double atanQ = atan(Q / twoyb);
-    return A * (log(y * y / Y) + 2. * b / Q * atanQ - b * y0 / Y0 * (log(dify * dify / Y) + 2. * (b + 2. * y0) / Q * atanQ));
+// One Pade-like fit of VWN: eps(y) = A { ln(y^2/Y) + 2b/Q atan(Q/(2y+b)) - b y0/Y0 [ ln((y-y0)^2/Y) + 2(b+2y0)/Q atan(Q/(2y+b)) ] },
+// y = sqrt(rs), Y(y) = y^2 + b y + c, Q = sqrt(4c - b^2).  Three parameter sets (VWNExcCor.h:23-41): paramagnetic,
+// ferromagnetic, and the spin stiffness alpha_c.
+struct VwnFit { double A, y0, b, c; };
+constexpr VwnFit kPara{0.0310907, -0.10498, 3.72744, 12.93532};
+constexpr VwnFit kFerro{0.01554535, -0.325, 7.06042, 18.0578};
+constexpr VwnFit kStiff{-1. / (6. * kPi * kPi), -0.0047584, 1.13107, 13.0045};
+constexpr double poly_at(const VwnFit& p, double y) { return y * y + p.b * y + p.c; }
+
+struct FitValue { double eps, slope; };     // eps: the fit itself (VWNExcCor.h:43-50); slope: its rs-derivative term (VWNExcCor.h:52-55)
+
+// NESTED selects how Y(y) is rounded: the LDA routines write y*y + b*y + c (VWNExcCor.h:89,119), the LSDA ones y*(y + b) + c
+// (VWNExcCor.h:182,187,192) -- both kept so that each path rounds like the reference's
+template <bool NESTED>
+__device__ __forceinline__ FitValue eval_fit(const VwnFit p, double y)
+{
+    const double Y = NESTED ? y * (y + p.b) + p.c : y * y + p.b * y + p.c;
+    const double Y0 = poly_at(p, p.y0);
+    const double dy = y - p.y0;
+    const double Q = sqrt(4 * p.c - p.b * p.b);
+    const double at = atan(Q / (2. * y + p.b));
+    FitValue v;
+    v.eps = p.A * (log(y * y / Y) + 2. * p.b / Q * at - p.b * p.y0 / Y0 * (log(dy * dy / Y) + 2. * (p.b + 2. * p.y0) / Q * at));
+    v.slope = p.A * (p.c * dy - p.b * p.y0 * y) / (dy * Y);
+    return v;
 }
 
-__device__ __forceinline__ double vwnEcDif(double y, double dify, double A, double y0, double b, double c, double Y)
-{   // VWNExcCor.h:52-55 (B.6)
-    return A * (c * dify - b * y0 * y) / (dify * Y);
-}
+__device__ __forceinline__ double wigner_seitz(double rho) { return pow(3. / (kFourPi * rho), kThird); }   // rs, eq 2 of the NIST note
 
-__device__ __forceinline__ double spin_f(double zeta, double p2third)
-{   // ExcCorBase.h:14-19
-    const double mul = 1. / (2. * (p2third - 1.));
-    return mul * (pow(1. + zeta, 4. * aThird) + pow(1. - zeta, 4. * aThird) - 2.);
-}
-
-__device__ __forceinline__ double spin_df(double zeta, double p2third)
-{   // ExcCorBase.h:21-26
-    const double mul = 2. / (3. * (p2third - 1.));
-    return mul * (pow(1. + zeta, aThird) - pow(1. - zeta, aThird));
-}
-
-__global__ void k_vwn_lda(const double* __restrict__ n, size_t sz, double* __restrict__ vexc, double* __restrict__ eexc, double X1)
+// LDA (VWNExcCor.h:73-128): v_xc and the double-counting term eps_xc - v_xc, both from one evaluation of the paramagnetic fit
+__global__ void k_vwn_lda(const double* __restrict__ n, size_t sz, double* __restrict__ vexc, double* __restrict__ eexc, double cx)
 {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < sz; i += (size_t)gridDim.x * blockDim.x) {
-        const double ro = n[i];
+        const double rho = n[i];
         double v = 0., e = 0.;
-        if (!(ro < 1E-18)) {                                          // VWNExcCor.h:82,112
-            const double rs = pow(3. / (fourM_PI * ro), aThird);
-            const double y = sqrt(rs);
-            const double Y = y * y + bP * y + cP;
-            const double dify = y - y0P;
-            const double ecd = vwnEcDif(y, dify, AP, y0P, bP, cP, Y);
-            v = -X1 / rs + vwnF(y, dify, AP, y0P, bP, cP, Y0P, Y) - aThird * ecd;       // VWNExcCor.h:94-97
-            e = (0.25 * X1) / rs + aThird * ecd;                                          // VWNExcCor.h:123-124
+        if (!(rho < 1E-18)) {                                         // VWNExcCor.h:82,112
+            const double rs = wigner_seitz(rho);
+            const FitValue c = eval_fit<false>(kPara, sqrt(rs));
+            v = -cx / rs + c.eps - kThird * c.slope;                  // VWNExcCor.h:94-97
+            e = (0.25 * cx) / rs + kThird * c.slope;                  // VWNExcCor.h:123-124
         }
         if (vexc) vexc[i] = v;
         if (eexc) eexc[i] = e;
     }
 }
 
+// LSDA (VWNExcCor.h:134-312).  With g(zeta) the spin interpolation of ExcCorBase.h:14-19, g''(0) = gdd and
+//     w(zeta) = g / gdd * (1 + beta zeta^4),   beta = gdd (eps_F - eps_P) / alpha_c - 1
+// the correlation energy is eps_P + alpha_c w (eqs 7-10 of the NIST note); the kernel forms its rs-derivative (`drs`) and
+// its zeta-derivative (`dz`) and assembles the common term and the two spin potentials from them.
 __global__ void k_vwn_lsda(const double* __restrict__ na, const double* __restrict__ nb, size_t sz, double* __restrict__ res,
-                           double* __restrict__ va, double* __restrict__ vb, double* __restrict__ eexc, double X1, double X2)
+                           double* __restrict__ va, double* __restrict__ vb, double* __restrict__ eexc, double cx, double cbrt2)
 {
-    const double X12 = X1 * X2;
-    const double fdd = 4. / (9. * (X2 - 1.));
-    const double X1d = 0.25 * X1;
+    const double gdd = 4. / (9. * (cbrt2 - 1.));
+    const double gscale = 1. / (2. * (cbrt2 - 1.)), dgscale = 2. / (3. * (cbrt2 - 1.));       // ExcCorBase.h:16,23
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < sz; i += (size_t)gridDim.x * blockDim.x) {
-        const double roa = na[i];
-        const double rob = nb[i];
-        const double n = roa + rob;
-        double r = 0., a = 0., b = 0., e = 0.;
-        if (!(n < 1E-18)) {                                           // VWNExcCor.h:160,260
-            const double rs = pow(3. / (fourM_PI * n), aThird);
-            const double rsa = pow(3. / (fourM_PI * roa), aThird);
-            const double rsb = pow(3. / (fourM_PI * rob), aThird);
-
-            const double exp_ = -X1 / rs;
-            const double exf = X2 * exp_;
-            const double exdif = exf - exp_;
-            const double exfa = -X12 / rsa;
-            const double exfb = -X12 / rsb;
-
-            const double zeta = (roa - rob) / n;
-            const double zeta3 = zeta * zeta * zeta;
-            const double zeta4 = zeta3 * zeta;
-            const double fval = spin_f(zeta, X2);
-            const double dfval = spin_df(zeta, X2);
+        const double up = na[i], dn = nb[i];
+        const double tot = up + dn;
+        double common = 0., vup = 0., vdn = 0., e = 0.;
+        if (!(tot < 1E-18)) {                                         // VWNExcCor.h:160,260
+            const double rs = wigner_seitz(tot);
+            const double z = (up - dn) / tot;
+            const double z3 = z * z * z, z4 = z3 * z;
+            const double g = gscale * (pow(1. + z, 4. * kThird) + pow(1. - z, 4. * kThird) - 2.);
+            const double dg = dgscale * (pow(1. + z, kThird) - pow(1. - z, kThird));
             const double y = sqrt(rs);
+            const FitValue P = eval_fit<true>(kPara, y), F = eval_fit<true>(kFerro, y), S = eval_fit<true>(kStiff, y);
 
-            const double YP = y * (y + bP) + cP;
-            const double difyP = y - y0P;
-            const double ecp = vwnF(y, difyP, AP, y0P, bP, cP, Y0P, YP);
-            const double YF = y * (y + bF) + cF;
-            const double difyF = y - y0F;
-            const double ecf = vwnF(y, difyF, AF, y0F, bF, cF, Y0F, YF);
-            const double YA = y * (y + balpha) + calpha;
-            const double difyA = y - y0alpha;
-            const double eca = vwnF(y, difyA, Aalpha, y0alpha, balpha, calpha, Y0alpha, YA);
+            const double gap = F.eps - P.eps;                                             // VWNExcCor.h:202
+            const double beta = gdd * gap / S.eps - 1.;
+            const double env = 1. + beta * z4;
+            const double w = g / gdd * env;
+            const double dbeta = gdd / S.eps * (F.slope - P.slope - S.slope * gap / S.eps);   // VWNExcCor.h:208
+            const double dw = g / gdd * z4 * dbeta;
+            const double drs = kThird * (P.slope + S.slope * w + S.eps * dw);             // VWNExcCor.h:212-213
+            const double dz = S.eps / gdd * (4. * beta * z3 * g + env * dg);               // VWNExcCor.h:216
 
-            const double ecpd = vwnEcDif(y, difyP, AP, y0P, bP, cP, YP);
-            const double ecfd = vwnEcDif(y, difyF, AF, y0F, bF, cF, YF);
-            const double ecad = vwnEcDif(y, difyA, Aalpha, y0alpha, balpha, calpha, YA);
+            const double xP = -cx / rs;                                                    // exchange of the unpolarised gas ...
+            const double xF = cbrt2 * xP;                                                  // ... and of the fully polarised one
+            common = P.eps + S.eps * w - drs;                                              // VWNExcCor.h:219-231
+            vup = -(cx * cbrt2) / wigner_seitz(up) + common + (1. - z) * dz;               // VWNExcCor.h:233
+            vdn = -(cx * cbrt2) / wigner_seitz(dn) + common - (1. + z) * dz;               // VWNExcCor.h:234
+            common += (xP + (xF - xP) * g);                                                // VWNExcCor.h:236
 
-            const double deltaecfp = ecf - ecp;
-            const double beta = fdd * deltaecfp / eca - 1.;
-            const double opbz4 = 1. + beta * zeta4;
-            const double interp = fval / fdd * opbz4;
-            const double deltaec = eca * interp;
-            const double betad = fdd / eca * (ecfd - ecpd - ecad * deltaecfp / eca);
-            const double interpd = fval / fdd * zeta4 * betad;
-            const double deriv = aThird * (ecpd + ecad * interp + eca * interpd);
-            const double dterm = eca / fdd * (4. * beta * zeta3 * fval + opbz4 * dfval);
-
-            r = ecp + deltaec - deriv;                                 // VWNExcCor.h:219-231
-            a = exfa + r + (1. - zeta) * dterm;                        // VWNExcCor.h:233
-            b = exfb + r - (1. + zeta) * dterm;                        // VWNExcCor.h:234
-            r += (exp_ + exdif * fval);                                // VWNExcCor.h:236
-
-            const double expd = X1d / rs;                              // VWNExcCor.h:271-272
-            const double exfd = X2 * expd;
-            e = expd + (exfd - expd) * fval + deriv;                   // VWNExcCor.h:306-308
+            const double xPd = (0.25 * cx) / rs;                                           // VWNExcCor.h:271-272
+            e = xPd + (cbrt2 * xPd - xPd) * g + drs;                                       // VWNExcCor.h:306-308
         }
-        if (res) res[i] = r;
-        if (va) va[i] = a;
-        if (vb) vb[i] = b;
+        if (res) res[i] = common;
+        if (va) va[i] = vup;
+        if (vb) vb[i] = vdn;
+        if (eexc) eexc[i] = e;
+    }
+}
+
+// Chachiyo's one-line correlation (ExcCor.h:27-95; the reference keeps it next to VWN, all its call sites commented out:
+// DFTAtom.cpp:383,412,421): eps_c = a ln(1 + b/rs + b/rs^2), a = (ln 2 - 1) / (2 pi^2).  LDA only, as in the reference.
+__global__ void k_chachiyo_lda(const double* __restrict__ n, size_t sz, double* __restrict__ vexc, double* __restrict__ eexc, double cx,
+                               double a, double b)
+{
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < sz; i += (size_t)gridDim.x * blockDim.x) {
+        const double rho = n[i];
+        double v = 0., e = 0.;
+        if (!(rho < 1E-18)) {                                         // ExcCor.h:50,79
+            const double rs = wigner_seitz(rho);
+            const double q1 = b / rs, q2 = q1 / rs;
+            const double tail = a / (1. + q1 + q2) * (q1 + 2. * q2) * rs / 3.;
+            v = -cx / rs + a * log(1. + q1 + q1 / rs) - tail;         // ExcCor.h:60-63
+            e = (0.25 * cx) / rs + tail;                              // ExcCor.h:89-91
+        }
+        if (vexc) vexc[i] = v;
         if (eexc) eexc[i] = e;
     }
 }
 
 }  // namespace
 
-// X1 = pow(3/(2 pi), 2/3), X2 = pow(2, 1/3) are evaluated once on the host with libm (VWNExcCor.h:75,139-140)
-static double host_X1() { return pow(3. / (2. * kPi), 2. * aThird); }
-static double host_X2() { return pow(2., aThird); }
+// the two irrational constants are evaluated once on the host with libm, as the reference does (VWNExcCor.h:75,139-140)
+static double host_X1() { return pow(3. / (2. * kPi), 2. * kThird); }
+static double host_X2() { return pow(2., kThird); }
+
+int dfta_launch_chachiyo_lda(dfta_ctx* ctx, int improved, const double* dN, size_t sz, double* dVexc, double* dEexc)
+{
+    const double a = (M_LN2 - 1.) / (2. * kPi * kPi);                 // ExcCor.h:32
+    const double b = improved ? 21.7392245 : 20.4562557;              // ExcCor.h:16,24
+    const int blocks = (int)std::min<size_t>((sz + 255) / 256, 2048);
+    hipLaunchKernelGGL(k_chachiyo_lda, dim3(blocks), dim3(256), 0, ctx->stream, dN, sz, dVexc, dEexc, host_X1(), a, b);
+    DFTA_CHECK_LAUNCH(ctx);
+    return DFTA_OK;
+}
 
 int dfta_launch_vwn_lda(dfta_ctx* ctx, const double* dN, size_t sz, double* dVexc, double* dEexc)
 {
@@ -204,6 +208,24 @@ extern "C" int dfta_vwn_lsda(dfta_ctx* ctx, const double* na, const double* nb, 
     if (vexc) DFTA_HIP(ctx, hipMemcpyAsync(vexc, dR.p, sizeof(double) * sz, hipMemcpyDeviceToHost, st));
     if (va) DFTA_HIP(ctx, hipMemcpyAsync(va, dVa.p, sizeof(double) * sz, hipMemcpyDeviceToHost, st));
     if (vb) DFTA_HIP(ctx, hipMemcpyAsync(vb, dVb.p, sizeof(double) * sz, hipMemcpyDeviceToHost, st));
+    if (eexcdif) DFTA_HIP(ctx, hipMemcpyAsync(eexcdif, dE.p, sizeof(double) * sz, hipMemcpyDeviceToHost, st));
+    DFTA_HIP(ctx, hipStreamSynchronize(st));
+    return DFTA_OK;
+}
+
+extern "C" int dfta_chachiyo_lda(dfta_ctx* ctx, int improved, const double* n, size_t sz, double* vexc, double* eexcdif)
+{
+    if (!ctx) return DFTA_ERR_INVALID;
+    if (int rc_ = dfta_use(ctx)) return rc_;
+    DFTA_REQUIRE(ctx, n && (vexc || eexcdif), "null input");
+    if (sz == 0) return DFTA_OK;
+    hipStream_t st = ctx->stream;
+    DevBuf<double> dN, dV, dE;
+    DFTA_HIP(ctx, dN.alloc(sz)); DFTA_HIP(ctx, dV.alloc(sz)); DFTA_HIP(ctx, dE.alloc(sz));
+    DFTA_HIP(ctx, hipMemcpyAsync(dN.p, n, sizeof(double) * sz, hipMemcpyHostToDevice, st));
+    int rc = dfta_launch_chachiyo_lda(ctx, improved, dN.p, sz, dV.p, dE.p);
+    if (rc) return rc;
+    if (vexc) DFTA_HIP(ctx, hipMemcpyAsync(vexc, dV.p, sizeof(double) * sz, hipMemcpyDeviceToHost, st));
     if (eexcdif) DFTA_HIP(ctx, hipMemcpyAsync(eexcdif, dE.p, sizeof(double) * sz, hipMemcpyDeviceToHost, st));
     DFTA_HIP(ctx, hipStreamSynchronize(st));
     return DFTA_OK;

@@ -65,6 +65,13 @@ int         dfta_ctx_device_info(const dfta_ctx* ctx, int* num_cu, char* name, i
  * l(l+1)/(r_i r_i)*0.5 are evaluated once on the host with libm in the reference's operation order and
  * uploaded, so device kernels never call exp() on grid quantities. */
 int    dfta_grid_create(dfta_ctx* ctx, int mg_levels, double delta, double Rmax, dfta_grid** out);
+/* Uniform grid r_i = i h, h = Rmax / (N - 1): replaces NumerovFunctionRegularGrid (Numerov.h:16-70), the h of
+ * DFTAtom.cpp:66-68 and PoissonSolver::FillR (PoissonSolver.cpp:200-210).  Every entry point below accepts either kind
+ * of grid: sweeps then follow the IsUniform() branches of Numerov.h:274-291,353-370,408-425 (cut-off radius
+ * 200/sqrt(2|E|), recurrence with h^2), the Poisson solver runs with deltaGrid = 0 (SolvePoissonUniform,
+ * PoissonSolver.h:20-49) and the SCF is CalculateUniformLDA / LSDA (DFTAtom.cpp:60-210, 646-844). */
+int    dfta_grid_create_uniform(dfta_ctx* ctx, int mg_levels, double Rmax, dfta_grid** out);
+int    dfta_grid_is_uniform(const dfta_grid* g);
 void   dfta_grid_destroy(dfta_grid* g);
 int    dfta_grid_num_nodes(const dfta_grid* g);
 double dfta_grid_rp(const dfta_grid* g);
@@ -176,12 +183,21 @@ int  dfta_poisson_iterate_gs(dfta_poisson* p, int lvl, double errorMin, int iter
 int  dfta_poisson_restrict(dfta_poisson* p, int lvl);
 int  dfta_poisson_prolong(dfta_poisson* p, int lvl_src);
 int  dfta_poisson_vcycle(dfta_poisson* p, double* err_out);
+/* PoissonSolver::SetBoundaries + FullCycle (PoissonSolver.cpp:29-33, PoissonSolver.h:89-124) on atom 0's level storage: the
+ * level-0 source is the one the last solve (or dfta_poisson_set_level) left there */
+int  dfta_poisson_full_cycle(dfta_poisson* p, double lowBoundary, double highBoundary, double errorMin, double errorMinLast,
+                             double* err_out, int* vcycles_out);
 
 /* ---- VWN exchange-correlation ---------------------------------------------------------------------------
  * VWNExchCor::Vexc / eexcDif, LDA (VWNExcCor.h:73-128) and LSDA (VWNExcCor.h:134-312). Host pointers. */
 int dfta_vwn_lda(dfta_ctx* ctx, const double* n, size_t sz, double* vexc, double* eexcdif);
 int dfta_vwn_lsda(dfta_ctx* ctx, const double* na, const double* nb, size_t sz,
                   double* vexc, double* va, double* vb, double* eexcdif);
+
+/* Chachiyo's correlation functional with Dirac exchange, LDA: ChachiyoExchCor<Param>::Vexc / eexcDif (ExcCor.h:27-95);
+ * improved != 0 selects ChachiyoExchCorImprovedParam (ExcCor.h:21-26).  The reference keeps it beside VWN with every
+ * call site commented out (DFTAtom.cpp:383,412,421). */
+int dfta_chachiyo_lda(dfta_ctx* ctx, int improved, const double* n, size_t sz, double* vexc, double* eexcdif);
 
 /* ---- quadrature --------------------------------------------------------------------------------------------
  * Integral::{Trapezoid,SimpsonOneThird,Simpson38,Boole,Romberg} (Integral.h:11-155); values: host. */
@@ -213,6 +229,17 @@ typedef struct dfta_step_stats {
 
 int  dfta_scf_create(dfta_ctx* ctx, const dfta_grid* g, int lsda, int natoms, const int* Z,
                      double alpha, int levels_mode, int tree_depth, dfta_scf** out);   /* DFTAtom.cpp:351-394 / 852-906 */
+/* The reference's compile-time alternatives as run-time options (NULL = what the reference runs). */
+#define DFTA_XC_VWN               0   /* VWNExchCor (live in the reference)                                  */
+#define DFTA_XC_CHACHIYO          1   /* ChachiyoExchCor<ChachiyoExchCorParam>, LDA only (ExcCor.h)           */
+#define DFTA_XC_CHACHIYO_IMPROVED 2   /* ChachiyoExchCor<ChachiyoExchCorImprovedParam> (DFTAtom.cpp:383)      */
+typedef struct dfta_scf_options {
+    int integrator;   /* DFTA_INT_*: quadrature of the energy integrals and of the normalisation (default SIMPSON38) */
+    int functional;   /* DFTA_XC_*                                                                                */
+    int aufbau;       /* DFTA_AUFBAU_*                                                                            */
+} dfta_scf_options;
+int  dfta_scf_create_ex(dfta_ctx* ctx, const dfta_grid* g, int lsda, int natoms, const int* Z, double alpha, int levels_mode,
+                        int tree_depth, const dfta_scf_options* options, dfta_scf** out);
 void dfta_scf_destroy(dfta_scf* s);
 int  dfta_scf_step(dfta_scf* s, dfta_step_stats* stats);                               /* DFTAtom.cpp:396-484 / 908-1009 */
 /* An atom that has met the reference's stop test (DFTAtom.cpp:474-479: |dE/E| < 1e-11 and all levels converged in two
@@ -222,7 +249,11 @@ int  dfta_scf_step(dfta_scf* s, dfta_step_stats* stats);                        
 int  dfta_scf_get_energies(dfta_scf* s, dfta_energies* e /* natoms */, int* finished /* natoms */);
 /* geometry of the level search: bisection-tree depth, number of (atom,spin,n,l) jobs, trial lanes per round */
 int  dfta_scf_info(const dfta_scf* s, int* tree_depth, int* njobs, long* trials_per_round);
-int  dfta_scf_poisson_info(const dfta_scf* s, int* G, int* degraded, int* aborts);   /* dfta_poisson_group_info of the SCF's solver */
+int  dfta_scf_poisson_info(const dfta_scf* s, int* G, int* degraded, int* aborts);
+/* Quadrature rule (DFTA_INT_*) of the live path: the five energy integrals of a step and the normalisation of every
+ * orbital.  The reference calls Integral::Simpson38 at all 22 sites (DFTAtom.cpp:27,51,459-467,...) although its README
+ * names Romberg (README.md:81); Simpson38 is the default, the other rules of Integral.h:11-155 are a switch away. */
+int  dfta_scf_set_integrator(dfta_scf* s, int rule);   /* dfta_poisson_group_info of the SCF's solver */
 int  dfta_scf_num_levels(const dfta_scf* s, int atom, int spin);
 int  dfta_scf_get_levels(dfta_scf* s, int atom, int spin, int* n, int* l, int* occ, double* E, int* converged);
 int  dfta_scf_get_array(dfta_scf* s, int atom, int which, double* out /* N */);  /* 0 density,1 densityA,2 densityB,3 potA,4 potB,5 U */
@@ -234,6 +265,13 @@ int  dfta_scf_get_records_dev(dfta_scf* s, double* dRecords /* natoms*64, device
  * AufbauPrinciple::GetSubshells + sort (AufbauPrinciple.h:36-75, DFTAtom.cpp:367); integer-only host code. */
 int dfta_get_subshells(int Z, int* n, int* l, int* occ, int cap);
 int dfta_split_spin(int Z, int* nA, int* nB, int* an, int* al, int* aocc, int* bn, int* bl, int* bocc, int cap); /* DFTAtom.cpp:611-638 */
+/* aufbau: DFTA_AUFBAU_REFERENCE = what the reference runs (Madelung order + the f-block exceptions: Cr 3d4 4s2, Cu 3d9 4s2);
+ * DFTA_AUFBAU_TRANSITION_METALS additionally applies AufbauPrinciple::AdjustForTransitionMetals (AufbauPrinciple.h:78-99),
+ * which the reference defines but never calls (Cr 3d5 4s1, Cu 3d10 4s1, Pd 4d10, Pt 5d9 6s1 ...). */
+#define DFTA_AUFBAU_REFERENCE          0
+#define DFTA_AUFBAU_TRANSITION_METALS  1
+int dfta_get_subshells_ex(int Z, int aufbau, int* n, int* l, int* occ, int cap);
+int dfta_split_spin_ex(int Z, int aufbau, int* nA, int* nB, int* an, int* al, int* aocc, int* bn, int* bl, int* bocc, int cap);
 
 #ifdef __cplusplus
 }

@@ -30,6 +30,7 @@
 #include "PoissonSolver.h"   // first: brings <math.h> that Numerov.h relies on
 #include "Numerov.h"
 #include "VWNExcCor.h"
+#include "ExcCor.h"
 #include "Integral.h"
 #include "AufbauPrinciple.h"
 #include "DFTAtom.h"
@@ -268,6 +269,18 @@ void ref_vwn_eexcdif_lsda(const double* na, const double* nb, double* res, int s
     std::vector<double> a(na, na + sz), b(nb, nb + sz);
     std::vector<double> r = DFT::VWNExchCor::eexcDif(a, b);
     std::memcpy(res, r.data(), sizeof(double) * r.size());
+}
+
+// ---- Chachiyo (ExcCor.h) ----------------------------------------------------------------------------
+void ref_chachiyo(int improved, const double* n, double* vexc, double* eexcdif, int sz)
+{
+    std::vector<double> v(n, n + sz);
+    std::vector<double> a = improved ? DFT::ChachiyoExchCor<DFT::ChachiyoExchCorImprovedParam>::Vexc(v)
+                                     : DFT::ChachiyoExchCor<DFT::ChachiyoExchCorParam>::Vexc(v);
+    std::vector<double> b = improved ? DFT::ChachiyoExchCor<DFT::ChachiyoExchCorImprovedParam>::eexcDif(v)
+                                     : DFT::ChachiyoExchCor<DFT::ChachiyoExchCorParam>::eexcDif(v);
+    std::memcpy(vexc, a.data(), sizeof(double) * a.size());
+    std::memcpy(eexcdif, b.data(), sizeof(double) * b.size());
 }
 
 // ---- quadrature --------------------------------------------------------------------------------

@@ -179,6 +179,7 @@ def ref():
         "ref_calculate_hp": (C.c_long, [C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_char_p, C.c_long]),
         "ref_calculate_hp_steps": (C.c_long, [C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int,
                                               C.c_char_p, C.c_long]),
+        "ref_chachiyo": (None, [C.c_int, c_dp, c_dp, c_dp, C.c_int]),
         "ref_unumerov_create": (vp, [c_dp, C.c_int, C.c_double]),
         "ref_unumerov_destroy": (None, [vp]),
         "ref_ucount_nodes": (C.c_int, [vp, C.c_uint, C.c_double, C.c_long]),

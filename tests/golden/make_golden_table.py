@@ -4,6 +4,7 @@
 
     python tests/golden/make_golden_table.py table [--jobs 6]    -> periodic_table_L17.json  (config 4)
     python tests/golden/make_golden_table.py l20                 -> l20.npz + l20_meta.json   (config 5)
+    python tests/golden/make_golden_table.py uniform             -> uniform.npz + uniform_meta.json
 
 table: DFT::DFTAtom::CalculateNonUniformLDA(Z, 17, 0.5, 50, 1e-4) for Z = 1..86, run to the reference's own stop
        (17-digit console protocol of oracle/ref_hp.cpp); stored per atom: number of steps, Finished flag, the
@@ -111,10 +112,88 @@ def l20():
         json.dump(meta, f, indent=1)
 
 
+def uniform():
+    """Uniform-grid path (NumerovFunctionRegularGrid, SolvePoissonUniform, CalculateUniformLDA/LSDA): -> uniform.npz / uniform_meta.json"""
+    r = O.ref()
+    out, meta = {}, {}
+    rng = np.random.default_rng(20261003)
+    L, R = 14, 25.0
+    N = r.ref_num_nodes(L)
+    h = R / (N - 1)
+    rr = h * np.arange(N)
+    meta["grid"] = {"L": L, "Rmax": R, "N": N, "h": h}
+    pots = {"coulomb10": np.concatenate([[0.0], -10.0 / rr[1:]]), "screened18": screened_potential(rr, 18.0)}
+    for pname, V in pots.items():
+        hd = r.ref_unumerov_create(O.dp(V), N, R)
+        Zp = 10.0 if pname.endswith("10") else 18.0
+        Es = np.concatenate([-rng.uniform(1e-3, Zp * Zp + 1, 16), -10.0 ** rng.uniform(-3, 1, 6), [-(Zp ** 2) / 2, -(Zp ** 2) / 8, -33.0, -31.0, 0.5, 50.0]])
+        rows, ms = [], []
+        P = np.zeros(N)
+        for l in range(4):
+            for E in Es:
+                u0 = r.ref_usolution_in_zero(hd, l, float(E))
+                for lim in (0, 2, 5):
+                    rows.append([l, E, lim, r.ref_ucount_nodes(hd, l, float(E), lim), u0])
+                mp_ = r.ref_umatch(hd, l, float(E), O.dp(P))
+                ms.append(np.concatenate([[l, E, mp_, np.nansum(P), np.nansum(np.abs(P))], P[:: N // 64][:64]]))
+        out["sweeps_" + pname] = np.array(rows)
+        out["match_" + pname] = np.array(ms)
+        r.ref_unumerov_destroy(hd)
+    # level driver on the screened potential (Ar configuration)
+    V = pots["screened18"]
+    lv = O.subshells(18)
+    hd = r.ref_unumerov_create(O.dp(V), N, R)
+    n = np.array([a for a, _, _ in lv], np.int32)
+    l = np.array([b for _, b, _ in lv], np.int32)
+    occ = np.array([c for _, _, c in lv], np.int32)
+    E = np.zeros(len(lv))
+    nd = np.zeros(N)
+    Eel, Bot = C.c_double(0), C.c_double(-18.0 * 18 - 1.0)
+    conv = r.ref_uloop_over_levels(hd, len(lv), O.ip(n), O.ip(l), O.ip(occ), O.dp(E), O.dp(nd), C.byref(Eel), C.byref(Bot))
+    out["levels_E"] = E
+    out["levels_newdensity_sample"] = nd[:: N // 256].copy()
+    out["levels_scalars"] = np.array([Eel.value, Bot.value, conv, nd.sum()])
+    r.ref_unumerov_destroy(hd)
+    # Poisson
+    Lp, Rp_ = 12, 25.0
+    Np = r.ref_num_nodes(Lp)
+    rp = (Rp_ / (Np - 1)) * np.arange(Np)
+    for tag, Z in (("Z2", 2), ("Z18", 18)):
+        rho = Z * np.exp(-2 * rp) / np.pi
+        q = r.ref_poisson_create(Lp, 0.0)
+        U = np.zeros(Np)
+        r.ref_solve_poisson_uniform(q, Z, Rp_, O.dp(rho), Np, O.dp(U))
+        out["poisson_%s_U" % tag] = U
+        r.ref_poisson_destroy(q)
+    meta["poisson_grid"] = {"L": Lp, "Rmax": Rp_}
+    # Chachiyo functional (ExcCor.h), both parameter sets, on a density ladder
+    nl = np.concatenate([10.0 ** np.linspace(-20, 6, 131), [0.0, 9.99e-19, 1e-18]])
+    out["chachiyo_n"] = nl
+    for imp in (0, 1):
+        v, e = np.zeros_like(nl), np.zeros_like(nl)
+        r.ref_chachiyo(imp, O.dp(nl), O.dp(v), O.dp(e), len(nl))
+        out["chachiyo_%d" % imp] = np.stack([v, e])
+    np.savez_compressed(os.path.join(HERE, "uniform.npz"), **out)
+    # end to end: Ne LDA and N LSDA on 4097 uniform nodes, Rmax 15
+    e2e = {}
+    for mode, Z, tag in ((2, 10, "Ne_uLDA_L12"), (3, 7, "N_uLSDA_L12")):
+        txt = run_ref(mode, Z, 12, 0.5, 15.0, 0.0)
+        steps = parse_run(txt)
+        e2e[tag] = {"Z": Z, "L": 12, "Rmax": 15.0, "nsteps": len(steps), "finished": "Finished!" in txt, "steps": steps[:3] + [steps[-1]],
+                    "etotal_all": [s["energies"][0] for s in steps], "banner": txt.splitlines()[0],
+                    "tail": txt.strip().splitlines()[-2:]}
+        print(tag, len(steps), steps[-1]["energies"], flush=True)
+    meta["end_to_end"] = e2e
+    with open(os.path.join(HERE, "uniform_meta.json"), "w") as f:
+        json.dump(meta, f, indent=1)
+
+
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "table"
     jobs = int(sys.argv[sys.argv.index("--jobs") + 1]) if "--jobs" in sys.argv else 6
     if what == "table":
         table(jobs)
+    elif what == "uniform":
+        uniform()
     else:
         l20()

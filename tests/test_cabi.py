@@ -67,3 +67,28 @@ def test_no_cpu_fallback():
             if f.endswith((".py", ".hip", ".cpp", ".h")):
                 txt = open(os.path.join(root, f)).read()
                 assert "dfta_oracle" not in txt and "libdfta_ref" not in txt and "_oracle" not in txt, f
+
+
+def test_aufbau_transition_metal_option():
+    """AufbauPrinciple::AdjustForTransitionMetals (AufbauPrinciple.h:78-99, unwired in the reference) as an option: the known
+    ground-state configurations of the d-block exceptions; every other atom is untouched.  Integer-only host code."""
+    import dftatom_amd as D
+    name = "spdf"
+
+    def cfg(Z, au):
+        return " ".join("%d%s%d" % (n + 1, name[l], occ) for n, l, occ in D.get_subshells(Z, au))
+    want = {24: ("3d4 4s2", "3d5 4s1"), 29: ("3d9 4s2", "3d10 4s1"), 41: ("4d3 5s2", "4d4 5s1"), 42: ("4d4 5s2", "4d5 5s1"),
+            44: ("4d6 5s2", "4d7 5s1"), 45: ("4d7 5s2", "4d8 5s1"), 46: ("4d8 5s2", "4d10"), 47: ("4d9 5s2", "4d10 5s1"),
+            78: ("5d8 6s2", "5d9 6s1"), 79: ("5d9 6s2", "5d10 6s1")}
+    for Z in range(1, 119):
+        ref, tm = cfg(Z, D.AUFBAU_REFERENCE), cfg(Z, D.AUFBAU_TRANSITION_METALS)
+        assert sum(o for _, _, o in D.get_subshells(Z, D.AUFBAU_TRANSITION_METALS)) == Z
+        if Z in want:
+            for part in want[Z][0].split():
+                assert part in ref.split(), (Z, ref)
+            for part in want[Z][1].split():
+                assert part in tm.split(), (Z, tm)
+            if Z == 46:
+                assert "5s" not in tm
+        else:
+            assert ref == tm, Z
