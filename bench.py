@@ -1,27 +1,40 @@
 #!/usr/bin/env python3
-"""bench.py -- SCF-step wall time and Numerov sweeps/s for Radon (Z=86) at 131073 grid points on MI355X.
+"""bench.py -- SCF-step wall time, Numerov sweeps/s and Poisson V-cycles/s for Radon (Z=86) at 131073 grid points on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--atoms B] [--lsda] [--levels 17] [--no-cpu]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--atoms B] [--lsda] [--levels 17] [--no-cpu] [--no-extras]
 
-Workload (BASELINE.json configs[1]): Rn Z=86 LDA, 17 multigrid levels (131073 nodes), delta = 1e-4, Rmax = 50,
-mixing 0.5 (README.md:54 of the reference); one "step" = one SCF iteration of the atom batch, state resident in
-HBM: level search for all 15 (n,l) subshells (speculative bisection trees of Numerov sweeps, un-chained
-brackets), density mixing, multigrid Poisson (100 V-cycles), VWN and the five Simpson-3/8 energy integrals.
-The timed steps continue the SCF iteration from the warm-up steps (synthetic start: the reference's flat density).
+Workload of the headline line (BASELINE.json configs[1]): Rn Z=86 LDA, 17 multigrid levels (131073 nodes), delta = 1e-4,
+Rmax = 50, mixing 0.5 (README.md:54 of the reference); one "step" = one SCF iteration of the atom batch, state resident in
+HBM: level search for all 15 (n,l) subshells (speculative bisection trees of Numerov sweeps, un-chained brackets), density
+mixing, multigrid Poisson (100 V-cycles), VWN and the five Simpson-3/8 energy integrals.  The timed steps continue the SCF
+iteration from the warm-up steps (synthetic start: the reference's flat density).
 
-value = reference-equivalent Numerov sweeps per second over the WHOLE step wall time, i.e. the sweeps the
-reference's own bisection path needs for these steps (CountNodes + SolutionInZero + Match) divided by the
-elapsed time including Poisson/XC/integrals -- the same quantity the CPU baseline reports.  Speculative
-sweeps actually launched are reported separately (`sweeps_issued_per_s`) and feed the roofline object.
+value = reference-equivalent Numerov sweeps per second over the WHOLE step wall time: the sweeps the reference's own
+bisection path needs for these steps (CountNodes + SolutionInZero + Match; `sweeps_reference` counts every call the reference
+makes, including the ~52 CountNodes calls per node-less level whose outcome -- "count < 0" -- is decided here without
+integrating; `sweeps_reference_executed` leaves those out) divided by the elapsed time including Poisson / XC / integrals:
+the same quantity the CPU baseline reports.
 
-N > 1 (launched by torch.distributed.run): atoms are independent, so every rank advances its own replica of
-the batch (weak scaling, no data-path collective); the per-atom result records are all_gathered over RCCL
-once after the last step, inside the timed region.
+Objects on the JSON line:
+  roofline       the DOMINANT kernel of the timed region (by HIP-event time): the persistent multigrid kernel or the sweep
+                 kernel; achieved = algorithmic bytes / its HIP-event time, against 8 TB/s
+  kernels        both hot kernels, each with its own figures: the sweep kernel on ISSUED and on REFERENCE-EQUIVALENT bytes
+                 plus its VALU-issue ceiling (the resource that binds it), the multigrid kernel on the 8d bytes
+  extra          (N = 1 only) two more measured workloads, each with the same per-kernel figures: a machine-filling batch of
+                 64 Rn atoms and Rn LSDA (BASELINE configs[2])
+  cpu_baseline   the oracle on the host: 1 core (how the reference runs), 1 core with tables, and all cores (replicas)
+
+N > 1 (launched by torch.distributed.run): atoms are independent, so every rank advances its own replica of the batch (weak
+scaling, no data-path collective); the per-atom result records are all_gathered over RCCL once after the last step, inside
+the timed region.
 """
 import argparse
 import ctypes as C
+import glob
+import hashlib
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -30,37 +43,204 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 NUMEROV_BYTES_PER_POINT = 8    # one fp64 V_i per traversed grid point per trial
-POISSON_BYTES_PER_VCYCLE = {14: 6162448, 17: 49285736, 20: 394267840}
+POISSON_BYTES_PER_VCYCLE = {14: 6162448, 17: 49285736, 20: 394267840}   # SURVEY.md section 8(d), every pass counted
+# fp64 VALU issue: one wave64 instruction per SIMD every 1.86 ns (profiles/microbench/issue_rate.hip), 256 CUs x 4 SIMDs
+VALU_WAVE_INSTR_PER_S = 256 * 4 / 1.86e-9
+# wave-level VALU instructions per grid point of one 64-trial block in k_sweep_pipe (numerov.hip): producers 15 (f: 4, d: 2,
+# reciprocal: 5, lane broadcasts: 4), integrator 8, counter ~1
+SWEEP_VALU_PER_BLOCK_POINT = 24
+GRIDS = {14: (5e-4, 25.0), 17: (1e-4, 50.0), 20: (1.25e-5, 50.0)}
 
 
-def cpu_baseline(levels, delta, rmax, lsda, budget_steps):
-    """The oracle (plain-C restatement of the reference, 1 thread) timed on this host: `budget_steps` SCF steps."""
+# ---------------------------------------------------------------------------------------------------------------
+# CPU baseline: the oracle (test infrastructure, used here as the measured CPU leg only)
+# ---------------------------------------------------------------------------------------------------------------
+def cpu_worker(levels, lsda, steps, tables):
+    """runs in its own process: `steps` SCF steps of Rn on the oracle, prints one JSON line"""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import _oracle as O
+    delta, rmax = GRIDS.get(levels, (1e-4, 50.0))
     o = O.oracle()
     t0 = time.time()
     s = o.dfo_scf_create(int(lsda), 86, levels, 0.5, rmax, delta, 1)
     t_setup = time.time() - t0
+    if tables:
+        o.dfo_tables_enable(C.byref(s.contents.g))
     e = O.Energies()
     sweeps = 0
     vcycles0 = s.contents.ps.contents.n_vcycles
     t0 = time.time()
-    for _ in range(budget_steps):
+    for _ in range(steps):
         o.dfo_scf_step(s, C.byref(e))
         for arr, n in ((s.contents.la, s.contents.nla), (s.contents.lb, s.contents.nlb if lsda else 0)):
             for i in range(n):
                 sweeps += arr[i].n_count + arr[i].n_zero + 1
     dt = time.time() - t0
     vc = s.contents.ps.contents.n_vcycles - vcycles0
+    o.dfo_tables_disable()
     o.dfo_scf_destroy(s)
-    return {"value": sweeps / dt, "unit": "sweeps/s", "cores": 1, "kind": "port",
-            "sample": "%d SCF steps of Rn %s @ %d levels on the oracle (oracle/dfta_oracle.c, gcc -O2, 1 thread): %.2f s, "
-                      "%d sweeps, %d V-cycles; setup (flat density + Poisson) %.2f s excluded"
-                      % (budget_steps, "LSDA" if lsda else "LDA", levels, dt, sweeps, vc, t_setup),
-            "ms_per_step": 1e3 * dt / budget_steps, "vcycles_per_s": vc / dt}
+    print(json.dumps({"sweeps": sweeps, "seconds": dt, "vcycles": vc, "setup_s": t_setup, "etotal": e.Etotal}))
+
+
+def _spawn_cpu(levels, lsda, steps, tables, n):
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-worker", str(levels), str(int(lsda)), str(steps), str(int(tables))]
+    t0 = time.time()
+    procs = [subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True) for _ in range(n)]
+    outs = [json.loads(p.communicate()[0].strip().splitlines()[-1]) for p in procs]
+    return outs, time.time() - t0
+
+
+def cpu_model():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(levels, lsda, steps):
+    """The oracle (plain-C restatement of the reference) timed on this host, in child processes."""
+    nproc = os.cpu_count() or 1
+    one, _ = _spawn_cpu(levels, lsda, steps, False, 1)
+    tab, _ = _spawn_cpu(levels, lsda, steps, True, 1)
+    nall = min(nproc, 64)
+    allc, wall = _spawn_cpu(levels, lsda, steps, False, nall)
+    o, t = one[0], tab[0]
+    assert abs(o["etotal"] - t["etotal"]) == 0.0                     # the table variant is bit-identical
+    tag = "Rn %s @ %d levels" % ("LSDA" if lsda else "LDA", levels)
+    return {"value": o["sweeps"] / o["seconds"], "unit": "sweeps/s", "cores": 1, "kind": "port",
+            "sample": "%d SCF steps of %s on the oracle (oracle/dfta_oracle.c, gcc -O2 -ffp-contract=off, 1 thread): %.2f s, %d sweeps, "
+                      "%d V-cycles; setup (flat density + Poisson) %.2f s excluded" % (steps, tag, o["seconds"], o["sweeps"], o["vcycles"], o["setup_s"]),
+            "ms_per_step": 1e3 * o["seconds"] / steps, "vcycles_per_s": o["vcycles"] / o["seconds"],
+            "cpu_model": cpu_model(), "nproc": nproc,
+            "table_variant": {"value": t["sweeps"] / t["seconds"], "unit": "sweeps/s", "cores": 1, "ms_per_step": 1e3 * t["seconds"] / steps,
+                              "note": "r_i and exp(2 i delta) looked up instead of re-evaluated per point; results bit-identical"},
+            "all_cores": {"value": sum(x["sweeps"] for x in allc) / max(x["seconds"] for x in allc), "unit": "sweeps/s", "cores": nall,
+                          "vcycles_per_s": sum(x["vcycles"] for x in allc) / max(x["seconds"] for x in allc),
+                          "note": "%d independent replicas of the same run, one process per core (atoms are the parallel axis of the "
+                                  "reference's algorithm; the reference itself is single-threaded), %d steps each, slowest replica's time"
+                                  % (nall, steps)}}
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# profiles
+# ---------------------------------------------------------------------------------------------------------------
+def source_sha():
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "dftatom_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "dftatom_amd", "csrc", "*.h"))):
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the newest committed rocprofv3 PMC passes of this same command
+    (profiles/*_hbm_traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate passes; FETCH_SIZE doubled as
+    MI355X_MICROARCH.md prescribes for gfx950).  bench.py cannot run the profiler on itself: the number is the measured one of
+    that profile, returned with its tag -- and withheld (null) when the kernels' sources have changed since it was taken."""
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.json")), key=os.path.getmtime)
+    if not files:
+        return None, None
+    try:
+        with open(files[-1]) as f:
+            d = json.load(f)
+        tag = {"profile": os.path.basename(files[-1]), "source_sha": d.get("source_sha"), "current": d.get("source_sha") == source_sha()}
+        if not tag["current"]:
+            return None, tag
+        return float(d["kernels"][kernel]["hbm_bytes_per_launch_fetch_doubled"]), tag
+    except Exception:
+        return None, None
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# one measured workload
+# ---------------------------------------------------------------------------------------------------------------
+def run_workload(D, ctx, grid, levels, atoms, lsda, steps, warmup, tree_depth, barrier, torch, after_steps=None):
+    scf = D.Scf(ctx, grid, [86] * atoms, lsda=lsda, alpha=0.5, levels_mode=D.LEVELS_BATCHED, tree_depth=tree_depth)
+    for _ in range(warmup):
+        scf.step()
+    barrier()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    keys = ("sweeps_issued", "sweeps_reference", "sweeps_reference_executed", "points_traversed", "points_reference", "vcycles", "rounds",
+            "ms_sweep_kernels", "ms_levels", "ms_poisson", "ms_tail")
+    tot = {k: 0 for k in keys}
+    t0 = time.time()
+    ev0.record()
+    for _ in range(steps):
+        st = scf.step()
+        for k in keys:
+            tot[k] += getattr(st, k)
+    if after_steps:
+        after_steps(scf)
+    ev1.record()
+    barrier()
+    tot["elapsed"] = time.time() - t0
+    tot["ev_ms"] = ev0.elapsed_time(ev1)
+    tot["steps"] = steps
+    tot["trials_per_round"] = scf.trials_per_round
+    tot["tree_depth"] = scf.tree_depth
+    tot["poisson_G"] = scf.poisson_info()[0]
+    tot["energies"] = scf.energies()[0][0].as_list()
+    return scf, tot
+
+
+def kernel_figures(tot, levels, N, atoms):
+    """per-kernel roofline figures of a workload (HIP-event times measured inside the library on the launch stream)"""
+    forced = os.environ.get("DFTA_SWEEP_KERNEL", "")
+    piped = forced == "pipe" or (forced != "fused" and tot["trials_per_round"] // 64 <= 768)
+    sname = "k_sweep_pipe" if piped else "k_sweep"
+    t_sw = tot["ms_sweep_kernels"] * 1e-3
+    launches = max(tot["rounds"], 1)
+    b_issued = NUMEROV_BYTES_PER_POINT * tot["points_traversed"]
+    b_ref = NUMEROV_BYTES_PER_POINT * tot["points_reference"]
+    block_points = tot["points_traversed"] / 64.0       # lower bound: 64 live lanes in every block
+    sweep = {"kernel": sname + " (Numerov CountNodes / SolutionInZero sweeps)", "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
+             "launches": launches, "avg_launch_ms": tot["ms_sweep_kernels"] / launches,
+             "achieved_issued": b_issued / t_sw / 1e9 if t_sw else None, "frac_issued": b_issued / t_sw / 1e9 / HBM_PEAK_GBS if t_sw else None,
+             "achieved_reference_equivalent": b_ref / t_sw / 1e9 if t_sw else None,
+             "frac_reference_equivalent": b_ref / t_sw / 1e9 / HBM_PEAK_GBS if t_sw else None,
+             "bytes_per_launch_issued": b_issued / launches, "bytes_per_launch_reference_equivalent": b_ref / launches,
+             "binding_resource": "fp64 VALU issue of the integrator wave (one block of 64 trials per CU; sequential three-term recurrence)",
+             "valu_issue": {"wave_instr_per_block_point": SWEEP_VALU_PER_BLOCK_POINT, "block_points_per_s": block_points / t_sw if t_sw else None,
+                            "ceiling_wave_instr_per_s": VALU_WAVE_INSTR_PER_S,
+                            "frac": SWEEP_VALU_PER_BLOCK_POINT * block_points / t_sw / VALU_WAVE_INSTR_PER_S if t_sw else None,
+                            "ns_per_point_per_block": 1e9 * t_sw / (launches * N) if t_sw else None,
+                            "note": "static instruction count from numerov.hip x measured points; profiles/*_sq_counters.json holds SQ_INSTS_VALU"},
+             "note": "8 B per traversed grid point per trial (SURVEY 8d). ISSUED = every trial of the speculative trees; REFERENCE-EQUIVALENT = "
+                     "only the trials on the reference's bisection path (what its sequential loop integrates). The 64 trials of a block share "
+                     "one table row, so physical HBM traffic is far below either figure."}
+    t_ps = tot["ms_poisson"] * 1e-3
+    b_ps = POISSON_BYTES_PER_VCYCLE.get(levels, 376 * N) * tot["vcycles"]
+    psolves = max(tot["steps"], 1)
+    pois = {"kernel": "k_poisson_solve (persistent multigrid: FMG ramp + 100 V-cycles per launch)", "bound": "hbm", "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "launches": psolves, "avg_launch_ms": tot["ms_poisson"] / psolves,
+            "achieved": b_ps / t_ps / 1e9 if t_ps else None, "frac": b_ps / t_ps / 1e9 / HBM_PEAK_GBS if t_ps else None,
+            "bytes_per_launch": b_ps / psolves, "vcycles_per_s": tot["vcycles"] / t_ps if t_ps else None,
+            "workgroups": atoms * tot["poisson_G"],
+            "binding_resource": "latency of the ordered Gauss-Seidel recurrence: %d atom(s) x %d workgroups of 256 lanes on 256 CUs, every sweep "
+                                "%d+95 dependent steps" % (atoms, tot["poisson_G"], max(1, (N - 1) // (256 * tot["poisson_G"]))),
+            "note": "algorithmic bytes per V-cycle with every pass counted (GS 24 B/pt x 3 sweeps per visit, restrict, prolong: SURVEY 8d); the "
+                    "level storage of one atom (6.3 MB at 17 levels) stays in LDS / L2, so HBM is not what this kernel waits for"}
+    return sweep, pois
+
+
+def summarize(tot, levels, N, atoms, lsda, world, delta, rmax):
+    sweep, pois = kernel_figures(tot, levels, N, atoms)
+    return {"workload": "Rn Z=86 %s, %d multigrid levels (%d pts), delta=%g, Rmax=%g, mixing 0.5, %d atom(s)/GPU, un-chained clamped brackets, "
+                        "tree depth %d" % ("LSDA" if lsda else "LDA", levels, N, delta, rmax, atoms, tot["tree_depth"]),
+            "sweeps_per_s": tot["sweeps_reference"] / tot["elapsed"], "sweeps_executed_per_s": tot["sweeps_reference_executed"] / tot["elapsed"],
+            "sweeps_issued_per_s": tot["sweeps_issued"] / tot["elapsed"], "vcycles_per_s": tot["vcycles"] / tot["elapsed"],
+            "ms_per_step": 1e3 * tot["elapsed"] / tot["steps"], "steps": tot["steps"], "rounds_per_step": tot["rounds"] / tot["steps"],
+            "phase_ms_per_step": {"levels": tot["ms_levels"] / tot["steps"], "poisson": tot["ms_poisson"] / tot["steps"],
+                                  "tail": tot["ms_tail"] / tot["steps"], "hip_event_total": tot["ev_ms"] / tot["steps"]},
+            "kernels": {"sweep": sweep, "poisson": pois}}
 
 
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "--cpu-worker":
+        cpu_worker(int(sys.argv[2]), bool(int(sys.argv[3])), int(sys.argv[4]), bool(int(sys.argv[5])))
+        return
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
@@ -70,6 +250,7 @@ def main():
     ap.add_argument("--lsda", action="store_true")
     ap.add_argument("--tree-depth", type=int, default=0)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--no-extras", action="store_true", help="skip the 64-atom batch and the LSDA workloads")
     ap.add_argument("--cpu-steps", type=int, default=3)
     args = ap.parse_args()
 
@@ -87,13 +268,10 @@ def main():
         dist.init_process_group(backend="nccl", rank=rank, world_size=world)
 
     import dftatom_amd as D
-    grids = {14: (5e-4, 25.0), 17: (1e-4, 50.0), 20: (1.25e-5, 50.0)}
-    delta, rmax = grids.get(args.levels, (1e-4, 50.0))
+    delta, rmax = GRIDS.get(args.levels, (1e-4, 50.0))
     stream = torch.cuda.current_stream().cuda_stream
     ctx = D.Context(local_rank, stream)
     grid = D.Grid(ctx, args.levels, delta, rmax)
-    scf = D.Scf(ctx, grid, [86] * args.atoms, lsda=args.lsda, alpha=0.5, levels_mode=D.LEVELS_BATCHED,
-                tree_depth=args.tree_depth)
     records = torch.zeros((args.atoms, D.RECORD_DOUBLES), dtype=torch.float64, device="cuda")
 
     def barrier():
@@ -102,55 +280,43 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        scf.step()
-    barrier()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    tot = {"issued": 0, "ref": 0, "points": 0, "vcycles": 0, "rounds": 0, "ms_sweep": 0.0, "ms_levels": 0.0,
-           "ms_poisson": 0.0, "ms_tail": 0.0}
-    t0 = time.time()
-    ev0.record()
-    for _ in range(args.steps):
-        st = scf.step()
-        tot["issued"] += st.sweeps_issued
-        tot["ref"] += st.sweeps_reference
-        tot["points"] += st.points_traversed
-        tot["vcycles"] += st.vcycles
-        tot["rounds"] += st.rounds
-        tot["ms_sweep"] += st.ms_sweep_kernels
-        tot["ms_levels"] += st.ms_levels
-        tot["ms_poisson"] += st.ms_poisson
-        tot["ms_tail"] += st.ms_tail
-    scf.records_into(records.data_ptr())
-    if world > 1:
-        gathered = [torch.empty_like(records) for _ in range(world)]
-        dist.all_gather(gathered, records)
-    ev1.record()
-    barrier()
-    elapsed = time.time() - t0
-    ev_ms = ev0.elapsed_time(ev1)
+    def gather(scf):
+        scf.records_into(records.data_ptr())
+        if world > 1:
+            gathered = [torch.empty_like(records) for _ in range(world)]
+            dist.all_gather(gathered, records)
 
+    scf, tot = run_workload(D, ctx, grid, args.levels, args.atoms, args.lsda, args.steps, args.warmup, args.tree_depth, barrier, torch, gather)
+    elapsed = tot["elapsed"]
     # max over ranks of the elapsed time, sums of the work
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        w = torch.tensor([tot["ref"], tot["issued"], tot["vcycles"]], dtype=torch.float64, device="cuda")
+        w = torch.tensor([tot["sweeps_reference"], tot["sweeps_issued"], tot["vcycles"], tot["sweeps_reference_executed"]], dtype=torch.float64, device="cuda")
         dist.all_reduce(w, op=dist.ReduceOp.SUM)
-        ref_all, issued_all, vc_all = (float(x) for x in w.tolist())
+        ref_all, issued_all, vc_all, exe_all = (float(x) for x in w.tolist())
     else:
-        ref_all, issued_all, vc_all = float(tot["ref"]), float(tot["issued"]), float(tot["vcycles"])
+        ref_all, issued_all, vc_all, exe_all = (float(tot[k]) for k in ("sweeps_reference", "sweeps_issued", "vcycles", "sweeps_reference_executed"))
+    scf.close()
 
     if rank == 0:
-        en, fin = scf.energies()
         ncu, devname = ctx.device_info()
-        launches = max(tot["rounds"], 1)
-        # dfta_launch_sweep picks the pipelined kernel for up to 768 blocks of 64 trials per round (numerov.hip:kPipeMaxBlocks)
-        forced = os.environ.get("DFTA_SWEEP_KERNEL", "")
-        piped = forced == "pipe" or (forced != "fused" and scf.trials_per_round // 64 <= 768)
-        kname = "k_sweep_pipe" if piped else "k_sweep"
-        bytes_total = NUMEROV_BYTES_PER_POINT * tot["points"]
-        achieved = bytes_total / (tot["ms_sweep"] * 1e-3) / 1e9 if tot["ms_sweep"] > 0 else 0.0
+        sweep, pois = kernel_figures(tot, args.levels, grid.N, args.atoms)
+        dominant = pois if tot["ms_poisson"] >= tot["ms_sweep_kernels"] else sweep
+        dkey = "k_poisson_solve" if dominant is pois else ("k_sweep_pipe" if "k_sweep_pipe" in sweep["kernel"] else "k_sweep")
+        traffic, ttag = pmc_traffic(dkey)
+        roof = {"bound": "hbm", "kernel": dominant["kernel"],
+                "achieved": dominant["achieved"] if dominant is pois else dominant["achieved_reference_equivalent"],
+                "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": dominant["frac"] if dominant is pois else dominant["frac_reference_equivalent"],
+                "traffic": traffic, "traffic_source": ttag,
+                "bytes_per_launch": dominant["bytes_per_launch"] if dominant is pois else dominant["bytes_per_launch_reference_equivalent"],
+                "avg_launch_ms": dominant["avg_launch_ms"], "launches": dominant["launches"],
+                "share_of_step_ms": {"k_poisson_solve": tot["ms_poisson"] / args.steps, "sweep kernel": tot["ms_sweep_kernels"] / args.steps},
+                "binding_resource": dominant["binding_resource"],
+                "note": "dominant kernel of the timed region by HIP-event time; achieved = algorithmic bytes of SURVEY 8d per launch / average "
+                        "launch duration; see `kernels` for both hot kernels (the sweep kernel also on issued bytes and against its VALU-issue ceiling)"}
         out = {
             "metric": "numerov_sweeps_per_s (reference-equivalent, whole SCF step; Rn Z=86 @ %d pts)" % grid.N,
             "value": ref_all / elapsed,
@@ -166,61 +332,39 @@ def main():
             "data": "synthetic (reference's flat start density, SCF iterations %d..%d)" % (args.warmup, args.warmup + args.steps - 1),
             "config": {"workload": "Rn Z=86 %s, %d multigrid levels (%d pts), delta=%g, Rmax=%g, mixing 0.5, %d atom(s)/GPU, "
                                    "un-chained clamped brackets, tree depth %d" % ("LSDA" if args.lsda else "LDA", args.levels, grid.N,
-                                                                           delta, rmax, args.atoms, scf_depth(scf)),
+                                                                           delta, rmax, args.atoms, tot["tree_depth"]),
                        "atoms_per_gpu": args.atoms, "parallelism": "replicas x%d" % world},
             "scf_step_ms": 1e3 * elapsed / args.steps,
+            "sweeps_reference_definition": "every SolveSchrodinger* call of the reference's LoopOverLevels for these steps (CountNodes + "
+                                           "SolutionInZero + Match); sweeps_executed_per_s leaves out the CountNodes calls of node-less levels' "
+                                           "second bisection, which are decided without integrating",
+            "sweeps_executed_per_s": exe_all / elapsed,
             "sweeps_issued_per_s": issued_all / elapsed,
             "poisson_vcycles_per_s": vc_all / elapsed,
-            "poisson_vcycles_per_s_kernel": tot["vcycles"] / (tot["ms_poisson"] * 1e-3) if tot["ms_poisson"] > 0 else None,
+            "poisson_vcycles_per_s_kernel": pois["vcycles_per_s"],
             "phase_ms_per_step": {"levels": tot["ms_levels"] / args.steps, "poisson": tot["ms_poisson"] / args.steps,
-                                  "tail": tot["ms_tail"] / args.steps, "hip_event_total": ev_ms / args.steps},
+                                  "tail": tot["ms_tail"] / args.steps, "hip_event_total": tot["ev_ms"] / args.steps},
             "rounds_per_step": tot["rounds"] / args.steps,
-            "energies_last_step": en[0].as_list(),
+            "energies_last_step": tot["energies"],
             "device": devname, "compute_units": ncu,
-            "roofline": {"bound": "hbm", "kernel": kname + " (Numerov count/zero sweeps)",
-                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": pmc_traffic(kname),
-                         "bytes_per_launch": bytes_total / launches, "avg_launch_ms": tot["ms_sweep"] / launches,
-                         "launches": launches,
-                         "note": "algorithmic bytes = 8 B x traversed grid points of every ISSUED trial (SURVEY 8d); the 64 trials "
-                                 "of a block share the potential table, so HBM traffic is far below this figure -- the kernel is "
-                                 "bound by the sequential fp64 recurrence (VALU issue + LDS hand-over), see DESIGN.md"},
-            "poisson_roofline": {"bound": "hbm", "kernel": "k_poisson_solve (persistent multigrid)",
-                                 "achieved": (POISSON_BYTES_PER_VCYCLE.get(args.levels, 0) * tot["vcycles"] /
-                                              (tot["ms_poisson"] * 1e-3) / 1e9) if tot["ms_poisson"] > 0 else None,
-                                 "peak": HBM_PEAK_GBS, "unit": "GB/s"},
+            "roofline": roof,
+            "kernels": {"sweep": sweep, "poisson": pois},
         }
-        if out["poisson_roofline"]["achieved"]:
-            out["poisson_roofline"]["frac"] = out["poisson_roofline"]["achieved"] / HBM_PEAK_GBS
+        if world == 1 and not args.no_extras:
+            extra = {}
+            for name, atoms, lsda, st, wu in (("batch64_lda", 64, False, 3, 1), ("rn_lsda", 1, True, 3, 2)):
+                s2, t2 = run_workload(D, ctx, grid, args.levels, atoms, lsda, st, wu, 0, barrier, torch)
+                s2.close()
+                extra[name] = summarize(t2, args.levels, grid.N, atoms, lsda, world, delta, rmax)
+            out["extra"] = extra
         if not args.no_cpu:
-            out["cpu_baseline"] = cpu_baseline(args.levels, delta, rmax, args.lsda, args.cpu_steps)
+            out["cpu_baseline"] = cpu_baseline(args.levels, args.lsda, args.cpu_steps)
         print(json.dumps(out))
-    scf.close()
     grid.close()
     ctx.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-
-
-def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same command
-    (profiles/*_hbm_traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate passes; raw sum, see the file
-    for the gfx950 FETCH_SIZE caveat).  bench.py cannot run the profiler on itself, so the number is the
-    measured one of the latest committed profile, or null when none is present."""
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.json")))
-    if not files:
-        return None
-    try:
-        with open(files[-1]) as f:
-            return float(json.load(f)["kernels"][kernel]["hbm_bytes_per_launch_raw"])
-    except Exception:
-        return None
-
-
-def scf_depth(scf):
-    return int(getattr(scf, "tree_depth", 0)) or 0
 
 
 if __name__ == "__main__":

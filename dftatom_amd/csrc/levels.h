@@ -62,6 +62,7 @@ struct Job {
     double hist_T[3], hist_d[3];
     int hist_ok;                     // 0: none, 1: end points only, 2: end points and distances
     int frozen;                      // the job's atom has finished its SCF: the result of its last solve stands, nothing is integrated
+    long long n_points;              // grid points traversed by the sweeps ON the bisection path (n_count + n_zero executed ones) + the match solve
 };
 
 struct LevelStats {
@@ -86,7 +87,7 @@ struct LevelSolver {
     int *d_chain_off = nullptr, *d_chain_off_b = nullptr, *d_v_off = nullptr, *d_slot_v = nullptr, *d_slot_l = nullptr;
     double2* d_tab = nullptr;
     double *d_E = nullptr, *d_us = nullptr, *d_us1 = nullptr, *d_u0 = nullptr, *d_phi = nullptr;
-    int *d_limit = nullptr, *d_start = nullptr, *d_count = nullptr, *d_istop = nullptr;
+    int *d_limit = nullptr, *d_start = nullptr, *d_count = nullptr, *d_istop = nullptr, *d_trip = nullptr;
     int *d_wave_kind = nullptr, *d_wave_slot = nullptr, *d_wave_first = nullptr, *d_wave_cnt = nullptr;
     unsigned long long* d_counters = nullptr;   // [0] issued trials, [1] traversed points, [2] scratch
     double *d_Psi = nullptr, *d_Q = nullptr;     // njobs*N each

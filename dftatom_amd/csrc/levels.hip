@@ -363,7 +363,7 @@ __device__ __forceinline__ void secant_predict(dfta::Job& j, const double2* __re
 }
 
 __device__ void walk_job(dfta::Job& j, const int* __restrict__ count, const double* __restrict__ u0, const double* __restrict__ phi,
-                         const int* __restrict__ istop, int tpj, int base, const double2* __restrict__ veff)
+                         const int* __restrict__ istop, const int* __restrict__ trip, int tpj, int base, const double2* __restrict__ veff)
 {
     Cursor c;
     c.init(j.spine, capz_of(j, tpj));
@@ -375,6 +375,7 @@ __device__ void walk_job(dfta::Job& j, const int* __restrict__ count, const doub
             const double e = (hi + lo) / 2;
             const int cn = count[base + h];
             ++j.n_count;
+            j.n_points += trip[base + h];
             const bool bit = !(cn > j.nodes);                        // 1: boe = E
             if (bit) lo = e; else hi = e;
             {
@@ -420,6 +421,7 @@ __device__ void walk_job(dfta::Job& j, const int* __restrict__ count, const doub
             const double e = (hi + lo) / 2;
             const int cn = count[base + h];
             ++j.n_count;
+            j.n_points += trip[base + h];
             const bool bit = (cn < j.nodes);                         // 1: boe = E
             if (bit) lo = e; else hi = e;
             c.advance(bit, pred_bit(j, 1, j.phase_done));
@@ -438,6 +440,7 @@ __device__ void walk_job(dfta::Job& j, const int* __restrict__ count, const doub
         if (!j.haveSgn) {
             const double d0 = u0[base];
             ++j.n_zero;
+            j.n_points += trip[base];
             j.sgnBottom = d0 > 0;
             j.haveSgn = 1;
         }
@@ -449,6 +452,7 @@ __device__ void walk_job(dfta::Job& j, const int* __restrict__ count, const doub
             const double e = (hi + lo) / 2;
             const double d = u0[base + h];
             ++j.n_zero;
+            j.n_points += trip[base + h];
             ++j.iter3;
             const bool bit = ((d > 0) == (j.sgnBottom != 0));        // 1: BottomEnergy = E
             if (bit) lo = e; else hi = e;
@@ -546,7 +550,8 @@ __global__ __launch_bounds__(64) void k_scout(dfta::Job* __restrict__ jobs, int 
 
 __global__ void k_walk(dfta::Job* __restrict__ jobs, const int* __restrict__ chain_off, int nchains, int tpj,
                        const int* __restrict__ count, const double* __restrict__ u0, const double* __restrict__ phi,
-                       const int* __restrict__ istop, const double2* __restrict__ tab, int N, int* __restrict__ ndone)
+                       const int* __restrict__ istop, const int* __restrict__ trip, const double2* __restrict__ tab, int N,
+                       int* __restrict__ ndone)
 {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= nchains) return;
@@ -572,7 +577,7 @@ __global__ void k_walk(dfta::Job* __restrict__ jobs, const int* __restrict__ cha
             jobs[k] = j;
             break;                                                  // its trials are generated next round
         }
-        walk_job(j, count, u0, phi, istop, tpj, k * tpj, tab + (size_t)j.slot * N);
+        walk_job(j, count, u0, phi, istop, trip, tpj, k * tpj, tab + (size_t)j.slot * N);
         jobs[k] = j;
         if (j.phase == PH_DONE) { ++done; continue; }
         break;
@@ -682,10 +687,13 @@ __global__ void k_job_energies(const dfta::Job* __restrict__ jobs, int njobs, do
     l[k] = jobs[k].l;
 }
 
-__global__ void k_store_match(dfta::Job* __restrict__ jobs, int njobs, const int* __restrict__ mp)
+__global__ void k_store_match(dfta::Job* __restrict__ jobs, int njobs, const int* __restrict__ mp, const int* __restrict__ jstart)
 {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k < njobs && !jobs[k].frozen) jobs[k].matchPoint = mp[k];
+    if (k < njobs && !jobs[k].frozen) {
+        jobs[k].matchPoint = mp[k];
+        jobs[k].n_points += jstart[k];        // inward from the cut-off to the match point + outward up to it
+    }
 }
 
 // frozen jobs are skipped by the match / normalise kernels: their cut-off index is replaced by -1
@@ -704,12 +712,12 @@ LevelSolver::~LevelSolver() { release(); }
 void LevelSolver::release()
 {
     void* ptrs[] = {d_jobs, d_chain_off, d_chain_off_b, d_v_off, d_slot_v, d_slot_l, d_tab, d_E, d_limit, d_start, d_us, d_us1, d_count,
-                    d_u0, d_phi, d_istop, d_wave_kind, d_wave_slot, d_wave_first, d_wave_cnt, d_counters, d_Psi, d_Q, d_jE, d_jslot, d_jl,
+                    d_u0, d_phi, d_istop, d_trip, d_wave_kind, d_wave_slot, d_wave_first, d_wave_cnt, d_counters, d_Psi, d_Q, d_jE, d_jslot, d_jl,
                     d_jstart, d_jus, d_jus1, d_jmp, d_slot_min, d_bounds};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (hipEvent_t& e : ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
     d_jobs = nullptr; d_chain_off = nullptr; d_chain_off_b = nullptr; d_v_off = nullptr; d_slot_v = nullptr; d_slot_l = nullptr; d_tab = nullptr;
-    d_E = nullptr; d_limit = nullptr; d_start = nullptr; d_us = nullptr; d_us1 = nullptr; d_count = nullptr; d_u0 = nullptr; d_phi = nullptr; d_istop = nullptr;
+    d_E = nullptr; d_limit = nullptr; d_start = nullptr; d_us = nullptr; d_us1 = nullptr; d_count = nullptr; d_u0 = nullptr; d_phi = nullptr; d_istop = nullptr; d_trip = nullptr;
     d_wave_kind = nullptr; d_wave_slot = nullptr; d_wave_first = nullptr; d_wave_cnt = nullptr; d_counters = nullptr;
     d_Psi = nullptr; d_Q = nullptr; d_jE = nullptr; d_jslot = nullptr; d_jl = nullptr; d_jstart = nullptr; d_jus = nullptr;
     d_jus1 = nullptr; d_jmp = nullptr; d_slot_min = nullptr; d_bounds = nullptr;
@@ -784,7 +792,7 @@ int LevelSolver::setup(dfta_ctx* c, const dfta_grid* grid, int mode_, int tree_d
     ALLOC(d_slot_l, int, nslots); UPLOAD(d_slot_l, slot_l);
     ALLOC(d_tab, double2, (size_t)nslots * N);
     ALLOC(d_E, double, ntrials); ALLOC(d_limit, int, ntrials); ALLOC(d_start, int, ntrials);
-    ALLOC(d_us, double, ntrials); ALLOC(d_us1, double, ntrials); ALLOC(d_count, int, ntrials); ALLOC(d_u0, double, ntrials); ALLOC(d_phi, double, ntrials); ALLOC(d_istop, int, ntrials);
+    ALLOC(d_us, double, ntrials); ALLOC(d_us1, double, ntrials); ALLOC(d_count, int, ntrials); ALLOC(d_u0, double, ntrials); ALLOC(d_phi, double, ntrials); ALLOC(d_istop, int, ntrials); ALLOC(d_trip, int, ntrials);
     ALLOC(d_wave_kind, int, nwaves);
     ALLOC(d_wave_slot, int, nwaves); UPLOAD(d_wave_slot, wave_slot);
     ALLOC(d_wave_first, int, nwaves); UPLOAD(d_wave_first, wave_first);
@@ -802,6 +810,7 @@ int LevelSolver::setup(dfta_ctx* c, const dfta_grid* grid, int mode_, int tree_d
     DFTA_HIP(ctx, hipEventCreate(&ev[1]));
     DFTA_HIP(ctx, hipMemsetAsync(d_count, 0, sizeof(int) * ntrials, st));
     DFTA_HIP(ctx, hipMemsetAsync(d_u0, 0, sizeof(double) * ntrials, st));
+    DFTA_HIP(ctx, hipMemsetAsync(d_trip, 0, sizeof(int) * ntrials, st));
     DFTA_HIP(ctx, hipStreamSynchronize(st));
     return DFTA_OK;
 }
@@ -903,14 +912,14 @@ int LevelSolver::run(const double* dV, const double* job_bottom, int run_mode, d
         DFTA_CHECK_LAUNCH(ctx);
         if (stats) DFTA_HIP(ctx, hipEventRecord(ev[0], st));
         rc = dfta_launch_sweep(ctx, g, DFTA_SWEEP_COUNT, d_wave_kind, nwaves, d_tab, d_wave_slot, d_wave_first, d_wave_cnt, d_E,
-                               d_limit, d_start, d_us, d_us1, d_count, d_u0, nullptr, d_counters + 1, g->uniform ? nullptr : d_bounds, d_phi,
+                               d_limit, d_start, d_us, d_us1, d_count, d_u0, d_trip, d_counters + 1, g->uniform ? nullptr : d_bounds, d_phi,
                                d_istop, d_slot_l);
         if (rc) return rc;
         if (stats) DFTA_HIP(ctx, hipEventRecord(ev[1], st));
         hipLaunchKernelGGL(k_scout, dim3(njobs), dim3(64), 0, st, d_jobs, tpj, d_E, d_start, d_u0);
         DFTA_CHECK_LAUNCH(ctx);
         DFTA_HIP(ctx, hipMemsetAsync(d_ndone, 0, sizeof(int), st));
-        hipLaunchKernelGGL(k_walk, dim3((run_chains + 63) / 64), dim3(64), 0, st, d_jobs, d_chains, run_chains, tpj, d_count, d_u0, d_phi, d_istop, d_tab, N, d_ndone);
+        hipLaunchKernelGGL(k_walk, dim3((run_chains + 63) / 64), dim3(64), 0, st, d_jobs, d_chains, run_chains, tpj, d_count, d_u0, d_phi, d_istop, d_trip, d_tab, N, d_ndone);
         DFTA_CHECK_LAUNCH(ctx);
         hipLaunchKernelGGL(k_plan, dim3((njobs + 63) / 64), dim3(64), 0, st, d_jobs, njobs, tpj, use_prediction ? 0 : 1);
         DFTA_CHECK_LAUNCH(ctx);
@@ -957,7 +966,7 @@ int LevelSolver::run(const double* dV, const double* job_bottom, int run_mode, d
     rc = dfta_launch_match(ctx, g, njobs, d_tab, d_jslot, d_jE, d_jstart, d_jus, d_jus1, d_jl, d_Psi, d_Q, d_jmp, g->uniform ? nullptr : d_bounds,
                            d_Q);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_store_match, dim3((njobs + 63) / 64), dim3(64), 0, st, d_jobs, njobs, d_jmp);
+    hipLaunchKernelGGL(k_store_match, dim3((njobs + 63) / 64), dim3(64), 0, st, d_jobs, njobs, d_jmp, d_jstart);
     DFTA_CHECK_LAUNCH(ctx);
     hipLaunchKernelGGL(k_normalize, dim3(njobs), dim3(256), 0, st, d_Psi, d_Q, N, g->d_eh, g->d_cnst, nfrozen ? d_jstart : nullptr, g->uniform ? g->h : 1.0, integ_rule);
     DFTA_CHECK_LAUNCH(ctx);

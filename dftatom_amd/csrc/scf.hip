@@ -435,8 +435,15 @@ int dfta_scf_step(dfta_scf* s, dfta_step_stats* stats)
         stats->sweeps_issued = ls.sweeps_issued;
         stats->points_traversed = ls.points_traversed;
         long ref = 0;
-        for (const auto& j : s->h_jobs) if (!j.frozen) ref += j.n_count + j.n_zero + 1;   // + the matched solve of each level
+        long long pts = 0, skipped = 0;
+        for (const auto& j : s->h_jobs) if (!j.frozen) {
+            ref += j.n_count + j.n_zero + 1;   // + the matched solve of each level
+            pts += j.n_points;
+            if (j.nodes == 0) skipped += j.cur_len[1];     // the second bisection of a node-less level is pure arithmetic
+        }
         stats->sweeps_reference = ref;
+        stats->sweeps_reference_executed = ref - (long)skipped;
+        stats->points_reference = (long)pts;
         unsigned long long vc = 0;
         rc = dfta_poisson_take_vcycles(s->poisson, &vc);
         if (rc) return rc;

@@ -225,6 +225,9 @@ typedef struct dfta_step_stats {
     float  ms_levels, ms_poisson, ms_tail;   /* HIP-event times of the three phases       */
     float  ms_sweep_kernels;     /* HIP-event time summed over the sweep-kernel launches only */
     float  ms_poisson_kernel;    /* HIP-event time of the persistent multigrid kernel        */
+    long   sweeps_reference_executed; /* sweeps_reference minus the CountNodes calls of node-less levels' second
+                                    bisection ("count < 0": decided without integrating, levels.hip) */
+    long   points_reference;     /* grid points traversed by the executed sweeps on the reference's path */
 } dfta_step_stats;
 
 int  dfta_scf_create(dfta_ctx* ctx, const dfta_grid* g, int lsda, int natoms, const int* Z,

@@ -44,8 +44,35 @@ void dfo_grid_init(dfo_grid* g, int N, double delta, double Rmax)   /* Numerov.h
     g->delta2p4 = delta2 * 0.25;
 }
 
+/* Optional "table" variant of the CPU baseline: the two exp() values per grid point that the
+ * reference re-evaluates in every sweep are computed once per grid and looked up.  Same values, same arithmetic after
+ * the lookup, hence bit-identical results (tests/test_oracle_golden.py); only the timing differs.  One grid at a time,
+ * not thread safe (each cpu_baseline worker is its own process). */
+static struct { int N; double delta, Rmax; double* pos; double* e2; } dfo_tab = {0, 0, 0, 0, 0};
+void dfo_tables_enable(const dfo_grid* g)
+{
+    dfo_tables_disable();
+    dfo_tab.pos = (double*)malloc(sizeof(double) * (size_t)g->N);
+    dfo_tab.e2 = (double*)malloc(sizeof(double) * (size_t)g->N);
+    for (long i = 0; i < g->N; ++i) {
+        dfo_tab.pos[i] = g->Rp * (exp((double)i * g->delta) - 1.);
+        dfo_tab.e2[i] = exp((double)i * g->twodelta);
+    }
+    dfo_tab.N = g->N; dfo_tab.delta = g->delta; dfo_tab.Rmax = g->Rmax;
+}
+void dfo_tables_disable(void)
+{
+    free(dfo_tab.pos); free(dfo_tab.e2);
+    dfo_tab.pos = dfo_tab.e2 = 0; dfo_tab.N = 0;
+}
+static inline int dfo_tab_hit(const dfo_grid* g, long i)
+{
+    return dfo_tab.N == g->N && dfo_tab.delta == g->delta && dfo_tab.Rmax == g->Rmax && i >= 0 && i < g->N;
+}
+
 double dfo_position(const dfo_grid* g, long i)   /* Numerov.h:181-184 */
 {
+    if (dfo_tab_hit(g, i)) return dfo_tab.pos[i];
     return g->Rp * (exp((double)i * g->delta) - 1.);
 }
 
@@ -58,6 +85,7 @@ double dfo_veff(const dfo_grid* g, const double* V, unsigned l, long i)   /* Num
 double dfo_f(const dfo_grid* g, const double* V, unsigned l, double E, long i)   /* Numerov.h:96-101 */
 {
     const double effectivePotential = dfo_veff(g, V, l, i);
+    if (dfo_tab_hit(g, i)) return 2. * (effectivePotential - E) * g->Rp2delta2 * dfo_tab.e2[i] + g->delta2p4;
     return 2. * (effectivePotential - E) * g->Rp2delta2 * exp((double)i * g->twodelta) + g->delta2p4;
 }
 

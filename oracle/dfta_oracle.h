@@ -39,6 +39,9 @@ typedef struct dfo_grid {
 int    dfo_num_nodes(int levels);                                   /* PoissonSolver.h:127-135 */
 void   dfo_grid_init(dfo_grid* g, int N, double delta, double Rmax); /* Numerov.h:76-87 */
 double dfo_position(const dfo_grid* g, long i);                      /* Numerov.h:181-184 */
+/* "table" variant of the CPU baseline: r_i and exp(2 i delta) looked up instead of re-evaluated (bit-identical results) */
+void   dfo_tables_enable(const dfo_grid* g);
+void   dfo_tables_disable(void);
 double dfo_veff(const dfo_grid* g, const double* V, unsigned l, long i);        /* Numerov.h:89-94 */
 double dfo_f(const dfo_grid* g, const double* V, unsigned l, double E, long i); /* Numerov.h:96-101 */
 double dfo_far(const dfo_grid* g, double position, double E);        /* Numerov.h:103-108 */

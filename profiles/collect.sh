@@ -6,7 +6,7 @@
 # Raw output goes to gpurun_out/<tag>_*/ (scratch); profiles/summarize.py turns it into the committed summaries.
 set -u
 TAG=${1:-r01}
-ARGS=${2:-"--steps 3 --warmup 1 --no-cpu"}
+ARGS=${2:-"--steps 3 --warmup 1 --no-cpu --no-extras"}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/${TAG}
 mkdir -p "$OUT"

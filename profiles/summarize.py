@@ -75,7 +75,10 @@ def main():
             with open(os.path.join(pdir, tag + "_bench_under_rocprof.json"), "w") as fh:
                 json.dump(json.loads(lines[-1]), fh, indent=1)
     fetch, write = counters(os.path.join(raw, "fetch")), counters(os.path.join(raw, "write"))
-    traffic = {"command": "rocprofv3 --pmc <FETCH_SIZE | WRITE_SIZE> --kernel-trace --output-format csv -- python3 bench.py " + args +
+    sys.path.insert(0, ROOT)
+    import bench
+    traffic = {"source_sha": bench.source_sha(),
+               "command": "rocprofv3 --pmc <FETCH_SIZE | WRITE_SIZE> --kernel-trace --output-format csv -- python3 bench.py " + args +
                           "  (separate passes, MI355X gfx950, ROCm 7.2; profiles/collect.sh)",
                "unit": "FETCH_SIZE / WRITE_SIZE as reported by rocprofv3 (KiB); bytes = value * 1024.  MI355X_MICROARCH.md (HBM): on gfx950 "
                        "FETCH_SIZE reports 1/2 of the bytes of wide coalesced streaming reads and is uncalibrated for other access "
@@ -97,7 +100,7 @@ def main():
             json.dump(traffic, fh, indent=1)
     sq = counters(os.path.join(raw, "sq"))
     if sq:
-        o = {"command": "rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY "
+        o = {"source_sha": bench.source_sha(), "command": "rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY "
                         "SQ_WAIT_INST_ANY --kernel-trace -- python3 bench.py " + args, "kernels": {}}
         for k, cs in sq.items():
             o["kernels"][k] = {c: {"launches": len(v), "mean_per_launch": sum(v) / len(v)} for c, v in cs.items()}

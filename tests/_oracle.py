@@ -84,6 +84,8 @@ def oracle():
         "dfo_num_nodes": (C.c_int, [C.c_int]),
         "dfo_grid_init": (None, [G, C.c_int, C.c_double, C.c_double]),
         "dfo_position": (C.c_double, [G, C.c_long]),
+        "dfo_tables_enable": (None, [G]),
+        "dfo_tables_disable": (None, []),
         "dfo_veff": (C.c_double, [G, c_dp, C.c_uint, C.c_long]),
         "dfo_f": (C.c_double, [G, c_dp, C.c_uint, C.c_double, C.c_long]),
         "dfo_far": (C.c_double, [G, C.c_double, C.c_double]),
