@@ -62,6 +62,9 @@ struct Job {
     double hist_T[3], hist_d[3];
     int hist_ok;                     // 0: none, 1: end points only, 2: end points and distances
     int frozen;                      // the job's atom has finished its SCF: the result of its last solve stands, nothing is integrated
+    // Trial slots of the job in the current round: [tbase, tbase + tcap).  Static (k * tpj, tpj) when the launch fills the
+    // machine; re-allotted every round by k_allot when a handful of jobs leave compute units idle (levels.hip).
+    int tbase, tcap;
     long long n_points;              // grid points traversed by the sweeps ON the bisection path (n_count + n_zero executed ones) + the match solve
 };
 
@@ -88,7 +91,8 @@ struct LevelSolver {
     double2* d_tab = nullptr;
     double *d_E = nullptr, *d_us = nullptr, *d_us1 = nullptr, *d_u0 = nullptr, *d_phi = nullptr;
     int *d_limit = nullptr, *d_start = nullptr, *d_count = nullptr, *d_istop = nullptr, *d_trip = nullptr;
-    int *d_wave_kind = nullptr, *d_wave_slot = nullptr, *d_wave_first = nullptr, *d_wave_cnt = nullptr;
+    int *d_wave_kind = nullptr, *d_wave_slot = nullptr, *d_wave_first = nullptr, *d_wave_cnt = nullptr, *d_wave_job = nullptr;
+    bool dynamic = false;          // trial slots re-allotted among the active jobs every round (few jobs: latency mode)
     unsigned long long* d_counters = nullptr;   // [0] issued trials, [1] traversed points, [2] scratch
     double *d_Psi = nullptr, *d_Q = nullptr;     // njobs*N each
     double *d_jE = nullptr, *d_jus = nullptr, *d_jus1 = nullptr;

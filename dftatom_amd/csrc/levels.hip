@@ -71,7 +71,7 @@ __device__ __forceinline__ bool pred_bit(const dfta::Job& j, int ph, int k)
 }
 
 // ---- expand: trial energies of the current round of every job, plus their far boundary values ----------------------
-__global__ __launch_bounds__(256) void k_expand(const dfta::Job* __restrict__ jobs, int tpj, int ntrials, const double* __restrict__ r,
+__global__ __launch_bounds__(256) void k_expand(const dfta::Job* __restrict__ jobs, const int* __restrict__ wave_job, int ntrials, const double* __restrict__ r,
                                                 int N, double delta, double far_thr, double* __restrict__ E,
                                                 int* __restrict__ limit, int* __restrict__ start, double* __restrict__ us,
                                                 double* __restrict__ us1, int* __restrict__ wave_kind,
@@ -79,9 +79,15 @@ __global__ __launch_bounds__(256) void k_expand(const dfta::Job* __restrict__ jo
 {
     const int gt = blockIdx.x * blockDim.x + threadIdx.x;
     if (gt >= ntrials) return;       // ntrials is a multiple of 64: whole waves leave
-    const int job = gt / tpj;
-    const int h = gt - job * tpj;
+    const int job = wave_job[gt >> 6];
+    if (job < 0) {                    // a block of 64 slots that no job owns this round
+        E[gt] = 0; limit[gt] = 0; start[gt] = 0;
+        if ((gt & 63) == 0) wave_kind[gt >> 6] = DFTA_SWEEP_ZERO;
+        return;
+    }
     const dfta::Job j = jobs[job];
+    const int tpj = j.tcap;
+    const int h = gt - j.tbase;
     bool active = false;
     double e = 0;
     const int capz = capz_of(j, tpj);
@@ -293,7 +299,9 @@ __device__ __forceinline__ void plan_round(dfta::Job& j, const dfta::Job* __rest
         }
     } else if (j.phase == PH_ZERO) {
         // l == 0: no inner turning point, the count changes exactly where u(0) changes sign -- at the upper end
-        if (j.l == 0) predict_from_bracket(j, j.boe, j.toe, j.top - kGuard, j.top + kGuard, true);
+        // (inside ~2e-11 |E| of it the sign of u(0), like the count, is round-off: a spine that runs into that band misses and
+        // forfeits the round's tree)
+        if (j.l == 0) { const double gd = kGuard + kNoise * fabs(j.top); predict_from_bracket(j, j.boe, j.toe, j.top - gd, j.top + gd, true); }
         else if (j.se_state == 1 && j.se_tok && !j.miss) predict_from_bracket(j, j.boe, j.toe, j.se_tlo - kGuard, j.se_thi + kGuard, true);
         else if (j.se_state == 1) predict_from_bracket(j, j.boe, j.toe, j.se_lo - kGuard, j.se_hi + kGuard, true);
     }
@@ -363,8 +371,9 @@ __device__ __forceinline__ void secant_predict(dfta::Job& j, const double2* __re
 }
 
 __device__ void walk_job(dfta::Job& j, const int* __restrict__ count, const double* __restrict__ u0, const double* __restrict__ phi,
-                         const int* __restrict__ istop, const int* __restrict__ trip, int tpj, int base, const double2* __restrict__ veff)
+                         const int* __restrict__ istop, const int* __restrict__ trip, const double2* __restrict__ veff)
 {
+    const int tpj = j.tcap, base = j.tbase;
     Cursor c;
     c.init(j.spine, capz_of(j, tpj));
     if (j.phase == PH_TOP) {                                        // DFTAtom.cpp:568-585
@@ -473,14 +482,15 @@ __device__ void walk_job(dfta::Job& j, const int* __restrict__ count, const doub
 }
 
 // ---- scouts: bracket of the sign change of u(0) inside the band, one wave per job, before the walk of the round ------
-__global__ __launch_bounds__(64) void k_scout(dfta::Job* __restrict__ jobs, int tpj, const double* __restrict__ E,
+__global__ __launch_bounds__(64) void k_scout(dfta::Job* __restrict__ jobs, const double* __restrict__ E,
                                               const int* __restrict__ start, const double* __restrict__ u0)
 {
     const int job = blockIdx.x, lane = threadIdx.x;
     const dfta::Job j = jobs[job];
+    const int tpj = j.tcap;
     const int capz = capz_of(j, tpj);
     if (!(j.phase == PH_TOP || j.phase == PH_BOTTOM) || capz >= tpj) return;
-    const int base = job * tpj;
+    const int base = j.tbase;
     // samples [capz, tpj) in ascending energy, m consecutive ones per lane
     const int n = tpj - capz, m = n / 64;
     const bool bracketed = j.se_state == 1;
@@ -548,7 +558,7 @@ __global__ __launch_bounds__(64) void k_scout(dfta::Job* __restrict__ jobs, int 
     jobs[job].se_thi = thi;
 }
 
-__global__ void k_walk(dfta::Job* __restrict__ jobs, const int* __restrict__ chain_off, int nchains, int tpj,
+__global__ void k_walk(dfta::Job* __restrict__ jobs, const int* __restrict__ chain_off, int nchains,
                        const int* __restrict__ count, const double* __restrict__ u0, const double* __restrict__ phi,
                        const int* __restrict__ istop, const int* __restrict__ trip, const double2* __restrict__ tab, int N,
                        int* __restrict__ ndone)
@@ -577,7 +587,7 @@ __global__ void k_walk(dfta::Job* __restrict__ jobs, const int* __restrict__ cha
             jobs[k] = j;
             break;                                                  // its trials are generated next round
         }
-        walk_job(j, count, u0, phi, istop, trip, tpj, k * tpj, tab + (size_t)j.slot * N);
+        walk_job(j, count, u0, phi, istop, trip, tab + (size_t)j.slot * N);
         jobs[k] = j;
         if (j.phase == PH_DONE) { ++done; continue; }
         break;
@@ -586,12 +596,13 @@ __global__ void k_walk(dfta::Job* __restrict__ jobs, const int* __restrict__ cha
 }
 
 // spines of the next round, after every walk of this one (a job reads its sibling's first-bisection result)
-__global__ void k_plan(dfta::Job* __restrict__ jobs, int njobs, int tpj, int nopredict)
+__global__ void k_plan(dfta::Job* __restrict__ jobs, int njobs, int nopredict)
 {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= njobs) return;
     dfta::Job j = jobs[k];
     if (j.phase != PH_TOP && j.phase != PH_BOTTOM && j.phase != PH_ZERO) return;
+    const int tpj = j.tcap;
     plan_round(j, jobs, tpj);
     if (nopredict) { j.spine = 0; j.capz = tpj; j.use_sp = 0; j.sp_len = 0; j.sp_bits = 0; }     // plain trees only (DFTA_LEVELS_NOPREDICT)
     jobs[k].spine = j.spine;
@@ -599,6 +610,93 @@ __global__ void k_plan(dfta::Job* __restrict__ jobs, int njobs, int tpj, int nop
     jobs[k].use_sp = j.use_sp;
     jobs[k].sp_bits = j.sp_bits;
     jobs[k].sp_len = j.sp_len;
+}
+
+// ---- latency mode: the trial slots of a round are re-allotted among the jobs that are still searching -----------------
+// With a handful of jobs (one atom) a round is one pass of at most `budget / 64` blocks over the compute units whatever
+// the blocks do, and the number of rounds is set by the slowest job: the levels whose last decisions cannot be predicted
+// (the count / the sign of u(0) are not monotonic in E below ~1e-11 |E|: 7 decisions for an outer level, 14-16 for 2s / 1s)
+// need one tree of that depth or several rounds of shallower ones.  So each round every active job asks for what it can
+// use -- probe + spine + a tree as deep as the decisions that remain after the spine (6 .. kMaxTreeDepth), twice that when
+// it also scouts -- and the requests are cut back, deepest tree first, until they fit.  Which midpoints are integrated
+// changes, the decisions taken do not (the walk follows the reference's predicates on whatever nodes it finds).
+constexpr int kMaxTreeDepth = 14;
+__device__ __forceinline__ int decisions_left(const dfta::Job& j)
+{
+    double w = j.toe - j.boe;
+    int n = 0;
+    if (j.phase == PH_ZERO) { while (!(w < kEnergyErr) && n < 64) { w *= 0.5; ++n; } }
+    else                    { while (w > kEnergyErr && n < 64) { w *= 0.5; ++n; } }
+    return n;
+}
+
+__global__ __launch_bounds__(64) void k_allot(dfta::Job* __restrict__ jobs, int njobs, int budget, int nopredict, int* __restrict__ wave_job,
+                                              int* __restrict__ wave_slot)
+{
+    __shared__ int s_S[64], s_r[64], s_sc[64], s_act[64], s_rem[64];
+    const int k = threadIdx.x;            // njobs <= 64 in this mode
+    bool act = false;
+    int S = 0, r = 0, sc = 0, rem = 0;
+    if (k < njobs) {
+        dfta::Job j = jobs[k];
+        act = (j.phase == PH_TOP || j.phase == PH_BOTTOM || j.phase == PH_ZERO);
+        if (act) {
+            plan_round(j, jobs, 1 << 14);                      // what would it do with room to spare?
+            if (nopredict) { j.spine = 0; j.capz = 1 << 14; }
+            S = j.spine;
+            sc = j.capz < (1 << 14);
+            // a tree that ends the phase if one of up to kMaxTreeDepth levels can, else equal shares of the rounds it takes anyway
+            const int left = decisions_left(j) - S;
+            if (left <= kMaxTreeDepth) r = left < 6 ? 6 : left;
+            else { const int nr = (left + 9) / 10; r = (left + nr - 1) / nr; }
+            // rounds this job still has in front of it (a level's three bisections take about 3 + 2 + 2 rounds): the slots go to
+            // the jobs that are furthest behind, because the round count of a step is theirs
+            rem = (left + 9) / 10 + (j.phase == PH_TOP ? 4 : (j.phase == PH_BOTTOM ? 2 : 0));
+        }
+    }
+    if (k < 64) { s_S[k] = S; s_r[k] = r; s_sc[k] = sc; s_act[k] = act ? 1 : 0; s_rem[k] = rem; }
+    __syncthreads();
+    if (k == 0) {
+        auto slots = [&](int q) { const int t = 1 + s_S[q] + (1 << s_r[q]); const int u = (t + 127) & ~127; return s_sc[q] ? 2 * u : u; };
+        for (int floor = 8; floor >= 6; floor -= 2) {
+            while (true) {
+                int tot = 0, pick = -1;
+                for (int q = 0; q < njobs; ++q)
+                    if (s_act[q]) {
+                        tot += slots(q);
+                        // cut the job that is least behind (then the deepest tree among equals)
+                        if (s_r[q] > floor && (pick < 0 || s_rem[q] < s_rem[pick] || (s_rem[q] == s_rem[pick] && s_r[q] > s_r[pick]))) pick = q;
+                    }
+                if (tot <= budget || pick < 0) break;
+                --s_r[pick];
+            }
+        }
+        int base = 0;
+        for (int q = 0; q < njobs; ++q) {
+            int cap = 0;
+            if (s_act[q]) { cap = slots(q); if (base + cap > budget) cap = ((budget - base) / 128) * 128; }
+            jobs[q].tbase = base;
+            jobs[q].tcap = cap;
+            for (int w = base >> 6; w < (base + cap) >> 6; ++w) { wave_job[w] = q; wave_slot[w] = jobs[q].slot; }
+            base += cap;
+        }
+        for (int w = base >> 6; w < budget >> 6; ++w) { wave_job[w] = -1; wave_slot[w] = 0; }
+    }
+    __syncthreads();
+    if (k < njobs && act) {                                    // the plan for the slots the job really got
+        dfta::Job j = jobs[k];
+        if (j.tcap < 128) {                                    // nothing left for it this round (cannot happen while budget >= 128 njobs)
+            jobs[k].spine = 0; jobs[k].capz = j.tcap; jobs[k].use_sp = 0; jobs[k].sp_bits = 0; jobs[k].sp_len = 0;
+            return;
+        }
+        plan_round(j, jobs, j.tcap);
+        if (nopredict) { j.spine = 0; j.capz = j.tcap; j.use_sp = 0; j.sp_len = 0; j.sp_bits = 0; }
+        jobs[k].spine = j.spine;
+        jobs[k].capz = j.capz;
+        jobs[k].use_sp = j.use_sp;
+        jobs[k].sp_bits = j.sp_bits;
+        jobs[k].sp_len = j.sp_len;
+    }
 }
 
 // ---- normalise (DFTAtom.cpp:36-56) ------------------------------------------------------------------------------
@@ -712,13 +810,13 @@ LevelSolver::~LevelSolver() { release(); }
 void LevelSolver::release()
 {
     void* ptrs[] = {d_jobs, d_chain_off, d_chain_off_b, d_v_off, d_slot_v, d_slot_l, d_tab, d_E, d_limit, d_start, d_us, d_us1, d_count,
-                    d_u0, d_phi, d_istop, d_trip, d_wave_kind, d_wave_slot, d_wave_first, d_wave_cnt, d_counters, d_Psi, d_Q, d_jE, d_jslot, d_jl,
+                    d_u0, d_phi, d_istop, d_trip, d_wave_job, d_wave_kind, d_wave_slot, d_wave_first, d_wave_cnt, d_counters, d_Psi, d_Q, d_jE, d_jslot, d_jl,
                     d_jstart, d_jus, d_jus1, d_jmp, d_slot_min, d_bounds};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (hipEvent_t& e : ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
     d_jobs = nullptr; d_chain_off = nullptr; d_chain_off_b = nullptr; d_v_off = nullptr; d_slot_v = nullptr; d_slot_l = nullptr; d_tab = nullptr;
     d_E = nullptr; d_limit = nullptr; d_start = nullptr; d_us = nullptr; d_us1 = nullptr; d_count = nullptr; d_u0 = nullptr; d_phi = nullptr; d_istop = nullptr; d_trip = nullptr;
-    d_wave_kind = nullptr; d_wave_slot = nullptr; d_wave_first = nullptr; d_wave_cnt = nullptr; d_counters = nullptr;
+    d_wave_kind = nullptr; d_wave_slot = nullptr; d_wave_first = nullptr; d_wave_cnt = nullptr; d_counters = nullptr; d_wave_job = nullptr;
     d_Psi = nullptr; d_Q = nullptr; d_jE = nullptr; d_jslot = nullptr; d_jl = nullptr; d_jstart = nullptr; d_jus = nullptr;
     d_jus1 = nullptr; d_jmp = nullptr; d_slot_min = nullptr; d_bounds = nullptr;
 }
@@ -762,6 +860,14 @@ int LevelSolver::setup(dfta_ctx* c, const dfta_grid* grid, int mode_, int tree_d
     depth = d;
     tpj = 1 << d;
     ntrials = static_cast<long>(njobs) * tpj;
+    // latency mode (the pipelined kernel's regime: at most ~1.5 passes of one block per compute unit): the slots of a
+    // round are re-allotted among the active jobs (k_allot); the budget is one full pass at least
+    dynamic = (tree_depth <= 0) && njobs <= 64 && ntrials / 64 <= 384 && getenv("DFTA_LEVELS_STATIC") == nullptr;
+    if (dynamic) {
+        long blocks = std::max(ctx->num_cu, 1);
+        if (const char* e = getenv("DFTA_LEVELS_BUDGET_BLOCKS")) blocks = std::max(64, atoi(e));     // measurements
+        ntrials = std::max<long>(ntrials, 64L * blocks);
+    }
     nwaves = static_cast<int>(ntrials / 64);
 
     // table slots: one per distinct (v, l)
@@ -778,8 +884,13 @@ int LevelSolver::setup(dfta_ctx* c, const dfta_grid* grid, int mode_, int tree_d
     }
     h_jobs_template = jobs;
     nslots = static_cast<int>(slot_v.size());
-    std::vector<int> wave_slot(nwaves), wave_first(nwaves), wave_cnt(nwaves, 64);
-    for (int w = 0; w < nwaves; ++w) { wave_slot[w] = jobs[(w * 64) / tpj].slot; wave_first[w] = w * 64; }
+    std::vector<int> wave_slot(nwaves), wave_first(nwaves), wave_cnt(nwaves, 64), wave_job(nwaves);
+    for (int w = 0; w < nwaves; ++w) {
+        const int q = (w * 64) / tpj;
+        wave_job[w] = q < njobs ? q : -1;
+        wave_slot[w] = q < njobs ? jobs[q].slot : 0;
+        wave_first[w] = w * 64;
+    }
 
     hipStream_t st = ctx->stream;
 #define ALLOC(ptr, type, count) DFTA_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ptr), sizeof(type) * (size_t)(count)))
@@ -797,6 +908,7 @@ int LevelSolver::setup(dfta_ctx* c, const dfta_grid* grid, int mode_, int tree_d
     ALLOC(d_wave_slot, int, nwaves); UPLOAD(d_wave_slot, wave_slot);
     ALLOC(d_wave_first, int, nwaves); UPLOAD(d_wave_first, wave_first);
     ALLOC(d_wave_cnt, int, nwaves); UPLOAD(d_wave_cnt, wave_cnt);
+    ALLOC(d_wave_job, int, nwaves); UPLOAD(d_wave_job, wave_job);
     ALLOC(d_counters, unsigned long long, 4);
     ALLOC(d_Psi, double, (size_t)njobs * N);
     ALLOC(d_Q, double, (size_t)njobs * N);
@@ -842,6 +954,8 @@ int LevelSolver::run(const double* dV, const double* job_bottom, int run_mode, d
             continue;
         }
         j.frozen = 0;
+        j.tbase = k * tpj;
+        j.tcap = tpj;
         j.bottom0 = job_bottom[k];
         const bool first = (k == 0 || jobs[k].v != jobs[k - 1].v);
         if (!chained || first) { j.phase = PH_TOP; j.toe = 50; j.boe = j.bottom0; }   // DFTAtom.cpp:499
@@ -900,14 +1014,22 @@ int LevelSolver::run(const double* dV, const double* job_bottom, int run_mode, d
         DFTA_CHECK_LAUNCH(ctx);
     }
 
-    hipLaunchKernelGGL(k_plan, dim3((njobs + 63) / 64), dim3(64), 0, st, d_jobs, njobs, tpj, use_prediction ? 0 : 1);     // spines of the first round
-    DFTA_CHECK_LAUNCH(ctx);
+    auto plan = [&]() -> int {          // spines (and, in latency mode, the slots) of the next round
+        if (dynamic)
+            hipLaunchKernelGGL(k_allot, dim3(1), dim3(64), 0, st, d_jobs, njobs, (int)ntrials, use_prediction ? 0 : 1, d_wave_job, d_wave_slot);
+        else
+            hipLaunchKernelGGL(k_plan, dim3((njobs + 63) / 64), dim3(64), 0, st, d_jobs, njobs, use_prediction ? 0 : 1);
+        DFTA_CHECK_LAUNCH(ctx);
+        return DFTA_OK;
+    };
+    rc = plan();
+    if (rc) return rc;
     int* d_ndone = reinterpret_cast<int*>(d_counters + 2);
     int rounds = 0;
     float ms_sweep = 0;
     const int max_rounds = 4096;
     while (rounds < max_rounds) {
-        hipLaunchKernelGGL(k_expand, dim3((unsigned)((ntrials + 255) / 256)), dim3(256), 0, st, d_jobs, tpj, (int)ntrials, g->d_r, N, g->delta,
+        hipLaunchKernelGGL(k_expand, dim3((unsigned)((ntrials + 255) / 256)), dim3(256), 0, st, d_jobs, d_wave_job, (int)ntrials, g->d_r, N, g->delta,
                            g->far_arg_threshold, d_E, d_limit, d_start, d_us, d_us1, d_wave_kind, d_counters, g->uniform, g->Rmax, g->h);
         DFTA_CHECK_LAUNCH(ctx);
         if (stats) DFTA_HIP(ctx, hipEventRecord(ev[0], st));
@@ -916,13 +1038,13 @@ int LevelSolver::run(const double* dV, const double* job_bottom, int run_mode, d
                                d_istop, d_slot_l);
         if (rc) return rc;
         if (stats) DFTA_HIP(ctx, hipEventRecord(ev[1], st));
-        hipLaunchKernelGGL(k_scout, dim3(njobs), dim3(64), 0, st, d_jobs, tpj, d_E, d_start, d_u0);
+        hipLaunchKernelGGL(k_scout, dim3(njobs), dim3(64), 0, st, d_jobs, d_E, d_start, d_u0);
         DFTA_CHECK_LAUNCH(ctx);
         DFTA_HIP(ctx, hipMemsetAsync(d_ndone, 0, sizeof(int), st));
-        hipLaunchKernelGGL(k_walk, dim3((run_chains + 63) / 64), dim3(64), 0, st, d_jobs, d_chains, run_chains, tpj, d_count, d_u0, d_phi, d_istop, d_trip, d_tab, N, d_ndone);
+        hipLaunchKernelGGL(k_walk, dim3((run_chains + 63) / 64), dim3(64), 0, st, d_jobs, d_chains, run_chains, d_count, d_u0, d_phi, d_istop, d_trip, d_tab, N, d_ndone);
         DFTA_CHECK_LAUNCH(ctx);
-        hipLaunchKernelGGL(k_plan, dim3((njobs + 63) / 64), dim3(64), 0, st, d_jobs, njobs, tpj, use_prediction ? 0 : 1);
-        DFTA_CHECK_LAUNCH(ctx);
+        rc = plan();
+        if (rc) return rc;
         int ndone = 0;
         DFTA_HIP(ctx, hipMemcpyAsync(&ndone, d_ndone, sizeof(int), hipMemcpyDeviceToHost, st));
         DFTA_HIP(ctx, hipStreamSynchronize(st));

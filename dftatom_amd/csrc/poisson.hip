@@ -174,7 +174,7 @@ __device__ __forceinline__ double group_sum(Atom& A, double v, double* red)
 
 // -DDFTA_POISSON_PROF: time (s_memtime ticks of workgroup 0) per operation kind and level, printed when the solver is destroyed
 #ifdef DFTA_POISSON_PROF
-__device__ unsigned long long g_prof[6 * 24];
+__device__ unsigned long long g_prof[8 * 24];
 #define PROF_T0() const long long prof_t0 = clock64()
 #define PROF_ADD(cat, lvl) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_prof[(cat) * 24 + (lvl)] += clock64() - prof_t0; } while (0)
 #else
@@ -757,6 +757,31 @@ __device__ __forceinline__ void copy_rows(Dst* dst, int dstride, const Src* src,
     for (; k < C; ++k) dst[k * dstride + tid] = src[k * sstride + tid];
 }
 
+// Two arrays at once, 16 rows of each in flight: the copy into the staging memory is a chain of round trips to L2 / the
+// Infinity Cache (the level was last written by this or by another compute unit), not a bandwidth problem -- 32 loads per
+// lane and trip instead of 8 cut a 32-row copy from eight trips to two.
+template <typename DA, typename SA>
+__device__ __forceinline__ void copy_rows2(DA* dstA, DA* dstB, int dstride, const SA* srcA, const SA* srcB, int sstride, int C)
+{
+    const int tid = threadIdx.x;
+    int k = 0;
+    for (; k + 16 <= C; k += 16) {
+        double a[16], b[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) { a[q] = srcA[(k + q) * sstride + tid]; b[q] = srcB[(k + q) * sstride + tid]; }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) { dstA[(k + q) * dstride + tid] = a[q]; dstB[(k + q) * dstride + tid] = b[q]; }
+    }
+    for (; k + 4 <= C; k += 4) {
+        double a[4], b[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { a[q] = srcA[(k + q) * sstride + tid]; b[q] = srcB[(k + q) * sstride + tid]; }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { dstA[(k + q) * dstride + tid] = a[q]; dstB[(k + q) * dstride + tid] = b[q]; }
+    }
+    for (; k < C; ++k) { dstA[k * dstride + tid] = srcA[k * sstride + tid]; dstB[k * dstride + tid] = srcB[k * sstride + tid]; }
+}
+
 // PoissonSolver::IterateGaussSeidel (PoissonSolver.cpp:66-77)
 __device__ __forceinline__ double iterate_gs(const MgDesc& D, Atom& A, int l, double errorMin, int iterno, double* red, long* nsweeps)
 {
@@ -883,13 +908,15 @@ __device__ __forceinline__ double iterate_gs(const MgDesc& D, Atom& A, int l, do
         double* PP = A.stage + kStagePad;
         double* SS = PP + kStageArr;
         const int C1 = 1 << L.logC;
-        copy_rows(PP, kThreads, G0, kThreads, C1);
-        copy_rows(SS, kThreads, Sg, kThreads, C1);
+        { PROF_T0();
+        copy_rows2(PP, SS, kThreads, G0, Sg, kThreads, C1);
         if (tid == 0) PP[L.n - 1] = G0[L.n - 1];
         __syncthreads();
+        PROF_ADD(5, l); }
         const int lo_g = tid << L.logC;
         double err = 1E10;
         int done = 0;
+        PROF_T0();
         for (int i = 0; i < iterno; ++i) {
             double err2;
             switch (L.logC) {
@@ -905,12 +932,15 @@ __device__ __forceinline__ double iterate_gs(const MgDesc& D, Atom& A, int l, do
             ++*nsweeps;
             if (err < errorMin) break;
         }
+        PROF_ADD(7, l);
         // after `done` sweeps the current copy is G1 for odd counts, G0 for even ones
         double* Gout = (done & 1) ? G1 : G0;
+        { PROF_T0();
         copy_rows(Gout, kThreads, PP, kThreads, C1);
         if (tid == 0) Gout[L.n - 1] = PP[L.n - 1];
         if (done & 1) A.cur ^= (1u << l);
         __syncthreads();
+        PROF_ADD(6, l); }
         return err;
     }
     if (D.lv[l].stage == 2) {
@@ -937,6 +967,7 @@ __device__ __forceinline__ double iterate_gs(const MgDesc& D, Atom& A, int l, do
         const bool fold_r = (l > 0 && A.pend_r == l);
         A.pend = 0;
         A.pend_r = 0;
+        PROF_T0();
         if (fold_r) {
             // PoissonSolver::Restrict (PoissonSolver.cpp:126-157) from level l-1 folded into the copy: the source of every
             // staged node -- own columns and halo columns -- comes straight from the fine level (complete and visible since
@@ -977,8 +1008,7 @@ __device__ __forceinline__ double iterate_gs(const MgDesc& D, Atom& A, int l, do
                 if (g == A.G - 1) Sgw[C << logT] = 0;          // source of node n-1
             }
         } else if (!fold) {
-            copy_rows(PP, kStageRS, Gin + col0, 1 << logT, C);
-            copy_rows(SS, kStageRS, Sg + col0, 1 << logT, C);
+            copy_rows2(PP, SS, kStageRS, Gin + col0, Sg + col0, 1 << logT, C);
             for (int idx = tid; idx < C * kStageH; idx += kThreads) {       // halo columns (member 0: in-bounds padding / the
                 const int k = idx / kStageH, c = idx % kStageH - kStageH;   // previous level's tail, never used)
                 PP[k * kStageRS + c] = Gin[(k << logT) + col0 + c];
@@ -1027,6 +1057,7 @@ __device__ __forceinline__ double iterate_gs(const MgDesc& D, Atom& A, int l, do
             }
         }
         __syncthreads();
+        PROF_ADD(5, l);
         auto write_out = [&]() {
             copy_rows(Gout + col0, 1 << logT, PP, kStageRS, C);
             if (g == A.G - 1 && tid == 0) Gout[C << logT] = PP[C * kStageRS];
@@ -1048,7 +1079,7 @@ __device__ __forceinline__ double iterate_gs(const MgDesc& D, Atom& A, int l, do
             ++*nsweeps;
             const bool last = (i == iterno - 1);
             __syncthreads();
-            if (last) write_out();
+            if (last) { PROF_T0(); write_out(); PROF_ADD(6, l); }
             else {
                 // agent-scope atomic stores / loads: coherent without cache maintenance (group_sum_fast)
                 if (tid < (Hc << L.logC)) {                    // the last Hc lanes' nodes: what the next member's warm-up reads
@@ -1470,6 +1501,7 @@ __device__ __forceinline__ double run_cycles(const MgDesc& D, Atom& A, int first
                 if (CS && D.cs_top > 0 && dir > 0 && lvl == D.cs_top && lvl > from && to == last && step > 2 * nramp + 1) {
                     // the rest of this leg and the beginning of the next one (coarse_section)
                     if (A.g == 0) {
+                        PROF_T0();
                         long nsw = 0;
                         coarse_section_enter(D, A);
                         __syncthreads();
@@ -1479,6 +1511,7 @@ __device__ __forceinline__ double run_cycles(const MgDesc& D, Atom& A, int first
                         c.sweeps += static_cast<long>(red[17]);
                         coarse_section_leave(D, A);
                         __syncthreads();
+                        PROF_ADD(5, 20);
                     }
                     cs_skip = true;
                     break;
@@ -1555,8 +1588,10 @@ __global__ __launch_bounds__(kThreads) void k_poisson_solve(const MgDesc* __rest
     }
     __syncthreads();
     Counters c{0, 0};
+    PROF_T0();
     initialize(D, A, 0.0, (double)Z[a]);
     const double err = run_cycles<true>(D, A, 0, 100, 1E-3, 1E-14, red, c);      // FullCycle(1E-3, 1E-14), PoissonSolver.h:78
+    PROF_ADD(5, 21);
     const double* __restrict__ P = A.cur_phi(0, L0);
     if (coop0 || A.g == 0)
         for (int i = coop0 ? A.lane() : static_cast<int>(threadIdx.x); i < N; i += coop0 ? kThreads * A.G : kThreads)
@@ -1910,17 +1945,17 @@ void dfta_poisson_destroy(dfta_poisson* p)
     if (p->fallback) dfta_poisson_destroy(p->fallback);
 #ifdef DFTA_POISSON_PROF
     {
-        unsigned long long h[6 * 24];
+        unsigned long long h[8 * 24];
         if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_prof), sizeof(h)) == hipSuccess) {
-            const char* names[6] = {"restrict", "prolong ", "iterate ", "grp_sum ", "gs_lds  ", "other   "};
+            const char* names[8] = {"restrict", "prolong ", "iterate ", "grp_sum ", "gs_lds  ", "copy_in ", "copy_out", "sweeps1 "};
             unsigned long long tot = 0;
-            for (int c = 0; c < 6; ++c) {
+            for (int c = 0; c < 8; ++c) {
                 fprintf(stderr, "[poisson prof] %s:", names[c]);
-                for (int l = 0; l < 18; ++l) { fprintf(stderr, " %llu", h[c * 24 + l]); tot += h[c * 24 + l]; }
+                for (int l = 0; l < 22; ++l) { fprintf(stderr, " %llu", h[c * 24 + l]); tot += h[c * 24 + l]; }
                 fprintf(stderr, "\n");
             }
             fprintf(stderr, "[poisson prof] total ticks %llu\n", tot);
-            unsigned long long z[6 * 24] = {0};
+            unsigned long long z[8 * 24] = {0};
             (void)hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof(z));
         }
     }
