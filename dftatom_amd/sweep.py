@@ -1,7 +1,7 @@
 """Host-side sharding of independent atoms over ranks (periodic-table sweep, BASELINE.json config 4).
 
 Atoms are independent SCF problems: there is no exchange during the solve.  Ranks get a
-static longest-processing-time partition (cost ~ number of subshells, i.e. Numerov jobs per SCF step) and
+static longest-processing-time partition (cost ~ subshells x expected SCF steps: Numerov jobs over the atom's run) and
 the only collective is one all_gather of fixed-size result records (RECORD_DOUBLES doubles per atom) at
 the end.  The same code runs over RCCL (backend "nccl", GPU tensors) and, in the CPU tests, over gloo.
 """
@@ -16,9 +16,29 @@ def subshell_count(Z):
     return len(get_subshells(Z))
 
 
+# SCF steps until the stop test |dE/E| < 1e-11 held in two consecutive steps (or the cap of 100, DFTAtom.cpp:396), Z = 1..86,
+# LDA, 131073 nodes, mixing 0.5: what the compiled reference took (tests/golden/periodic_table_L17.json).  The stop step is
+# round-off noise in its last digits, but which atoms are slow (open shells: up to the cap) is not.
+EXPECTED_STEPS = (100, 100, 81, 68, 100, 64, 51, 100, 65, 38, 100, 30, 36, 57, 100, 44, 100, 68, 44, 68,
+                  31, 64, 66, 51, 100, 76, 99, 41, 100, 100, 59, 42, 55, 78, 100, 89, 100, 34, 43, 100,
+                  95, 31, 100, 56, 97, 100, 49, 83, 100, 44, 32, 88, 97, 81, 100, 35, 62, 65, 42, 93,
+                  51, 77, 34, 27, 42, 76, 63, 100, 100, 100, 100, 35, 100, 47, 69, 100, 67, 31, 33, 100,
+                  60, 100, 32, 58, 27, 35)
+
+
+def expected_steps(Z):
+    return EXPECTED_STEPS[Z - 1] if 1 <= Z <= len(EXPECTED_STEPS) else 100
+
+
+def atom_cost(Z):
+    """Work of one atom of a sweep: Numerov jobs per SCF step x expected SCF steps (a finished atom is frozen and costs nothing
+    more, dfta_scf_step), SURVEY.md section 8e."""
+    return subshell_count(Z) * expected_steps(Z)
+
+
 def partition_atoms(Zs, world_size, cost=None):
     """Static LPT assignment: returns a list (per rank) of lists of Z, deterministic on every rank."""
-    cost = cost or subshell_count
+    cost = cost or atom_cost
     order = sorted(Zs, key=lambda z: (-cost(z), z))
     loads = [0] * world_size
     shards = [[] for _ in range(world_size)]

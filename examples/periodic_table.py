@@ -1,8 +1,9 @@
 """Periodic-table sweep (BASELINE.json config 4): LDA ground states of Z = 1 .. 86 on the 131073-node grid.
 
-Atoms are independent: every rank takes its shard of `dftatom_amd.sweep.partition_atoms`, advances all its atoms together
-(one `Scf` batch: every kernel works on the whole shard) until each has met the reference's stop test or `--max-steps`,
-and the fixed-size result records are gathered once (RCCL all_gather when launched under torch.distributed).
+Atoms are independent: every rank takes its shard of `dftatom_amd.sweep.partition_atoms` (longest-processing-time on
+subshells x expected SCF steps), advances all its atoms together (one `Scf` batch: every kernel works on the whole shard)
+until each has met the reference's stop test or `--max-steps`; an atom that has finished is frozen in its own stop state and
+costs nothing more (dfta_scf_step).  The fixed-size result records are gathered once (RCCL all_gather under torch.distributed).
 
     python examples/periodic_table.py                       # one GPU
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 examples/periodic_table.py
@@ -25,7 +26,7 @@ def main():
     ap.add_argument("--zmin", type=int, default=1)
     ap.add_argument("--zmax", type=int, default=86)
     ap.add_argument("--levels", type=int, default=17)
-    ap.add_argument("--max-steps", type=int, default=60)
+    ap.add_argument("--max-steps", type=int, default=100, help="the reference's cap (DFTAtom.cpp:396)")
     ap.add_argument("--out", default="")
     args = ap.parse_args()
 
@@ -66,7 +67,8 @@ def main():
             ref = NIST_LDA.get(r["Z"])
             print("Z %3d  Etotal %16.6f  steps %3d  finished %d%s" % (r["Z"], r["Etotal"], r["steps"], r["finished"],
                   "   NIST LDA %.6f (diff %.1e)" % (ref, r["Etotal"] - ref) if ref else ""))
-        print("%d atoms, %d GPU(s), %d SCF steps of the whole batch, %.1f s" % (len(rows), world, steps, elapsed))
+        print("%d atoms, %d GPU(s), %d SCF steps of the longest-running atom of rank 0, %d atom-steps in all, %d finished, %.1f s"
+              % (len(rows), world, steps, sum(r["steps"] for r in rows), sum(r["finished"] for r in rows), elapsed))
         if args.out:
             with open(args.out, "w") as f:
                 json.dump({"n_gpus": world, "levels": args.levels, "steps": steps, "seconds": elapsed,

@@ -16,9 +16,14 @@ def test_partition_is_balanced_and_complete():
     for world in (1, 2, 4, 8):
         shards = sweep.partition_atoms(Zs, world)
         assert sorted(z for s in shards for z in s) == Zs
-        loads = [sum(sweep.subshell_count(z) for z in s) for s in shards]
-        assert sum(loads) == 814
-        assert max(loads) - min(loads) <= 15           # LPT: within one atom's cost
+        assert sum(sweep.subshell_count(z) for z in Zs) == 814
+        # cost of an atom = Numerov jobs per step x expected SCF steps: LPT keeps the ranks within
+        # one atom's cost of each other
+        loads = [sum(sweep.atom_cost(z) for z in s) for s in shards]
+        assert max(loads) - min(loads) <= max(sweep.atom_cost(z) for z in Zs)
+        assert max(loads) <= 1.03 * sum(loads) / world + 1
+        by_jobs = sweep.partition_atoms(Zs, world, cost=sweep.subshell_count)     # the round-1 weight is still available
+        assert sorted(z for s in by_jobs for z in s) == Zs
     assert sweep.partition_atoms(Zs, 8) == sweep.partition_atoms(Zs, 8)   # deterministic on every rank
 
 
