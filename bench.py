@@ -21,7 +21,8 @@ Objects on the JSON line:
   kernels        both hot kernels, each with its own figures: the sweep kernel on ISSUED and on REFERENCE-EQUIVALENT bytes
                  plus its VALU-issue ceiling (the resource that binds it), the multigrid kernel on the 8d bytes
   extra          (N = 1 only) two more measured workloads, each with the same per-kernel figures: a machine-filling batch of
-                 64 Rn atoms and Rn LSDA (BASELINE configs[2])
+                 256 Rn atoms (one workgroup per atom in the multigrid kernel, four waves per SIMD in the sweep kernel) and
+                 Rn LSDA (BASELINE configs[2])
   cpu_baseline   the oracle on the host: 1 core (how the reference runs), 1 core with tables, and all cores (replicas)
 
 N > 1 (launched by torch.distributed.run): atoms are independent, so every rank advances its own replica of the batch (weak
@@ -250,7 +251,7 @@ def main():
     ap.add_argument("--lsda", action="store_true")
     ap.add_argument("--tree-depth", type=int, default=0)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
-    ap.add_argument("--no-extras", action="store_true", help="skip the 64-atom batch and the LSDA workloads")
+    ap.add_argument("--no-extras", action="store_true", help="skip the 256-atom batch and the LSDA workloads")
     ap.add_argument("--cpu-steps", type=int, default=3)
     args = ap.parse_args()
 
@@ -352,7 +353,7 @@ def main():
         }
         if world == 1 and not args.no_extras:
             extra = {}
-            for name, atoms, lsda, st, wu in (("batch64_lda", 64, False, 3, 1), ("rn_lsda", 1, True, 3, 2)):
+            for name, atoms, lsda, st, wu in (("batch256_lda", 256, False, 3, 1), ("rn_lsda", 1, True, 3, 2)):
                 s2, t2 = run_workload(D, ctx, grid, args.levels, atoms, lsda, st, wu, 0, barrier, torch)
                 s2.close()
                 extra[name] = summarize(t2, args.levels, grid.N, atoms, lsda, world, delta, rmax)
