@@ -21,6 +21,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <numeric>
+#include <type_traits>
 #include <vector>
 
 #include "internal.h"
@@ -112,6 +113,8 @@ __global__ void k_boundary_uniform(const double* __restrict__ E, int ntrials, Gr
 typedef unsigned long long lanemask_t;
 constexpr int kChunk = 8;             // grid points per prefetched batch of the sweep body
 constexpr int kBoundFrom = kChunk;    // the sweep body never touches i < kChunk (tail loop)
+constexpr int kTinyFrom = 128;        // from this index outwards |f| is small enough for the series reciprocal where the slot's bound says so
+constexpr double kTinyF = 12. / 2048.;   // |f| < 12 * 2^-11  <=>  |f/12| < 2^-11
 constexpr int kPipeChunk = 24;        // grid points per stage of the pipelined kernel
 constexpr int kPipeMaxBlocks = 768;   // above this many 64-trial blocks the fused kernel fills every SIMD anyway
 
@@ -132,6 +135,21 @@ __device__ __forceinline__ double div_in_range(double w, double d)
     const double q = w * r;
     const double rem = __builtin_fma(-d, q, w);
     return __builtin_fma(rem, r, q);
+}
+
+// The correctly rounded reciprocal of d = 1 - x for |x| < 2^-11 without v_rcp_f64 (a quarter-rate instruction: ~5 issue
+// slots): r0 = 1 + x + x^2 + x^3 + x^4 is within max(|x|^5, 2^-52) < 2^-52 of 1/d, one Newton step squares that (pre-rounding
+// error ~2^-104, the same as rcp + two steps), and reciprocals of 53-bit numbers stay further than that from a rounding
+// boundary -- so r is RN(1/d), the value the compiler's division sequence arrives at, and the quotient w * r corrected by
+// fma(-d, q, w) * r is the same IEEE quotient (tests compare sweeps bit for bit with the plain division).
+__device__ __forceinline__ double recip_series(double x, double d)
+{
+    double t = __builtin_fma(x, x, x);
+    t = __builtin_fma(x, t, x);
+    t = __builtin_fma(x, t, x);
+    const double r0 = 1.0 + t;
+    const double e = __builtin_fma(-d, r0, 1.0);
+    return __builtin_fma(r0, e, r0);
 }
 
 // One Numerov step for every lane of the wave (Numerov.h:311-321).  `tv` is wave-uniform (SGPRs).
@@ -240,11 +258,16 @@ __device__ __forceinline__ void sweep_wave(const SweepArgs& a, const GridScalars
     const int limit = (KIND == DFTA_SWEEP_COUNT) ? a.limit[t] : 0;
 
     // can the whole wave use the division fast path?  |f| <= max|veff| R2 e2 + |E| max R2 e2 + delta^2/4 < 6 => d in (0.5, 1.5)
-    bool fast = false;
+    // tiny: |f| < 12 * 2^-11 for every point the lane visits at or beyond kTinyFrom (e2 grows with i: the lane's own start
+    // index bounds the |E| term) -- there the reciprocal comes from a short series instead of v_rcp_f64 (recip_series)
+    bool fast = false, tiny = false;
     if (a.bounds) {
         const double2 bd = a.bounds[(size_t)slot * a.bstride];
         const bool lane_ok = !valid || (bd.x + fabs(E) * bd.y + d2p4 < 6.0);
         fast = (__ballot(lane_ok) == ~0ull);
+        const double2 bt = a.bounds[(size_t)slot * a.bstride + a.bstride - 1];
+        const bool lane_tiny = !valid || (bt.x + fabs(E) * (R2 * T[start].y) + d2p4 < kTinyF);
+        tiny = fast && (__ballot(lane_tiny) == ~0ull);
     }
 
     // prologue (Numerov.h:293-306): the two far boundary points of this lane
@@ -320,17 +343,20 @@ __device__ __forceinline__ void sweep_wave(const SweepArgs& a, const GridScalars
         for (int k = 0; k < CH; ++k) B[k] = T[i - CH - k];
         // one batch: CUR = T[i .. i-CH+1] and OTH = T[i-CH .. i-2CH+1] are both requested and i >= 2*CH.
         // Returns true when the body is finished (tail loop takes over at the new i).
-        auto batch = [&](double2 (&CUR)[CH], double2 (&OTH)[CH]) -> bool {
-            double f[CH], d[CH], r[CH], veff[CH];
+        // The arithmetic of one batch in one of three division modes, chosen per batch (wave-uniform) so that the point
+        // loop is straight-line code: 0 = IEEE division, 1 = the compiler's division sequence without its scaling steps
+        // (rcp + two Newton steps, div_in_range), 2 = the same with the reciprocal from a series (recip_series).
+        auto arith = [&](auto MODE_, double2 (&CUR)[CH], double (&uu)[CH], double (&veff)[CH]) {
+            constexpr int MODE = decltype(MODE_)::value;
+            double f[CH], d[CH], r[CH];
 #pragma unroll
             for (int k = 0; k < CH; ++k) {
                 veff[k] = CUR[k].x;
                 f[k] = (CUR[k].x - E) * R2 * CUR[k].y + d2p4;                // Numerov.h:100
-                d[k] = 1. - kH2p12 * f[k];
-            }
-            if (fast) {
-#pragma unroll
-                for (int k = 0; k < CH; ++k) {                               // reciprocal of hipcc's fp64 division sequence
+                const double x = kH2p12 * f[k];
+                d[k] = 1. - x;
+                if (MODE == 2) r[k] = recip_series(x, d[k]);
+                if (MODE == 1) {                                             // reciprocal of hipcc's fp64 division sequence
                     double rr = __builtin_amdgcn_rcp(d[k]);
                     double e = __builtin_fma(-d[k], rr, 1.0);
                     rr = __builtin_fma(rr, e, rr);
@@ -343,38 +369,44 @@ __device__ __forceinline__ void sweep_wave(const SweepArgs& a, const GridScalars
 #pragma unroll
                 for (int k = 0; k < CH; ++k) CUR[k] = T[i - 2 * CH - k];
             }
-            double uu[CH];
-            const double ucarry = s.u;                                        // u at the point above this batch
 #pragma unroll
             for (int k = 0; k < CH; ++k) {
-                const double wnext = 2. * s.w - s.wprev + s.u * s.fprev;     // Numerov.h:311 (h2 == 1)
+                // Numerov.h:311 (h2 == 1): 2 w is exact, so fma(2, w, -wprev) is the reference's 2 w - wprev
+                const double wnext = __builtin_fma(2., s.w, -s.wprev) + s.u * s.fprev;
                 s.wprev = s.w;
                 s.w = wnext;
                 s.prevSol = s.u;
-                if (fast) {
+                if (MODE == 0) s.u = wnext / d[k];                            // getU, Numerov.h:510-513
+                else {
                     const double q = wnext * r[k];
                     const double rem = __builtin_fma(-d[k], q, wnext);
                     s.u = __builtin_fma(rem, r[k], q);
-                } else {
-                    s.u = wnext / d[k];                                       // getU, Numerov.h:510-513
                 }
                 s.fprev = f[k];
                 uu[k] = s.u;
             }
+        };
+        auto batch = [&](double2 (&CUR)[CH], double2 (&OTH)[CH]) -> bool {
+            double uu[CH], veff[CH];
+            const double ucarry = s.u;                                        // u at the point above this batch
+            if (!fast) arith(std::integral_constant<int, 0>{}, CUR, uu, veff);
+            else if (tiny && i - CH + 1 >= kTinyFrom) arith(std::integral_constant<int, 2>{}, CUR, uu, veff);
+            else arith(std::integral_constant<int, 1>{}, CUR, uu, veff);
             if (KIND == DFTA_SWEEP_COUNT) {
                 const lanemask_t act = c.live & vmask;
                 bool quiet = false;
                 if (!poisoned) {
-                    double mn = uu[0], mx = uu[0], ma = uu[0], vmn = veff[0], vmx = veff[0];
+                    double mn = uu[0], mx = uu[0], vmn = veff[0], vmx = veff[0];
 #pragma unroll
                     for (int k = 1; k < CH; ++k) {
                         asm("v_min_f64 %0, %1, %2" : "=v"(mn) : "v"(mn), "v"(uu[k]));
                         asm("v_max_f64 %0, %1, %2" : "=v"(mx) : "v"(mx), "v"(uu[k]));
-                        asm("v_max_f64 %0, |%1|, |%2|" : "=v"(ma) : "v"(ma), "v"(uu[k]));
                         asm("v_min_f64 %0, %1, %2" : "=v"(vmn) : "v"(vmn), "v"(veff[k]));
                         asm("v_max_f64 %0, %1, %2" : "=v"(vmx) : "v"(vmx), "v"(veff[k]));
                     }
-                    const lanemask_t fin = __ballot(fabs(ma) < INFINITY && uu[CH - 1] == uu[CH - 1]);
+                    // an infinity or a NaN anywhere in the batch is still there at its last point: once w is not finite it
+                    // never is again (2 w - wprev + u f keeps inf or turns it into NaN), so the last value speaks for all
+                    const lanemask_t fin = __ballot(fabs(uu[CH - 1]) < INFINITY);
                     const lanemask_t allpos = __ballot(mn > 0), nonepos = __ballot(mx <= 0);
                     const lanemask_t le_all = __ballot(vmx <= E), gt_all = __ballot(vmn > E);
                     const lanemask_t ok = fin & ((c.oldSgn & allpos) | (~c.oldSgn & nonepos)) & ((le_all & last_le) | (gt_all & ~last_le));
@@ -875,9 +907,9 @@ __global__ __launch_bounds__(kPipeThreads) void k_sweep_pipe(SweepArgs a, GridSc
 // integrated by the tail loop with the plain IEEE division.
 __global__ __launch_bounds__(256) void k_slot_bounds(const double2* __restrict__ tab, int N, double R2, double2* __restrict__ bounds, int bstride)
 {
-    __shared__ double red[8];
+    __shared__ double red[12];
     const double2* T = tab + (size_t)blockIdx.x * N;
-    double m0 = 0, m1 = 0;
+    double m0 = 0, m1 = 0, t0 = 0;
     bool bad = false;
     for (int i = kBoundFrom + threadIdx.x; i < N; i += 256) {
         const double2 t = T[i];
@@ -886,20 +918,26 @@ __global__ __launch_bounds__(256) void k_slot_bounds(const double2* __restrict__
         if (!(v == v) || !(w == w)) bad = true;
         m0 = v > m0 ? v : m0;
         m1 = w > m1 ? w : m1;
+        if (i >= kTinyFrom) t0 = v > t0 ? v : t0;
     }
-    if (bad) { m0 = INFINITY; m1 = INFINITY; }
+    if (bad) { m0 = INFINITY; m1 = INFINITY; t0 = INFINITY; }
     for (int off = 32; off > 0; off >>= 1) {
-        const double o0 = __shfl_xor(m0, off), o1 = __shfl_xor(m1, off);
+        const double o0 = __shfl_xor(m0, off), o1 = __shfl_xor(m1, off), o2 = __shfl_xor(t0, off);
         m0 = o0 > m0 ? o0 : m0;
         m1 = o1 > m1 ? o1 : m1;
+        t0 = o2 > t0 ? o2 : t0;
     }
-    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = m0; red[4 + (threadIdx.x >> 6)] = m1; }
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = m0; red[4 + (threadIdx.x >> 6)] = m1; red[8 + (threadIdx.x >> 6)] = t0; }
     __syncthreads();
     if (threadIdx.x == 0) {
         double2 o;
         o.x = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
         o.y = fmax(fmax(red[4], red[5]), fmax(red[6], red[7]));
         bounds[(size_t)blockIdx.x * bstride] = o;
+        double2 tb;                                                 // series reciprocal: max |veff| R2 e2 over i >= kTinyFrom
+        tb.x = fmax(fmax(red[8], red[9]), fmax(red[10], red[11]));
+        tb.y = o.y;
+        bounds[(size_t)blockIdx.x * bstride + bstride - 1] = tb;
     }
 }
 
@@ -907,7 +945,7 @@ __global__ __launch_bounds__(256) void k_slot_bounds(const double2* __restrict__
 __global__ void k_block_minmax(const double2* __restrict__ tab, int N, double2* __restrict__ bounds, int bstride)
 {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= bstride - 1) return;
+    if (b >= bstride - 2) return;
     const double2* T = tab + (size_t)blockIdx.y * N;
     double mn = INFINITY, mx = -INFINITY;
     for (int i = b * kPipeChunk + 1; i <= (b + 1) * kPipeChunk && i < N; ++i) { mn = fmin(mn, T[i].x); mx = fmax(mx, T[i].x); }
@@ -1420,7 +1458,9 @@ void host_boundary(const dfta_grid* g, double E, int* start, double* us, double*
 
 }  // namespace
 
-int dfta_bounds_stride(const dfta_grid* g) { return 1 + (g->N + kPipeChunk - 1) / kPipeChunk + 1; }
+// per slot: [0] the fast-division bounds, [1 ..] {min, max} of veff per block of kPipeChunk points, [stride-1] the bounds over
+// i >= kTinyFrom (series reciprocal)
+int dfta_bounds_stride(const dfta_grid* g) { return 1 + (g->N + kPipeChunk - 1) / kPipeChunk + 1 + 1; }
 
 // Launch plumbing shared with levels.hip ------------------------------------------------------------------
 int dfta_launch_build_tab(dfta_ctx* ctx, const dfta_grid* g, double2* tab, const double* dV, const int* d_slot_v,

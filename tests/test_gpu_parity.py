@@ -424,7 +424,9 @@ def test_full_size_sweep_kernels_agree(ctx, grid17):
     g = O.make_grid(*GRIDS["L17"])
     V = screened_potential(grid17.r(), 86.0)
     rng = np.random.default_rng(7)
-    nt = 64 * 40 + 17
+    # 25 617 trials x ~1e5 points x two kinds: ~5e9 divisions through three independent routes -- the fused kernel's series
+    # reciprocal (recip_series) or rcp + Newton, the pipelined kernel's producers, and (sample) the oracle's IEEE division
+    nt = 64 * 400 + 17
     E = np.concatenate([-10.0 ** rng.uniform(-3, 3.9, nt // 2), -(250.0 + rng.uniform(0, 1e-6, nt - nt // 2))])
     E[::97] = rng.uniform(0, 50, len(E[::97]))
     l = rng.integers(0, 4, nt).astype(np.int32)
