@@ -1137,3 +1137,243 @@ int dfo_scf_step(dfo_scf* s, dfo_energies* e)   /* DFTAtom.cpp:396-484 (LDA) / 9
     s->lastTimeConverged = conv;
     return 0;
 }
+
+/* ======================================================================================= */
+/* uniform grid r_i = i h (NumerovFunctionRegularGrid, Numerov.h:16-70, and the            */
+/* IsUniform() branches of Numerov.h:272-504; DFTAtom.cpp:21-33, 213-325;                  */
+/* PoissonSolver.h:20-49, PoissonSolver.cpp:200-210)                                       */
+/* ======================================================================================= */
+static inline double uveff(const double* V, unsigned l, double position, long i)   /* Numerov.h:21-24 */
+{
+    return V[i] + l * (l + 1.) / (position * position) * 0.5;
+}
+static inline double ufunc(const double* V, unsigned l, double E, double position, long i)   /* Numerov.h:26-31 */
+{
+    return 2. * (uveff(V, l, position, i) - E);
+}
+static inline double ufar(double position, double E) { return exp(-position * sqrt(2. * fabs(E))); }       /* Numerov.h:33-36 */
+static inline double uzero(double position, unsigned l) { return pow(position, (double)l + 1.); }           /* Numerov.h:38-41 */
+static inline double umax_radius(double E) { return 200. / sqrt(2. * fabs(E)); }                            /* Numerov.h:53-56 */
+
+int dfo_ucount_nodes(const dfo_ugrid* g, const double* V, unsigned l, double E, long nodesLimit, long* start)   /* Numerov.h:272-349 */
+{
+    double startPoint = g->Rmax;
+    long steps = g->N - 1;
+    const double h = startPoint / steps, h2 = h * h, hp12 = h2 / 12.;            /* Numerov.h:276-278 */
+    { const double m = umax_radius(E); if (m < startPoint) startPoint = m; }      /* std::min(startPoint, GetMaxRadius) */
+    steps = (long)(startPoint / h);
+    if (start) *start = steps;
+
+    double position = startPoint;
+    double solution = ufar(position, E);
+    double prevSol = solution;
+    double funcVal = ufunc(V, l, E, position, steps);
+    double wprev = (1 - hp12 * funcVal) * solution;
+    position -= h;
+    solution = ufar(position, E);
+    funcVal = ufunc(V, l, E, position, steps - 1);
+    double w = (1 - hp12 * funcVal) * solution;
+
+    int oldSgn = (solution > 0);
+    int nodesCount = 0;
+    int firstClassicalReturnPoint = 0;
+    for (long i = steps - 2; i > 0; --i) {
+        const double wnext = 2. * w - wprev + h2 * solution * funcVal;
+        position = h * i;
+        wprev = w;
+        w = wnext;
+        funcVal = ufunc(V, l, E, position, i);
+        prevSol = solution;
+        solution = w / (1. - hp12 * funcVal);
+        if (fabs(solution) == INFINITY) return nodesCount;
+        const int newSgn = (solution > 0);
+        if (newSgn != oldSgn) {
+            ++nodesCount;
+            if (nodesCount > nodesLimit) return nodesCount;
+            oldSgn = newSgn;
+        }
+        const double effPotential = uveff(V, l, position, i);
+        if (effPotential <= E) firstClassicalReturnPoint = 1;
+        else if (firstClassicalReturnPoint && effPotential > E) return nodesCount;
+    }
+    if (nodesCount <= nodesLimit) {
+        solution = solution * (2 + h2 * funcVal) - prevSol;
+        if ((solution > 0) != oldSgn) ++nodesCount;
+    }
+    return nodesCount;
+}
+
+double dfo_usolution_in_zero(const dfo_ugrid* g, const double* V, unsigned l, double E)   /* Numerov.h:351-401 */
+{
+    double startPoint = g->Rmax;
+    long steps = g->N - 1;
+    const double h = startPoint / steps, h2 = h * h, hp12 = h2 / 12.;
+    { const double m = umax_radius(E); if (m < startPoint) startPoint = m; }
+    steps = (long)(startPoint / h);
+
+    double position = startPoint;
+    double solution = ufar(position, E);
+    double prevSol = solution;
+    double funcVal = ufunc(V, l, E, position, steps);
+    double wprev = (1 - hp12 * funcVal) * solution;
+    position -= h;
+    solution = ufar(position, E);
+    funcVal = ufunc(V, l, E, position, steps - 1);
+    double w = (1 - hp12 * funcVal) * solution;
+    for (long i = steps - 2; i > 0; --i) {
+        const double wnext = 2. * w - wprev + h2 * solution * funcVal;
+        position = h * i;
+        wprev = w;
+        w = wnext;
+        funcVal = ufunc(V, l, E, position, i);
+        prevSol = solution;
+        solution = w / (1. - hp12 * funcVal);
+    }
+    return solution * (2 + h2 * funcVal) - prevSol;
+}
+
+long dfo_umatch(const dfo_ugrid* g, const double* V, unsigned l, double E, double* Psi)   /* Numerov.h:403-504 */
+{
+    double startPoint = g->Rmax;
+    long steps = g->N - 1;
+    const long highLimit = steps + 1;
+    double h = startPoint / steps;
+    { const double m = umax_radius(E); if (m < startPoint) startPoint = m; }
+    steps = (long)(startPoint / h);
+    for (long i = steps + 1; i < highLimit; ++i) Psi[i] = 0;
+    h = startPoint / steps;                                  /* Numerov.h:430: the step is re-derived from the truncated count */
+    const double h2 = h * h, hp12 = h2 / 12.;
+    const long size = steps + 1;
+
+    double position = startPoint;
+    double solution = ufar(position, E);
+    Psi[steps] = solution;
+    double funcVal = ufunc(V, l, E, position, steps);
+    double wprev = (1 - hp12 * funcVal) * solution;
+    position -= h;
+    Psi[steps - 1] = solution = ufar(position, E);
+    funcVal = ufunc(V, l, E, position, steps - 1);
+    double w = (1 - hp12 * funcVal) * solution;
+
+    long matchPoint = 2;
+    for (long i = steps - 2; i > 0; --i) {
+        const double wnext = 2. * w - wprev + h2 * solution * funcVal;
+        position = h * i;
+        wprev = w;
+        w = wnext;
+        funcVal = ufunc(V, l, E, position, i);
+        Psi[i] = solution = w / (1. - hp12 * funcVal);
+        if (solution < Psi[i + 1] || fabs(solution) > 1E15) { matchPoint = i; break; }
+    }
+    position = 0;
+    Psi[0] = solution = 0;
+    wprev = 0;
+    position += h;
+    Psi[1] = solution = uzero(position, l);
+    funcVal = ufunc(V, l, E, position, 1);
+    w = (1 - hp12 * funcVal) * solution;
+    for (long i = 2; i < matchPoint; ++i) {
+        const double wnext = 2. * w - wprev + h2 * solution * funcVal;
+        position = h * i;
+        wprev = w;
+        w = wnext;
+        funcVal = ufunc(V, l, E, position, i);
+        Psi[i] = solution = w / (1. - hp12 * funcVal);
+    }
+    w = 2. * w - wprev + h2 * solution * funcVal;
+    position = h * matchPoint;
+    funcVal = ufunc(V, l, E, position, matchPoint);
+    solution = w / (1. - hp12 * funcVal);
+    const double factor = solution / Psi[matchPoint];
+    Psi[matchPoint] = solution;
+    for (long i = matchPoint + 1; i < size; ++i) Psi[i] *= factor;
+    return matchPoint;
+}
+
+void dfo_normalize_uniform(double* Psi, int n, double h)   /* DFTAtom.cpp:21-33 */
+{
+    double* result2 = (double*)malloc(sizeof(double) * (size_t)n);
+    for (int i = 0; i < n; ++i) result2[i] = Psi[i] * Psi[i];
+    const double integralForSquare = dfo_simpson38(h, result2, n);
+    const double unorm = 1. / sqrt(integralForSquare);
+    for (int i = 0; i < n; ++i) Psi[i] *= unorm;
+    free(result2);
+}
+
+int dfo_uloop_over_levels(const dfo_ugrid* g, const double* V, dfo_level* levels, int nlevels, double* newDensity,
+                          double* Eelectronic, double* BottomEnergy)   /* DFTAtom.cpp:213-325 */
+{
+    static const double energyErr = 1E-12;
+    int reallyConverged = 1;
+    const int n = g->N;
+    double* result = (double*)malloc(sizeof(double) * (size_t)n);
+    for (int k = 0; k < nlevels; ++k) {
+        dfo_level* level = &levels[k];
+        const int NumNodes = level->n - level->l;
+        const unsigned L = (unsigned)level->l;
+        double TopEnergy = 50;
+        {   /* LocateInterval, DFTAtom.cpp:287-325 */
+            double toe = TopEnergy, boe = *BottomEnergy;
+            int calls = 0;
+            while (toe - boe > energyErr) {
+                const double E = (toe + boe) / 2;
+                ++calls;
+                if (dfo_ucount_nodes(g, V, L, E, NumNodes, NULL) > NumNodes) toe = E; else boe = E;
+            }
+            TopEnergy = toe;
+            boe = *BottomEnergy;
+            while (toe - boe > energyErr) {
+                const double E = (toe + boe) / 2;
+                ++calls;
+                if (dfo_ucount_nodes(g, V, L, E, NumNodes, NULL) < NumNodes) boe = E; else toe = E;
+            }
+            *BottomEnergy = toe;
+            level->n_count = calls;
+        }
+        level->top = TopEnergy;
+        level->bottom = *BottomEnergy;
+        double delta = dfo_usolution_in_zero(g, V, L, *BottomEnergy);
+        int nzero = 1;
+        const int sgnBottom = delta > 0;
+        int didNotConverge = 1;
+        for (int i = 0; i < 500; ++i) {
+            level->E = (TopEnergy + *BottomEnergy) / 2;
+            delta = dfo_usolution_in_zero(g, V, L, level->E);
+            ++nzero;
+            if ((delta > 0) == sgnBottom) *BottomEnergy = level->E; else TopEnergy = level->E;
+            const double absdelta = fabs(delta);
+            if (TopEnergy - *BottomEnergy < energyErr && !isnan(absdelta) && absdelta < 1E15) { didNotConverge = 0; break; }
+        }
+        level->E = *BottomEnergy;
+        level->n_zero = nzero;
+        level->converged = !didNotConverge;
+        if (didNotConverge) reallyConverged = 0;
+        *BottomEnergy = level->E - 3;
+        level->matchPoint = dfo_umatch(g, V, L, level->E, result);
+        dfo_normalize_uniform(result, n, g->h);
+        for (int i = 0; i < n - 1; ++i) newDensity[i] += level->occ * result[i] * result[i];
+        *Eelectronic += level->occ * level->E;
+    }
+    free(result);
+    return reallyConverged;
+}
+
+double dfo_solve_poisson_uniform(dfo_poisson* p, int Z, double maxRadius, const double* density, double* U)
+/* PoissonSolver.h:20-49 + PoissonSolver.cpp:200-210; p must have been created with deltaGrid == 0 */
+{
+    double* Source = p->Src[0];
+    const size_t size = (size_t)p->n[0];
+    {   /* FillR(Source, 0, maxRadius) */
+        const size_t N = size - 1;
+        const double firstR = 0;
+        for (size_t i = 0; i < size; ++i) Source[i] = (firstR * (N - i) + maxRadius * i) / N;
+    }
+    const double delta = Source[1] - Source[0];
+    const double delta2 = delta * delta;
+    const double delta2fourM_PI = delta2 * fourM_PI;
+    for (size_t i = 0; i < size; ++i) Source[i] *= delta2fourM_PI * density[i];
+    p->lowB = 0; p->highB = Z;
+    const double err = dfo_full_cycle(p, 1E-3, 1E-14);
+    memcpy(U, p->Phi[0], sizeof(double) * size);
+    return err;
+}

@@ -3,7 +3,7 @@
  *
  * This is a plain-C restatement of the arithmetic of aromanro/DFTAtom's numerical core
  * (Numerov shooting, level driver, multigrid Poisson, VWN, Newton-Cotes/Romberg quadrature,
- * Aufbau filling, one SCF step).  Every function cites the reference file:line it follows.
+ * Aufbau filling, one SCF step; since round 2 also the uniform-grid Numerov / level driver / Poisson).  Every function cites the reference file:line it follows.
  * It exists to CHECK the HIP path: only tests/, __graft_entry__.smoke() and bench.py's
  * cpu_baseline leg may load it.  The product library (dftatom_amd/csrc) never links, loads
  * or calls anything in this directory.
@@ -161,6 +161,16 @@ dfo_scf* dfo_scf_create(int lsda, int Z, int mgLevels, double alpha, double MaxR
 void     dfo_scf_destroy(dfo_scf* s);
 /* one iteration of the `for sp` loop body; returns 1 when the reference would print Finished! */
 int      dfo_scf_step(dfo_scf* s, dfo_energies* e);   /* DFTAtom.cpp:396-484 / 908-1009 */
+
+/* ---- uniform grid r_i = i h (Numerov.h:16-70 + IsUniform() branches, DFTAtom.cpp:21-33,213-325, PoissonSolver.h:20-49) ---- */
+typedef struct dfo_ugrid { int N; double Rmax; double h; } dfo_ugrid;   /* h = Rmax / (N - 1) */
+int    dfo_ucount_nodes(const dfo_ugrid* g, const double* V, unsigned l, double E, long nodesLimit, long* start);
+double dfo_usolution_in_zero(const dfo_ugrid* g, const double* V, unsigned l, double E);
+long   dfo_umatch(const dfo_ugrid* g, const double* V, unsigned l, double E, double* Psi);
+void   dfo_normalize_uniform(double* Psi, int n, double h);
+int    dfo_uloop_over_levels(const dfo_ugrid* g, const double* V, dfo_level* levels, int nlevels, double* newDensity,
+                             double* Eelectronic, double* BottomEnergy);
+double dfo_solve_poisson_uniform(dfo_poisson* p, int Z, double maxRadius, const double* density, double* U);
 
 #ifdef __cplusplus
 }

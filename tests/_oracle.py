@@ -30,6 +30,10 @@ class Grid(C.Structure):
                 ("twodelta", C.c_double), ("Rp2delta2", C.c_double), ("delta2p4", C.c_double)]
 
 
+class UGrid(C.Structure):
+    _fields_ = [("N", C.c_int), ("Rmax", C.c_double), ("h", C.c_double)]
+
+
 class Level(C.Structure):
     _fields_ = [("n", C.c_int), ("l", C.c_int), ("occ", C.c_int), ("E", C.c_double),
                 ("top", C.c_double), ("bottom", C.c_double), ("n_count", C.c_int), ("n_zero", C.c_int),
@@ -120,6 +124,12 @@ def oracle():
         "dfo_romberg": (C.c_double, [C.c_double, c_dp, C.c_int, C.c_double, C.c_int]),
         "dfo_get_subshells": (C.c_int, [C.c_int, C.POINTER(Level)]),
         "dfo_initialize_levels": (None, [C.c_int, c_ip, c_ip, C.POINTER(Level), c_ip, C.POINTER(Level), c_ip]),
+        "dfo_ucount_nodes": (C.c_int, [C.POINTER(UGrid), c_dp, C.c_uint, C.c_double, C.c_long, c_lp]),
+        "dfo_usolution_in_zero": (C.c_double, [C.POINTER(UGrid), c_dp, C.c_uint, C.c_double]),
+        "dfo_umatch": (C.c_long, [C.POINTER(UGrid), c_dp, C.c_uint, C.c_double, c_dp]),
+        "dfo_normalize_uniform": (None, [c_dp, C.c_int, C.c_double]),
+        "dfo_uloop_over_levels": (C.c_int, [C.POINTER(UGrid), c_dp, C.POINTER(Level), C.c_int, c_dp, c_dp, c_dp]),
+        "dfo_solve_poisson_uniform": (C.c_double, [C.POINTER(Poisson), C.c_int, C.c_double, c_dp, c_dp]),
         "dfo_scf_create": (C.POINTER(Scf), [C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int]),
         "dfo_scf_destroy": (None, [C.POINTER(Scf)]),
         "dfo_scf_step": (C.c_int, [C.POINTER(Scf), C.POINTER(Energies)]),
@@ -208,6 +218,11 @@ def make_grid(levels, delta, Rmax):
     o = oracle()
     o.dfo_grid_init(C.byref(g), o.dfo_num_nodes(levels), delta, Rmax)
     return g
+
+
+def make_ugrid(levels, Rmax):
+    N = oracle().dfo_num_nodes(levels)
+    return UGrid(N, Rmax, Rmax / (N - 1))
 
 
 def grid_r(g):

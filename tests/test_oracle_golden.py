@@ -337,3 +337,45 @@ def test_reference_rounding_sensitivity_of_scf_steps(tmp_path):
     assert diffs[0][0] < 2e-9                      # same potential: only the sweeps' roundings differ
     assert 1e-9 < diffs[1][0] < 1e-6               # one Poisson solve later: the noise floor of the SCF itself
     assert diffs[1][1] < 1e-9                      # total energies stay inside the 1e-9 relative gate
+
+
+def test_uniform_grid_oracle_vs_golden():
+    """The oracle's uniform-grid restatement against tests/golden/uniform.npz (vectors of the compiled reference): sweeps,
+    match, level driver and SolvePoissonUniform, bit for bit -- the pin that travels to machines without /root/reference."""
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    data = np.load(os.path.join(here, "uniform.npz"))
+    meta = json.load(open(os.path.join(here, "uniform_meta.json")))
+    o = O.oracle()
+    m = meta["grid"]
+    g = O.make_ugrid(m["L"], m["Rmax"])
+    assert g.N == m["N"] and g.h == m["h"]
+    rr = g.h * np.arange(g.N)
+    pots = {"coulomb10": np.concatenate([[0.0], -10.0 / rr[1:]]), "screened18": screened_potential(rr, 18.0)}
+    P = np.zeros(g.N)
+    for pname, V in pots.items():
+        rows = data["sweeps_" + pname]
+        for l, E, lim, cnt, u0 in rows[::5]:
+            assert o.dfo_ucount_nodes(C.byref(g), O.dp(V), int(l), float(E), int(lim), None) == int(cnt)
+            got = o.dfo_usolution_in_zero(C.byref(g), O.dp(V), int(l), float(E))
+            assert got == u0 or (np.isnan(got) and np.isnan(u0))
+        for row in data["match_" + pname][::4]:
+            mp = o.dfo_umatch(C.byref(g), O.dp(V), int(row[0]), float(row[1]), O.dp(P))
+            assert mp == int(row[2]) and np.nansum(P) == row[3] and np.nansum(np.abs(P)) == row[4]
+    V = pots["screened18"]
+    lv = O.subshells(18)
+    lev = O.levels_array(lv)
+    nd = np.zeros(g.N)
+    eel, bot = C.c_double(0), C.c_double(-18.0 * 18 - 1.0)
+    conv = o.dfo_uloop_over_levels(C.byref(g), O.dp(V), lev, len(lv), O.dp(nd), C.byref(eel), C.byref(bot))
+    assert [lev[k].E for k in range(len(lv))] == list(data["levels_E"])
+    assert np.array_equal(nd[:: g.N // 256], data["levels_newdensity_sample"])
+    assert [eel.value, bot.value, float(conv), nd.sum()] == list(data["levels_scalars"])
+    pg = meta["poisson_grid"]
+    gp = O.make_ugrid(pg["L"], pg["Rmax"])
+    rp = gp.h * np.arange(gp.N)
+    for tag, Z in (("Z2", 2), ("Z18", 18)):
+        p = o.dfo_poisson_create(pg["L"], 0.0)
+        U = np.zeros(gp.N)
+        o.dfo_solve_poisson_uniform(p, Z, pg["Rmax"], O.dp(Z * np.exp(-2 * rp) / np.pi), O.dp(U))
+        assert np.array_equal(U, data["poisson_%s_U" % tag])
+        o.dfo_poisson_destroy(p)

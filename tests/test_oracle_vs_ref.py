@@ -112,3 +112,58 @@ def test_open_shell_lsda_differs_from_lda_and_matches_ref():
         assert [e.Etotal, e.Ekinetic, e.Ecoul, e.Enuclear, e.Exc] == steps[k]["energies"]
     assert s.contents.nla == 3 and s.contents.nlb == 2
     o.dfo_scf_destroy(s)
+
+
+def test_uniform_grid_restatement_bit_exact_vs_reference():
+    """The oracle's uniform-grid functions (NumerovFunctionRegularGrid sweeps and match incl. the re-derived step, the
+    uniform LoopOverLevels / NormalizeUniform, SolvePoissonUniform) against the compiled reference: bit for bit."""
+    r, o = O.ref(), O.oracle()
+    L, R = 12, 25.0
+    g = O.make_ugrid(L, R)
+    N = g.N
+    rr = g.h * np.arange(N)
+    rng = np.random.default_rng(11)
+    for Z, V in ((10.0, np.concatenate([[0.0], -10.0 / rr[1:]])), (18.0, screened_potential(rr, 18.0))):
+        hd = r.ref_unumerov_create(O.dp(V), N, R)
+        Es = np.concatenate([-rng.uniform(1e-3, Z * Z + 1, 12), [-(Z ** 2) / 2, -33.0, -31.0, -1e-3, 0.5, 50.0]])
+        Pr, Po = np.zeros(N), np.zeros(N)
+        for l in range(4):
+            for E in Es:
+                for lim in (0, 3):
+                    assert o.dfo_ucount_nodes(C.byref(g), O.dp(V), l, float(E), lim, None) == r.ref_ucount_nodes(hd, l, float(E), lim)
+                a, b = o.dfo_usolution_in_zero(C.byref(g), O.dp(V), l, float(E)), r.ref_usolution_in_zero(hd, l, float(E))
+                assert a == b or (np.isnan(a) and np.isnan(b))
+                assert o.dfo_umatch(C.byref(g), O.dp(V), l, float(E), O.dp(Po)) == r.ref_umatch(hd, l, float(E), O.dp(Pr))
+                assert np.array_equal(Po, Pr, equal_nan=True)
+        # level driver
+        lv = O.subshells(int(Z))
+        n = np.array([a for a, _, _ in lv], np.int32)
+        l_ = np.array([b for _, b, _ in lv], np.int32)
+        occ = np.array([c for _, _, c in lv], np.int32)
+        Er, ndr = np.zeros(len(lv)), np.zeros(N)
+        eel_r, bot_r = C.c_double(0), C.c_double(-Z * Z - 1.0)
+        conv_r = r.ref_uloop_over_levels(hd, len(lv), O.ip(n), O.ip(l_), O.ip(occ), O.dp(Er), O.dp(ndr), C.byref(eel_r), C.byref(bot_r))
+        lev = O.levels_array(lv)
+        ndo = np.zeros(N)
+        eel_o, bot_o = C.c_double(0), C.c_double(-Z * Z - 1.0)
+        conv_o = o.dfo_uloop_over_levels(C.byref(g), O.dp(V), lev, len(lv), O.dp(ndo), C.byref(eel_o), C.byref(bot_o))
+        assert conv_o == conv_r and eel_o.value == eel_r.value and bot_o.value == bot_r.value
+        assert [lev[k].E for k in range(len(lv))] == list(Er)
+        assert np.array_equal(ndo, ndr)
+        r.ref_unumerov_destroy(hd)
+    # NormalizeUniform alone, and SolvePoissonUniform (deltaGrid = 0)
+    psi = rng.standard_normal(N)
+    a, b = psi.copy(), psi.copy()
+    o.dfo_normalize_uniform(O.dp(a), N, g.h)
+    r.ref_normalize_uniform(O.dp(b), N, g.h)
+    assert np.array_equal(a, b)
+    for Z in (2, 18):
+        rho = Z * np.exp(-2 * rr) / np.pi
+        q = r.ref_poisson_create(L, 0.0)
+        p = o.dfo_poisson_create(L, 0.0)
+        Ur, Uo = np.zeros(N), np.zeros(N)
+        r.ref_solve_poisson_uniform(q, Z, R, O.dp(rho), N, O.dp(Ur))
+        o.dfo_solve_poisson_uniform(p, Z, R, O.dp(rho), O.dp(Uo))
+        assert np.array_equal(Uo, Ur)
+        r.ref_poisson_destroy(q)
+        o.dfo_poisson_destroy(p)
