@@ -115,7 +115,7 @@ constexpr int kChunk = 8;             // grid points per prefetched batch of the
 constexpr int kBoundFrom = kChunk;    // the sweep body never touches i < kChunk (tail loop)
 constexpr int kTinyFrom = 128;        // from this index outwards |f| is small enough for the series reciprocal where the slot's bound says so
 constexpr double kTinyF = 12. / 2048.;   // |f| < 12 * 2^-11  <=>  |f/12| < 2^-11
-constexpr int kPipeChunk = 24;        // grid points per stage of the pipelined kernel
+constexpr int kPipeChunk = 32;        // grid points per stage of the pipelined kernel
 constexpr int kPipeMaxBlocks = 768;   // above this many 64-trial blocks the fused kernel fills every SIMD anyway
 
 struct SweepState {
@@ -519,8 +519,9 @@ typedef double v2d __attribute__((ext_vector_type(2)));
 template <int CH>
 struct PipeShared {
     v2d rows[4][CH];             // table rows {veff_i, e2_i} of the last four chunks (wave-uniform data)
-    double prod[3][CH][2][64];   // f_i and the refined reciprocal r_i of d_i = 1 - f_i/12, per point and lane
-    double u[2][CH][64];         // integrator -> counter
+    double prod[4][CH][2][64];   // f_i and the refined reciprocal r_i of d_i = 1 - f_i/12, per point and lane
+    double st[4][4][64];         // integrator -> counter, per chunk and lane: w, wprev, u after the chunk's last point and
+                                 // { min, max } of the high words of u over the chunk (two int32 in one double)
     double fin[64];              // u(0) of every lane at the end of a COUNT sweep
     double fin1[64];             // and u at grid point 1
     int stop;                    // set by the counter when every lane has left CountNodes' loop
@@ -547,8 +548,18 @@ __device__ __forceinline__ double read_lane(double v, int k)
     return __builtin_bit_cast(double, ((long long)hi << 32) | lo);
 }
 
+__device__ __forceinline__ int hi_word(double v) { return (int)(__builtin_bit_cast(long long, v) >> 32); }
+
 // s_barrier without the vmcnt(0) that __syncthreads() implies: table prefetches stay in flight across the barrier
+#ifdef DFTA_PIPE_PROF
+// measurements only: per role { ticks waiting at the barrier (LDS drain included), barriers } of block 0
+__device__ unsigned long long g_pipe_prof[8 * 2];
+#define PIPE_BARRIER() do { const unsigned long long t0_ = __builtin_readcyclecounter(); \
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); \
+        if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) { g_pipe_prof[(threadIdx.x >> 6) * 2] += __builtin_readcyclecounter() - t0_; g_pipe_prof[(threadIdx.x >> 6) * 2 + 1] += 1; } } while (0)
+#else
 #define PIPE_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#endif
 
 struct PipeTrial {          // what every wave of the block knows about its lane's trial
     double E;
@@ -575,7 +586,7 @@ __device__ __forceinline__ bool pipe_producer(PipeShared<CH>& sh, const double2*
     load(X1, 1);
     load(X2, 2);
     load(X3, 3);
-    int ps = 0;                                            // it % 3
+    int ps = 0;                                            // it % 4
     volatile int* stop = &sh.stop;
     auto stage = [&](v2d& X, int it) -> bool {
         tab_wait<3>(X);                                    // the load of X is older than the three behind it
@@ -596,9 +607,9 @@ __device__ __forceinline__ bool pipe_producer(PipeShared<CH>& sh, const double2*
             P[kk * 128 + 64] = rr;
         }
         load(X, it + 4);
-        ps = ps == 2 ? 0 : ps + 1;
+        ps = (ps + 1) & 3;
         PIPE_BARRIER();
-        return COUNT && (it & 1) && *stop != 0;
+        return COUNT && (it & 7) == 7 && *stop != 0;
     };
     bool stopped = false;
     for (int it = 0; it < tr.nit; it += 4) {
@@ -657,8 +668,26 @@ __device__ __forceinline__ void sweep_pipe(const SweepArgs& a, const GridScalars
         return __ballot(joins) == 0ull;
     };
 
+    // the state a lane starts from at i = my_hi (integrator; counter when it integrates a chunk again)
+    auto initial_state = [&]() -> SweepState {
+        SweepState s;
+        const double2 ts = T[start];
+        const double2 t1 = T[start - 1];
+        const double us = a.us[t];
+        s.u = a.us1[t];
+        s.fprev = (ts.x - E) * R2 * ts.y + d2p4;
+        s.wprev = (1 - kH2p12 * s.fprev) * us;
+        s.fprev = (t1.x - E) * R2 * t1.y + d2p4;
+        s.w = (1 - kH2p12 * s.fprev) * s.u;
+        s.prevSol = us;
+        return s;
+    };
+
     // the producer on SIMD 0 shares it with the counter: it takes a quarter of the chunk, the other two 3/8 each
-    constexpr int kP0 = CH / 4, kP1 = (CH - kP0) / 2;
+#ifndef DFTA_PIPE_P0
+#define DFTA_PIPE_P0 (CH / 4)
+#endif
+    constexpr int kP0 = DFTA_PIPE_P0, kP1 = (CH - kP0) / 2;
     if (role == 0)      stopped = pipe_producer<COUNT, CH, 0, kP0>(sh, T, tr, lane, R2, d2p4);
     else if (role == 1) stopped = pipe_producer<COUNT, CH, kP0, kP1>(sh, T, tr, lane, R2, d2p4);
     else if (role == 3) stopped = pipe_producer<COUNT, CH, kP0 + kP1, CH - kP0 - kP1>(sh, T, tr, lane, R2, d2p4);
@@ -670,58 +699,75 @@ __device__ __forceinline__ void sweep_pipe(const SweepArgs& a, const GridScalars
             const bool lane_ok = !valid || (bd.x + fabs(E) * bd.y + d2p4 < 6.0);
             fast = (__ballot(lane_ok) == ~0ull);
         }
-        SweepState s;
-        {
-            const double2 ts = T[start];
-            const double2 t1 = T[start - 1];
-            const double us = a.us[t];
-            s.u = a.us1[t];
-            s.fprev = (ts.x - E) * R2 * ts.y + d2p4;
-            s.wprev = (1 - kH2p12 * s.fprev) * us;
-            s.fprev = (t1.x - E) * R2 * t1.y + d2p4;
-            s.w = (1 - kH2p12 * s.fprev) * s.u;
-            s.prevSol = us;
-        }
+        SweepState s = initial_state();
         const SweepState s0 = s;                               // a lane (re)starts from here at i = my_hi
+        // {f, r} of the points ahead, in registers: entry e of a chunk lives in R.f[e], R.r[e]; when a stage begins the first
+        // kAhead entries of its chunk are there, the others follow while the chunk is integrated -- and then the first kAhead
+        // of the next chunk (whose buffer the producers completed a stage ago) -- four reads per three points, so that the
+        // last one is issued a quarter of a chunk before the barrier (which waits for the wave's outstanding LDS operations).
+        // Only the entries between "read" and "used" are live: ~kAhead + CH/4 of them.
+        constexpr int kAhead = CH / 2, kRd = CH - CH / 4;
+        static_assert(kRd * 4 == CH * 3 && kAhead * 2 == CH, "chunk size must be a multiple of four");
         struct Regs { double f[CH], r[CH]; };
-        Regs RA, RB;
-        int ls = 0;                                            // (it - 1) % 3: the prod buffer of the chunk to load
-        auto stage = [&](Regs& cur, Regs& nxt, int it) -> bool {
-            // chunk it-1 goes into registers while chunk it-2 is integrated (reads of a chunk that does not exist
-            // return stale LDS contents that are never used)
-            const double* P = &sh.prod[ls][0][0][lane];
-            if (it >= 1) ls = ls == 2 ? 0 : ls + 1;
+        Regs R;
+        auto stage = [&](int it) -> bool {
+            // chunk it-2 is integrated (reads of a chunk that does not exist return stale LDS contents that are never used)
             const int c = it - 2;
+            const double* Pc = &sh.prod[c & 3][0][0][lane];
+            const double* Pn = &sh.prod[(c + 1) & 3][0][0][lane];
+            auto fetch = [&](int q) {                          // entry q + kAhead of the running sequence (q: compile time)
+                const int e = q + kAhead;
+                if (e < CH) { R.f[e] = Pc[e * 128]; R.r[e] = Pc[e * 128 + 64]; }
+                else        { R.f[e - CH] = Pn[(e - CH) * 128]; R.r[e - CH] = Pn[(e - CH) * 128 + 64]; }
+            };
             const bool have = c >= 0 && c < nch;
             const int top = (nch - c) * CH;
-            double* U = &sh.u[c & 1][0][lane];
+            // What the counter gets of a chunk (COUNT): not the CH values of u (a 64-lane ds_write costs the integrator
+            // 6 .. 18 ns), but min and max of their HIGH WORDS as signed integers -- min > 0 means every u > 0, max < 0
+            // every u < 0 or -0 (one v_min3_i32 + one v_max3_i32 per two points) -- and w, wprev, u after the last
+            // point, from which the counter integrates the next chunk itself in the rare case that it has to look at
+            // every point.
+            int hmin = 0x7fffffff, hmax = (int)0x80000000;
             if (have && fast && plain_chunk(top)) {
                 // Straight-line code for all 64 lanes: lanes that have not started yet integrate garbage (they are reset
-                // to s0 when they join, in the other branch).  The LDS reads of the next chunk are interleaved with
-                // the recurrence (6 VALU : 2 DS reads per point) -- issued in one burst they would stall the wave.
-                double uprev = 0;
+                // to s0 when they join, in the other branch).  The LDS reads are interleaved with the recurrence (8 VALU,
+                // then 1 or 2 DS reads per point) -- issued in one burst they would stall the wave.
+                int hprev = 0;
 #pragma unroll
                 for (int k = 0; k < CH; ++k) {
+                    const double fk = R.f[k], rk = R.r[k];
                     // Numerov.h:311 (h2 == 1): 2 w is exact, so fma(2, w, -wprev) is the reference's 2 w - wprev
                     const double wnext = __builtin_fma(2., s.w, -s.wprev) + s.u * s.fprev;
                     s.wprev = s.w;
                     s.w = wnext;
                     s.prevSol = s.u;
-                    const double d = 1. - kH2p12 * cur.f[k];                 // off the loop-carried chain
-                    const double q = wnext * cur.r[k];
+                    const double d = 1. - kH2p12 * fk;                       // off the loop-carried chain
+                    const double q = wnext * rk;
                     const double rem = __builtin_fma(-d, q, wnext);
-                    s.u = __builtin_fma(rem, cur.r[k], q);
-                    s.fprev = cur.f[k];
-                    if (COUNT) { if (k & 1) { U[(k - 1) * 64] = uprev; U[k * 64] = s.u; } else uprev = s.u; }
-                    nxt.f[k] = P[k * 128];
-                    nxt.r[k] = P[k * 128 + 64];
-                    __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                    if (COUNT && (k & 1)) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                    s.u = __builtin_fma(rem, rk, q);
+                    s.fprev = fk;
+                    if (COUNT) {
+                        const int h = hi_word(s.u);
+                        if (k & 1) {
+                            asm("v_min3_i32 %0, %1, %2, %3" : "=v"(hmin) : "v"(hmin), "v"(hprev), "v"(h));
+                            asm("v_max3_i32 %0, %1, %2, %3" : "=v"(hmax) : "v"(hmax), "v"(hprev), "v"(h));
+                        } else hprev = h;
+                    }
+                    if (k < kRd) {
+                        const int q0 = (4 * k) / 3, q1 = (4 * (k + 1)) / 3;
+                        fetch(q0);
+                        if (q1 - q0 == 2) fetch(q0 + 1);
+                    }
+                    if (COUNT && (k & 1)) __builtin_amdgcn_sched_group_barrier(0x002, 10, 0);
+                    else                  __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
+                    if (k < kRd) {
+                        if ((4 * (k + 1)) / 3 - (4 * k) / 3 == 2) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                        else                                      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    }
                 }
             } else {
 #pragma unroll
-                for (int k = 0; k < CH; ++k) { nxt.f[k] = P[k * 128]; nxt.r[k] = P[k * 128 + 64]; }
+                for (int q = 0; q < CH - kAhead; ++q) fetch(q);              // the rest of this chunk
                 __builtin_amdgcn_sched_barrier(0);
                 if (have) {
 #pragma unroll
@@ -734,34 +780,46 @@ __device__ __forceinline__ void sweep_pipe(const SweepArgs& a, const GridScalars
                             s.wprev = s.w;
                             s.w = wnext;
                             s.prevSol = s.u;
-                            const double d = 1. - kH2p12 * cur.f[k];
+                            const double d = 1. - kH2p12 * R.f[k];
                             if (fdiv) {
-                                const double q = wnext * cur.r[k];
+                                const double q = wnext * R.r[k];
                                 const double rem = __builtin_fma(-d, q, wnext);
-                                s.u = __builtin_fma(rem, cur.r[k], q);
+                                s.u = __builtin_fma(rem, R.r[k], q);
                             } else {
                                 s.u = wnext / d;                                          // getU, Numerov.h:510-513
                             }
-                            s.fprev = cur.f[k];
+                            s.fprev = R.f[k];
                         }
-                        if (COUNT) U[k * 64] = s.u;
+                        if (COUNT) { const int h = hi_word(s.u); hmin = min(hmin, h); hmax = max(hmax, h); }
                     }
                 }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = CH - kAhead; q < CH; ++q) fetch(q);             // the beginning of the next one
+            }
+            if (COUNT && have) {
+                double* ST = &sh.st[c & 3][0][lane];
+                ST[0] = s.w;
+                ST[64] = s.wprev;
+                ST[128] = s.u;
+                ST[192] = __builtin_bit_cast(double, ((long long)hmax << 32) | (unsigned)hmin);
             }
             if (have && fast) {
-                // the reciprocal path needs |w| in range: leave it for good when any started lane gets near the edges
-                // (16 decades of cancellation + 1.6 decades per step of a chunk above the 2^-969 limit of v_div_scale)
+                // the reciprocal path needs |w| in [2^-969, 2^767) -- outside, v_div_scale rescales the operands -- all the way
+                // through the next chunk: leave it for good when any started lane gets within 1.6 decades per step of a chunk
+                // (a generous bound for |f| < 6) of the edges, plus 16 decades for a value next to a node at the lower one
+                static_assert(CH <= 32, "range margins of the reciprocal path");
+                constexpr double kLo = CH <= 16 ? 1e-250 : CH <= 24 ? 1e-237 : 1e-224;
+                constexpr double kHi = CH <= 16 ? 1e200 : CH <= 24 ? 1e192 : 1e179;
                 const double au = fabs(s.u);
-                const bool ok = !(valid && my_hi > top - CH) || (au < 1e200 && (au > 1e-250 || s.u == 0.0));
+                const bool ok = !(valid && my_hi > top - CH) || (au < kHi && (au > kLo || s.u == 0.0));
                 fast = (__ballot(ok) == ~0ull);
             }
             PIPE_BARRIER();
-            return COUNT && (it & 1) && *stop != 0;
+            return COUNT && (it & 7) == 7 && *stop != 0;
         };
-        for (int it = 0; it < nit; it += 2) {
-            if (stage(RA, RB, it)) { stopped = true; break; }
-            if (stage(RB, RA, it + 1)) { stopped = true; break; }
-        }
+        for (int it = 0; it < nit; ++it)
+            if (stage(it)) { stopped = true; break; }
         if (my_hi == 0) s = s0;                                // start == 2: nothing to integrate, u(0) comes from the boundary values
         if (!COUNT) {
             if (valid) {
@@ -790,23 +848,30 @@ __device__ __forceinline__ void sweep_pipe(const SweepArgs& a, const GridScalars
         // { min, max } of veff per block, fetched one chunk ahead (vector load with a zero lane offset: a scalar load
         // would be drained by the lgkmcnt(0) of every barrier)
         const double2* __restrict__ blkmm =
-            a.bounds ? a.bounds + (size_t)slot * a.bstride + 1 + __builtin_amdgcn_mbcnt_hi(0u, __builtin_amdgcn_mbcnt_lo(0u, 0u)) : nullptr;
-        double2 mm_next = blkmm ? blkmm[max(nch - 1, 0)] : double2{0., 0.};
+            a.bounds ? a.bounds + (size_t)slot * a.bstride + 1 : nullptr;
+        // 64 consecutive entries at a time, one per lane (block bhi - lane), the next 64 already on their way; the entry of
+        // a chunk is broadcast from its lane
+        auto mm_fetch = [&](int bhi) -> double2 { return blkmm ? blkmm[max(bhi - lane, 0)] : double2{0., 0.}; };
+        double2 mmv = mm_fetch(nch - 1), mmv_next = mm_fetch(nch - 1 - 64);
         lanemask_t last_le = 0;       // veff <= E at the last point that went through count_step
         bool poisoned = true;         // last_le unusable (nothing processed yet, or a NaN veff)
         double phi = NAN, ucarry = NAN;   // see SweepArgs::phi; u at the last point of the previous chunk
+        double fcarry = 0;                // f at that point
         int istop = -1;
+        const SweepState s0 = COUNT ? initial_state() : SweepState{};
         for (int it = 0; it < nit; ++it) {
             const int cc = it - 3;
             if (COUNT && cc >= 0 && cc < nch) {
                 const int top = (nch - cc) * CH;
-                const double* U = &sh.u[cc & 1][0][lane];
+                const double* ST = &sh.st[cc & 3][0][lane];
+                const double* F = &sh.prod[cc & 3][0][0][lane];
                 const v2d* rows = &sh.rows[cc & 3][0];
-                double u[CH];
-#pragma unroll
-                for (int k = 0; k < CH; ++k) u[k] = U[k * 64];
-                const double2 mm = mm_next;                                                  // block nch - 1 - cc
-                if (blkmm) mm_next = blkmm[max(nch - 2 - cc, 0)];
+                const double ulast = ST[128];
+                const long long hmm = __builtin_bit_cast(long long, ST[192]);
+                const int hmin = (int)hmm, hmax = (int)(hmm >> 32);
+                const double flast = F[(CH - 1) * 128];
+                const double2 mm = double2{read_lane(mmv.x, cc & 63), read_lane(mmv.y, cc & 63)};   // block nch - 1 - cc
+                if ((cc & 63) == 63) { mmv = mmv_next; mmv_next = mm_fetch(nch - 1 - (cc + 1) - 64); }
                 bool quiet = false;
                 const lanemask_t started = __ballot(valid && my_hi >= top);
                 const lanemask_t act = c.live & started;
@@ -814,17 +879,12 @@ __device__ __forceinline__ void sweep_pipe(const SweepArgs& a, const GridScalars
                     // Nothing can change in this chunk if, for every active lane, veff stays on the side of E it was on
                     // at the last examined point, u keeps its sign and stays finite: then cross = tp = 0 and flag, live,
                     // oldSgn are fixed points of count_step (flag already holds stay & m_le, live already lost flag & m_gt).
-                    // Per lane: min, max and max |.| of u over the chunk (a NaN survives to the last point of the chunk
-                    // through the recurrence, and a NaN veff makes u NaN, so the min/max dropping NaNs is harmless).
-                    double mn = u[0], mx = u[0], ma = u[0];
-#pragma unroll
-                    for (int k = 1; k < CH; ++k) {
-                        asm("v_min_f64 %0, %1, %2" : "=v"(mn) : "v"(mn), "v"(u[k]));
-                        asm("v_max_f64 %0, %1, %2" : "=v"(mx) : "v"(mx), "v"(u[k]));
-                        asm("v_max_f64 %0, |%1|, |%2|" : "=v"(ma) : "v"(ma), "v"(u[k]));
-                    }
-                    const lanemask_t fin = __ballot(fabs(ma) < INFINITY && u[CH - 1] == u[CH - 1]);
-                    const lanemask_t allpos = __ballot(mn > 0), nonepos = __ballot(mx <= 0);
+                    // Per lane, from the integrator: u after the chunk's last point (an infinity or a NaN survives to there
+                    // through the recurrence, and a NaN veff makes u NaN) and min / max of the high words of u over the
+                    // chunk: min > 0 -- every u positive; max < 0 -- every sign bit set.  (+0 and the denormals below
+                    // 2^-1042 count as "cannot tell": the chunk is then examined point by point.)
+                    const lanemask_t fin = __ballot(fabs(ulast) < INFINITY);
+                    const lanemask_t allpos = __ballot(hmin > 0), nonepos = __ballot(hmax < 0);
                     const lanemask_t le_all = __ballot(mm.y <= E), gt_all = __ballot(mm.x > E);
                     const lanemask_t ok = fin & ((c.oldSgn & allpos) | (~c.oldSgn & nonepos)) & ((le_all & last_le) | (gt_all & ~last_le));
                     quiet = (~ok & act) == 0ull;
@@ -833,6 +893,34 @@ __device__ __forceinline__ void sweep_pipe(const SweepArgs& a, const GridScalars
                     if (diag) trips += CH * (int)((act >> lane) & 1ull);
                     wave_trips += (unsigned long long)CH * __popcll(act);
                 } else {
+                    // The chunk again, point by point: u is integrated once more from the state the integrator left after
+                    // the chunk before (IEEE division: bit for bit what the integrator's reciprocal path returns).
+                    SweepState s = s0;
+                    if (cc > 0) {
+                        const double* SP = &sh.st[(cc - 1) & 3][0][lane];
+                        s.w = SP[0];
+                        s.wprev = SP[64];
+                        s.u = SP[128];
+                        s.fprev = fcarry;
+                    }
+                    double u[CH];
+#pragma unroll
+                    for (int k = 0; k < CH; ++k) u[k] = F[k * 128];            // f_i first, overwritten by u_i below
+#pragma unroll
+                    for (int k = 0; k < CH; ++k) {
+                        const int i = top - k;
+                        const double f = u[k];
+                        if (valid && i <= my_hi) {
+                            if (i == my_hi) s = s0;
+                            const double wnext = 2. * s.w - s.wprev + s.u * s.fprev;
+                            s.wprev = s.w;
+                            s.w = wnext;
+                            const double d = 1. - kH2p12 * f;
+                            s.u = wnext / d;
+                            s.fprev = f;
+                        }
+                        u[k] = s.u;
+                    }
                     lanemask_t m_le = 0, m_gt = 0;
 #pragma unroll
                     for (int k = 0; k < CH; ++k) {
@@ -857,10 +945,11 @@ __device__ __forceinline__ void sweep_pipe(const SweepArgs& a, const GridScalars
                     poisoned = ((m_le | m_gt) != ~0ull);
                     if ((c.live & vmask) == 0ull && lane == 0) *stop = 1;
                 }
-                ucarry = u[CH - 1];
+                ucarry = ulast;
+                fcarry = flast;
             }
             PIPE_BARRIER();
-            if (COUNT && (it & 1) && *stop != 0) { stopped = true; break; }
+            if (COUNT && (it & 7) == 7 && *stop != 0) { stopped = true; break; }
         }
         if (COUNT) {
             if (!stopped) PIPE_BARRIER();          // pairs with the barrier below: sh.fin is complete
@@ -1789,3 +1878,12 @@ extern "C" int dfta_numerov_match(dfta_ctx* ctx, const dfta_grid* g, int boundar
     }
     return DFTA_OK;
 }
+
+#ifdef DFTA_PIPE_PROF
+extern "C" int dfta_debug_pipe_prof(unsigned long long* out)
+{
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pipe_prof), sizeof(g_pipe_prof)) != hipSuccess) return 1;
+    unsigned long long z[16] = {0};
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_pipe_prof), z, sizeof(z)) == hipSuccess ? 0 : 1;
+}
+#endif
