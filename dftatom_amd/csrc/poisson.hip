@@ -1357,6 +1357,48 @@ __device__ __forceinline__ double seq_sweep_inplace(const double* __restrict__ S
     return err2;
 }
 
+// lane t <- v of lane t-1 (DPP wave_shr:1 on both halves), lane 0 keeps `keep`
+__device__ __forceinline__ double lane_shr1(double keep, double v)
+{
+    const long long k = __builtin_bit_cast(long long, keep), x = __builtin_bit_cast(long long, v);
+    const int lo = __builtin_amdgcn_update_dpp((int)k, (int)x, 0x138, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp((int)(k >> 32), (int)(x >> 32), 0x138, 0xf, 0xf, false);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned)lo);
+}
+
+// The same sweep (n <= 65 nodes, natural order) by the 64 lanes of a wave: lane t keeps S, the old right neighbour and the
+// old value of node t + 1 in registers and recomputes its node in every step from the candidate of lane t - 1, handed on
+// through a DPP lane shift (lane 0: from the boundary value).  The candidate of node i is final from step i on -- its
+// left neighbour's is final one step earlier and its other inputs never change -- so after n - 2 steps every lane holds
+// exactly what the sequential loop computes: the same n - 2 dependent updates, but 7 instructions each (5 flops, 2 lane
+// shifts) instead of a scalar loop with its LDS traffic (~46 ns per node).  Returns this lane's share of sum dPhi^2.
+__device__ __forceinline__ double seq_sweep_wave(const double* __restrict__ Sg, double* __restrict__ Pg, const int n, const double dh)
+{
+    typedef __attribute__((address_space(3))) double lds_f64;
+    typedef __attribute__((address_space(3))) const double lds_cf64;
+    lds_cf64* S = (lds_cf64*)(Sg);
+    lds_f64* P = (lds_f64*)(Pg);
+    const int i = (threadIdx.x & 63) + 1;             // this lane's node
+    const bool mine = i < n - 1;
+    const double s = mine ? S[i] : 0.0;
+    const double xp = mine ? P[i + 1] : 0.0;
+    const double old = mine ? P[i] : 0.0;
+    double yin = 2.0 * P[0];                          // stays the boundary value in lane 0
+    double cand = 0;
+    // (extra steps are harmless -- the candidates are at their fixed point -- so the trip count is rounded up to the unroll)
+    for (int k = 0; k < n - 2; k += 4) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            cand = gs_point2(s, yin, xp, dh);
+            yin = lane_shr1(yin, cand);
+        }
+    }
+    const double x = 0.5 * cand;
+    const double dif = old - x;
+    if (mine) P[i] = x;
+    return mine ? dif * dif : 0.0;
+}
+
 // IterateGaussSeidel on the LDS copy of level l; all 64 lanes of the wave call
 __device__ __forceinline__ double cs_iterate(const MgDesc& D, Atom& A, int l, double errorMin, int iterno, long* nsweeps)
 {
@@ -1378,8 +1420,13 @@ __device__ __forceinline__ double cs_iterate(const MgDesc& D, Atom& A, int l, do
             }
             for (int off = 32; off > 0; off >>= 1) err2 += __shfl_xor(err2, off);
         } else {
+#ifdef DFTA_POISSON_SEQ_ONE_LANE
             if (lane == 0) err2 = seq_sweep_inplace(S, P, L.n, dh);
             err2 = __shfl(err2, 0);
+#else
+            err2 = seq_sweep_wave(S, P, L.n, dh);
+            for (int off = 32; off > 0; off >>= 1) err2 += __shfl_xor(err2, off);
+#endif
         }
         err = sqrt(err2);
         ++*nsweeps;

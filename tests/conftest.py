@@ -21,3 +21,13 @@ def golden():
     with open(os.path.join(here, "golden_meta.json")) as f:
         meta = json.load(f)
     return data, meta
+
+
+@pytest.fixture(scope="session")
+def torch_first():
+    """GPU tests that hand torch tensors to the library share one process with it: initialise torch's HIP runtime before
+    the library touches the device ("import torch first"), whatever order the modules run in."""
+    import torch
+    if torch.cuda.is_available():
+        torch.cuda.init()
+    return torch

@@ -17,7 +17,7 @@ from golden.make_golden import GRIDS    # noqa: E402
 
 
 @pytest.fixture(scope="module")
-def ctx():
+def ctx(torch_first):
     c = D.Context(0)
     yield c
     c.close()

@@ -40,7 +40,7 @@ ROOT = os.path.dirname(HERE)
 
 
 @pytest.fixture(scope="module")
-def ctx():
+def ctx(torch_first):
     c = D.Context(0)
     yield c
     c.close()

@@ -25,7 +25,7 @@ from golden.make_golden import GRIDS, screened_potential   # noqa: E402
 
 
 @pytest.fixture(scope="module")
-def ctx():
+def ctx(torch_first):
     c = D.Context(0)
     yield c
     c.close()
