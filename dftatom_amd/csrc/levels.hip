@@ -633,7 +633,7 @@ __device__ __forceinline__ int decisions_left(const dfta::Job& j)
 __global__ __launch_bounds__(64) void k_allot(dfta::Job* __restrict__ jobs, int njobs, int budget, int nopredict, int* __restrict__ wave_job,
                                               int* __restrict__ wave_slot)
 {
-    __shared__ int s_S[64], s_r[64], s_sc[64], s_act[64], s_rem[64];
+    __shared__ int s_S[64], s_r[64], s_sc[64], s_act[64], s_rem[64], s_base[64], s_cap[64];
     const int k = threadIdx.x;            // njobs <= 64 in this mode
     bool act = false;
     int S = 0, r = 0, sc = 0, rem = 0;
@@ -675,16 +675,28 @@ __global__ __launch_bounds__(64) void k_allot(dfta::Job* __restrict__ jobs, int 
         for (int q = 0; q < njobs; ++q) {
             int cap = 0;
             if (s_act[q]) { cap = slots(q); if (base + cap > budget) cap = ((budget - base) / 128) * 128; }
-            jobs[q].tbase = base;
-            jobs[q].tcap = cap;
-            for (int w = base >> 6; w < (base + cap) >> 6; ++w) { wave_job[w] = q; wave_slot[w] = jobs[q].slot; }
+            s_base[q] = base;
+            s_cap[q] = cap;
             base += cap;
         }
-        for (int w = base >> 6; w < budget >> 6; ++w) { wave_job[w] = -1; wave_slot[w] = 0; }
     }
     __syncthreads();
+    // the block table of the round, by all lanes (a lone thread pays a memory round trip per entry)
+    const int my_slot = k < njobs ? jobs[k].slot : 0;
+    s_S[k] = my_slot;                                          // (the spine lengths are not needed any more)
+    __syncthreads();
+    for (int w = k; w < (budget >> 6); w += 64) {
+        int q = -1;
+        for (int t = 0; t < njobs; ++t)
+            if (w * 64 >= s_base[t] && w * 64 < s_base[t] + s_cap[t]) q = t;
+        wave_job[w] = q;
+        wave_slot[w] = q >= 0 ? s_S[q] : 0;
+    }
+    if (k < njobs) { jobs[k].tbase = s_base[k]; jobs[k].tcap = s_cap[k]; }
     if (k < njobs && act) {                                    // the plan for the slots the job really got
         dfta::Job j = jobs[k];
+        j.tbase = s_base[k];
+        j.tcap = s_cap[k];
         if (j.tcap < 128) {                                    // nothing left for it this round (cannot happen while budget >= 128 njobs)
             jobs[k].spine = 0; jobs[k].capz = j.tcap; jobs[k].use_sp = 0; jobs[k].sp_bits = 0; jobs[k].sp_len = 0;
             return;

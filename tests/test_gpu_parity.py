@@ -101,6 +101,50 @@ def test_sweeps_ragged_batches_and_two_potentials(ctx, grid14, sweep_kernel):
     assert D.numerov_sweeps(ctx, grid14, D.SWEEP_ZERO, V, [], [])["u0"].size == 0      # empty batch
 
 
+def test_sweeps_pathological_potentials(ctx, grid14, sweep_kernel):
+    """The paths that realistic potentials hardly touch: |f| beyond the range of the reciprocal division (every point takes
+    the IEEE division), solutions that overflow to infinity or underflow towards the denormals (lanes leave the fast path),
+    NaN and infinite table entries (the counter's veff bookkeeping is poisoned), wells with dozens of nodes per trial (most
+    chunks are examined point by point: the counter integrates them again from the integrator's hand-over).  Counts, exit
+    points (trip), cut-off indices and u(0) must equal the oracle's for every trial."""
+    o = O.oracle()
+    g = O.make_grid(*GRIDS["L14"])
+    r = grid14.r()
+    N = grid14.N
+    base = _pots(grid14)["screened86"]
+    rng = np.random.default_rng(7)
+    pots = {
+        "scaled_1e4": base * 1e4,                                     # |f| >> 6 over most of the grid
+        "barrier": np.where((r > 0.5) & (r < 3.0), 5e3, base),        # exponential growth across a wall: overflow
+        "deep_well": np.where(r < 20.0, -400.0, 0.0),                 # hundreds of nodes at E ~ -1
+        "nan_hole": np.where((np.arange(N) > 9000) & (np.arange(N) < 9004), np.nan, base),
+        "inf_spike": np.where(np.arange(N) == 7000, np.inf, base),
+        "ninf_spike": np.where(np.arange(N) == 12000, -np.inf, base),
+        "zero": np.zeros(N),
+        "noise": base + rng.standard_normal(N) * 50.0,
+    }
+    names = list(pots)
+    V = np.stack([pots[k] for k in names])
+    nt = 2 * 64 * len(names) + 37
+    vidx = (np.arange(nt) % len(names)).astype(np.int32)
+    l = rng.integers(0, 4, nt).astype(np.int32)
+    E = np.where(rng.random(nt) < 0.15, rng.uniform(0, 30, nt), -10.0 ** rng.uniform(-3, 3.5, nt))
+    E[::17] = 0.0
+    lim = rng.choice([0, 1, 3, 40, 100000], nt).astype(np.int32)
+    c = D.numerov_sweeps(ctx, grid14, D.SWEEP_COUNT, V, l, E, lim, vidx=vidx)
+    z = D.numerov_sweeps(ctx, grid14, D.SWEEP_ZERO, V, l, E, vidx=vidx)
+    bad = []
+    for k in range(nt):
+        st, tr = C.c_long(), C.c_long()
+        want = o.dfo_count_nodes(C.byref(g), O.dp(V[vidx[k]]), int(l[k]), float(E[k]), int(lim[k]), C.byref(st), C.byref(tr))
+        u0 = o.dfo_solution_in_zero(C.byref(g), O.dp(V[vidx[k]]), int(l[k]), float(E[k]), None)
+        same_u0 = (z["u0"][k] == u0) or (np.isnan(u0) and np.isnan(z["u0"][k]))
+        if not (c["count"][k] == want and c["start"][k] == st.value and c["trip"][k] == tr.value and same_u0):
+            bad.append((names[vidx[k]], int(l[k]), float(E[k]), int(lim[k]), int(c["count"][k]), want, int(c["trip"][k]), tr.value,
+                        float(z["u0"][k]), u0))
+    assert not bad, bad[:5]
+
+
 def test_device_boundary_values(ctx, grid14):
     """cut-off index identical, start values from the device exp(): u(0) within 1e-10 relative, same node counts"""
     V = _pots(grid14)["screened86"]
