@@ -520,8 +520,8 @@ template <int CH>
 struct PipeShared {
     v2d rows[4][CH];             // table rows {veff_i, e2_i} of the last four chunks (wave-uniform data)
     double prod[4][CH][2][64];   // f_i and the refined reciprocal r_i of d_i = 1 - f_i/12, per point and lane
-    double st[4][4][64];         // integrator -> counter, per chunk and lane: w, wprev, u after the chunk's last point and
-                                 // { min, max } of the high words of u over the chunk (two int32 in one double)
+    double st[4][4][64];         // integrator -> counter, per chunk and lane: w, wprev, u after the chunk's last point and a
+                                 // summary of the signs of u over the chunk (two int32 in one double, see sweep_pipe)
     double fin[64];              // u(0) of every lane at the end of a COUNT sweep
     double fin1[64];             // and u at grid point 1
     int stop;                    // set by the counter when every lane has left CountNodes' loop
@@ -549,6 +549,7 @@ __device__ __forceinline__ double read_lane(double v, int k)
 }
 
 __device__ __forceinline__ int hi_word(double v) { return (int)(__builtin_bit_cast(long long, v) >> 32); }
+constexpr int kSignWord = 0x7fffdead;   // second word of a chunk summary that holds sign bits (the high word of a NaN no arithmetic produces)
 
 // s_barrier without the vmcnt(0) that __syncthreads() implies: table prefetches stay in flight across the barrier
 #ifdef DFTA_PIPE_PROF
@@ -723,16 +724,23 @@ __device__ __forceinline__ void sweep_pipe(const SweepArgs& a, const GridScalars
             const bool have = c >= 0 && c < nch;
             const int top = (nch - c) * CH;
             // What the counter gets of a chunk (COUNT): not the CH values of u (a 64-lane ds_write costs the integrator
-            // 6 .. 18 ns), but min and max of their HIGH WORDS as signed integers -- min > 0 means every u > 0, max < 0
-            // every u < 0 or -0 (one v_min3_i32 + one v_max3_i32 per two points) -- and w, wprev, u after the last
-            // point, from which the counter integrates the next chunk itself in the rare case that it has to look at
-            // every point.
+            // 6 .. 18 ns), but a summary of their signs and w, wprev, u after the last point, from which the counter
+            // integrates the chunk itself in the rare case that it has to look at every point.  Summary of a chunk from the
+            // straight-line path: the CH sign bits of u, first point in the top bit (one v_alignbit_b32 per point; second word
+            // kSignWord).  There d is in (0.5, 1.5) and |w| >= 2^-969 or 0, so u = +-0 only where w = 0, and then
+            // w_next = -w_prev: a zero inside a run of values is always followed by the opposite sign (or by zeros to the
+            // end of the sweep) -- as long as the chunk's last value is finite and not zero, "u > 0" is "sign bit clear" at
+            // every point where it matters and the sign changes of the word are CountNodes' crossings.  Summary from the
+            // general path: min and max of the HIGH WORDS as signed integers (min > 0: every u > 0; max < 0: every sign
+            // bit set; +0 counts as "cannot tell").
             int hmin = 0x7fffffff, hmax = (int)0x80000000;
+            unsigned sw = 0;
+            bool straight = false;
             if (have && fast && plain_chunk(top)) {
+                straight = true;
                 // Straight-line code for all 64 lanes: lanes that have not started yet integrate garbage (they are reset
                 // to s0 when they join, in the other branch).  The LDS reads are interleaved with the recurrence (8 VALU,
                 // then 1 or 2 DS reads per point) -- issued in one burst they would stall the wave.
-                int hprev = 0;
 #pragma unroll
                 for (int k = 0; k < CH; ++k) {
                     const double fk = R.f[k], rk = R.r[k];
@@ -746,20 +754,14 @@ __device__ __forceinline__ void sweep_pipe(const SweepArgs& a, const GridScalars
                     const double rem = __builtin_fma(-d, q, wnext);
                     s.u = __builtin_fma(rem, rk, q);
                     s.fprev = fk;
-                    if (COUNT) {
-                        const int h = hi_word(s.u);
-                        if (k & 1) {
-                            asm("v_min3_i32 %0, %1, %2, %3" : "=v"(hmin) : "v"(hmin), "v"(hprev), "v"(h));
-                            asm("v_max3_i32 %0, %1, %2, %3" : "=v"(hmax) : "v"(hmax), "v"(hprev), "v"(h));
-                        } else hprev = h;
-                    }
+                    if (COUNT) sw = __builtin_amdgcn_alignbit(sw, (unsigned)hi_word(s.u), 31);   // (sw << 1) | sign bit
                     if (k < kRd) {
                         const int q0 = (4 * k) / 3, q1 = (4 * (k + 1)) / 3;
                         fetch(q0);
                         if (q1 - q0 == 2) fetch(q0 + 1);
                     }
-                    if (COUNT && (k & 1)) __builtin_amdgcn_sched_group_barrier(0x002, 10, 0);
-                    else                  __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
+                    if (COUNT) __builtin_amdgcn_sched_group_barrier(0x002, 9, 0);
+                    else       __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
                     if (k < kRd) {
                         if ((4 * (k + 1)) / 3 - (4 * k) / 3 == 2) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
                         else                                      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
@@ -790,7 +792,7 @@ __device__ __forceinline__ void sweep_pipe(const SweepArgs& a, const GridScalars
                             }
                             s.fprev = R.f[k];
                         }
-                        if (COUNT) { const int h = hi_word(s.u); hmin = min(hmin, h); hmax = max(hmax, h); }
+                        if (COUNT) { const int h = hi_word(s.u); hmin = min(hmin, h); hmax = max(hmax, h == kSignWord ? 0x7ff80000 : h); }
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -802,7 +804,8 @@ __device__ __forceinline__ void sweep_pipe(const SweepArgs& a, const GridScalars
                 ST[0] = s.w;
                 ST[64] = s.wprev;
                 ST[128] = s.u;
-                ST[192] = __builtin_bit_cast(double, ((long long)hmax << 32) | (unsigned)hmin);
+                ST[192] = straight ? __builtin_bit_cast(double, ((long long)kSignWord << 32) | sw)
+                                   : __builtin_bit_cast(double, ((long long)hmax << 32) | (unsigned)hmin);
             }
             if (have && fast) {
                 // the reciprocal path needs |w| in [2^-969, 2^767) -- outside, v_div_scale rescales the operands -- all the way
@@ -869,6 +872,8 @@ __device__ __forceinline__ void sweep_pipe(const SweepArgs& a, const GridScalars
                 const double ulast = ST[128];
                 const long long hmm = __builtin_bit_cast(long long, ST[192]);
                 const int hmin = (int)hmm, hmax = (int)(hmm >> 32);
+                const bool signs = (__builtin_amdgcn_readfirstlane(hmax) == kSignWord);   // wave-uniform, as the integrator's path is
+                const unsigned sw = (unsigned)hmin;
                 const double flast = F[(CH - 1) * 128];
                 const double2 mm = double2{read_lane(mmv.x, cc & 63), read_lane(mmv.y, cc & 63)};   // block nch - 1 - cc
                 if ((cc & 63) == 63) { mmv = mmv_next; mmv_next = mm_fetch(nch - 1 - (cc + 1) - 64); }
@@ -884,10 +889,43 @@ __device__ __forceinline__ void sweep_pipe(const SweepArgs& a, const GridScalars
                     // chunk: min > 0 -- every u positive; max < 0 -- every sign bit set.  (+0 and the denormals below
                     // 2^-1042 count as "cannot tell": the chunk is then examined point by point.)
                     const lanemask_t fin = __ballot(fabs(ulast) < INFINITY);
-                    const lanemask_t allpos = __ballot(hmin > 0), nonepos = __ballot(hmax < 0);
                     const lanemask_t le_all = __ballot(mm.y <= E), gt_all = __ballot(mm.x > E);
-                    const lanemask_t ok = fin & ((c.oldSgn & allpos) | (~c.oldSgn & nonepos)) & ((le_all & last_le) | (gt_all & ~last_le));
-                    quiet = (~ok & act) == 0ull;
+                    const lanemask_t v_ok = (le_all & last_le) | (gt_all & ~last_le);
+                    lanemask_t allpos, nonepos;
+                    if (signs) {
+                        // Sign bits of every point.  With veff on its side and everything finite, count_step only counts
+                        // crossings and moves oldSgn: x has a bit for every point whose sign differs from the point before
+                        // (the first one from oldSgn), so the chunk is settled here unless a lane runs out of budget -- then
+                        // the exit point is needed -- or ends on a zero.
+                        const unsigned mask = CH >= 32 ? 0xffffffffu : ((1u << (CH & 31)) - 1u);
+                        const unsigned prevbit = ((c.oldSgn >> lane) & 1ull) ? 0u : 1u;
+                        const unsigned x = (sw ^ ((sw >> 1) | (prevbit << (CH - 1)))) & mask;
+                        const int crosses = __popc(x);
+                        const bool lane_act = (act >> lane) & 1ull;
+                        const lanemask_t settled = fin & v_ok & __ballot(ulast != 0.0) & __ballot(budget - crosses > 0);
+                        if ((~settled & act) == 0ull) {
+                            quiet = true;
+                            if (lane_act) budget -= crosses;
+                            const lanemask_t lastpos = __ballot((sw & 1u) == 0u);
+                            c.oldSgn = (c.oldSgn & ~act) | (lastpos & act);
+                        }
+                        allpos = nonepos = 0;
+                    } else {
+                        allpos = __ballot(hmin > 0);
+                        nonepos = __ballot(hmax < 0);
+                        const lanemask_t ok = fin & ((c.oldSgn & allpos) | (~c.oldSgn & nonepos)) & v_ok;
+                        quiet = (~ok & act) == 0ull;
+                    }
+#ifdef DFTA_PIPE_PROF
+                    if (lane == 0) {
+                        const lanemask_t sgn_ok = fin & ((c.oldSgn & allpos) | (~c.oldSgn & nonepos));
+                        atomicAdd(&g_pipe_prof[10], 1ull);                                       // plain chunks examined
+                        if (!quiet) atomicAdd(&g_pipe_prof[(~v_ok & act) ? 12 : 11], 1ull);      // 11: sign / finiteness only, 12: veff side
+                        (void)sgn_ok;
+                    }
+                } else if (lane == 0) {
+                    atomicAdd(&g_pipe_prof[13], 1ull);                                           // joins, innermost chunk, poisoned
+#endif
                 }
                 if (quiet) {
                     if (diag) trips += CH * (int)((act >> lane) & 1ull);
