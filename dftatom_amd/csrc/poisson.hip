@@ -89,6 +89,12 @@ __device__ __forceinline__ int node_of(const Lvl& L, int idx)
 // Level storage of one atom.  The chunked levels live in global memory (L2-resident: 6.3 MB per atom at 17
 // levels); the sequential levels (n < 257, 261 nodes in total) live in LDS for the whole solve -- they are visited
 // 6 times per V-cycle by a single lane and would otherwise pay a global-memory round trip per node.
+constexpr unsigned long long kFastSentinel = 0x7FF8DEAD7FF8DEADull;
+constexpr int kXchg = 128;       // doubles per member and buffer of the boundary exchange (<= 96 halo nodes; the first node in the last one)
+// per atom: [6 G + 2] partial sums of the members and the published state, [3 G] slots of the fast sum, [3 G kXchg] boundary
+// nodes exchanged between neighbours in the middle of a staged visit
+__host__ __device__ constexpr size_t group_part_doubles(int G) { return (size_t)9 * G + 2 + (size_t)3 * G * kXchg; }
+
 struct Atom {
     double* phi0;     // two copies of every level (global)
     double* phi1;
@@ -103,6 +109,7 @@ struct Atom {
     double* part;           // [2][3][G] partial sums of the members (double-buffered by barrier parity) + [1] published `cur`
     double* fslot;          // [3][G] slots of the fast sum (group_sum_fast), sentinel-filled before the launch
     unsigned fseq;          // fast sums taken so far
+    double* xchg;           // [3][G][kXchg] boundary nodes of the fast exchange, sentinel-filled before the launch
     int pend;               // > 0: the prolongation from this level is folded into the staged copy-in of the level below it
     int pend_r;             // > 0: the restriction TO this level is folded into its staged copy-in
     int spin_max;           // polls of a group barrier before the waiting member gives up and raises the abort flag
@@ -182,53 +189,67 @@ __device__ unsigned long long g_prof[8 * 24];
 #define PROF_ADD(cat, lvl)
 #endif
 
-// Sum over the group for the sweeps in the middle of a staged visit, where the members exchange only a few values.
-// Everything exchanged (the boundary nodes before the call, the partial sums here) is written and read with agent-scope
-// atomic accesses, one release before the sum is published and one acquire after the last one has arrived order them, and
-// the barrier is implicit -- every
-// member publishes its partial sum into its slot of a buffer that holds a sentinel (a NaN with a payload no arithmetic
-// produces) and polls the others' slots until none holds the sentinel: one round trip instead of three (arrival counter,
-// poll, read of the sums).  Three buffers rotate: after the sum of sweep s is
-// complete everybody has finished reading sweep s-1's buffer (they have all published sweep s), so each member resets its
-// slot of that one; it is used again in sweep s+2, a whole sweep later.  Sums are added in member order, as in group_sum.
-constexpr unsigned long long kFastSentinel = 0x7FF8DEAD7FF8DEADull;
-__device__ __forceinline__ double group_sum_fast(Atom& A, double v, double* red)
+// Sum over the group for the sweeps in the middle of a staged visit, where the members exchange only a partial sum and the
+// <= 97 nodes next to their parts' boundaries.  Everything travels through agent-scope atomic stores into slots that hold a
+// sentinel (a NaN with a payload no arithmetic produces) and is polled with agent-scope atomic loads until the sentinel is
+// gone: coherent without cache maintenance, and every datum validates itself -- an agent-scope store can overtake an earlier
+// one on its way to another XCD (measured), so "the sum has arrived" says nothing about the nodes.  One round trip for
+// everything: while the first wave polls the G sums, the second and third poll the left neighbour's nodes straight into
+// the halo columns and the fourth the right neighbour's first node (round 1: arrival counter, poll, read of the sums, then
+// the nodes: three trips and two fences).  Three buffers rotate: when the sums of exchange s are complete everybody has
+// read what it needed of exchange s-1 (they have all published s), so each member resets its part of that buffer; it is
+// used again in exchange s+2, a whole sweep later.  Sums are added in member order, as in group_sum.
+__device__ __forceinline__ double exchange_poll(Atom& A, const double* p)
+{
+    int spins = A.gave_up ? A.spin_max : 0;
+    while (true) {
+        const double x = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (static_cast<unsigned long long>(__double_as_longlong(x)) != kFastSentinel) return x;
+        if (++spins > A.spin_max) {      // a lost member must not hang the GPU: raise the group's abort flag
+            __hip_atomic_fetch_or(A.ctr, 0x80000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            A.gave_up = true;
+            return 0.0;
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+// this member's node `idx` of the exchange that travels with the next fast sum
+__device__ __forceinline__ void exchange_store(Atom& A, int idx, double v)
+{
+    __hip_atomic_store(A.xchg + (static_cast<size_t>(A.fseq % 3u) * A.G + A.g) * kXchg + idx, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// PP: the staged part (element 0 = its first node); nhalo = Hc << logC nodes of the left neighbour go to the halo columns
+// (node idx: row idx & (C-1), column -Hc + (idx >> logC)), the right neighbour's first node to PP[C * RS]
+template <int RS>
+__device__ __forceinline__ double group_sum_fast(Atom& A, double v, double* red, double* PP, int logC, int Hc)
 {
     const double mine = block_sum(v, red);      // its barriers wait for every store of this member issued so far
     if (A.G == 1) return mine;
     const unsigned s = A.fseq++;
-    double* cur = A.fslot + (s % 3u) * A.G;
-    if (threadIdx.x < 64) {
-        if (threadIdx.x == 0) {
-            // the boundary nodes published before this call must be visible wherever this sum is (measured: without the
-            // release an agent-scope store can overtake earlier ones on its way to the other XCDs)
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            __hip_atomic_store(cur + A.g, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+    const int tid = threadIdx.x, C = 1 << logC;
+    if (tid < 64) {
+        double* cur = A.fslot + (s % 3u) * A.G;
+        if (tid == 0) __hip_atomic_store(cur + A.g, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         double x = 0;
-        if (static_cast<int>(threadIdx.x) < A.G) {
-            int spins = A.gave_up ? A.spin_max : 0;
-            while (true) {
-                x = __hip_atomic_load(cur + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (static_cast<unsigned long long>(__double_as_longlong(x)) != kFastSentinel) break;
-                if (++spins > A.spin_max) {      // a lost member must not hang the GPU: raise the group's abort flag
-                    __hip_atomic_fetch_or(A.ctr, 0x80000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    A.gave_up = true;
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(1);
-            }
-        }
+        if (tid < A.G) x = exchange_poll(A, cur + tid);
         double tot = 0;
         for (int m = 0; m < A.G; ++m) tot += __shfl(x, m);
-        if (threadIdx.x == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        if (tid == 0) {
             red[18] = tot;
             __hip_atomic_store(A.fslot + ((s + 2u) % 3u) * A.G + A.g, __longlong_as_double(static_cast<long long>(kFastSentinel)),
                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+    } else if (tid < 192) {
+        const int idx = tid - 64;
+        if (A.g > 0 && idx < (Hc << logC))
+            PP[(idx & (C - 1)) * RS + (idx >> logC) - Hc] = exchange_poll(A, A.xchg + (static_cast<size_t>(s % 3u) * A.G + A.g - 1) * kXchg + idx);
+    } else if (tid == 192) {
+        if (A.g < A.G - 1) PP[C * RS] = exchange_poll(A, A.xchg + (static_cast<size_t>(s % 3u) * A.G + A.g + 1) * kXchg + kXchg - 1);
     }
     __syncthreads();
+    if (tid < kXchg)
+        __hip_atomic_store(A.xchg + (static_cast<size_t>((s + 2u) % 3u) * A.G + A.g) * kXchg + tid,
+                           __longlong_as_double(static_cast<long long>(kFastSentinel)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return red[18];
 }
 
@@ -1081,28 +1102,22 @@ __device__ __forceinline__ double iterate_gs(const MgDesc& D, Atom& A, int l, do
             __syncthreads();
             if (last) { PROF_T0(); write_out(); PROF_ADD(6, l); }
             else {
-                // agent-scope atomic stores / loads: coherent without cache maintenance (group_sum_fast)
+                // into the sentinel-filled slots of the exchange that travels with the fast sum (group_sum_fast)
                 if (tid < (Hc << L.logC)) {                    // the last Hc lanes' nodes: what the next member's warm-up reads
                     const int k = tid & (C - 1), c = kThreads - Hc + (tid >> L.logC);
-                    __hip_atomic_store(&Gout[(k << logT) + col0 + c], PP[k * kStageRS + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    exchange_store(A, tid, PP[k * kStageRS + c]);
                 }
-                if (tid == 0)                                  // the first node: right neighbour of the previous member's last one
-                    __hip_atomic_store(&Gout[col0], PP[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (tid == 0) exchange_store(A, kXchg - 1, PP[0]);   // the first node: right neighbour of the previous member's last one
             }
-            { PROF_T0(); err = sqrt(last ? group_sum(A, err2, red) : group_sum_fast(A, err2, red)); PROF_ADD(3, l); }
+            { PROF_T0(); err = sqrt(last ? group_sum(A, err2, red) : group_sum_fast<kStageRS>(A, err2, red, PP, L.logC, Hc)); PROF_ADD(3, l); }
             if (last) break;
             if (err < errorMin) {                              // the reference stops here: publish everything, meet once more
                 write_out();
                 group_sync(A);
                 break;
             }
-            if (g > 0 && tid < (Hc << L.logC)) {
-                const int k = tid & (C - 1), c = -Hc + (tid >> L.logC);
-                PP[k * kStageRS + c] = __hip_atomic_load(&Gout[(k << logT) + col0 + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            if (g < A.G - 1 && tid == 0) PP[C * kStageRS] = __hip_atomic_load(&Gout[end_g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // (the neighbours' nodes arrived with the sum: halo columns and PP[C * kStageRS] are up to date)
             { double* t = Gin; Gin = Gout; Gout = t; }
-            __syncthreads();
         }
         if (done & 1) A.cur ^= (1u << l);
         return err;
@@ -1614,8 +1629,9 @@ __global__ __launch_bounds__(kThreads) void k_poisson_solve(const MgDesc* __rest
     A.g = blockIdx.x & (D.G - 1);
     A.ctr = group_ctr + a;
     A.bar = 0;
-    A.part = group_part + (size_t)a * (9 * D.G + 2);
+    A.part = group_part + (size_t)a * group_part_doubles(D.G);
     A.fslot = A.part + 6 * D.G + 2;
+    A.xchg = A.part + 9 * D.G + 2;
     A.fseq = 0;
     A.pend = 0;
     A.pend_r = 0;
@@ -1667,6 +1683,7 @@ __global__ __launch_bounds__(kThreads) void k_unit(const MgDesc* __restrict__ Dp
     A.bar = 0;
     A.part = group_part;
     A.fslot = A.part + 6 * D.G + 2;
+    A.xchg = A.part + 9 * D.G + 2;
     A.fseq = 0;
     A.pend = 0;
     A.pend_r = 0;
@@ -1776,7 +1793,7 @@ int dfta_poisson_solve_launch(dfta_poisson* p, const int* dZ, const double* dDen
     dfta_ctx* ctx = p->ctx;
     if (p->degraded) return dfta_poisson_solve_launch(p->fallback, dZ, dDensity, dU, dVcycles, dErr, dSkip);
     DFTA_HIP(ctx, hipMemsetAsync(p->d_group_ctr, 0, sizeof(unsigned) * p->batch, ctx->stream));
-    DFTA_HIP(ctx, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(p->d_group_part), 0x7FF8DEAD, (size_t)p->batch * (9 * p->D.G + 2) * 2, ctx->stream));   // group_sum_fast's sentinel
+    DFTA_HIP(ctx, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(p->d_group_part), 0x7FF8DEAD, (size_t)p->batch * group_part_doubles(p->D.G) * 2, ctx->stream));   // group_sum_fast's sentinel
     if (p->D.G == 1) {
         hipLaunchKernelGGL(k_poisson_solve, dim3(p->batch), dim3(kThreads), 0, ctx->stream, p->d_desc, p->d_phi0, p->d_phi1, p->d_src, dZ,
                            dDensity, p->g->d_rsrc, p->g->d_psrc, dU, dVcycles, dErr, p->d_total_vcycles, p->d_group_ctr, p->d_group_part,
@@ -1967,7 +1984,7 @@ static int poisson_create_impl(dfta_ctx* ctx, const dfta_grid* g, int batch, int
     if (e == hipSuccess) e = hipMemcpyAsync(p->d_desc, &p->D, sizeof(MgDesc), hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->d_total_vcycles), sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->d_group_ctr), sizeof(unsigned) * batch);
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->d_group_part), sizeof(double) * (size_t)batch * (9 * D.G + 2));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->d_group_part), sizeof(double) * (size_t)batch * group_part_doubles(D.G));
     if (e == hipSuccess) e = hipMemsetAsync(p->d_phi0, 0, tot * sizeof(double), ctx->stream);
     if (e == hipSuccess) e = hipMemsetAsync(p->d_phi1, 0, tot * sizeof(double), ctx->stream);
     if (e == hipSuccess) e = hipMemsetAsync(p->d_src, 0, tot * sizeof(double), ctx->stream);
@@ -2134,7 +2151,7 @@ static int unit_op(dfta_poisson* p, int op, int lvl, int sweeps, double* out_hos
     DFTA_HIP(ctx, dOut.alloc(std::max(nout, 1)));
     DFTA_HIP(ctx, hipMemcpyAsync(p->d_cur, p->h_cur.data(), sizeof(int) * kMaxLevels, hipMemcpyHostToDevice, st));
     DFTA_HIP(ctx, hipMemsetAsync(p->d_group_ctr, 0, sizeof(unsigned), st));
-    DFTA_HIP(ctx, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(p->d_group_part), 0x7FF8DEAD, (size_t)(9 * p->D.G + 2) * 2, st));
+    DFTA_HIP(ctx, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(p->d_group_part), 0x7FF8DEAD, (size_t)group_part_doubles(p->D.G) * 2, st));
     if (int rc = launch_unit(p, op, lvl, sweeps, dOut.p)) return rc;
     DFTA_HIP(ctx, hipMemcpyAsync(p->h_cur.data(), p->d_cur, sizeof(int) * kMaxLevels, hipMemcpyDeviceToHost, st));
     if (out_host && nout > 0) DFTA_HIP(ctx, hipMemcpyAsync(out_host, dOut.p, sizeof(double) * nout, hipMemcpyDeviceToHost, st));
@@ -2160,7 +2177,7 @@ int dfta_poisson_iterate_gs(dfta_poisson* p, int lvl, double errorMin, int itern
     DFTA_HIP(ctx, hipMemcpyAsync(dOut.p, &errorMin, sizeof(double), hipMemcpyHostToDevice, st));
     DFTA_HIP(ctx, hipMemcpyAsync(p->d_cur, p->h_cur.data(), sizeof(int) * kMaxLevels, hipMemcpyHostToDevice, st));
     DFTA_HIP(ctx, hipMemsetAsync(p->d_group_ctr, 0, sizeof(unsigned), st));
-    DFTA_HIP(ctx, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(p->d_group_part), 0x7FF8DEAD, (size_t)(9 * p->D.G + 2) * 2, st));
+    DFTA_HIP(ctx, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(p->d_group_part), 0x7FF8DEAD, (size_t)group_part_doubles(p->D.G) * 2, st));
     if (int rc = launch_unit(p, 4, lvl, iterno, dOut.p)) return rc;
     double out[2] = {0, 0};
     DFTA_HIP(ctx, hipMemcpyAsync(p->h_cur.data(), p->d_cur, sizeof(int) * kMaxLevels, hipMemcpyDeviceToHost, st));
@@ -2186,7 +2203,7 @@ int dfta_poisson_full_cycle(dfta_poisson* p, double lowBoundary, double highBoun
     std::fill(p->h_cur.begin(), p->h_cur.end(), 0);       // Initialize starts from copy 0 of every level
     DFTA_HIP(ctx, hipMemcpyAsync(p->d_cur, p->h_cur.data(), sizeof(int) * kMaxLevels, hipMemcpyHostToDevice, st));
     DFTA_HIP(ctx, hipMemsetAsync(p->d_group_ctr, 0, sizeof(unsigned), st));
-    DFTA_HIP(ctx, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(p->d_group_part), 0x7FF8DEAD, (size_t)(9 * p->D.G + 2) * 2, st));
+    DFTA_HIP(ctx, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(p->d_group_part), 0x7FF8DEAD, (size_t)group_part_doubles(p->D.G) * 2, st));
     if (int rc = launch_unit(p, 5, 0, 0, dOut.p)) return rc;
     DFTA_HIP(ctx, hipMemcpyAsync(p->h_cur.data(), p->d_cur, sizeof(int) * kMaxLevels, hipMemcpyDeviceToHost, st));
     DFTA_HIP(ctx, hipMemcpyAsync(io, dOut.p, sizeof(double) * 2, hipMemcpyDeviceToHost, st));
