@@ -263,15 +263,20 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (there is no CPU fallback for the product path)")
-    torch.cuda.set_device(local_rank)
+    # DFTA_BENCH_SHARED_GPU=1 (testing the N > 1 control flow on a one-GPU box): every rank uses device 0 and the
+    # collectives run over gloo on host tensors; never a measurement
+    shared = world > 1 and os.environ.get("DFTA_BENCH_SHARED_GPU") == "1"
+    dev_index = 0 if shared else local_rank
+    cdev = "cpu" if shared else "cuda"
+    torch.cuda.set_device(dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+        dist.init_process_group(backend="gloo" if shared else "nccl", rank=rank, world_size=world)
 
     import dftatom_amd as D
     delta, rmax = GRIDS.get(args.levels, (1e-4, 50.0))
     stream = torch.cuda.current_stream().cuda_stream
-    ctx = D.Context(local_rank, stream)
+    ctx = D.Context(dev_index, stream)
     grid = D.Grid(ctx, args.levels, delta, rmax)
     records = torch.zeros((args.atoms, D.RECORD_DOUBLES), dtype=torch.float64, device="cuda")
 
@@ -284,17 +289,18 @@ def main():
     def gather(scf):
         scf.records_into(records.data_ptr())
         if world > 1:
-            gathered = [torch.empty_like(records) for _ in range(world)]
-            dist.all_gather(gathered, records)
+            mine = records.to(cdev)
+            gathered = [torch.empty_like(mine) for _ in range(world)]
+            dist.all_gather(gathered, mine)
 
     scf, tot = run_workload(D, ctx, grid, args.levels, args.atoms, args.lsda, args.steps, args.warmup, args.tree_depth, barrier, torch, gather)
     elapsed = tot["elapsed"]
     # max over ranks of the elapsed time, sums of the work
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        w = torch.tensor([tot["sweeps_reference"], tot["sweeps_issued"], tot["vcycles"], tot["sweeps_reference_executed"]], dtype=torch.float64, device="cuda")
+        w = torch.tensor([tot["sweeps_reference"], tot["sweeps_issued"], tot["vcycles"], tot["sweeps_reference_executed"]], dtype=torch.float64, device=cdev)
         dist.all_reduce(w, op=dist.ReduceOp.SUM)
         ref_all, issued_all, vc_all, exe_all = (float(x) for x in w.tolist())
     else:
@@ -358,8 +364,10 @@ def main():
                 s2.close()
                 extra[name] = summarize(t2, args.levels, grid.N, atoms, lsda, world, delta, rmax)
             out["extra"] = extra
-        if not args.no_cpu:
+        if world == 1 and not args.no_cpu:      # rank 0 at N = 1 only: the other ranks of a larger job would sit at the final barrier
             out["cpu_baseline"] = cpu_baseline(args.levels, args.lsda, args.cpu_steps)
+        if shared:
+            out["data"] += " -- SHARED-GPU TEST MODE (all ranks on device 0, gloo): not a measurement"
         print(json.dumps(out))
     grid.close()
     ctx.close()

@@ -83,3 +83,28 @@ def test_headless_front_end_reproduces_readme_argon():
     assert all(abs(a - b) <= 1.5e-6 for a, b in zip(vals, want)), (vals, want)
     nsteps = sum(1 for ln in lines if ln.startswith("Step:"))
     assert 25 <= nsteps <= 60          # the stop step itself is round-off noise (README: 32, compiled reference here: 35)
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_control_flow():
+    """bench.py under torch.distributed.run with two ranks, as the driver launches it for N > 1 -- on this one-GPU box both
+    ranks share device 0 and the collectives run over gloo (DFTA_BENCH_SHARED_GPU=1): the barriers, the max-over-ranks time,
+    the summed work and rank 0's single JSON line are exercised, the number itself means nothing."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, DFTA_BENCH_SHARED_GPU="1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                         env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["config"]["parallelism"] == "replicas x2" and "cpu_baseline" not in d and "roofline" in d
