@@ -38,7 +38,13 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    # DFTA_BENCH_SHARED_GPU=1 (tests on a one-GPU box): every rank on device 0, records gathered over gloo from host memory
+    shared = world > 1 and os.environ.get("DFTA_BENCH_SHARED_GPU") == "1"
+    if shared:
+        local = 0
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+    elif world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     torch.cuda.set_device(local)
     ctx = D.Context(local, torch.cuda.current_stream().cuda_stream)
@@ -59,7 +65,8 @@ def main():
             break
     block = torch.zeros((cap, D.RECORD_DOUBLES), dtype=torch.float64, device="cuda")
     scf.records_into(block.data_ptr())          # rows beyond len(mine) stay zero (Z = 0: no atom)
-    table = sweep.gather_records(block, dist if world > 1 else None)
+    ctx.synchronize()
+    table = sweep.gather_records(block.cpu() if shared else block, dist if world > 1 else None)
     elapsed = time.time() - t0
     if rank == 0:
         rows = [sweep.record_fields(table[z]) for z in sorted(table)]

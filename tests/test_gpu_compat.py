@@ -108,3 +108,31 @@ def test_bench_two_ranks_control_flow():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["value"] > 0
     assert d["config"]["parallelism"] == "replicas x2" and "cpu_baseline" not in d and "roofline" in d
+
+
+@pytest.mark.gpu
+def test_periodic_table_two_ranks_equal_one_rank(tmp_path):
+    """examples/periodic_table.py (BASELINE config 4) for Z = 1..8 at 16385 nodes: two ranks (sharing device 0 on this box,
+    records gathered over gloo) must return, atom for atom, the bits of the single-process run -- shards do not interact."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = os.path.join(root, "examples", "periodic_table.py")
+    one, two = str(tmp_path / "one.json"), str(tmp_path / "two.json")
+    common = ["--zmin", "1", "--zmax", "8", "--levels", "14"]
+    r1 = subprocess.run([sys.executable, script, *common, "--out", one], capture_output=True, text=True, timeout=600, cwd=root)
+    assert r1.returncode == 0, r1.stderr[-2000:]
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, DFTA_BENCH_SHARED_GPU="1")
+    r2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                         "--master-port", str(port), script, *common, "--out", two], env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert r2.returncode == 0, r2.stderr[-2000:]
+    a, b = json.load(open(one)), json.load(open(two))
+    assert b["n_gpus"] == 2 and len(a["atoms"]) == len(b["atoms"]) == 8
+    for x, y in zip(a["atoms"], b["atoms"]):
+        assert x == y, (x, y)
+    assert all(x["finished"] for x in a["atoms"])
