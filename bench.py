@@ -48,7 +48,7 @@ POISSON_BYTES_PER_VCYCLE = {14: 6162448, 17: 49285736, 20: 394267840}   # SURVEY
 # fp64 VALU issue: one wave64 instruction per SIMD every 1.86 ns (profiles/microbench/issue_rate.hip), 256 CUs x 4 SIMDs
 VALU_WAVE_INSTR_PER_S = 256 * 4 / 1.86e-9
 # wave-level VALU instructions per grid point of one 64-trial block in k_sweep_pipe (numerov.hip): producers 15 (f: 4, d: 2,
-# reciprocal: 5, lane broadcasts: 4), integrator 8, counter ~1
+# reciprocal: 5, lane broadcasts: 4), integrator 8 (+1 for the sign word of a COUNT sweep), counter < 1
 SWEEP_VALU_PER_BLOCK_POINT = 24
 GRIDS = {14: (5e-4, 25.0), 17: (1e-4, 50.0), 20: (1.25e-5, 50.0)}
 

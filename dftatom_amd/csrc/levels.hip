@@ -757,12 +757,12 @@ __global__ void k_accumulate_density(const double* __restrict__ Psi, const dfta:
 }
 
 // min_i Veff_l(i), i = 1..N-1, of every table slot (one block per slot; NaN entries are ignored)
-__global__ __launch_bounds__(256) void k_slot_min(const double2* __restrict__ tab, int N, double* __restrict__ slot_min)
+__global__ __launch_bounds__(1024) void k_slot_min(const double2* __restrict__ tab, int N, double* __restrict__ slot_min)
 {
-    __shared__ double red[4];
+    __shared__ double red[16];
     const double2* T = tab + (size_t)blockIdx.x * N;
     double m = INFINITY;
-    for (int i = 1 + threadIdx.x; i < N; i += 256) {
+    for (int i = 1 + threadIdx.x; i < N; i += 1024) {
         const double v = T[i].x;
         if (v < m) m = v;
     }
@@ -772,7 +772,11 @@ __global__ __launch_bounds__(256) void k_slot_min(const double2* __restrict__ ta
     }
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
     __syncthreads();
-    if (threadIdx.x == 0) slot_min[blockIdx.x] = fmin(fmin(red[0], red[1]), fmin(red[2], red[3]));
+    if (threadIdx.x == 0) {
+        double r = red[0];
+        for (int w = 1; w < 16; ++w) r = fmin(r, red[w]);
+        slot_min[blockIdx.x] = r;
+    }
 }
 
 // BATCHED: every level starts un-chained from max(-Z^2-1, min Veff_l): no eigenvalue lies below the minimum of
@@ -1020,7 +1024,7 @@ int LevelSolver::run(const double* dV, const double* job_bottom, int run_mode, d
     int rc = dfta_launch_build_tab(ctx, g, d_tab, dV, d_slot_v, d_slot_l, nslots, d_bounds);
     if (rc) return rc;
     if (!chained && clamp_bottoms) {
-        hipLaunchKernelGGL(k_slot_min, dim3(nslots), dim3(256), 0, st, d_tab, N, d_slot_min);
+        hipLaunchKernelGGL(k_slot_min, dim3(nslots), dim3(1024), 0, st, d_tab, N, d_slot_min);
         DFTA_CHECK_LAUNCH(ctx);
         hipLaunchKernelGGL(k_clamp_bottoms, dim3((njobs + 63) / 64), dim3(64), 0, st, d_jobs, njobs, d_slot_min);
         DFTA_CHECK_LAUNCH(ctx);

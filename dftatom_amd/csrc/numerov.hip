@@ -1032,13 +1032,15 @@ __global__ __launch_bounds__(kPipeThreads) void k_sweep_pipe(SweepArgs a, GridSc
 // per slot: { max_i |veff_i| R2 e2_i, max_i R2 e2_i } over i = kBoundFrom .. N-1 (NaN poisons the bound -> slow division).
 // The innermost points are excluded: there f ~ l(l+1)/i^2 (f_1 = 12 for l = 3, i.e. 1 - f/12 = 0), and they are always
 // integrated by the tail loop with the plain IEEE division.
-__global__ __launch_bounds__(256) void k_slot_bounds(const double2* __restrict__ tab, int N, double R2, double2* __restrict__ bounds, int bstride)
+constexpr int kBoundsThreads = 1024;   // one block per slot: the loop is a chain of memory round trips, so as many loads in flight as a block can hold
+__global__ __launch_bounds__(kBoundsThreads) void k_slot_bounds(const double2* __restrict__ tab, int N, double R2, double2* __restrict__ bounds, int bstride)
 {
-    __shared__ double red[12];
+    constexpr int kW = kBoundsThreads / 64;
+    __shared__ double red[3 * kW];
     const double2* T = tab + (size_t)blockIdx.x * N;
     double m0 = 0, m1 = 0, t0 = 0;
     bool bad = false;
-    for (int i = kBoundFrom + threadIdx.x; i < N; i += 256) {
+    for (int i = kBoundFrom + threadIdx.x; i < N; i += kBoundsThreads) {
         const double2 t = T[i];
         const double w = R2 * t.y;
         const double v = fabs(t.x) * w;
@@ -1054,17 +1056,13 @@ __global__ __launch_bounds__(256) void k_slot_bounds(const double2* __restrict__
         m1 = o1 > m1 ? o1 : m1;
         t0 = o2 > t0 ? o2 : t0;
     }
-    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = m0; red[4 + (threadIdx.x >> 6)] = m1; red[8 + (threadIdx.x >> 6)] = t0; }
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = m0; red[kW + (threadIdx.x >> 6)] = m1; red[2 * kW + (threadIdx.x >> 6)] = t0; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        double2 o;
-        o.x = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
-        o.y = fmax(fmax(red[4], red[5]), fmax(red[6], red[7]));
-        bounds[(size_t)blockIdx.x * bstride] = o;
-        double2 tb;                                                 // series reciprocal: max |veff| R2 e2 over i >= kTinyFrom
-        tb.x = fmax(fmax(red[8], red[9]), fmax(red[10], red[11]));
-        tb.y = o.y;
-        bounds[(size_t)blockIdx.x * bstride + bstride - 1] = tb;
+        double a = red[0], b = red[kW], c = red[2 * kW];
+        for (int w = 1; w < kW; ++w) { a = fmax(a, red[w]); b = fmax(b, red[kW + w]); c = fmax(c, red[2 * kW + w]); }
+        bounds[(size_t)blockIdx.x * bstride] = double2{a, b};
+        bounds[(size_t)blockIdx.x * bstride + bstride - 1] = double2{c, b};   // series reciprocal: max |veff| R2 e2 over i >= kTinyFrom
     }
 }
 
@@ -1598,7 +1596,7 @@ int dfta_launch_build_tab(dfta_ctx* ctx, const dfta_grid* g, double2* tab, const
     DFTA_CHECK_LAUNCH(ctx);
     if (bounds && !g->uniform) {
         const int bstride = dfta_bounds_stride(g);
-        hipLaunchKernelGGL(k_slot_bounds, dim3(nslots), dim3(256), 0, ctx->stream, tab, g->N, 2. * g->Rp2delta2, bounds, bstride);
+        hipLaunchKernelGGL(k_slot_bounds, dim3(nslots), dim3(kBoundsThreads), 0, ctx->stream, tab, g->N, 2. * g->Rp2delta2, bounds, bstride);
         hipLaunchKernelGGL(k_block_minmax, dim3((bstride + 254) / 256, nslots), dim3(256), 0, ctx->stream, tab, g->N, bounds, bstride);
         DFTA_CHECK_LAUNCH(ctx);
     }
