@@ -506,14 +506,17 @@ __global__ __launch_bounds__(256) void k_sweep(SweepArgs a, GridScalars gs, int 
 // 80-90 ns per point and trial block when the machine is not full -- the situation of a single atom (a few hundred
 // blocks on 1024 SIMDs).  Only 5 of those instructions form the loop-carried chain u -> u f -> w -> q -> rem -> u.
 // Here the work of a block is spread over the four SIMDs of a compute unit (wave w runs on SIMD w mod 4):
-//     waves 0,1,3  producers   f_i and the refined reciprocal r_i of d_i = 1 - f_i/12, 4/6/6 points of a chunk  -> LDS
-//     wave  2      integrator  the loop-carried recurrence (8 VALU instructions per point, d_i recomputed)  -> u_i to LDS
-//     wave  4      counter     CountNodes' bookkeeping on u_i: whole chunks are skipped when nothing can change,
-//                              else lane masks in scalar registers point by point; shares SIMD 0 with a producer
+//     waves 0,1,3  producers   f_i and the refined reciprocal r_i of d_i = 1 - f_i/12, 1/4 + 3/8 + 3/8 of a chunk  -> LDS
+//     wave  2      integrator  the loop-carried recurrence (8 VALU instructions per point, d_i recomputed); per chunk
+//                              it leaves w, wprev, u after the last point and the sign bits of u  -> LDS
+//     wave  4      counter     CountNodes' bookkeeping: a chunk in which veff stays on its side of E is settled from the
+//                              sign bits (crossings = sign changes); otherwise the counter integrates the chunk again
+//                              itself and replays it point by point with lane masks in scalar registers; shares
+//                              SIMD 0 with a producer
 // The stages are chunks of CH grid points apart (software pipeline, one s_barrier per chunk): at iteration `it` the
-// producers write chunk it, the integrator loads chunk it-1 into registers while it integrates chunk it-2, the
-// counter examines chunk it-3.  Every floating-point operation is the one the fused kernel executes, in the same
-// order, so results are bit-identical.
+// producers write chunk it, the integrator integrates chunk it-2 (reading the rest of it and the beginning of chunk
+// it-1 into a rolling register window), the counter examines chunk it-3.  Every floating-point operation is the one the
+// fused kernel executes, in the same order, so results are bit-identical.
 typedef double v2d __attribute__((ext_vector_type(2)));
 
 template <int CH>
@@ -848,8 +851,7 @@ __device__ __forceinline__ void sweep_pipe(const SweepArgs& a, const GridScalars
         const bool diag = (a.trip != nullptr);
         int trips = 0;
         unsigned long long wave_trips = 0;
-        // { min, max } of veff per block, fetched one chunk ahead (vector load with a zero lane offset: a scalar load
-        // would be drained by the lgkmcnt(0) of every barrier)
+        // { min, max } of veff per aligned block of CH points (k_block_minmax)
         const double2* __restrict__ blkmm =
             a.bounds ? a.bounds + (size_t)slot * a.bstride + 1 : nullptr;
         // 64 consecutive entries at a time, one per lane (block bhi - lane), the next 64 already on their way; the entry of
