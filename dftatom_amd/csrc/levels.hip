@@ -712,10 +712,11 @@ __global__ __launch_bounds__(64) void k_allot(dfta::Job* __restrict__ jobs, int 
 }
 
 // ---- normalise (DFTAtom.cpp:36-56) ------------------------------------------------------------------------------
-// one 256-thread block per job; wave 0 performs the Simpson 3/8 sum in the reference's order
-__global__ __launch_bounds__(256) void k_normalize(double* __restrict__ Psi, double* __restrict__ G, int N,
-                                                   const double* __restrict__ eh, const double* __restrict__ cnst,
-                                                   const int* __restrict__ jstart, double step, int rule)
+// one block per job; the first two waves perform the Simpson 3/8 sum in the reference's order (the other rules: the first wave)
+constexpr int kNormThreads = 1024;     // the two pointwise passes are chains of memory round trips of a single block
+__global__ __launch_bounds__(kNormThreads) void k_normalize(double* __restrict__ Psi, double* __restrict__ G, int N,
+                                                            const double* __restrict__ eh, const double* __restrict__ cnst,
+                                                            const int* __restrict__ jstart, double step, int rule)
 {
     __shared__ __attribute__((aligned(16))) double lds[dfta::kTile];
     __shared__ double rtab[64];
@@ -723,7 +724,7 @@ __global__ __launch_bounds__(256) void k_normalize(double* __restrict__ Psi, dou
     if (jstart && jstart[blockIdx.x] < 0) return;     // frozen job: its normalised Psi stands
     double* P = Psi + (size_t)blockIdx.x * N;
     double* g = G + (size_t)blockIdx.x * N;
-    for (int i = threadIdx.x; i < N; i += 256) {
+    for (int i = threadIdx.x; i < N; i += kNormThreads) {
         const double p = P[i] * eh[i];            // Psi[i] *= exp(i * deltaGrid * 0.5)
         P[i] = p;
         double r2 = p * p;
@@ -731,13 +732,17 @@ __global__ __launch_bounds__(256) void k_normalize(double* __restrict__ Psi, dou
         g[i] = r2;
     }
     __syncthreads();
-    if (threadIdx.x < 64) {
-        const double integral = dfta::wave_integrate(rule, g, N, step, lds, rtab);   // Simpson38(1, .) on the logarithmic grid, Simpson38(h, .) on the uniform one (DFTAtom.cpp:27,51)
+    // Simpson38(1, .) on the logarithmic grid, Simpson38(h, .) on the uniform one (DFTAtom.cpp:27,51)
+    if (rule == DFTA_INT_SIMPSON38) {
+        const double integral = dfta::block_simpson38(g, N, step, lds, rtab);
+        if (threadIdx.x == 0) s_unorm = 1. / sqrt(integral);
+    } else if (threadIdx.x < 64) {
+        const double integral = dfta::wave_integrate(rule, g, N, step, lds, rtab);
         if (threadIdx.x == 0) s_unorm = 1. / sqrt(integral);
     }
     __syncthreads();
     const double unorm = s_unorm;
-    for (int i = threadIdx.x; i < N; i += 256) P[i] *= unorm;
+    for (int i = threadIdx.x; i < N; i += kNormThreads) P[i] *= unorm;
 }
 
 // newDensity[v][i] += occ * Psi[i] * Psi[i] for i < N-1, levels of a potential in their order (DFTAtom.cpp:558-559)
@@ -1106,7 +1111,7 @@ int LevelSolver::run(const double* dV, const double* job_bottom, int run_mode, d
     if (rc) return rc;
     hipLaunchKernelGGL(k_store_match, dim3((njobs + 63) / 64), dim3(64), 0, st, d_jobs, njobs, d_jmp, d_jstart);
     DFTA_CHECK_LAUNCH(ctx);
-    hipLaunchKernelGGL(k_normalize, dim3(njobs), dim3(256), 0, st, d_Psi, d_Q, N, g->d_eh, g->d_cnst, nfrozen ? d_jstart : nullptr, g->uniform ? g->h : 1.0, integ_rule);
+    hipLaunchKernelGGL(k_normalize, dim3(njobs), dim3(kNormThreads), 0, st, d_Psi, d_Q, N, g->d_eh, g->d_cnst, nfrozen ? d_jstart : nullptr, g->uniform ? g->h : 1.0, integ_rule);
     DFTA_CHECK_LAUNCH(ctx);
     if (dNewDensity) {
         hipLaunchKernelGGL(k_accumulate_density, dim3(std::min(256, (N + 255) / 256), nV), dim3(256), 0, st, d_Psi, d_jobs, d_v_off,

@@ -89,6 +89,67 @@ __device__ __forceinline__ double wave_simpson38(const double* __restrict__ v, i
     return sum * delta * coef;
 }
 
+// Integral::Simpson38 by TWO waves: its two running sums (sum1 over i % 3 != 0, sum2 over i % 3 == 0) are independent chains,
+// each in the reference's order.  Threads 0..127 of the block fetch a tile and store it de-interleaved -- sum1's elements in
+// lds[0..511], sum2's in lds[512..767] -- then wave 0 adds up the first region while wave 1 adds up the second: the longer chain
+// has 2/3 of the elements of the single-wave version.  EVERY thread of the block must call (block-wide barriers); all return
+// the same value.  lds: kTile doubles, xch: 2 doubles.
+__device__ __forceinline__ double block_simpson38(const double* __restrict__ v, int sz, double delta, double* lds, double* xch)
+{
+    typedef double v2 __attribute__((ext_vector_type(2)));
+    const int tid = threadIdx.x, wave = tid >> 6;
+    const long count = static_cast<long>(sz) - 2;       // elements j = 0 .. count-1 are the nodes i = j + 1
+    constexpr int kPer = kTile / 128;
+    double nxt[kPer];
+    auto fetch = [&](long base) {
+#pragma unroll
+        for (int k = 0; k < kPer; ++k) {
+            const long j = base + k * 128 + tid;
+            nxt[k] = (tid < 128 && j < count) ? v[1 + j] : 0.0;
+        }
+    };
+    // one chain: n elements of a region, added in order; reads as 16-byte broadcasts, 32 elements in flight ahead of the adds
+    auto chain = [&](const double* region, int n, double acc) -> double {
+        constexpr int kBlk = 32;
+        int j = 0;
+        for (; j + kBlk <= n; j += kBlk) {
+            v2 x[kBlk / 2];
+            const v2* __restrict__ src = reinterpret_cast<const v2*>(region + j);
+#pragma unroll
+            for (int q = 0; q < kBlk / 2; ++q) x[q] = src[q];
+#pragma unroll
+            for (int q = 0; q < kBlk / 2; ++q) { acc += x[q].x; acc += x[q].y; }
+        }
+        for (; j < n; ++j) acc += region[j];
+        return acc;
+    };
+    double acc = 0;
+    fetch(0);
+    for (long base = 0; base < count; base += kTile) {
+        const int nt = (count - base) < kTile ? static_cast<int>(count - base) : kTile;
+        if (tid < 128) {
+#pragma unroll
+            for (int k = 0; k < kPer; ++k) {
+                const int j = k * 128 + tid, t = j / 3, r = j - 3 * t;       // base is a multiple of 3: the pattern restarts per tile
+                lds[r < 2 ? 2 * t + r : 512 + t] = nxt[k];
+            }
+        }
+        if (base + kTile < count) fetch(base + kTile);
+        __syncthreads();
+        const int triples = nt / 3, rest = nt - 3 * triples;
+        if (wave == 0)      acc = chain(lds, 2 * triples + (rest < 2 ? rest : 2), acc);
+        else if (wave == 1) acc = chain(lds + 512, triples, acc);
+        __syncthreads();
+    }
+    if (tid == 0) xch[0] = acc;
+    if (tid == 64) xch[1] = acc;
+    __syncthreads();
+    double sum = v[0] + v[sz - 1];
+    sum += 3. * xch[0] + 2. * xch[1];
+    constexpr double coef = 3. / 8.;
+    return sum * delta * coef;
+}
+
 // Integral::Romberg(delta, values, 1E-18, 3) (Integral.h:106-155): the trapezoid refinement of level i adds
 // values[n], values[n + oldStep], ... (n = numPoints >> i, oldStep = numPoints >> (i-1)) in that order; the extrapolation
 // table is filled exactly as the reference does.  rtab: 2 * 32 doubles of LDS private to the wave.  All 64 lanes call

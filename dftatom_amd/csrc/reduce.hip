@@ -8,14 +8,17 @@
 
 namespace {
 
-// one wave per vector: out[k] = Integral::<rule>(delta, vals + k * stride)
-__global__ __launch_bounds__(64) void k_integrate(const double* __restrict__ vals, int n, size_t stride, int rule, double delta,
-                                                  double* __restrict__ out)
+// one block of two waves per vector: out[k] = Integral::<rule>(delta, vals + k * stride); Simpson 3/8 -- the live rule -- on both
+// waves (its two sums are independent chains), the other rules on the first
+__global__ __launch_bounds__(128) void k_integrate(const double* __restrict__ vals, int n, size_t stride, int rule, double delta,
+                                                   double* __restrict__ out)
 {
     __shared__ __attribute__((aligned(16))) double lds[dfta::kTile];
     __shared__ double rtab[64];
     const double* v = vals + (size_t)blockIdx.x * stride;
-    const double r = dfta::wave_integrate(rule, v, n, delta, lds, rtab);
+    double r = 0;
+    if (rule == DFTA_INT_SIMPSON38) r = dfta::block_simpson38(v, n, delta, lds, rtab);
+    else if (threadIdx.x < 64)      r = dfta::wave_integrate(rule, v, n, delta, lds, rtab);
     if (threadIdx.x == 0) out[blockIdx.x] = r;
 }
 
@@ -23,7 +26,7 @@ __global__ __launch_bounds__(64) void k_integrate(const double* __restrict__ val
 
 int dfta_launch_integrate_ordered(dfta_ctx* ctx, int rule, double delta, const double* dVals, int n, int nvec, size_t stride, double* dOut)
 {
-    hipLaunchKernelGGL(k_integrate, dim3(nvec), dim3(64), 0, ctx->stream, dVals, n, stride, rule, delta, dOut);
+    hipLaunchKernelGGL(k_integrate, dim3(nvec), dim3(128), 0, ctx->stream, dVals, n, stride, rule, delta, dOut);
     DFTA_CHECK_LAUNCH(ctx);
     return DFTA_OK;
 }
