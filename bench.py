@@ -251,7 +251,7 @@ def main():
     ap.add_argument("--lsda", action="store_true")
     ap.add_argument("--tree-depth", type=int, default=0)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
-    ap.add_argument("--no-extras", action="store_true", help="skip the 256-atom batch and the LSDA workloads")
+    ap.add_argument("--no-extras", action="store_true", help="skip the extra workloads (256-atom batch, LSDA, 1 048 577 nodes)")
     ap.add_argument("--cpu-steps", type=int, default=3)
     args = ap.parse_args()
 
@@ -358,11 +358,21 @@ def main():
             "kernels": {"sweep": sweep, "poisson": pois},
         }
         if world == 1 and not args.no_extras:
+            # further measured workloads with the same per-kernel figures: a machine-filling batch, LSDA (BASELINE config 3) and
+            # the 1 048 577-node stress of config 5 (one atom and a batch of 16); a few seconds each
             extra = {}
-            for name, atoms, lsda, st, wu in (("batch256_lda", 256, False, 3, 1), ("rn_lsda", 1, True, 3, 2)):
-                s2, t2 = run_workload(D, ctx, grid, args.levels, atoms, lsda, st, wu, 0, barrier, torch)
+            for name, lv, atoms, lsda, st, wu in (("batch256_lda", args.levels, 256, False, 3, 1), ("rn_lsda", args.levels, 1, True, 3, 2),
+                                                  ("rn_lsda_l20", 20, 1, True, 2, 1), ("rn_lsda_l20_batch16", 20, 16, True, 2, 1)):
+                if lv == args.levels:
+                    g2, d2, r2 = grid, delta, rmax
+                else:
+                    d2, r2 = GRIDS[lv]
+                    g2 = D.Grid(ctx, lv, d2, r2)
+                s2, t2 = run_workload(D, ctx, g2, lv, atoms, lsda, st, wu, 0, barrier, torch)
                 s2.close()
-                extra[name] = summarize(t2, args.levels, grid.N, atoms, lsda, world, delta, rmax)
+                extra[name] = summarize(t2, lv, g2.N, atoms, lsda, world, d2, r2)
+                if g2 is not grid:
+                    g2.close()
             out["extra"] = extra
         if world == 1 and not args.no_cpu:      # rank 0 at N = 1 only: the other ranks of a larger job would sit at the final barrier
             out["cpu_baseline"] = cpu_baseline(args.levels, args.lsda, args.cpu_steps)
