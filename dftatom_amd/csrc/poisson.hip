@@ -929,9 +929,65 @@ __device__ __forceinline__ double iterate_gs(const MgDesc& D, Atom& A, int l, do
         double* PP = A.stage + kStagePad;
         double* SS = PP + kStageArr;
         const int C1 = 1 << L.logC;
+        const bool fold = (A.pend == l + 1);                  // prolongation from level l+1 taken in while staging (do_prolong)
+        const bool fold_r = (l > 0 && A.pend_r == l);         // restriction from level l-1 computed while staging (do_restrict)
+        A.pend = 0;
+        A.pend_r = 0;
         { PROF_T0();
-        copy_rows2(PP, SS, kThreads, G0, Sg, kThreads, C1);
-        if (tid == 0) PP[L.n - 1] = G0[L.n - 1];
+        if (fold_r) {
+            // PoissonSolver::Restrict (PoissonSolver.cpp:126-157) from level l-1 (same workgroup, same lane columns: coarse node
+            // (t, k) sits under the fine nodes (t, 2k-1 .. 2k+1)) straight into the staging memory: Phi starts from 0, the
+            // source also goes to the level's global array for the visit on the way back up.  Arithmetic of restrict_to.
+            const Lvl Lf = D.lv[l - 1];
+            const int logT = L.logT, Cf = 1 << Lf.logC;
+            const double* __restrict__ pf = (((A.cur >> (l - 1)) & 1u) ? A.phi1 : A.phi0) + Lf.off;
+            const double* __restrict__ sf = A.src + Lf.off;
+            double* __restrict__ sc = A.src + L.off;
+            const double dc = L.d;
+            double pm = pf[((Cf - 1) << logT) + (tid > 0 ? tid - 1 : 0)];
+#pragma unroll 4
+            for (int k = 0; k < C1; ++k) {
+                const double p0 = pf[((2 * k) << logT) + tid];
+                const double pp = pf[((2 * k + 1) << logT) + tid];
+                const double s0 = sf[((2 * k) << logT) + tid];
+                double sv = 4. * (s0 + pm - 2. * p0 + pp) - dc * (pp - pm);
+                if (k == 0 && tid == 0) sv = 0;                    // coarse node 0
+                sc[(k << logT) + tid] = sv;
+                SS[k * kThreads + tid] = sv;
+                PP[k * kThreads + tid] = 0;
+                pm = pp;
+            }
+            if (tid == 0) { sc[C1 << logT] = 0; PP[L.n - 1] = 0; }  // coarse node n-1
+        } else if (fold) {
+            // PoissonSolver::Prolong (PoissonSolver.cpp:110-123) from level l+1 added to what is staged (arithmetic of
+            // prolong_from: fine(2j) += coarse(j), fine(2j-1) += 0.5 (coarse(j-1) + coarse(j))); the level's global copy is
+            // brought up to date by the write-out at the end of the visit
+            const Lvl Lc = D.lv[l + 1];
+            const double* __restrict__ Pc = A.cur_phi(l + 1, Lc);
+            auto corr = [&](int i, bool odd) -> double {
+                if (!odd) return Pc[addr(Lc, i >> 1)];
+                return 0.5 * (Pc[addr(Lc, (i - 1) >> 1)] + Pc[addr(Lc, (i + 1) >> 1)]);
+            };
+            for (int k0 = 0; k0 < C1; k0 += 4) {                    // C1 >= 8 on these levels
+                double a[4], b[4], cadd[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int k = k0 + q;
+                    a[q] = G0[k * kThreads + tid];
+                    b[q] = Sg[k * kThreads + tid];
+                    cadd[q] = corr((tid << L.logC) + k, (q & 1) != 0);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    PP[(k0 + q) * kThreads + tid] = a[q] + cadd[q];
+                    SS[(k0 + q) * kThreads + tid] = b[q];
+                }
+            }
+            if (tid == 0) PP[L.n - 1] = G0[L.n - 1] + corr(L.n - 1, false);
+        } else {
+            copy_rows2(PP, SS, kThreads, G0, Sg, kThreads, C1);
+            if (tid == 0) PP[L.n - 1] = G0[L.n - 1];
+        }
         __syncthreads();
         PROF_ADD(5, l); }
         const int lo_g = tid << L.logC;
@@ -1281,6 +1337,12 @@ __device__ __forceinline__ void initialize(const MgDesc& D, Atom& A, double lowB
 __device__ __forceinline__ void do_restrict(const MgDesc& D, Atom& A, int lvl, bool may_fold = false)
 {
     if (may_fold && lvl < D.kcoop && D.lv[lvl].stage == 2 && !D.nofold) { A.pend_r = lvl; return; }
+    // both levels workgroup 0's, staged, on the same lane columns: folded into the copy-in likewise (iterate_gs, stage 1)
+    if (may_fold && lvl - 1 >= D.kcoop && D.lv[lvl].stage == 1 && D.lv[lvl - 1].stage == 1 && D.lv[lvl].logT == D.lv[lvl - 1].logT &&
+        D.lv[lvl].logC >= 2 && !D.nofold) {
+        if (A.g == 0) A.pend_r = lvl;
+        return;
+    }
     if (lvl - 1 < D.kcoop || A.g == 0) restrict_to(D, A, lvl);
 }
 
@@ -1299,6 +1361,8 @@ __device__ __forceinline__ void do_prolong(const MgDesc& D, Atom& A, int lvl, bo
         }
         if (may_fold && D.lv[lvl - 1].stage == 2 && !D.nofold) { A.pend = lvl; return; }
         prolong_from(D, A, lvl);
+    } else if (may_fold && D.lv[lvl - 1].stage == 1 && D.lv[lvl - 1].logC >= 2 && !D.lv[lvl].seq && !D.nofold) {
+        if (A.g == 0) A.pend = lvl;                            // workgroup 0's own staged level: folded into its copy-in
     } else if (A.g == 0) prolong_from(D, A, lvl);
 }
 
