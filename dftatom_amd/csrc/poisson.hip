@@ -183,7 +183,10 @@ __device__ __forceinline__ double group_sum(Atom& A, double v, double* red)
 #ifdef DFTA_POISSON_PROF
 __device__ unsigned long long g_prof[8 * 24];
 #define PROF_T0() const long long prof_t0 = clock64()
-#define PROF_ADD(cat, lvl) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_prof[(cat) * 24 + (lvl)] += clock64() - prof_t0; } while (0)
+__device__ unsigned long long g_prof_member[64 * 4];     // per member of atom 0: ticks in the exchange / in the LDS sweeps (all shared levels)
+#define PROF_ADD(cat, lvl) do { if (threadIdx.x == 0) { const unsigned long long dt_ = clock64() - prof_t0; \
+        if (blockIdx.x == 0) g_prof[(cat) * 24 + (lvl)] += dt_; \
+        if (blockIdx.x < 64 && ((cat) == 3 || (cat) == 4 || (cat) == 5)) g_prof_member[blockIdx.x * 4 + (cat) - 3] += dt_; } } while (0)
 #else
 #define PROF_T0()
 #define PROF_ADD(cat, lvl)
@@ -220,7 +223,11 @@ __device__ __forceinline__ void exchange_store(Atom& A, int idx, double v)
 }
 // PP: the staged part (element 0 = its first node); nhalo = Hc << logC nodes of the left neighbour go to the halo columns
 // (node idx: row idx & (C-1), column -Hc + (idx >> logC)), the right neighbour's first node to PP[C * RS]
-template <int RS>
+// FENCED: the sum that ends a visit, after the member has written its part out with plain stores -- a release before the sum
+// is published and an acquire after the last one has arrived make those stores visible to every member (the next operation
+// reads other members' columns with plain loads); no nodes travel with it.  One trip instead of the three of group_sum
+// (arrival counter, poll, read of the slots).
+template <int RS, bool FENCED = false>
 __device__ __forceinline__ double group_sum_fast(Atom& A, double v, double* red, double* PP, int logC, int Hc)
 {
     const double mine = block_sum(v, red);      // its barriers wait for every store of this member issued so far
@@ -229,16 +236,19 @@ __device__ __forceinline__ double group_sum_fast(Atom& A, double v, double* red,
     const int tid = threadIdx.x, C = 1 << logC;
     if (tid < 64) {
         double* cur = A.fslot + (s % 3u) * A.G;
+        if (FENCED && tid == 0) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         if (tid == 0) __hip_atomic_store(cur + A.g, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         double x = 0;
         if (tid < A.G) x = exchange_poll(A, cur + tid);
         double tot = 0;
         for (int m = 0; m < A.G; ++m) tot += __shfl(x, m);
         if (tid == 0) {
+            if (FENCED) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             red[18] = tot;
             __hip_atomic_store(A.fslot + ((s + 2u) % 3u) * A.G + A.g, __longlong_as_double(static_cast<long long>(kFastSentinel)),
                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+    } else if (FENCED) {
     } else if (tid < 192) {
         const int idx = tid - 64;
         if (A.g > 0 && idx < (Hc << logC))
@@ -1165,7 +1175,7 @@ __device__ __forceinline__ double iterate_gs(const MgDesc& D, Atom& A, int l, do
                 }
                 if (tid == 0) exchange_store(A, kXchg - 1, PP[0]);   // the first node: right neighbour of the previous member's last one
             }
-            { PROF_T0(); err = sqrt(last ? group_sum(A, err2, red) : group_sum_fast<kStageRS>(A, err2, red, PP, L.logC, Hc)); PROF_ADD(3, l); }
+            { PROF_T0(); err = sqrt(last ? group_sum_fast<kStageRS, true>(A, err2, red, PP, L.logC, Hc) : group_sum_fast<kStageRS>(A, err2, red, PP, L.logC, Hc)); PROF_ADD(3, l); }
             if (last) break;
             if (err < errorMin) {                              // the reference stops here: publish everything, meet once more
                 write_out();
@@ -2097,6 +2107,12 @@ void dfta_poisson_destroy(dfta_poisson* p)
                 fprintf(stderr, "\n");
             }
             fprintf(stderr, "[poisson prof] total ticks %llu\n", tot);
+            unsigned long long hm[64 * 4];
+            if (hipMemcpyFromSymbol(hm, HIP_SYMBOL(g_prof_member), sizeof(hm)) == hipSuccess) {
+                for (int m = 0; m < 16; ++m) fprintf(stderr, "[poisson prof] member %2d: exchange %llu  sweeps %llu  copy-in %llu\n", m, hm[m * 4], hm[m * 4 + 1], hm[m * 4 + 2]);
+                unsigned long long zz[64 * 4] = {0};
+                (void)hipMemcpyToSymbol(HIP_SYMBOL(g_prof_member), zz, sizeof(zz));
+            }
             unsigned long long z[8 * 24] = {0};
             (void)hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof(z));
         }
