@@ -332,6 +332,7 @@ __device__ __forceinline__ void plan_round(dfta::Job& j, const dfta::Job* __rest
 // the point where CountNodes stops, in grid cells -- the count changes where F crosses 0.  The error bound is the
 // interpolation error of the secant with the second divided difference taken from the third sample (times 4).
 constexpr double kSecantNoise = 3e-11;
+__device__ double g_secant_kappa = 0.25;     // 0: secant only (DFTA_LEVELS_SECANT_KAPPA overrides, read when a solver is created)
 __device__ __forceinline__ void secant_predict(dfta::Job& j, const double2* __restrict__ veff /* table rows of the job's slot */)
 {
     j.sc_ok = 0;
@@ -363,7 +364,21 @@ __device__ __forceinline__ void secant_predict(dfta::Job& j, const double2* __re
     if (!found || !(t > a && t < b)) return;
     // 4 x |f2 / f1| (b - a)^2 / 4 for the secant, plus the scale below which the count is no longer a monotonic function of
     // the energy (round-off of the sweep: about 1e-11 of |E|)
-    const double e = (at_step ? 0.0 : fabs(f2 / f1) * w * w) + kSecantNoise * fabs(t);
+    double e = (at_step ? 0.0 : fabs(f2 / f1) * w * w) + kSecantNoise * fabs(t);
+    // The third sample gives more than a bound: the parabola through the three samples (Newton form
+    // xa + f1 (E - a) + f2 (E - a)(E - b)) meets the stop point at t - f2 (t - a)(t - b) / f1 to first order -- measured, the
+    // end point of the bisection sits at -0.20 .. -0.25 of the secant's error bound, i.e. ON that correction, time after
+    // time.  The corrected estimate is trusted to a fraction g_secant_kappa of the correction itself (plus the noise floor);
+    // it is dropped where it would cross the turning-point step that the secant's solution lies under.
+    if (!at_step && g_secant_kappa > 0) {
+        double tq = t;
+        for (int it = 0; it < 2; ++it) tq = a + (static_cast<double>(s) - xa - f2 * (tq - a) * (tq - b)) / f1;
+        const double Ej = (ia != 0 && s >= 1) ? veff[s].x : 1e300;
+        if (tq > a && tq < b && tq < Ej) {
+            const double e2 = g_secant_kappa * fabs(tq - t) + kSecantNoise * fabs(tq);
+            if (e2 < e) { e = e2; t = tq; }
+        }
+    }
     if (!(e < w * 0.125)) return;
     j.sc_lo = t - e;
     j.sc_hi = t + e;
@@ -848,6 +863,10 @@ int LevelSolver::setup(dfta_ctx* c, const dfta_grid* grid, int mode_, int tree_d
     release();
     ctx = c; g = grid; mode = mode_; nV = nV_;
     use_prediction = getenv("DFTA_LEVELS_NOPREDICT") == nullptr;   // measurements / tests: every spine and scout off
+    if (const char* e = getenv("DFTA_LEVELS_SECANT_KAPPA")) {        // experiments: trust in the parabolic correction of the secant estimate
+        const double k = atof(e);
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_secant_kappa), &k, sizeof(k));
+    }
     debug_rounds = getenv("DFTA_DEBUG_ROUNDS") ? atoi(getenv("DFTA_DEBUG_ROUNDS")) : 0;
     njobs = static_cast<int>(specs.size());
     if (njobs == 0) return DFTA_OK;
@@ -1082,6 +1101,12 @@ int LevelSolver::run(const double* dV, const double* job_bottom, int run_mode, d
             for (int q = 0; q < njobs; ++q)
                 if (dbg[q].phase != PH_DONE) fprintf(stderr, " %d:%d/%d", q, dbg[q].phase, dbg[q].phase_done);
             fprintf(stderr, "\n");
+            if (debug_rounds >= 3)
+                for (int q = 0; q < njobs; ++q) {
+                    const Job& J = dbg[q];
+                    fprintf(stderr, "   J %2d ph %d done %d l %d boe %.17g toe %.17g top %.17g sc_ok %d sc_lo %.17g sc_hi %.17g spine %d use_sp %d miss %d tcap %d\n",
+                            q, J.phase, J.phase_done, J.l, J.boe, J.toe, J.top, J.sc_ok, J.sc_lo, J.sc_hi, J.spine, J.use_sp, J.miss, J.tcap);
+                }
             if (debug_rounds >= 2)
                 for (int q = 0; q < njobs; ++q) {
                     const Job& J = dbg[q];
