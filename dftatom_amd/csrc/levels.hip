@@ -648,10 +648,10 @@ __device__ __forceinline__ int decisions_left(const dfta::Job& j)
 __global__ __launch_bounds__(64) void k_allot(dfta::Job* __restrict__ jobs, int njobs, int budget, int nopredict, int* __restrict__ wave_job,
                                               int* __restrict__ wave_slot)
 {
-    __shared__ int s_S[64], s_r[64], s_sc[64], s_act[64], s_rem[64], s_base[64], s_cap[64];
+    __shared__ int s_S[64], s_r[64], s_sc[64], s_act[64], s_rem[64], s_base[64], s_cap[64], s_left[64];
     const int k = threadIdx.x;            // njobs <= 64 in this mode
     bool act = false;
-    int S = 0, r = 0, sc = 0, rem = 0;
+    int S = 0, r = 0, sc = 0, rem = 0, left = 0;
     if (k < njobs) {
         dfta::Job j = jobs[k];
         act = (j.phase == PH_TOP || j.phase == PH_BOTTOM || j.phase == PH_ZERO);
@@ -660,19 +660,44 @@ __global__ __launch_bounds__(64) void k_allot(dfta::Job* __restrict__ jobs, int 
             if (nopredict) { j.spine = 0; j.capz = 1 << 14; }
             S = j.spine;
             sc = j.capz < (1 << 14);
-            // a tree that ends the phase if one of up to kMaxTreeDepth levels can, else equal shares of the rounds it takes anyway
-            const int left = decisions_left(j) - S;
-            if (left <= kMaxTreeDepth) r = left < 6 ? 6 : left;
-            else { const int nr = (left + 9) / 10; r = (left + nr - 1) / nr; }
+            // a tree that ends the phase if ten levels can (1024 trials: what a job's share of a pass affords), else equal shares
+            // of the rounds it takes anyway; deeper phase-ending trees are handed out below, from what the others leave
+            left = decisions_left(j) - S;
+            if (left <= 10) r = left < 6 ? 6 : left;
+            else { const int nr = (left + 9) / 10; r = (left + nr - 1) / nr; if (r < 6) r = 6; }
             // rounds this job still has in front of it (a level's three bisections take about 3 + 2 + 2 rounds): the slots go to
             // the jobs that are furthest behind, because the round count of a step is theirs
             rem = (left + 9) / 10 + (j.phase == PH_TOP ? 4 : (j.phase == PH_BOTTOM ? 2 : 0));
         }
     }
-    if (k < 64) { s_S[k] = S; s_r[k] = r; s_sc[k] = sc; s_act[k] = act ? 1 : 0; s_rem[k] = rem; }
+    if (k < 64) { s_S[k] = S; s_r[k] = r; s_sc[k] = sc; s_act[k] = act ? 1 : 0; s_rem[k] = rem; s_left[k] = left; }
     __syncthreads();
     if (k == 0) {
-        auto slots = [&](int q) { const int t = 1 + s_S[q] + (1 << s_r[q]); const int u = (t + 127) & ~127; return s_sc[q] ? 2 * u : u; };
+        auto slots_at = [&](int q, int depth) { const int t = 1 + s_S[q] + (1 << depth); const int u = (t + 127) & ~127; return s_sc[q] ? 2 * u : u; };
+        auto slots = [&](int q) { return slots_at(q, s_r[q]); };
+        // What the modest requests leave goes, furthest-behind job first, to deeper trees that SAVE A ROUND of the phase: the
+        // smallest depth with ceil(left / depth) one less than now, up to kMaxTreeDepth levels.  (Round 2 first let every job ask
+        // for its phase-ending tree outright: a level with 14 undecided decisions then asked for the whole pass, was cut to 13 --
+        // two rounds all the same -- and the cuts took the ninth level from a job that needed exactly nine: an extra round for a
+        // single decision.  And a level with 23 decisions left got three rounds of 8 where 12 + 11 were affordable.)
+        {
+            int tot = 0;
+            for (int q = 0; q < njobs; ++q) if (s_act[q]) tot += slots(q);
+            bool stuck[64];
+            for (int q = 0; q < 64; ++q) stuck[q] = false;
+            while (true) {
+                int pick = -1;
+                for (int q = 0; q < njobs; ++q)
+                    if (s_act[q] && !stuck[q] && s_r[q] < s_left[q] &&
+                        (pick < 0 || s_rem[q] > s_rem[pick] || (s_rem[q] == s_rem[pick] && s_left[q] < s_left[pick]))) pick = q;
+                if (pick < 0) break;
+                const int nr = (s_left[pick] + s_r[pick] - 1) / s_r[pick];                 // rounds of this phase at the present depth
+                const int target = nr > 1 ? (s_left[pick] + nr - 2) / (nr - 1) : s_left[pick];
+                const int cost = target <= kMaxTreeDepth ? slots_at(pick, target) - slots(pick) : (1 << 30);
+                if (target > s_r[pick] && tot + cost <= budget) { s_r[pick] = target; tot += cost; --s_rem[pick]; }
+                else stuck[pick] = true;
+            }
+        }
         for (int floor = 8; floor >= 6; floor -= 2) {
             while (true) {
                 int tot = 0, pick = -1;
