@@ -249,6 +249,13 @@ __device__ __forceinline__ void predict_from_bracket(dfta::Job& j, double lo, do
     j.sp_len = k;
 }
 
+// The band of energies around a transition inside which CountNodes' count and the sign of u(0) are round-off (not monotonic in
+// E).  Spines stop there -- a predicted decision inside it is a coin toss, and a miss forfeits the round's tree.  Measured on
+// Rn's fifteen levels (16384-point scans of the count and of sign u(0) around every transition, end of round 2): the band is
+// 1.2e-12 .. 7.4e-12 |E| wide (6p: 1.4e-11 |E| = 2.5e-12 absolute), the same for both predicates.  Guards: rel |E| + abs on either
+// side of a predicted transition (sibling's end point, own top for l = 0), g_secant_noise |E| added to the secant's error bound.
+// Round 1 used 2e-11 / 64e-12 / 3e-11; DFTA_LEVELS_NOISE="rel,abs,secant" overrides (read when a solver is created).
+__device__ double g_noise_rel = 1e-11, g_noise_abs = 16e-12, g_secant_noise = 1.5e-11;
 // Spine of the job's next round.  `jobs` is read for the sibling only (k_plan runs after every walk of the round).
 __device__ __forceinline__ void plan_round(dfta::Job& j, const dfta::Job* __restrict__ jobs, int tpj)
 {
@@ -276,8 +283,8 @@ __device__ __forceinline__ void plan_round(dfta::Job& j, const dfta::Job* __rest
     }
     // the last decisions before the predicted flip are left to the tree: at that scale (a few 1e-11) the counted nodes
     // and the sign of u(0) are not monotonic in the energy, and a miss on the spine costs the whole round
-    constexpr double kGuard = 64 * kEnergyErr;
-    constexpr double kNoise = 2e-11;
+    const double kGuard = g_noise_abs;
+    const double kNoise = g_noise_rel;
     bool secant = false;
     if (j.phase == PH_TOP) {
         if (j.sc_ok && j.miss < 2) {
@@ -331,7 +338,6 @@ __device__ __forceinline__ void plan_round(dfta::Job& j, const dfta::Job* __rest
 // F(E) = (stop index of the sample - stop index of the boe-side sample) + phi -- the distance of the nearest zero of u from
 // the point where CountNodes stops, in grid cells -- the count changes where F crosses 0.  The error bound is the
 // interpolation error of the secant with the second divided difference taken from the third sample (times 4).
-constexpr double kSecantNoise = 3e-11;
 __device__ double g_secant_kappa = 0.25;     // 0: secant only (DFTA_LEVELS_SECANT_KAPPA overrides, read when a solver is created)
 __device__ __forceinline__ void secant_predict(dfta::Job& j, const double2* __restrict__ veff /* table rows of the job's slot */)
 {
@@ -364,7 +370,7 @@ __device__ __forceinline__ void secant_predict(dfta::Job& j, const double2* __re
     if (!found || !(t > a && t < b)) return;
     // 4 x |f2 / f1| (b - a)^2 / 4 for the secant, plus the scale below which the count is no longer a monotonic function of
     // the energy (round-off of the sweep: about 1e-11 of |E|)
-    double e = (at_step ? 0.0 : fabs(f2 / f1) * w * w) + kSecantNoise * fabs(t);
+    double e = (at_step ? 0.0 : fabs(f2 / f1) * w * w) + g_secant_noise * fabs(t);
     // The third sample gives more than a bound: the parabola through the three samples (Newton form
     // xa + f1 (E - a) + f2 (E - a)(E - b)) meets the stop point at t - f2 (t - a)(t - b) / f1 to first order -- measured, the
     // end point of the bisection sits at -0.20 .. -0.25 of the secant's error bound, i.e. ON that correction, time after
@@ -375,7 +381,7 @@ __device__ __forceinline__ void secant_predict(dfta::Job& j, const double2* __re
         for (int it = 0; it < 2; ++it) tq = a + (static_cast<double>(s) - xa - f2 * (tq - a) * (tq - b)) / f1;
         const double Ej = (ia != 0 && s >= 1) ? veff[s].x : 1e300;
         if (tq > a && tq < b && tq < Ej) {
-            const double e2 = g_secant_kappa * fabs(tq - t) + kSecantNoise * fabs(tq);
+            const double e2 = g_secant_kappa * fabs(tq - t) + g_secant_noise * fabs(tq);
             if (e2 < e) { e = e2; t = tq; }
         }
     }
@@ -564,7 +570,7 @@ __global__ __launch_bounds__(64) void k_scout(dfta::Job* __restrict__ jobs, cons
             const double f1 = (phi_hi - plo) / w;
             const double f2 = ((pc - phi_hi) / (c - nhi) - f1) / (c - nlo);
             const double t = nlo + w * (plo / (plo - phi_hi));
-            const double e = fabs(f2 / f1) * w * w + kSecantNoise * fabs(t);
+            const double e = fabs(f2 / f1) * w * w + g_secant_noise * fabs(t);
             if (e < w * 0.125) { tok = 1; tlo = t - e; thi = t + e; }
         }
     }
@@ -888,6 +894,13 @@ int LevelSolver::setup(dfta_ctx* c, const dfta_grid* grid, int mode_, int tree_d
     release();
     ctx = c; g = grid; mode = mode_; nV = nV_;
     use_prediction = getenv("DFTA_LEVELS_NOPREDICT") == nullptr;   // measurements / tests: every spine and scout off
+    if (const char* e = getenv("DFTA_LEVELS_NOISE")) {               // experiments: "rel,abs,secant" of the noise band (levels.hip)
+        double v[3] = {1e-11, 16e-12, 1.5e-11};
+        sscanf(e, "%lf,%lf,%lf", &v[0], &v[1], &v[2]);
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_noise_rel), &v[0], sizeof(double));
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_noise_abs), &v[1], sizeof(double));
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_secant_noise), &v[2], sizeof(double));
+    }
     if (const char* e = getenv("DFTA_LEVELS_SECANT_KAPPA")) {        // experiments: trust in the parabolic correction of the secant estimate
         const double k = atof(e);
         (void)hipMemcpyToSymbol(HIP_SYMBOL(g_secant_kappa), &k, sizeof(k));
