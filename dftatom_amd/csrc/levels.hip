@@ -894,16 +894,14 @@ int LevelSolver::setup(dfta_ctx* c, const dfta_grid* grid, int mode_, int tree_d
     release();
     ctx = c; g = grid; mode = mode_; nV = nV_;
     use_prediction = getenv("DFTA_LEVELS_NOPREDICT") == nullptr;   // measurements / tests: every spine and scout off
-    if (const char* e = getenv("DFTA_LEVELS_NOISE")) {               // experiments: "rel,abs,secant" of the noise band (levels.hip)
-        double v[3] = {1e-11, 16e-12, 1.5e-11};
-        sscanf(e, "%lf,%lf,%lf", &v[0], &v[1], &v[2]);
+    {   // tuning of the predictions (never of a result): the defaults, or what the environment says, every time a solver is made
+        double v[3] = {1e-11, 16e-12, 1.5e-11}, k = 0.25;
+        if (const char* e = getenv("DFTA_LEVELS_NOISE")) sscanf(e, "%lf,%lf,%lf", &v[0], &v[1], &v[2]);   // "rel,abs,secant" of the noise band
+        if (const char* e = getenv("DFTA_LEVELS_SECANT_KAPPA")) k = atof(e);                                // trust in the parabolic correction
         (void)hipMemcpyToSymbol(HIP_SYMBOL(g_noise_rel), &v[0], sizeof(double));
         (void)hipMemcpyToSymbol(HIP_SYMBOL(g_noise_abs), &v[1], sizeof(double));
         (void)hipMemcpyToSymbol(HIP_SYMBOL(g_secant_noise), &v[2], sizeof(double));
-    }
-    if (const char* e = getenv("DFTA_LEVELS_SECANT_KAPPA")) {        // experiments: trust in the parabolic correction of the secant estimate
-        const double k = atof(e);
-        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_secant_kappa), &k, sizeof(k));
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_secant_kappa), &k, sizeof(double));
     }
     debug_rounds = getenv("DFTA_DEBUG_ROUNDS") ? atoi(getenv("DFTA_DEBUG_ROUNDS")) : 0;
     njobs = static_cast<int>(specs.size());

@@ -379,13 +379,16 @@ def test_predictions_never_change_results(ctx, grid14):
     """The level solver's speculation (spines from history, sibling, top rule, scouts, secants) only selects which of the
     reference's midpoints are integrated early: with all of it switched off (plain bisection trees) every SCF step gives
     the same bits -- energies, eigenvalues and the reference-equivalent sweep counts"""
-    def run(nopredict):
-        old = os.environ.get("DFTA_LEVELS_NOPREDICT")
+    knobs = ("DFTA_LEVELS_NOPREDICT", "DFTA_LEVELS_NOISE", "DFTA_LEVELS_SECANT_KAPPA", "DFTA_LEVELS_STATIC")
+
+    def run(nopredict, **env):
+        old = {k: os.environ.get(k) for k in knobs}
         try:
+            for k in knobs:
+                os.environ.pop(k, None)
             if nopredict:
                 os.environ["DFTA_LEVELS_NOPREDICT"] = "1"
-            else:
-                os.environ.pop("DFTA_LEVELS_NOPREDICT", None)
+            os.environ.update(env)
             scf = D.Scf(ctx, grid14, [36], lsda=False)               # Kr: s, p and d levels
             out = []
             for _ in range(5):
@@ -396,16 +399,27 @@ def test_predictions_never_change_results(ctx, grid14):
             scf.close()
             return out
         finally:
-            if old is None:
-                os.environ.pop("DFTA_LEVELS_NOPREDICT", None)
-            else:
-                os.environ["DFTA_LEVELS_NOPREDICT"] = old
+            for k in knobs:
+                if old[k] is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = old[k]
     a, b = run(False), run(True)
     for k, (x, y) in enumerate(zip(a, b)):
         assert x[0] == y[0], k
         assert np.array_equal(x[1].view(np.int64), y[1].view(np.int64)), k
         assert x[2] == y[2], k                                        # the reference's path length
     assert sum(x[3] for x in a) < sum(y[3] for y in b)                # ... in fewer rounds
+    # the tuning knobs of the predictions -- reckless guards around the round-off band, blind trust in the parabolic end-point
+    # estimate, fixed trial slots -- cost or save rounds, never a bit of the result
+    for env in ({"DFTA_LEVELS_NOISE": "1e-14,1e-13,1e-14", "DFTA_LEVELS_SECANT_KAPPA": "0.001"},
+                {"DFTA_LEVELS_NOISE": "1e-9,1e-9,1e-9", "DFTA_LEVELS_SECANT_KAPPA": "0"},
+                {"DFTA_LEVELS_STATIC": "1"}):
+        c = run(False, **env)
+        for k, (x, y) in enumerate(zip(a, c)):
+            assert x[0] == y[0], (env, k)
+            assert np.array_equal(x[1].view(np.int64), y[1].view(np.int64)), (env, k)
+            assert x[2] == y[2], (env, k)
 
 
 def test_scf_odd_batches_are_uniform(ctx, grid14):
