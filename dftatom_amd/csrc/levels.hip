@@ -654,7 +654,7 @@ __device__ __forceinline__ int decisions_left(const dfta::Job& j)
 __global__ __launch_bounds__(64) void k_allot(dfta::Job* __restrict__ jobs, int njobs, int budget, int nopredict, int* __restrict__ wave_job,
                                               int* __restrict__ wave_slot)
 {
-    __shared__ int s_S[64], s_r[64], s_sc[64], s_act[64], s_rem[64], s_base[64], s_cap[64], s_left[64];
+    __shared__ int s_S[64], s_base[64], s_cap[64];
     const int k = threadIdx.x;            // njobs <= 64 in this mode
     bool act = false;
     int S = 0, r = 0, sc = 0, rem = 0, left = 0;
@@ -676,57 +676,73 @@ __global__ __launch_bounds__(64) void k_allot(dfta::Job* __restrict__ jobs, int 
             rem = (left + 9) / 10 + (j.phase == PH_TOP ? 4 : (j.phase == PH_BOTTOM ? 2 : 0));
         }
     }
-    if (k < 64) { s_S[k] = S; s_r[k] = r; s_sc[k] = sc; s_act[k] = act ? 1 : 0; s_rem[k] = rem; s_left[k] = left; }
-    __syncthreads();
-    if (k == 0) {
-        auto slots_at = [&](int q, int depth) { const int t = 1 + s_S[q] + (1 << depth); const int u = (t + 127) & ~127; return s_sc[q] ? 2 * u : u; };
-        auto slots = [&](int q) { return slots_at(q, s_r[q]); };
-        // What the modest requests leave goes, furthest-behind job first, to deeper trees that SAVE A ROUND of the phase: the
-        // smallest depth with ceil(left / depth) one less than now, up to kMaxTreeDepth levels.  (Round 2 first let every job ask
-        // for its phase-ending tree outright: a level with 14 undecided decisions then asked for the whole pass, was cut to 13 --
-        // two rounds all the same -- and the cuts took the ninth level from a job that needed exactly nine: an extra round for a
-        // single decision.  And a level with 23 decisions left got three rounds of 8 where 12 + 11 were affordable.)
-        {
-            int tot = 0;
-            for (int q = 0; q < njobs; ++q) if (s_act[q]) tot += slots(q);
-            bool stuck[64];
-            for (int q = 0; q < 64; ++q) stuck[q] = false;
-            while (true) {
-                int pick = -1;
-                for (int q = 0; q < njobs; ++q)
-                    if (s_act[q] && !stuck[q] && s_r[q] < s_left[q] &&
-                        (pick < 0 || s_rem[q] > s_rem[pick] || (s_rem[q] == s_rem[pick] && s_left[q] < s_left[pick]))) pick = q;
-                if (pick < 0) break;
-                const int nr = (s_left[pick] + s_r[pick] - 1) / s_r[pick];                 // rounds of this phase at the present depth
-                const int target = nr > 1 ? (s_left[pick] + nr - 2) / (nr - 1) : s_left[pick];
-                const int cost = target <= kMaxTreeDepth ? slots_at(pick, target) - slots(pick) : (1 << 30);
-                if (target > s_r[pick] && tot + cost <= budget) { s_r[pick] = target; tot += cost; --s_rem[pick]; }
-                else stuck[pick] = true;
-            }
-        }
-        for (int floor = 8; floor >= 6; floor -= 2) {
-            while (true) {
-                int tot = 0, pick = -1;
-                for (int q = 0; q < njobs; ++q)
-                    if (s_act[q]) {
-                        tot += slots(q);
-                        // cut the job that is least behind (then the deepest tree among equals)
-                        if (s_r[q] > floor && (pick < 0 || s_rem[q] < s_rem[pick] || (s_rem[q] == s_rem[pick] && s_r[q] > s_r[pick]))) pick = q;
-                    }
-                if (tot <= budget || pick < 0) break;
-                --s_r[pick];
-            }
-        }
-        int base = 0;
-        for (int q = 0; q < njobs; ++q) {
-            int cap = 0;
-            if (s_act[q]) { cap = slots(q); if (base + cap > budget) cap = ((budget - base) / 128) * 128; }
-            s_base[q] = base;
-            s_cap[q] = cap;
-            base += cap;
+    // One lane per job from here on (the kernel is one wave): selections are wave-wide maxima of a key, sums are wave sums.
+    auto wave_max = [](int v) { for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off)); return v; };
+    auto wave_sum = [](int v) { for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off); return v; };
+    auto slots_at = [&](int depth) { const int t = 1 + S + (1 << depth); const int u = (t + 127) & ~127; return sc ? 2 * u : u; };
+    int tot = wave_sum(act ? slots_at(r) : 0);
+    // What the modest requests leave goes, furthest-behind job first, to deeper trees that SAVE A ROUND of the phase: the
+    // smallest depth with ceil(left / depth) one less than now, up to kMaxTreeDepth levels.  (Round 2 first let every job ask
+    // for its phase-ending tree outright: a level with 14 undecided decisions then asked for the whole pass, was cut to 13 --
+    // two rounds all the same -- and the cuts took the ninth level from a job that needed exactly nine: an extra round for a
+    // single decision.  And a level with 23 decisions left got three rounds of 8 where 12 + 11 were affordable.)
+    {
+        bool stuck = !act;
+        for (int guard = 0; guard < 256; ++guard) {
+            // furthest behind first (largest rem), then the fewest decisions left, then the lowest job
+            const bool cand = act && !stuck && r < left;
+            const int key = cand ? (((rem & 0x3fff) << 16) | ((255 - min(left, 255)) << 8) | (63 - k)) : -1;
+            const int best = wave_max(key);
+            if (best < 0) break;
+            const int lane_pick = 63 - (best & 0xff);
+            const int nr = (left + max(r, 1) - 1) / max(r, 1);                   // rounds of this phase at the present depth
+            const int target = nr > 1 ? (left + nr - 2) / (nr - 1) : left;
+            const int cost = (target <= kMaxTreeDepth && target > r) ? slots_at(target) - slots_at(r) : (1 << 29);
+            const int c = __shfl(cost, lane_pick);
+            const bool ok = tot + c <= budget;                                   // wave-uniform
+            if (k == lane_pick) { if (ok) { r = target; --rem; } else stuck = true; }
+            if (ok) tot += c;
         }
     }
-    __syncthreads();
+    // still too much: cut the job that is least behind (then the deepest tree among equals), down to 8 levels first, then to 6
+    for (int floor = 8; floor >= 6 && tot > budget; floor -= 2) {
+        for (int guard = 0; guard < 1024 && tot > budget; ++guard) {
+            const bool cand = act && r > floor;
+            const int key = cand ? ((((0x3fff - (rem & 0x3fff))) << 16) | (r << 8) | (63 - k)) : -1;
+            const int best = wave_max(key);
+            if (best < 0) break;
+            const int lane_pick = 63 - (best & 0xff);
+            const int delta = slots_at(r) - slots_at(max(r - 1, 0));
+            tot -= __shfl(delta, lane_pick);
+            if (k == lane_pick) --r;
+        }
+    }
+    // slots in job order; what does not fit any more (cuts exhausted) is clamped exactly as a sequential pass would
+    {
+        int cap = act ? slots_at(r) : 0;
+        int base = cap;                                                          // inclusive prefix sum
+        for (int off = 1; off < 64; off <<= 1) { const int v = __shfl_up(base, off); if (k >= off) base += v; }
+        base -= cap;
+        if (tot > budget) {                                                      // rare: sequential semantics by one lane
+            s_S[k] = cap;
+            __syncthreads();
+            if (k == 0) {
+                int b = 0;
+                for (int q = 0; q < njobs; ++q) {
+                    int cq = s_S[q];
+                    if (b + cq > budget) cq = ((budget - b) / 128) * 128;
+                    s_base[q] = b;
+                    s_cap[q] = cq;
+                    b += cq;
+                }
+            }
+            __syncthreads();
+        } else {
+            s_base[k] = base;
+            s_cap[k] = cap;
+            __syncthreads();
+        }
+    }
     // the block table of the round, by all lanes (a lone thread pays a memory round trip per entry)
     const int my_slot = k < njobs ? jobs[k].slot : 0;
     s_S[k] = my_slot;                                          // (the spine lengths are not needed any more)
