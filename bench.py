@@ -258,7 +258,30 @@ def main():
     import torch            # before dftatom_amd: one HIP runtime per process
     import torch.distributed as dist
 
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` without a launcher: start the N ranks here (one process per GPU, torch.distributed.run
+        # over 127.0.0.1) BEFORE anything touches the GPU -- torch.cuda.device_count() does not initialise HIP -- and return
+        # the job's exit code.  The ranks print the one JSON line (rank 0) on this process' stdout.
+        shared_test = os.environ.get("DFTA_BENCH_SHARED_GPU") == "1"
+        have = torch.cuda.device_count()
+        if have < args.gpus and not shared_test:
+            sys.stderr.write("bench.py: --gpus %d requested but only %d HIP device(s) are visible\n" % (args.gpus, have))
+            raise SystemExit(2)
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        raise SystemExit(subprocess.call(cmd, env=env))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.stderr.write("bench.py: --gpus %d does not match WORLD_SIZE=%d of the launcher\n" % (args.gpus, world))
+        raise SystemExit(2)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():

@@ -118,6 +118,7 @@ SIGNATURES = {
     "dfta_split_spin_ex": (C.c_int, [C.c_int, C.c_int, c_ip, c_ip, c_ip, c_ip, c_ip, c_ip, c_ip, c_ip, C.c_int]),
     "dfta_chachiyo_lda": (C.c_int, [vp, C.c_int, c_dp, C.c_size_t, c_dp, c_dp]),
     "dfta_split_spin": (C.c_int, [C.c_int, c_ip, c_ip, c_ip, c_ip, c_ip, c_ip, c_ip, c_ip, C.c_int]),
+    "dfta_ctx_measure_hbm": (C.c_int, [vp, C.c_size_t, C.c_int, c_dp, c_dp]),
 }
 
 _lib = None
@@ -184,6 +185,12 @@ class Context:
     def set_sweep_kernel(self, which):
         """SWEEP_KERNEL_AUTO / _FUSED / _PIPELINED: which (bit-identical) Numerov sweep kernel later calls launch."""
         self.check(self.lib.dfta_ctx_set_sweep_kernel(self.h, int(which)))
+
+    def measure_hbm(self, doubles_per_array=1 << 27, reps=5):
+        """attainable HBM bandwidth (GB/s) of the device: (copy, triad) -- measurement aid for the roofline denominators"""
+        c, t = C.c_double(), C.c_double()
+        self.check(self.lib.dfta_ctx_measure_hbm(self.h, int(doubles_per_array), int(reps), C.byref(c), C.byref(t)))
+        return c.value, t.value
 
     def last_kernel_ms(self):
         ms = C.c_float()

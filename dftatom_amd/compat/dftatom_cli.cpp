@@ -7,7 +7,8 @@
 // CalculateUniformLDA / LSDA, which the GUI has commented out.  --ini reads the keys the reference persists with
 // wxFileConfig (Options.cpp:42-49: Z, MultigridLevels, MaxR, deltaGrid, alpha, Method; same defaults: 36, 12, 10, 0.001,
 // 0.5, 0), one `key=value` per line, an optional leading '/' and [section] lines ignored.  Values are validated like the
-// options dialog does (OptionsFrame.cpp:46,152-175: Z 1..118, levels 10..20, MaxR 1..90, deltaGrid and alpha in (0, 1]).
+// options dialog does (OptionsFrame.cpp:46,152-175: Z 1..118, levels 10..20, MaxR 1..90, deltaGrid in (0, 1], alpha in [0, 1]);
+// any other method value is refused (exit code 2).
 // --integrator: trapezoid | simpson13 | simpson38 (default, what the reference calls) | boole | romberg (README.md:81).
 #include <cstdlib>
 #include <cstring>
@@ -47,11 +48,13 @@ bool load_ini(const char* path, Options& o)
 
 const char* validate(const Options& o, bool uniform)
 {
+    // the options dialog's ranges (OptionsFrame.cpp:46-50,152-171); method 2 / 3 (uniform grid) is this front end's extension
     if (o.Z < 1 || o.Z > 118) return "Z must be between 1 and 118";
-    if (o.MultigridLevels < 3 || o.MultigridLevels > 24) return "MultigridLevels out of range";
-    if (!(o.MaxR > 0)) return "MaxR must be positive";
+    if (o.MultigridLevels < 10 || o.MultigridLevels > 20) return "Please enter between 10 and 20 levels";
+    if (!(o.MaxR >= 1 && o.MaxR <= 90)) return "MaxR must be between 1 and 90";
     if (!uniform && !(o.deltaGrid > 0 && o.deltaGrid <= 1)) return "deltaGrid must be in (0, 1]";
     if (!(o.alpha >= 0 && o.alpha <= 1)) return "alpha must be in [0, 1]";
+    if (o.method < 0 || o.method > 1) return "method must be 0 (LDA), 1 (LSDA), 2 (uniform LDA) or 3 (uniform LSDA)";
     return nullptr;
 }
 }  // namespace
@@ -92,7 +95,7 @@ int main(int argc, char** argv)
                   << "       " << argv[0] << " --ini DFTAtom.ini [--uniform] [chained] [--integrator=NAME]\n";
         return 2;
     }
-    if (o.method >= 2) { uniform = true; o.method -= 2; }
+    if (o.method == 2 || o.method == 3) { uniform = true; o.method -= 2; }
     if (const char* msg = validate(o, uniform)) { std::cerr << "error: " << msg << std::endl; return 2; }
     try {
         if (uniform) {

@@ -32,14 +32,30 @@ struct dfta_ctx {
         }                                                                                       \
     } while (0)
 
-// every C-ABI entry point makes the context's device current first: the caller (or another library in the process)
-// may have changed it since dfta_ctx_create
-static inline int dfta_use(dfta_ctx* ctx)
-{
-    if (!ctx) return DFTA_ERR_INVALID;
-    DFTA_HIP(ctx, hipSetDevice(ctx->device));
-    return DFTA_OK;
-}
+// Every C-ABI entry point makes the context's device current first -- the caller (or another library in the process) may
+// have changed it since dfta_ctx_create -- and puts the caller's device back when it returns: a process that drives several
+// GPUs (torch with another current device) must not find its current device changed by a library call.
+struct dfta_device_guard {
+    int prev = -1;
+    int rc = DFTA_OK;
+    explicit dfta_device_guard(dfta_ctx* ctx)
+    {
+        if (!ctx) { rc = DFTA_ERR_INVALID; return; }
+        int cur = -1;
+        if (hipGetDevice(&cur) == hipSuccess && cur == ctx->device) return;      // already current: nothing to do or undo
+        const hipError_t e = hipSetDevice(ctx->device);
+        if (e != hipSuccess) {
+            snprintf(ctx->err, sizeof(ctx->err), "hipSetDevice(%d) -> %s", ctx->device, hipGetErrorString(e));
+            rc = DFTA_ERR_HIP;
+            return;
+        }
+        prev = cur;
+    }
+    ~dfta_device_guard() { if (prev >= 0) (void)hipSetDevice(prev); }
+    dfta_device_guard(const dfta_device_guard&) = delete;
+    dfta_device_guard& operator=(const dfta_device_guard&) = delete;
+};
+#define DFTA_ENTER(ctx) dfta_device_guard dfta_guard_(ctx); if (dfta_guard_.rc) return dfta_guard_.rc
 
 #define DFTA_CHECK_LAUNCH(ctx) DFTA_HIP(ctx, hipGetLastError())
 

@@ -115,7 +115,7 @@ static double far_threshold()
 int dfta_grid_create(dfta_ctx* ctx, int mg_levels, double delta, double Rmax, dfta_grid** out)
 {
     if (!ctx || !out) return DFTA_ERR_INVALID;
-    if (int rc_ = dfta_use(ctx)) return rc_;
+    DFTA_ENTER(ctx);
     DFTA_REQUIRE(ctx, mg_levels >= 3 && mg_levels <= 24 && delta > 0 && Rmax > 0, "grid parameters");
     dfta_grid* g = new dfta_grid();
     g->ctx = ctx;
@@ -176,7 +176,7 @@ int dfta_grid_create(dfta_ctx* ctx, int mg_levels, double delta, double Rmax, df
 int dfta_grid_create_uniform(dfta_ctx* ctx, int mg_levels, double Rmax, dfta_grid** out)
 {
     if (!ctx || !out) return DFTA_ERR_INVALID;
-    if (int rc_ = dfta_use(ctx)) return rc_;
+    DFTA_ENTER(ctx);
     DFTA_REQUIRE(ctx, mg_levels >= 3 && mg_levels <= 24 && Rmax > 0, "grid parameters");
     dfta_grid* g = new dfta_grid();
     g->ctx = ctx;

@@ -405,7 +405,7 @@ __device__ void walk_job(dfta::Job& j, const int* __restrict__ count, const doub
             const double e = (hi + lo) / 2;
             const int cn = count[base + h];
             ++j.n_count;
-            j.n_points += trip[base + h];
+            if (trip) j.n_points += trip[base + h];
             const bool bit = !(cn > j.nodes);                        // 1: boe = E
             if (bit) lo = e; else hi = e;
             {
@@ -451,7 +451,7 @@ __device__ void walk_job(dfta::Job& j, const int* __restrict__ count, const doub
             const double e = (hi + lo) / 2;
             const int cn = count[base + h];
             ++j.n_count;
-            j.n_points += trip[base + h];
+            if (trip) j.n_points += trip[base + h];
             const bool bit = (cn < j.nodes);                         // 1: boe = E
             if (bit) lo = e; else hi = e;
             c.advance(bit, pred_bit(j, 1, j.phase_done));
@@ -470,7 +470,7 @@ __device__ void walk_job(dfta::Job& j, const int* __restrict__ count, const doub
         if (!j.haveSgn) {
             const double d0 = u0[base];
             ++j.n_zero;
-            j.n_points += trip[base];
+            if (trip) j.n_points += trip[base];
             j.sgnBottom = d0 > 0;
             j.haveSgn = 1;
         }
@@ -482,7 +482,7 @@ __device__ void walk_job(dfta::Job& j, const int* __restrict__ count, const doub
             const double e = (hi + lo) / 2;
             const double d = u0[base + h];
             ++j.n_zero;
-            j.n_points += trip[base + h];
+            if (trip) j.n_points += trip[base + h];
             ++j.iter3;
             const bool bit = ((d > 0) == (j.sgnBottom != 0));        // 1: BottomEnergy = E
             if (bit) lo = e; else hi = e;
@@ -1126,14 +1126,14 @@ int LevelSolver::run(const double* dV, const double* job_bottom, int run_mode, d
         DFTA_CHECK_LAUNCH(ctx);
         if (stats) DFTA_HIP(ctx, hipEventRecord(ev[0], st));
         rc = dfta_launch_sweep(ctx, g, DFTA_SWEEP_COUNT, d_wave_kind, nwaves, d_tab, d_wave_slot, d_wave_first, d_wave_cnt, d_E,
-                               d_limit, d_start, d_us, d_us1, d_count, d_u0, d_trip, d_counters + 1, g->uniform ? nullptr : d_bounds, d_phi,
+                               d_limit, d_start, d_us, d_us1, d_count, d_u0, stats ? d_trip : nullptr, stats ? d_counters + 1 : nullptr, g->uniform ? nullptr : d_bounds, d_phi,
                                d_istop, d_slot_l);
         if (rc) return rc;
         if (stats) DFTA_HIP(ctx, hipEventRecord(ev[1], st));
         hipLaunchKernelGGL(k_scout, dim3(njobs), dim3(64), 0, st, d_jobs, d_E, d_start, d_u0);
         DFTA_CHECK_LAUNCH(ctx);
         DFTA_HIP(ctx, hipMemsetAsync(d_ndone, 0, sizeof(int), st));
-        hipLaunchKernelGGL(k_walk, dim3((run_chains + 63) / 64), dim3(64), 0, st, d_jobs, d_chains, run_chains, d_count, d_u0, d_phi, d_istop, d_trip, d_tab, N, d_ndone);
+        hipLaunchKernelGGL(k_walk, dim3((run_chains + 63) / 64), dim3(64), 0, st, d_jobs, d_chains, run_chains, d_count, d_u0, d_phi, d_istop, stats ? d_trip : nullptr, d_tab, N, d_ndone);
         DFTA_CHECK_LAUNCH(ctx);
         rc = plan();
         if (rc) return rc;
@@ -1226,7 +1226,7 @@ extern "C" int dfta_solve_levels(dfta_ctx* ctx, const dfta_grid* g, int mode, in
                                  long* issued_sweeps)
 {
     if (!ctx || !g) return DFTA_ERR_INVALID;
-    if (int rc_ = dfta_use(ctx)) return rc_;
+    DFTA_ENTER(ctx);
     DFTA_REQUIRE(ctx, V && bottom0 && n && l && occ && results && nV > 0 && nlevels > 0, "null input");
     DFTA_REQUIRE(ctx, mode == DFTA_LEVELS_CHAINED || mode == DFTA_LEVELS_BATCHED, "mode");
     const int N = g->N;

@@ -1719,7 +1719,7 @@ extern "C" int dfta_numerov_sweeps(dfta_ctx* ctx, const dfta_grid* g, int kind, 
                                    int* count_out, double* u0_out, int* start_out, int* trip_out)
 {
     if (!ctx || !g) return DFTA_ERR_INVALID;
-    if (int rc_ = dfta_use(ctx)) return rc_;
+    DFTA_ENTER(ctx);
     DFTA_REQUIRE(ctx, ntrials >= 0, "negative trial count");
     if (ntrials == 0) return DFTA_OK;                       // empty batch
     DFTA_REQUIRE(ctx, V && l && E && nV > 0, "null input");
@@ -1805,7 +1805,7 @@ extern "C" int dfta_numerov_sweeps_dev(dfta_ctx* ctx, const dfta_grid* g, int ki
                                        int* dCount, double* dU0, int* dStartOut, int* dTrip)
 {
     if (!ctx || !g) return DFTA_ERR_INVALID;
-    if (int rc_ = dfta_use(ctx)) return rc_;
+    DFTA_ENTER(ctx);
     DFTA_REQUIRE(ctx, dV && group_off && group_vidx && group_l && dE && ngroups > 0, "null input");
     const int N = g->N;
     const int ntrials = group_off[ngroups];
@@ -1852,7 +1852,7 @@ extern "C" int dfta_numerov_match(dfta_ctx* ctx, const dfta_grid* g, int boundar
                                   const int* vidx, const int* l, const double* E, double* Psi_out, long* matchPoint_out)
 {
     if (!ctx || !g) return DFTA_ERR_INVALID;
-    if (int rc_ = dfta_use(ctx)) return rc_;
+    DFTA_ENTER(ctx);
     DFTA_REQUIRE(ctx, V && l && E && Psi_out && matchPoint_out && nV > 0 && ntrials >= 0, "null input");
     if (ntrials == 0) return DFTA_OK;
     const int N = g->N;

@@ -61,6 +61,7 @@ struct MgDesc {
     int levels;
     int G;           // workgroups per atom (power of two); 1: the whole solve runs in one workgroup
     int logG;
+    int fuse3;    // visits of three sweeps on staged levels of one workgroup run as ONE fused pass (gs_lds3); 0: $DFTA_POISSON_NOFUSE3
     int nofold;   // DFTA_POISSON_NOFOLD: restriction / prolongation as separate passes even where they could be folded into a staged copy-in
     int kcoop;       // levels 0 .. kcoop-1 are swept by all G workgroups together (256 G lanes), the others by workgroup 0
     int spin_max;    // bound of the group barriers' spin loops (Atom::spin_max)
@@ -210,6 +211,12 @@ __device__ __forceinline__ double exchange_poll(Atom& A, const double* p)
         if (static_cast<unsigned long long>(__double_as_longlong(x)) != kFastSentinel) return x;
         if (++spins > A.spin_max) {      // a lost member must not hang the GPU: raise the group's abort flag
             __hip_atomic_fetch_or(A.ctr, 0x80000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            A.gave_up = true;
+            return 0.0;
+        }
+        // somebody else has already given up on this group (the abort bit of the arrival counter): do not spin out the
+        // whole bound again in every thread at every later exchange
+        if ((spins & 1023) == 0 && (__hip_atomic_load(A.ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 0x80000000u)) {
             A.gave_up = true;
             return 0.0;
         }
@@ -562,6 +569,175 @@ __device__ __forceinline__ double gs_lds(const double* __restrict__ SSbase, doub
     }
     if (lo_g == 0) pp[0] = node0;
     return err2;
+}
+
+// ---- fused visit -------------------------------------------------------------------------------------------------
+// The three sweeps of IterateGaussSeidel(level, errorMin, 3) (PoissonSolver.cpp:66-77) in ONE in-place pass over a part staged in
+// LDS.  Sweep k+1 at node j needs sweep k at node j+1, so the three sweeps run as a software pipeline: at the step with stage-1
+// node tau the lane computes
+//     x1[tau]   = gs(S[tau],   x1[tau-1], x0[tau+1])
+//     x2[tau-1] = gs(S[tau-1], x2[tau-2], x1[tau])
+//     x3[tau-2] = gs(S[tau-2], x3[tau-3], x2[tau-1])
+// with the arithmetic of gs_point2, i.e. exactly what three sequential sweeps compute.  All three stages start kWarm3 nodes in front
+// of the lane's chunk from old values: a start-value error e decays as e b^j in stage 1, (1 + j/4) e b^j in stage 2 (which also
+// feeds on stage 1's error) and (1 + j/4 + j^2/32) e b^j in stage 3, b = (1 + d/2)/2; at j = 112 the third factor is 2^8.7 and
+// b^(112-95) <= 2^-16: a wider margin than the single sweep's 95 nodes.  The lane runs two nodes past its chunk (x1, x2 of the right
+// neighbour's first nodes, from old values read before the barrier).  One LDS read pair per step instead of three, no barrier and --
+// for a part shared by a group -- no exchange between the sweeps.  KST = which sweep's values are stored (3; 1 or 2 when the
+// reference would have stopped early: the caller restores the old values and repeats the pass).
+// Layout as gs_lds: node lo + r of lane tid at (r & (C-1)) * RS + (r >> LOGC) relative to the lane's column; the three nodes
+// behind the chunk of lane NT-1 are rows 0..2 of column NT (a right halo column) unless `last_lane`: then the chunk ends at the
+// level's last node, whose value is xN.  Returns the lane's shares of the three sums of dPhi^2.
+constexpr int kWarm3 = 112;
+template <int LOGC, int RS, int NT, int KST, bool CAREFUL>
+__device__ __forceinline__ void gs_lds3(const double* __restrict__ SSbase, double* __restrict__ PPbase, const int tid, const int lo_g,
+                                        const bool last_lane, const double xN, const double dh, double& e1, double& e2, double& e3)
+{
+    constexpr int C = 1 << LOGC, Cm1 = C - 1, kH = 8, W = kWarm3;
+    static_assert(C >= 4 && C <= 32 && W % (2 * kH) == 0, "fused pass: 4..32 nodes per lane");
+    typedef __attribute__((address_space(3))) double lds_f64;
+    typedef __attribute__((address_space(3))) const double lds_cf64;
+    const bool active = tid < NT;
+    lds_cf64* ps = (lds_cf64*)(SSbase) + tid;
+    lds_f64* pp = (lds_f64*)(PPbase) + tid;
+    asm volatile("" : "+v"(ps), "+v"(pp));
+    auto off = [](int r) constexpr -> int { return (r & Cm1) * RS + (r >> LOGC); };       // any r (arithmetic shift = floor)
+    const int neg_lo = -lo_g;
+    const double Y0 = 2.0 * PPbase[0];          // node 0 of the level (meaningful where a restart can happen at all)
+    double a1 = 0, a2 = 0, a3 = 0;
+    double y1 = 0, y2 = 0, y3 = 0, sA = 0, sB = 0, o0 = 0, x1p = 0, x2p = 0;
+    double xr0 = 0, xr1 = 0, xr2 = 0, sr0 = 0, sr1 = 0;
+    double ax[kH], as[kH], bx[kH], bv[kH];
+    // loads of the batch of 8 steps whose stage-1 nodes are lo + r0 .. lo + r0 + 7 (r0 a multiple of 8): S at the node, old Phi at
+    // the node behind it.  r0 is wave-uniform: one base per array and batch, the rows are instruction offsets.
+    auto load = [&](double (&X)[kH], double (&SV)[kH], const int r0) {
+        const int col = r0 >> LOGC;
+        if constexpr (C <= kH) {
+            lds_cf64* bs = ps + col;
+            lds_cf64* bp = (lds_cf64*)pp + col;
+#pragma unroll
+            for (int q = 0; q < kH; ++q) { SV[q] = bs[off(q)]; X[q] = bp[off(q + 1)]; }
+        } else {
+            const int k0 = r0 & Cm1;
+            lds_cf64* bs = ps + (k0 * RS + col);
+            lds_cf64* bp = (lds_cf64*)pp + (k0 * RS + col);
+#pragma unroll
+            for (int q = 0; q < kH; ++q) SV[q] = bs[q * RS];
+#pragma unroll
+            for (int q = 0; q < kH - 1; ++q) X[q] = bp[(q + 1) * RS];
+            lds_cf64* bw = (k0 + kH == C) ? (lds_cf64*)pp + (col + 1) : bp + kH * RS;     // the next column's first row
+            X[kH - 1] = *bw;
+        }
+    };
+    // warm-up batch: recurrences only
+    auto warm = [&](const double (&X)[kH], const double (&SV)[kH], const int r0) {
+#pragma unroll
+        for (int q = 0; q < kH; ++q) {
+            double t = gs_point2(SV[q], y1, X[q], dh);
+            if (CAREFUL && ((q & (C < kH ? Cm1 : kH - 1)) == 0)) t = (r0 + q == neg_lo) ? Y0 : t;           // stage 1 stands on node 0
+            const double x1 = 0.5 * t;
+            double u = gs_point2(sA, y2, x1, dh);
+            if (CAREFUL && (((q - 1) & (C < kH ? Cm1 : kH - 1)) == 0)) u = (r0 + q - 1 == neg_lo) ? Y0 : u;
+            const double x2 = 0.5 * u;
+            double v = gs_point2(sB, y3, x2, dh);
+            if (CAREFUL && (((q - 2) & (C < kH ? Cm1 : kH - 1)) == 0)) v = (r0 + q - 2 == neg_lo) ? Y0 : v;
+            y1 = t; y2 = u; y3 = v;
+            sB = sA; sA = SV[q];
+        }
+        o0 = X[kH - 1];
+    };
+    // own batch: recurrences, error norms, the store of sweep KST's values
+    auto own = [&](auto FIRST, const double (&X)[kH], const double (&SV)[kH], const int r0) {
+        constexpr bool first = decltype(FIRST)::value;
+        constexpr int nq = C < kH ? C : kH;
+        lds_f64* po = pp + r0 * RS;
+#pragma unroll
+        for (int q = 0; q < nq; ++q) {
+            const double xn = (q == nq - 1) ? ((r0 + nq == C) ? xr0 : X[q]) : X[q];
+            double t = gs_point2(SV[q], y1, xn, dh);
+            if (CAREFUL && first && q == 0) t = (lo_g == 0) ? Y0 : t;
+            const double x1 = 0.5 * t;
+            { const double d = o0 - x1; a1 = __builtin_fma(d, d, a1); }
+            double u = gs_point2(sA, y2, x1, dh);
+            if (CAREFUL && first && q == 1) u = (lo_g == 0) ? Y0 : u;
+            const double x2 = 0.5 * u;
+            if (!(first && q == 0)) { const double d = x1p - x2; a2 = __builtin_fma(d, d, a2); }
+            double v = gs_point2(sB, y3, x2, dh);
+            if (CAREFUL && first && q == 2) v = (lo_g == 0) ? Y0 : v;
+            const double x3 = 0.5 * v;
+            if (!(first && q < 2)) { const double d = x2p - x3; a3 = __builtin_fma(d, d, a3); }
+            if (KST == 1) po[q * RS] = x1;
+            if (KST == 2 && !(first && q == 0)) po[(q - 1) * RS] = x2;
+            if (KST == 3 && !(first && q < 2)) po[(q - 2) * RS] = x3;
+            y1 = t; y2 = u; y3 = v;
+            sB = sA; sA = SV[q];
+            o0 = xn; x1p = x1; x2p = x2;
+        }
+    };
+    if (active) {
+        y1 = 2.0 * pp[off(-W - 1)]; y2 = 2.0 * pp[off(-W - 2)]; y3 = 2.0 * pp[off(-W - 3)];
+        sA = ps[off(-W - 1)]; sB = ps[off(-W - 2)];
+        load(ax, as, -W);
+        for (int r0 = -W; r0 < 0; r0 += 2 * kH) {
+            load(bx, bv, r0 + kH);
+            __builtin_amdgcn_sched_barrier(0);
+            warm(ax, as, r0);
+            load(ax, as, r0 + 2 * kH);                  // the last one fetches the first own batch (still old values)
+            __builtin_amdgcn_sched_barrier(0);
+            warm(bx, bv, r0 + kH);
+        }
+        x1p = 0.5 * y1; x2p = 0.5 * y2;
+        // old values behind the chunk: the right neighbour overwrites them after the barrier
+        xr0 = last_lane ? xN : pp[off(C)];
+        xr1 = pp[off(C + 1)]; xr2 = pp[off(C + 2)];
+        sr0 = ps[off(C)]; sr1 = ps[off(C + 1)];
+    }
+    // all reads of other lanes' old values are done
+    if constexpr (NT == 64) { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+    else __syncthreads();
+    if (active) {
+        if constexpr (C <= kH) {
+            own(std::true_type{}, ax, as, 0);
+        } else {
+            for (int r0 = 0; r0 < C; r0 += 2 * kH) {
+                load(bx, bv, r0 + kH);
+                __builtin_amdgcn_sched_barrier(0);
+                if (r0 == 0) own(std::true_type{}, ax, as, 0); else own(std::false_type{}, ax, as, r0);
+                if (r0 + 2 * kH < C) load(ax, as, r0 + 2 * kH);
+                __builtin_amdgcn_sched_barrier(0);
+                own(std::false_type{}, bx, bv, r0 + kH);
+            }
+        }
+        if (KST >= 2) {
+            // two steps behind the chunk: x1 (x2) of the right neighbour's first node(s) from the old values read above; a chunk that
+            // ends at the level's last node finds the boundary value there
+            const double Y_N = 2.0 * xN;
+            double t = gs_point2(sr0, y1, xr1, dh);
+            t = last_lane ? Y_N : t;
+            double x1 = 0.5 * t;
+            double u = gs_point2(sA, y2, x1, dh);
+            double x2 = 0.5 * u;
+            { const double d = x1p - x2; a2 = __builtin_fma(d, d, a2); }
+            if (KST == 2) pp[Cm1 * RS] = x2;
+            if (KST == 3) {
+                double v = gs_point2(sB, y3, x2, dh);
+                double x3 = 0.5 * v;
+                { const double d = x2p - x3; a3 = __builtin_fma(d, d, a3); }
+                pp[(C - 2) * RS] = x3;
+                y1 = t; y2 = u; y3 = v; sB = sA; sA = sr0; x2p = x2;
+                t = gs_point2(sr1, y1, xr2, dh);
+                x1 = 0.5 * t;
+                u = gs_point2(sA, y2, x1, dh);
+                u = last_lane ? Y_N : u;
+                x2 = 0.5 * u;
+                v = gs_point2(sB, y3, x2, dh);
+                x3 = 0.5 * v;
+                { const double d = x2p - x3; a3 = __builtin_fma(d, d, a3); }
+                pp[Cm1 * RS] = x3;
+            }
+        }
+    }
+    e1 = a1; e2 = a2; e3 = a3;
 }
 
 // One sweep of an LDS-resident level by ONE thread, in the reference's order.  The loads of a batch (right neighbours,
@@ -943,7 +1119,7 @@ __device__ __forceinline__ double iterate_gs(const MgDesc& D, Atom& A, int l, do
         const bool fold_r = (l > 0 && A.pend_r == l);         // restriction from level l-1 computed while staging (do_restrict)
         A.pend = 0;
         A.pend_r = 0;
-        { PROF_T0();
+        auto stage_in = [&]() { PROF_T0();
         if (fold_r) {
             // PoissonSolver::Restrict (PoissonSolver.cpp:126-157) from level l-1 (same workgroup, same lane columns: coarse node
             // (t, k) sits under the fine nodes (t, 2k-1 .. 2k+1)) straight into the staging memory: Phi starts from 0, the
@@ -999,11 +1175,47 @@ __device__ __forceinline__ double iterate_gs(const MgDesc& D, Atom& A, int l, do
             if (tid == 0) PP[L.n - 1] = G0[L.n - 1];
         }
         __syncthreads();
-        PROF_ADD(5, l); }
+        PROF_ADD(5, l); };
+        stage_in();
         const int lo_g = tid << L.logC;
         double err = 1E10;
         int done = 0;
         PROF_T0();
+        bool fused_done = false;
+        if (D.fuse3 && iterno == 3 && L.logC >= 2) {
+            // the whole visit as one fused pass (gs_lds3); if the reference would have stopped after the first or the second sweep
+            // (rare: err < errorMin), the level is staged again and the visit runs sweep by sweep below
+            double f1, f2, f3;
+            const bool lastl = tid == kThreads - 1;
+            const double xN = PP[L.n - 1];
+            const bool careful = (__builtin_amdgcn_readfirstlane(lo_g) <= kWarm3);
+#define DFTA_GS3(LC) do { if (careful) gs_lds3<LC, kThreads, kThreads, 3, true>(SS, PP, tid, lo_g, lastl, xN, dh, f1, f2, f3); \
+                          else gs_lds3<LC, kThreads, kThreads, 3, false>(SS, PP, tid, lo_g, lastl, xN, dh, f1, f2, f3); } while (0)
+            switch (L.logC) {
+                case 2:  DFTA_GS3(2); break;
+                case 3:  DFTA_GS3(3); break;
+                case 4:  DFTA_GS3(4); break;
+                default: DFTA_GS3(5); break;
+            }
+#undef DFTA_GS3
+            for (int off = 32; off > 0; off >>= 1) { f1 += __shfl_xor(f1, off); f2 += __shfl_xor(f2, off); f3 += __shfl_xor(f3, off); }
+            __syncthreads();
+            if ((tid & 63) == 0) { red[tid >> 6] = f1; red[4 + (tid >> 6)] = f2; red[8 + (tid >> 6)] = f3; }
+            __syncthreads();
+            const double e1 = sqrt((red[0] + red[1]) + (red[2] + red[3]));
+            const double e2 = sqrt((red[4] + red[5]) + (red[6] + red[7]));
+            const double e3 = sqrt((red[8] + red[9]) + (red[10] + red[11]));
+            if (!(e1 < errorMin) && !(e2 < errorMin)) {
+                err = e3;
+                done = 3;
+                *nsweeps += 3;
+                fused_done = true;
+            } else {
+                __syncthreads();
+                stage_in();
+            }
+        }
+        if (!fused_done)
         for (int i = 0; i < iterno; ++i) {
             double err2;
             switch (L.logC) {
@@ -1963,7 +2175,7 @@ extern "C" {
 int dfta_poisson_create(dfta_ctx* ctx, const dfta_grid* g, int batch, dfta_poisson** out)
 {
     if (!ctx || !g || !out) return DFTA_ERR_INVALID;
-    if (int rc = dfta_use(ctx)) return rc;
+    DFTA_ENTER(ctx);
     return poisson_create_impl(ctx, g, batch, -1, out);
 }
 
@@ -2012,6 +2224,7 @@ static int poisson_create_impl(dfta_ctx* ctx, const dfta_grid* g, int batch, int
     if (D.kcoop == 0) logG = 0;
     D.logG = logG;
     D.nofold = getenv("DFTA_POISSON_NOFOLD") ? 1 : 0;
+    D.fuse3 = getenv("DFTA_POISSON_NOFUSE3") ? 0 : 1;
     D.G = 1 << logG;
     long off = kPad, soff = 0;
     double d = g->delta;                       // PoissonSolver.cpp:21-26 (0 on a uniform grid: PoissonSolver(levels), DFTAtom.cpp:89)
@@ -2127,7 +2340,7 @@ int dfta_poisson_solve(dfta_poisson* p, const int* Z, const double* density, dou
 {
     if (!p) return DFTA_ERR_INVALID;
     dfta_ctx* ctx = p->ctx;
-    if (int rc_ = dfta_use(ctx)) return rc_;
+    DFTA_ENTER(ctx);
     DFTA_REQUIRE(ctx, Z && density && U, "null input");
     const int N = p->g->N, B = p->batch;
     hipStream_t st = ctx->stream;
@@ -2155,7 +2368,7 @@ int dfta_poisson_solve_dev(dfta_poisson* p, const int* dZ, const double* dDensit
 {
     if (!p) return DFTA_ERR_INVALID;
     DFTA_REQUIRE(p->ctx, dZ && dDensity && dU, "null input");
-    if (int rc = dfta_use(p->ctx)) return rc;
+    DFTA_ENTER(p->ctx);
     // synchronises: the group barriers' abort flag is inspected after every solve (and the solve repeated with one
     // workgroup per atom if it was raised), so a DFTA_OK always means a completed solve
     int rc = dfta_poisson_solve_launch(p, dZ, dDensity, dU, nullptr, nullptr, nullptr);
@@ -2177,8 +2390,9 @@ int dfta_poisson_level_size(const dfta_poisson* p, int lvl)
 int dfta_poisson_set_level(dfta_poisson* p, int lvl, const double* Phi, const double* Src)
 {
     if (!p) return DFTA_ERR_INVALID;
+    if (p->degraded) return dfta_poisson_set_level(p->fallback, lvl, Phi, Src);     // the solves run on the fallback's storage
     dfta_ctx* ctx = p->ctx;
-    if (int rc_ = dfta_use(ctx)) return rc_;
+    DFTA_ENTER(ctx);
     DFTA_REQUIRE(ctx, lvl >= 0 && lvl < p->D.levels, "level");
     const Lvl& L = p->D.lv[lvl];
     std::vector<double> tmp(L.n);
@@ -2200,8 +2414,9 @@ int dfta_poisson_set_level(dfta_poisson* p, int lvl, const double* Phi, const do
 int dfta_poisson_get_level(dfta_poisson* p, int lvl, double* Phi, double* Src)
 {
     if (!p) return DFTA_ERR_INVALID;
+    if (p->degraded) return dfta_poisson_get_level(p->fallback, lvl, Phi, Src);
     dfta_ctx* ctx = p->ctx;
-    if (int rc_ = dfta_use(ctx)) return rc_;
+    DFTA_ENTER(ctx);
     DFTA_REQUIRE(ctx, lvl >= 0 && lvl < p->D.levels, "level");
     const Lvl& L = p->D.lv[lvl];
     std::vector<double> tmp(L.n);
@@ -2244,8 +2459,9 @@ static int launch_unit(dfta_poisson* p, int op, int lvl, int sweeps, double* dOu
 
 static int unit_op(dfta_poisson* p, int op, int lvl, int sweeps, double* out_host, int nout)
 {
+    if (p->degraded) return unit_op(p->fallback, op, lvl, sweeps, out_host, nout);
     dfta_ctx* ctx = p->ctx;
-    if (int rc_ = dfta_use(ctx)) return rc_;
+    DFTA_ENTER(ctx);
     hipStream_t st = ctx->stream;
     DevBuf<double> dOut;
     DFTA_HIP(ctx, dOut.alloc(std::max(nout, 1)));
@@ -2256,7 +2472,7 @@ static int unit_op(dfta_poisson* p, int op, int lvl, int sweeps, double* out_hos
     DFTA_HIP(ctx, hipMemcpyAsync(p->h_cur.data(), p->d_cur, sizeof(int) * kMaxLevels, hipMemcpyDeviceToHost, st));
     if (out_host && nout > 0) DFTA_HIP(ctx, hipMemcpyAsync(out_host, dOut.p, sizeof(double) * nout, hipMemcpyDeviceToHost, st));
     DFTA_HIP(ctx, hipStreamSynchronize(st));
-    return DFTA_OK;
+    return check_groups(p);          // a member lost at a barrier of a unit launch is an error, not a silent wrong answer
 }
 
 int dfta_poisson_gauss_seidel(dfta_poisson* p, int lvl, int sweeps, double* err_out)
@@ -2268,8 +2484,9 @@ int dfta_poisson_gauss_seidel(dfta_poisson* p, int lvl, int sweeps, double* err_
 int dfta_poisson_iterate_gs(dfta_poisson* p, int lvl, double errorMin, int iterno, double* err_out, int* sweeps_out)
 {
     if (!p) return DFTA_ERR_INVALID;
+    if (p->degraded) return dfta_poisson_iterate_gs(p->fallback, lvl, errorMin, iterno, err_out, sweeps_out);
     dfta_ctx* ctx = p->ctx;
-    if (int rc_ = dfta_use(ctx)) return rc_;
+    DFTA_ENTER(ctx);
     DFTA_REQUIRE(ctx, lvl >= 0 && lvl < p->D.levels && iterno >= 1 && iterno <= 1024, "level/iterno");
     hipStream_t st = ctx->stream;
     DevBuf<double> dOut;
@@ -2285,7 +2502,7 @@ int dfta_poisson_iterate_gs(dfta_poisson* p, int lvl, double errorMin, int itern
     DFTA_HIP(ctx, hipStreamSynchronize(st));
     if (err_out) *err_out = out[0];
     if (sweeps_out) *sweeps_out = (int)out[1];
-    return DFTA_OK;
+    return check_groups(p);
 }
 // PoissonSolver::FullCycle (PoissonSolver.h:89-124) on atom 0's level storage: Initialize from the level-0 source that
 // the last solve (or dfta_poisson_set_level) left there and from the boundary values, FMG ramp, up to 100 V-cycles
@@ -2293,8 +2510,9 @@ int dfta_poisson_full_cycle(dfta_poisson* p, double lowBoundary, double highBoun
                             double* err_out, int* vcycles_out)
 {
     if (!p) return DFTA_ERR_INVALID;
+    if (p->degraded) return dfta_poisson_full_cycle(p->fallback, lowBoundary, highBoundary, errorMin, errorMinLast, err_out, vcycles_out);
     dfta_ctx* ctx = p->ctx;
-    if (int rc_ = dfta_use(ctx)) return rc_;
+    DFTA_ENTER(ctx);
     hipStream_t st = ctx->stream;
     DevBuf<double> dOut;
     DFTA_HIP(ctx, dOut.alloc(4));
@@ -2310,7 +2528,7 @@ int dfta_poisson_full_cycle(dfta_poisson* p, double lowBoundary, double highBoun
     DFTA_HIP(ctx, hipStreamSynchronize(st));
     if (err_out) *err_out = io[0];
     if (vcycles_out) *vcycles_out = (int)io[1];
-    return DFTA_OK;
+    return check_groups(p);
 }
 
 int dfta_poisson_restrict(dfta_poisson* p, int lvl)

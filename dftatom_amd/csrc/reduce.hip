@@ -22,7 +22,59 @@ __global__ __launch_bounds__(128) void k_integrate(const double* __restrict__ va
     if (threadIdx.x == 0) out[blockIdx.x] = r;
 }
 
+// Attainable HBM bandwidth of this device: the second denominator of every roofline figure (SURVEY.md 8d asks for the spec
+// figure AND a stream measurement on the box).  Plain grid-stride kernels, 16 bytes per lane and access, buffers far larger
+// than the 256 MB Infinity Cache.
+__global__ __launch_bounds__(256) void k_stream_copy(const double2* __restrict__ a, double2* __restrict__ c, size_t n2)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += stride) c[i] = a[i];
+}
+__global__ __launch_bounds__(256) void k_stream_triad(double2* __restrict__ a, const double2* __restrict__ b, const double2* __restrict__ c,
+                                                      double s, size_t n2)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += stride) {
+        const double2 x = b[i], y = c[i];
+        a[i] = make_double2(x.x + s * y.x, x.y + s * y.y);
+    }
+}
+
 }  // namespace
+
+extern "C" int dfta_ctx_measure_hbm(dfta_ctx* ctx, size_t doubles_per_array, int reps, double* copy_gbs, double* triad_gbs)
+{
+    if (!ctx) return DFTA_ERR_INVALID;
+    DFTA_ENTER(ctx);
+    DFTA_REQUIRE(ctx, doubles_per_array >= (1u << 20) && doubles_per_array % 2 == 0 && reps >= 1 && reps <= 1000, "measure_hbm arguments");
+    const size_t n = doubles_per_array, n2 = n / 2;
+    DevBuf<double> A, B, Cc;
+    DFTA_HIP(ctx, A.alloc(n)); DFTA_HIP(ctx, B.alloc(n)); DFTA_HIP(ctx, Cc.alloc(n));
+    hipStream_t st = ctx->stream;
+    DFTA_HIP(ctx, hipMemsetAsync(A.p, 0, n * sizeof(double), st));
+    DFTA_HIP(ctx, hipMemsetAsync(B.p, 0, n * sizeof(double), st));
+    DFTA_HIP(ctx, hipMemsetAsync(Cc.p, 0, n * sizeof(double), st));
+    const int blocks = ctx->num_cu * 8;
+    double best[2] = {0, 0};
+    for (int which = 0; which < 2; ++which) {
+        for (int r = 0; r < reps + 1; ++r) {            // first repetition: warm-up
+            DFTA_HIP(ctx, hipEventRecord(ctx->ev[0], st));
+            if (which == 0) hipLaunchKernelGGL(k_stream_copy, dim3(blocks), dim3(256), 0, st, reinterpret_cast<const double2*>(A.p), reinterpret_cast<double2*>(Cc.p), n2);
+            else hipLaunchKernelGGL(k_stream_triad, dim3(blocks), dim3(256), 0, st, reinterpret_cast<double2*>(A.p), reinterpret_cast<const double2*>(B.p),
+                                    reinterpret_cast<const double2*>(Cc.p), 3.0, n2);
+            DFTA_CHECK_LAUNCH(ctx);
+            DFTA_HIP(ctx, hipEventRecord(ctx->ev[1], st));
+            DFTA_HIP(ctx, hipEventSynchronize(ctx->ev[1]));
+            float ms = 0;
+            DFTA_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
+            const double gbs = (which == 0 ? 2.0 : 3.0) * n * sizeof(double) / (ms * 1e-3) / 1e9;
+            if (r > 0 && gbs > best[which]) best[which] = gbs;
+        }
+    }
+    if (copy_gbs) *copy_gbs = best[0];
+    if (triad_gbs) *triad_gbs = best[1];
+    return DFTA_OK;
+}
 
 int dfta_launch_integrate_ordered(dfta_ctx* ctx, int rule, double delta, const double* dVals, int n, int nvec, size_t stride, double* dOut)
 {
@@ -44,7 +96,7 @@ int dfta_integral_shape_ok(int rule, int sz)
 extern "C" int dfta_integrate(dfta_ctx* ctx, int rule, double delta, const double* values, int sz, double* result)
 {
     if (!ctx) return DFTA_ERR_INVALID;
-    if (int rc_ = dfta_use(ctx)) return rc_;
+    DFTA_ENTER(ctx);
     DFTA_REQUIRE(ctx, values && result && sz >= 3 && rule >= 0 && rule <= DFTA_INT_ROMBERG, "integrate arguments");
     DFTA_REQUIRE(ctx, dfta_integral_shape_ok(rule, sz), "size");
     hipStream_t st = ctx->stream;

@@ -259,7 +259,7 @@ int dfta_scf_create_ex(dfta_ctx* ctx, const dfta_grid* g, int lsda, int natoms, 
                        int tree_depth, const dfta_scf_options* options, dfta_scf** out)
 {
     if (!ctx || !g || !out) return DFTA_ERR_INVALID;
-    if (int rc_ = dfta_use(ctx)) return rc_;
+    DFTA_ENTER(ctx);
     DFTA_REQUIRE(ctx, natoms >= 1 && Z && alpha >= 0 && alpha <= 1, "scf arguments");
     dfta_scf_options opt = {DFTA_INT_SIMPSON38, DFTA_XC_VWN, DFTA_AUFBAU_REFERENCE};
     if (options) opt = *options;
@@ -359,7 +359,7 @@ int dfta_scf_step(dfta_scf* s, dfta_step_stats* stats)
 {
     if (!s) return DFTA_ERR_INVALID;
     dfta_ctx* ctx = s->ctx;
-    if (int rc_ = dfta_use(ctx)) return rc_;
+    DFTA_ENTER(ctx);
     const dfta_grid* g = s->g;
     const int N = g->N, natoms = s->natoms;
     hipStream_t st = ctx->stream;
@@ -456,7 +456,7 @@ int dfta_scf_get_energies(dfta_scf* s, dfta_energies* e, int* finished)
 {
     if (!s) return DFTA_ERR_INVALID;
     dfta_ctx* ctx = s->ctx;
-    if (int rc_ = dfta_use(ctx)) return rc_;
+    DFTA_ENTER(ctx);
     for (int a = 0; a < s->natoms; ++a) {      // h_atoms is current: every step ends with its copy
         if (e) e[a] = s->h_atoms[a].e;
         if (finished) finished[a] = s->h_atoms[a].finished;
@@ -498,7 +498,7 @@ int dfta_scf_get_levels(dfta_scf* s, int atom, int spin, int* n, int* l, int* oc
 {
     if (!s) return DFTA_ERR_INVALID;
     dfta_ctx* ctx = s->ctx;
-    if (int rc_ = dfta_use(ctx)) return rc_;
+    DFTA_ENTER(ctx);
     DFTA_REQUIRE(ctx, atom >= 0 && atom < s->natoms && spin >= 0 && spin < s->nspin, "atom/spin");
     const std::vector<dfta::Job>& jobs = s->h_jobs;
     DFTA_REQUIRE(ctx, !jobs.empty(), "no SCF step has run yet");
@@ -519,7 +519,7 @@ int dfta_scf_get_array(dfta_scf* s, int atom, int which, double* out)
 {
     if (!s) return DFTA_ERR_INVALID;
     dfta_ctx* ctx = s->ctx;
-    if (int rc_ = dfta_use(ctx)) return rc_;
+    DFTA_ENTER(ctx);
     DFTA_REQUIRE(ctx, atom >= 0 && atom < s->natoms && out, "atom/out");
     const int N = s->g->N;
     const double* src = nullptr;
@@ -541,7 +541,7 @@ int dfta_scf_get_records_dev(dfta_scf* s, double* dRecords)
 {
     if (!s || !dRecords) return DFTA_ERR_INVALID;
     dfta_ctx* ctx = s->ctx;
-    if (int rc_ = dfta_use(ctx)) return rc_;
+    DFTA_ENTER(ctx);
     DFTA_HIP(ctx, hipMemcpyAsync(dRecords, s->d_records, sizeof(double) * (size_t)s->natoms * DFTA_RECORD_DOUBLES,
                                  hipMemcpyDeviceToDevice, ctx->stream));
     return DFTA_OK;

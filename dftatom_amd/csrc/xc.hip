@@ -169,7 +169,7 @@ int dfta_launch_vwn_lsda(dfta_ctx* ctx, const double* dNa, const double* dNb, si
 extern "C" int dfta_vwn_lda(dfta_ctx* ctx, const double* n, size_t sz, double* vexc, double* eexcdif)
 {
     if (!ctx) return DFTA_ERR_INVALID;
-    if (int rc_ = dfta_use(ctx)) return rc_;
+    DFTA_ENTER(ctx);
     DFTA_REQUIRE(ctx, n && (vexc || eexcdif), "null input");
     if (sz == 0) return DFTA_OK;
     hipStream_t st = ctx->stream;
@@ -191,7 +191,7 @@ extern "C" int dfta_vwn_lsda(dfta_ctx* ctx, const double* na, const double* nb, 
                              double* eexcdif)
 {
     if (!ctx) return DFTA_ERR_INVALID;
-    if (int rc_ = dfta_use(ctx)) return rc_;
+    DFTA_ENTER(ctx);
     DFTA_REQUIRE(ctx, na && nb, "null input");
     if (sz == 0) return DFTA_OK;
     hipStream_t st = ctx->stream;
@@ -216,7 +216,7 @@ extern "C" int dfta_vwn_lsda(dfta_ctx* ctx, const double* na, const double* nb, 
 extern "C" int dfta_chachiyo_lda(dfta_ctx* ctx, int improved, const double* n, size_t sz, double* vexc, double* eexcdif)
 {
     if (!ctx) return DFTA_ERR_INVALID;
-    if (int rc_ = dfta_use(ctx)) return rc_;
+    DFTA_ENTER(ctx);
     DFTA_REQUIRE(ctx, n && (vexc || eexcdif), "null input");
     if (sz == 0) return DFTA_OK;
     hipStream_t st = ctx->stream;

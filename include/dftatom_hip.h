@@ -57,6 +57,10 @@ int         dfta_ctx_last_kernel_ms(dfta_ctx* ctx, float* ms);
 int         dfta_ctx_set_sweep_kernel(dfta_ctx* ctx, int which);
 /* number of compute units / name of the device behind the context (reporting only) */
 int         dfta_ctx_device_info(const dfta_ctx* ctx, int* num_cu, char* name, int name_cap);
+/* Measurement aid (no counterpart in the reference): attainable HBM bandwidth of the device, GB/s, from a copy (c = a) and a
+ * triad (a = b + s c) kernel over arrays of `doubles_per_array` fp64 each (>= 2^20, even; use >= 2^27 to defeat the 256 MB
+ * Infinity Cache), best of `reps` timed repetitions after one warm-up.  bench.py quotes it next to the 8 TB/s spec figure. */
+int         dfta_ctx_measure_hbm(dfta_ctx* ctx, size_t doubles_per_array, int reps, double* copy_gbs, double* triad_gbs);
 
 /* ---- grid ------------------------------------------------------------------------------------------
  * Replaces NumerovFunctionNonUniformGrid's constructor and position/exp evaluations (Numerov.h:76-101,

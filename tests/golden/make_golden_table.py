@@ -6,7 +6,8 @@
     python tests/golden/make_golden_table.py l20                 -> l20.npz + l20_meta.json   (config 5)
     python tests/golden/make_golden_table.py uniform             -> uniform.npz + uniform_meta.json
 
-table: DFT::DFTAtom::CalculateNonUniformLDA(Z, 17, 0.5, 50, 1e-4) for Z = 1..86, run to the reference's own stop
+table: DFT::DFTAtom::CalculateNonUniformLDA(Z, 17, 0.5, 50, 1e-4) for Z = 1..118 (OptionsFrame.cpp:153 allows Z <= 118; round 3
+       added 87..118: Ac/Th/Pa/U/Np/Cm/Lr exceptions of AufbauPrinciple.h:101-117), run to the reference's own stop
        (17-digit console protocol of oracle/ref_hp.cpp); stored per atom: number of steps, Finished flag, the
        first two steps and the last one (eigenvalues + the five printed energies).  About 3 CPU-hours, spread
        over a process pool.
@@ -48,13 +49,13 @@ def one_atom(Z):
     return rec
 
 
-def table(jobs):
+def table(jobs, zmax=118):
     path = os.path.join(HERE, "periodic_table_L17.json")
     done = {}
     if os.path.exists(path):
         with open(path) as f:
             done = json.load(f)
-    todo = [Z for Z in range(86, 0, -1) if str(Z) not in done]      # heavy atoms first: better packing
+    todo = [Z for Z in range(zmax, 0, -1) if str(Z) not in done]      # heavy atoms first: better packing
     with mp.Pool(jobs) as pool:
         for rec in pool.imap_unordered(one_atom, todo):
             done[str(rec["Z"])] = rec

@@ -1,0 +1,162 @@
+"""Front-end parity of dftatom_cli: argument validation like the options dialog (CPU), and -- on the
+GPU -- the console protocol of the compiled reference for an LSDA run (method 1, "Alpha:/Beta:" lines, DFTAtom.cpp:1011-1021),
+the DFTAtom.ini keys of Options.cpp:42-67 and the --integrator switch.
+
+Golden text: tests/golden/cli_protocol.json (tests/golden/make_golden_cli.py: DFT::DFTAtom::Calculate* of the compiled
+reference, six printed decimals).  Printed values are compared to 1.5e-6 (one unit of the last printed digit plus the 1e-9
+relative the runs agree to); the step at which "Finished!" appears is round-off noise and is only bounded.
+"""
+import json
+import os
+import re
+import subprocess
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+EXE = os.path.join(ROOT, "dftatom_amd", "compat", "dftatom_cli")
+NUM = re.compile(r"-?\d+\.\d+")
+
+
+def _exe():
+    if not os.path.exists(EXE):
+        subprocess.check_call(["make", "-C", os.path.dirname(EXE)], stdout=subprocess.DEVNULL)
+    return EXE
+
+
+def _run(*args, **kw):
+    return subprocess.run([_exe(), *[str(a) for a in args]], capture_output=True, text=True, timeout=900, **kw)
+
+
+# ---- CPU: validation happens before anything touches a device -------------------------------------------------------
+@pytest.mark.parametrize("args,msg", [
+    ((0, 14, 0.5, 25, 0.0005, 0), "Z must be"),
+    ((119, 14, 0.5, 25, 0.0005, 0), "Z must be"),
+    ((18, 9, 0.5, 25, 0.0005, 0), "between 10 and 20 levels"),          # OptionsFrame.cpp:46-50
+    ((18, 21, 0.5, 25, 0.0005, 0), "between 10 and 20 levels"),
+    ((18, 14, 0.5, 0.5, 0.0005, 0), "MaxR"),                            # OptionsFrame.cpp:160 (1..90)
+    ((18, 14, 0.5, 91, 0.0005, 0), "MaxR"),
+    ((18, 14, 0.5, 25, 0, 0), "deltaGrid"),
+    ((18, 14, 1.5, 25, 0.0005, 0), "alpha"),
+    ((18, 14, 0.5, 25, 0.0005, 4), "method"),
+    ((18, 14, 0.5, 25, 0.0005, -1), "method"),
+])
+def test_cli_rejects_what_the_options_dialog_rejects(args, msg):
+    r = _run(*args)
+    assert r.returncode == 2 and msg in r.stderr and r.stdout == "", (r.returncode, r.stderr)
+
+
+def test_cli_ini_validation_and_usage(tmp_path):
+    ini = tmp_path / "DFTAtom.ini"
+    ini.write_text("/Z=18\n/MultigridLevels=25\n/MaxR=25\n/deltaGrid=0.0005\n/alpha=0.5\n/Method=0\n")
+    r = _run("--ini", ini)
+    assert r.returncode == 2 and "levels" in r.stderr
+    r = _run("--ini", tmp_path / "missing.ini")
+    assert r.returncode == 2 and "cannot read" in r.stderr
+    r = _run()
+    assert r.returncode == 2 and "usage" in r.stderr
+    r = _run(18, 14, 0.5, 25, 0.0005, 0, "--integrator=gauss")
+    assert r.returncode == 2 and "unknown integrator" in r.stderr
+
+
+# ---- GPU --------------------------------------------------------------------------------------------------------------
+def _golden(tag):
+    with open(os.path.join(HERE, "golden", "cli_protocol.json")) as f:
+        return json.load(f)[tag]
+
+
+def _steps(text):
+    """-> (banner, [lines of step k], tail lines after the last separator)"""
+    lines = text.splitlines()
+    steps, cur = [], None
+    for ln in lines[1:]:
+        if ln.startswith("Step:"):
+            cur = [ln]
+            steps.append(cur)
+        elif cur is not None:
+            cur.append(ln)
+    return lines[0], steps
+
+
+def _same_line(a, b, tol=1.5e-6):
+    if NUM.sub("#", a) != NUM.sub("#", b):
+        return False
+    return all(abs(float(x) - float(y)) <= tol + 1e-9 * abs(float(y)) for x, y in zip(NUM.findall(a), NUM.findall(b)))
+
+
+def _compare_protocol(got, want, nsteps):
+    gb, gs = _steps(got)
+    wb, ws = _steps(want)
+    assert gb == wb
+    for k in range(nsteps):
+        g = [ln for ln in gs[k] if ln.strip() and not ln.startswith("*")]
+        w = [ln for ln in ws[k] if ln.strip() and not ln.startswith("*")]
+        assert len(g) >= len(w) - 3, (k, g, w)
+        for a, b in zip(g, w):
+            if b.startswith(("Finished", "Alpha", "Beta")):
+                break
+            assert _same_line(a, b), (k, a, b)
+    return gs, ws
+
+
+@pytest.mark.gpu
+def test_cli_lsda_protocol_vs_compiled_reference():
+    """method 1 (CalculateNonUniformLSDA), reference's chained brackets: banner, untagged 'Energy 1s:' lines for both spins
+    (SURVEY C.8), energies, 'Finished!', and the Alpha:/Beta: configuration lines, against the compiled reference's text"""
+    ref = _golden("N_LSDA_L12")
+    r = _run(*ref["args"], "chained")
+    assert r.returncode == 0, r.stderr[-2000:]
+    gs, ws = _compare_protocol(r.stdout, ref["text"], 12)
+    assert abs(len(gs) - len(ws)) <= 6                       # the stop step is noise
+    gl = [ln.rstrip() for ln in r.stdout.strip().splitlines()]
+    wl = [ln.rstrip() for ln in ref["text"].strip().splitlines()]
+    assert gl[-2:] == wl[-2:] == ["Alpha: 1s1 2s1 2p3", "Beta: 1s1 2s1"]
+    assert "Finished!" in gl
+    # the last printed energies agree to the printed precision
+    ge = [ln for ln in gl if ln.startswith("Etotal")][-1]
+    we = [ln for ln in wl if ln.startswith("Etotal")][-1]
+    assert _same_line(ge, we, 2.5e-6), (ge, we)
+
+
+@pytest.mark.gpu
+def test_cli_ini_file_equals_positional_arguments(tmp_path):
+    """the keys wxFileConfig persists (Options.cpp:42-67: /Z /MultigridLevels /MaxR /deltaGrid /alpha /Method) drive the same run
+    as the positional form, and that run follows the compiled reference's protocol"""
+    ref = _golden("Ne_LDA_L12")
+    Z, L, alpha, R, d, method = ref["args"]
+    ini = tmp_path / "DFTAtom.ini"
+    ini.write_text("[General]\n/Z=%d\n/MultigridLevels=%d\n/MaxR=%g\n/deltaGrid=%g\n/alpha=%g\n/Method=%d\n" % (Z, L, R, d, alpha, method))
+    a = _run("--ini", ini, "chained")
+    b = _run(Z, L, alpha, R, d, method, "chained")
+    assert a.returncode == 0 and b.returncode == 0, (a.stderr[-1000:], b.stderr[-1000:])
+    assert a.stdout == b.stdout
+    _compare_protocol(a.stdout, ref["text"], 10)
+    assert a.stdout.strip().splitlines()[-1].strip() == "1s2 2s2 2p6"
+    # keys without the leading slash and in another order, defaults for what is missing (Options.cpp:42-49: alpha 0.5, Method 0)
+    ini.write_text("deltaGrid = %g\nMaxR=%g\nZ=%d\nMultigridLevels=%d\n" % (d, R, Z, L))
+    c = _run("--ini", ini, "chained")
+    assert c.returncode == 0 and c.stdout == b.stdout
+
+
+@pytest.mark.gpu
+def test_cli_integrator_switch():
+    """--integrator=romberg (README.md:81 names Romberg; the reference's code calls Simpson 3/8): same SCF, energies that agree
+    with the Simpson-3/8 run to quadrature accuracy but are not the same bits; simpson38 spelled out equals the default"""
+    ref = _golden("Ne_LDA_L12")
+    base = _run(*ref["args"])
+    s38 = _run(*ref["args"], "--integrator=simpson38")
+    rom = _run(*ref["args"], "--integrator=romberg")
+    boo = _run(*ref["args"], "--integrator=boole")
+    assert base.returncode == 0 and s38.returncode == 0 and rom.returncode == 0 and boo.returncode == 0
+    assert s38.stdout == base.stdout
+
+    def last_etotal(txt):
+        ln = [x for x in txt.splitlines() if x.startswith("Etotal")][-1]
+        return [float(v) for v in NUM.findall(ln)]
+    e0, er, eb = last_etotal(base.stdout), last_etotal(rom.stdout), last_etotal(boo.stdout)
+    for a, b in zip(e0, er):
+        assert abs(a - b) <= 2e-5 * max(1.0, abs(a)), (e0, er)
+    for a, b in zip(e0, eb):
+        assert abs(a - b) <= 2e-5 * max(1.0, abs(a)), (e0, eb)
+    assert "Finished!" in rom.stdout and rom.stdout.strip().splitlines()[-1].strip() == "1s2 2s2 2p6"

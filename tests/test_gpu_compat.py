@@ -111,6 +111,30 @@ def test_bench_two_ranks_control_flow():
 
 
 @pytest.mark.gpu
+def test_bench_gpus_flag_starts_the_ranks_itself():
+    """`python bench.py --gpus 2` with no launcher around it (the form the driver uses for N = 1) must start two ranks itself
+    and print one line with n_gpus = 2 (here both on device 0 over gloo: DFTA_BENCH_SHARED_GPU=1); without the shared-GPU test
+    mode it must refuse with a non-zero exit code when the box has fewer devices than ranks asked for."""
+    import json
+    import subprocess
+    import sys
+    import torch
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                         env=dict(env, DFTA_BENCH_SHARED_GPU="1"), capture_output=True, text=True, timeout=600, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "replicas x2" and d["value"] > 0
+    if torch.cuda.device_count() < 2:
+        bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                             env=env, capture_output=True, text=True, timeout=600, cwd=root)
+        assert bad.returncode != 0 and "only" in bad.stderr and not [ln for ln in bad.stdout.splitlines() if ln.startswith("{")]
+
+
+@pytest.mark.gpu
 def test_periodic_table_two_ranks_equal_one_rank(tmp_path):
     """examples/periodic_table.py (BASELINE config 4) for Z = 1..8 at 16385 nodes: two ranks (sharing device 0 on this box,
     records gathered over gloo) must return, atom for atom, the bits of the single-process run -- shards do not interact."""

@@ -138,8 +138,13 @@ def test_periodic_table_batch_vs_reference(ctx, grid17):
         |dE/E| < 1e-11 test within 100 steps although their energies have long settled), so step counts and Finished flags
         are reported, not compared."""
     table = json.load(open(os.path.join(HERE, "golden", "periodic_table_L17.json")))
-    Zs = sorted(int(z) for z in table)
-    assert Zs == list(range(1, 87)), "tests/golden/periodic_table_L17.json must hold Z = 1..86"
+    have = set(int(z) for z in table)
+    Zs = []
+    while len(Zs) + 1 in have:
+        Zs.append(len(Zs) + 1)
+    # Z = 1..86 is BASELINE config 4; round 3 extended the fixture to the front end's full range Z <= 118 (OptionsFrame.cpp:153;
+    # Ac/Th/Pa/U/Np/Cm/Lr exceptions of AufbauPrinciple.h:101-117)
+    assert len(Zs) >= 86, "tests/golden/periodic_table_L17.json must hold at least Z = 1..86"
     per_step, conv = {}, {}
     # steps 0 and 1 on the reference's own bisection path (bracket hand-over from level to level, DFTAtom.cpp:541)
     scf = D.Scf(ctx, grid17, Zs, lsda=False, levels_mode=D.LEVELS_CHAINED)
@@ -175,8 +180,8 @@ def test_periodic_table_batch_vs_reference(ctx, grid17):
         for key in ("lv", "etot", "comp"):
             conv[key] = max(conv.get(key, 0.0), c[key])
     fin_ref = np.array([table[str(z)]["finished"] for z in Zs])
-    print("periodic table: 86 atoms in one batch, %d steps of the batch; Finished here %d, in the reference %d (both %d)"
-          % (nsteps, int(fin.sum()), int(fin_ref.sum()), int((fin_ref & fin.astype(bool)).sum())))
+    print("periodic table: %d atoms in one batch, %d steps of the batch; Finished here %d, in the reference %d (both %d)"
+          % (len(Zs), nsteps, int(fin.sum()), int(fin_ref.sum()), int((fin_ref & fin.astype(bool)).sum())))
     print("  first two steps: max |dE_level| / |E| %.2e, energies %.2e rel" % (per_step["lvrel"], per_step["en"]))
     print("  final states   : eigenvalue excess %.2e Ha, Etotal %.2e, components %.2e; worst Etotal at Z=%d, worst component at Z=%d"
           % (conv["lv"], conv["etot"], conv["comp"], max(worst)[3], max(worst, key=lambda w: w[1])[3]))
