@@ -61,6 +61,8 @@ struct MgDesc {
     int levels;
     int G;           // workgroups per atom (power of two); 1: the whole solve runs in one workgroup
     int logG;
+    int res_kres;    // > 0: resident group (k_poisson_solve_res): levels 0 .. res_kres-1 live in the members' LDS; the level layout is that of G = 1
+    int res_logC0;   // log2(nodes per lane) of level 0 in a member's stretch (kResG members x kResNT lanes)
     int fuse3;    // visits of three sweeps on staged levels of one workgroup run as ONE fused pass (gs_lds3); 0: $DFTA_POISSON_NOFUSE3
     int nofold;   // DFTA_POISSON_NOFOLD: restriction / prolongation as separate passes even where they could be folded into a staged copy-in
     int kcoop;       // levels 0 .. kcoop-1 are swept by all G workgroups together (256 G lanes), the others by workgroup 0
@@ -113,6 +115,7 @@ struct Atom {
     double* xchg;           // [3][G][kXchg] boundary nodes of the fast exchange, sentinel-filled before the launch
     int pend;               // > 0: the prolongation from this level is folded into the staged copy-in of the level below it
     int pend_r;             // > 0: the restriction TO this level is folded into its staged copy-in
+    int pend_z;             // > 0: this level's Phi is zero and its source complete in global memory (written by the members of a resident group): staged as such
     int spin_max;           // polls of a group barrier before the waiting member gives up and raises the abort flag
     bool gave_up;           // this thread has timed out on a slot of group_sum_fast: it does not wait for that member again
     __device__ __forceinline__ int lane() const { return g * kThreads + static_cast<int>(threadIdx.x); }
@@ -1117,10 +1120,21 @@ __device__ __forceinline__ double iterate_gs(const MgDesc& D, Atom& A, int l, do
         const int C1 = 1 << L.logC;
         const bool fold = (A.pend == l + 1);                  // prolongation from level l+1 taken in while staging (do_prolong)
         const bool fold_r = (l > 0 && A.pend_r == l);         // restriction from level l-1 computed while staging (do_restrict)
+        const bool fold_z = (A.pend_z == l);                  // resident group: the members have written the source, Phi = 0
         A.pend = 0;
         A.pend_r = 0;
+        A.pend_z = 0;
         auto stage_in = [&]() { PROF_T0();
-        if (fold_r) {
+        if (fold_z) {
+            for (int k0 = 0; k0 < C1; k0 += 8) {
+                double b[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) b[q] = Sg[(k0 + q) * kThreads + tid];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { SS[(k0 + q) * kThreads + tid] = b[q]; PP[(k0 + q) * kThreads + tid] = 0; }
+            }
+            if (tid == 0) PP[L.n - 1] = 0;
+        } else if (fold_r) {
             // PoissonSolver::Restrict (PoissonSolver.cpp:126-157) from level l-1 (same workgroup, same lane columns: coarse node
             // (t, k) sits under the fine nodes (t, 2k-1 .. 2k+1)) straight into the staging memory: Phi starts from 0, the
             // source also goes to the level's global array for the visit on the way back up.  Arithmetic of restrict_to.
@@ -1886,6 +1900,663 @@ __device__ __forceinline__ double run_cycles(const MgDesc& D, Atom& A, int first
     return err;
 }
 
+// ==== resident shared levels =======================================================================================
+// The grouped solve above stages a shared level from global memory for every visit and writes it back: per V-cycle and
+// shared level two copies through the coherent level behind the XCDs' L2s, three exchanges and a full barrier (70 % of a
+// single-atom solve was hand-over).  Here a group of kResG member workgroups keeps its stretch of EVERY shared
+// level in LDS for the whole solve (node range [m, m+1) * 128 * C_l of level l: 128 lanes x C_l nodes, C_l = 32, 16, 8, 4 at 131073
+// nodes), with halo columns: the 115 nodes in front of the stretch (what the fused visit's warm-up reads) and up to ten nodes
+// behind it.  A visit is ONE fused pass (gs_lds3) followed by ONE exchange in sentinel-validated slots that carries the three
+// partial sums of dPhi^2, the new values of the nodes the neighbours keep in their halos and -- on the way down -- the tail
+// of the next level's source, so that restriction and prolongation are local (PoissonSolver.cpp:110-157 on own nodes and
+// halos).  One more workgroup per atom, the coarse workgroup, runs the levels below (<= 8193 nodes) with the code above and
+// meets the members at the two hand-overs of a cycle, through the global arrays of the first coarse level.
+#ifdef DFTA_POISSON_PROF
+__device__ unsigned long long g_rprof[2 * 8 * 8];    // [role][category][level & 7], ticks of member 0 / of the coarse workgroup of atom 0
+#define RPROF_T0() const long long rprof_t0 = clock64()
+#define RPROF_ADD(cat, lvl) do { if (threadIdx.x == 0) R.prof[(cat) * 8 + ((lvl) & 7)] += clock64() - rprof_t0; } while (0)   /* LDS: a global read-modify-write costs microseconds */
+#else
+#define RPROF_T0()
+#define RPROF_ADD(cat, lvl)
+#endif
+constexpr int kResNT = 128;                    // sweeping lanes of a member (its first two waves; all four move data)
+constexpr int kResG = 32;                      // members per atom
+constexpr int kResWG = kResG + 1;              // + the coarse workgroup (participant kResG of every exchange)
+constexpr int kResX = 272;                     // payload doubles per participant and buffer
+constexpr int kResMaxShared = 4;
+constexpr int kResXTail = 0, kResXSrc = 128, kResXHead = 256, kResXS0 = 266;
+__host__ __device__ constexpr size_t res_slot_doubles() { return (size_t)3 * kResWG * 4 + (size_t)3 * kResWG * kResX; }
+
+template <int LOGC> struct ResLay {
+    static constexpr int C = 1 << LOGC;
+    static constexpr int H = (kWarm3 + 3 + C - 1) / C;       // halo columns in front of the stretch
+    static constexpr int HN = H * C;                         // = nodes in the left halo
+    static constexpr int RS = H + kResNT + 1;                // + one column behind it
+    static constexpr int N = kResNT * C;                     // own nodes
+    // nodes behind the stretch that are kept up to date: what the fused pass reads (3 of Phi, 2 of the source) on the last
+    // shared level, and what the restriction of those needs on the levels above it
+    static constexpr int NRP = LOGC >= 5 ? 10 : (LOGC == 4 ? 6 : (LOGC == 3 ? 4 : 3));
+    static constexpr int NRS = LOGC >= 5 ? 9 : (LOGC == 4 ? 5 : (LOGC == 3 ? 3 : 2));
+    static constexpr int doubles = C * RS;
+    // node j relative to the member's first node (-HN <= j < N + C) -> index relative to column 0, row 0
+    __device__ static __forceinline__ int off(int j) { return (j & (C - 1)) * RS + (j >> LOGC); }
+};
+static_assert(ResLay<5>::HN <= 128 && ResLay<4>::HN <= 128 && ResLay<3>::HN <= 128 && ResLay<2>::HN <= 128, "payload layout");
+
+struct Res {
+    int role;                 // 0: member, 1: the coarse workgroup
+    int m;                    // member index
+    int kres;                 // shared levels 0 .. kres-1
+    int logC0;                // log2(nodes per lane) on level 0
+    double* shm;              // the member's LDS
+    int pat[kResMaxShared];   // column 0 of level l's Phi array inside it (the source follows C * RS doubles later); read through
+    int sat[kResMaxShared];   // res_pp / res_ss with compile-time indices only -- a dynamic index would move the struct to scratch
+    double* xs;               // [3][kResWG][4] sums
+    double* xp;               // [3][kResWG][kResX] payload
+    unsigned seq;             // exchanges so far
+#ifdef DFTA_POISSON_PROF
+    unsigned long long* prof; // [8][8] ticks per category and level, in LDS
+#endif
+};
+
+__device__ __forceinline__ double* res_pp(const Res& R, const int l)
+{
+    return R.shm + (l == 0 ? R.pat[0] : (l == 1 ? R.pat[1] : (l == 2 ? R.pat[2] : R.pat[3])));
+}
+__device__ __forceinline__ double* res_ss(const Res& R, const int l)
+{
+    return R.shm + (l == 0 ? R.sat[0] : (l == 1 ? R.sat[1] : (l == 2 ? R.sat[2] : R.sat[3])));
+}
+__device__ __forceinline__ void res_store(double* p, double v)
+{
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double* res_mine(const Res& R, int idx)     // slot idx of this participant's payload in the NEXT exchange
+{
+    return R.xp + ((size_t)(R.seq % 3u) * kResWG + (R.role ? kResG : R.m)) * kResX + idx;
+}
+
+// One exchange between the kResWG participants of an atom.  Everybody publishes four doubles (members: the partial sums of a
+// visit; the coarse workgroup: zeros and, in [3], the number it hands over) and receives their totals (added in a fixed tree
+// order, the same for everybody, so that all participants take the same decisions).  Members also receive up to two payload
+// values per thread from their neighbours' slots (published before the call with res_store(res_mine())): value v = tid and
+// v = tid + 256 with  v < 128: tail of the left neighbour (nt), 128 <= v < 256: source tail of the left neighbour (ns),
+// 256 <= v: head of the right neighbour (nh).  want_cb (coarse workgroup): thread 64 + m, m >= 1, receives in cb[] the four
+// values around the boundary between members m-1 and m (last node of m-1, first two nodes and first source value of m).
+// FENCED: release before publishing, acquire after the last arrival (plain stores / loads of global level storage around it).
+template <bool FENCED>
+__device__ __forceinline__ void res_exchange(Atom& A, Res& R, const double m0, const double m1, const double m2, const double m3,
+                                             const int nt, const int ns, const int nh, const int cb_hn, double* red,
+                                             double (&tot)[4], double& r0, double& r1, double (&cb)[4])
+{
+    const unsigned s = R.seq++;
+    const int b = s % 3u, tid = threadIdx.x;
+    const int me = R.role ? kResG : R.m;
+    double* slots = R.xs + (size_t)b * kResWG * 4;
+    const double* pay = R.xp + (size_t)b * kResWG * kResX;
+    if (tid == 0) {
+        if (FENCED) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        res_store(slots + me * 4 + 0, m0); res_store(slots + me * 4 + 1, m1);
+        res_store(slots + me * 4 + 2, m2); res_store(slots + me * 4 + 3, m3);
+    }
+    const double* p0 = nullptr;
+    const double* p1 = nullptr;
+    if (R.role == 0) {
+        if (tid < 128) { if (R.m > 0 && tid < nt) p0 = pay + (size_t)(R.m - 1) * kResX + tid; }
+        else { if (R.m > 0 && tid - 128 < ns) p0 = pay + (size_t)(R.m - 1) * kResX + tid; }
+        if (tid < nh && R.m < kResG - 1) p1 = pay + (size_t)(R.m + 1) * kResX + kResXHead + tid;
+    }
+    const double* pc[4] = {nullptr, nullptr, nullptr, nullptr};
+    if (R.role == 1 && cb_hn > 0 && tid > 64 && tid < 64 + kResG) {
+        const int m = tid - 64;
+        pc[0] = pay + (size_t)(m - 1) * kResX + kResXTail + cb_hn - 1;
+        pc[1] = pay + (size_t)m * kResX + kResXHead;
+        pc[2] = pay + (size_t)m * kResX + kResXHead + 1;
+        pc[3] = pay + (size_t)m * kResX + kResXS0;
+    }
+    auto ld = [](const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    auto is_sent = [](double x) { return static_cast<unsigned long long>(__double_as_longlong(x)) == kFastSentinel; };
+    // Up to ten values per thread.  Every round re-issues the loads of ALL values that have not arrived yet together (one round
+    // trip per round, not per value); a lost participant must not hang the GPU: after spin_max rounds the group's abort flag is
+    // raised (and honoured at once by everybody who sees it), the host repeats the solve with one workgroup per atom.
+    const double sentv = __longlong_as_double(static_cast<long long>(kFastSentinel));
+    double q[4] = {0, 0, 0, 0}, v0 = 0, v1 = 0, c4[4] = {0, 0, 0, 0};
+    const bool sums = tid < kResWG;             // first wave
+    const double* pq = slots + (sums ? tid : 0) * 4;
+    if (sums) { q[0] = sentv; q[1] = sentv; q[2] = sentv; q[3] = sentv; }
+    if (p0) v0 = sentv;
+    if (p1) v1 = sentv;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) if (pc[k]) c4[k] = sentv;
+    for (int spins = A.gave_up ? A.spin_max : 0;; ++spins) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) if (is_sent(q[k])) q[k] = ld(pq + k);
+        if (is_sent(v0)) v0 = ld(p0);
+        if (is_sent(v1)) v1 = ld(p1);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) if (is_sent(c4[k])) c4[k] = ld(pc[k]);
+        const bool missing = is_sent(q[0]) || is_sent(q[1]) || is_sent(q[2]) || is_sent(q[3]) || is_sent(v0) || is_sent(v1) ||
+                             is_sent(c4[0]) || is_sent(c4[1]) || is_sent(c4[2]) || is_sent(c4[3]);
+        if (!missing) break;
+        bool give_up = spins > A.spin_max;
+        if (!give_up && (spins & 255) == 255) give_up = (__hip_atomic_load(A.ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 0x80000000u) != 0;
+        if (give_up) {
+            __hip_atomic_fetch_or(A.ctr, 0x80000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            A.gave_up = true;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { if (is_sent(q[k])) q[k] = 0; if (is_sent(c4[k])) c4[k] = 0; }
+            if (is_sent(v0)) v0 = 0;
+            if (is_sent(v1)) v1 = 0;
+            break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+    if (tid < 64) {
+        const double extra = __shfl(q[3], kResG);             // the coarse workgroup's fourth value
+        if (tid >= kResG) q[3] = 0;
+        for (int off = 32; off > 0; off >>= 1) {
+            q[0] += __shfl_xor(q[0], off); q[1] += __shfl_xor(q[1], off); q[2] += __shfl_xor(q[2], off); q[3] += __shfl_xor(q[3], off);
+        }
+        if (tid == 0) {
+            if (FENCED) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            red[20] = q[0]; red[21] = q[1]; red[22] = q[2]; red[23] = extra;
+        }
+    }
+    __syncthreads();
+    tot[0] = red[20]; tot[1] = red[21]; tot[2] = red[22]; tot[3] = red[23];
+    // everybody has published exchange s, i.e. has read what it needed of exchange s-1: this participant's part of that buffer
+    // is reset (by the threads that will store into it again in exchange s+2)
+    {
+        const double sent = __longlong_as_double(static_cast<long long>(kFastSentinel));
+        const int bo = (s + 2u) % 3u;
+        if (tid < 4) res_store(R.xs + ((size_t)bo * kResWG + me) * 4 + tid, sent);
+        double* mine = R.xp + ((size_t)bo * kResWG + me) * kResX;
+        res_store(mine + tid, sent);
+        if (tid + 256 < kResX) res_store(mine + tid + 256, sent);
+    }
+    r0 = v0; r1 = v1;
+    cb[0] = c4[0]; cb[1] = c4[1]; cb[2] = c4[2]; cb[3] = c4[3];
+    __syncthreads();                                           // red[] may be reused
+}
+
+__device__ __forceinline__ double res_restrict_value(double s0, double pm, double p0, double pq, double dc)
+{
+    return 4. * (s0 + pm - 2. * p0 + pq) - dc * (pq - pm);     // PoissonSolver.cpp:126-157, the expression of restrict_to
+}
+
+// IterateGaussSeidel(l, errorMin, 3) on a shared level by a member.  down: the caller restricts to level l+1 next.
+template <int LOGC>
+__device__ __forceinline__ double res_visit(const MgDesc& D, Atom& A, Res& R, const int l, const double errorMin, const bool down,
+                                            double* red, long* nsweeps)
+{
+    using Y = ResLay<LOGC>;
+    using Yc = ResLay<(LOGC > 2 ? LOGC - 1 : 2)>;
+    constexpr int C = Y::C, RS = Y::RS;
+    const Lvl L = D.lv[l];
+    const double dh = L.d * 0.5;
+    const int tid = threadIdx.x;
+    double* PP = res_pp(R, l);
+    double* SS = res_ss(R, l);
+    const bool active = tid < kResNT;
+    const int lo_g = (R.m * kResNT + tid) << LOGC;
+    const bool lastl = (R.m == kResG - 1) && tid == kResNT - 1;
+    const double xN = PP[Y::off(Y::N)];
+    const bool careful = R.m == 0 && (__builtin_amdgcn_readfirstlane(lo_g) <= kWarm3);
+    const bool to_shared = down && (l + 1 < R.kres);
+    const bool to_coarse = down && (l + 1 == R.kres);
+    // the old values of the stretch, in case the reference stops after the first or second sweep: parked in the level's (otherwise
+    // unused) second global copy -- stores that nobody waits for; a thread reads back only what it wrote itself
+    double* __restrict__ park = A.phi1 + L.off + (size_t)R.m * Y::N;
+    RPROF_T0();
+    if (active) {
+#pragma unroll
+        for (int k = 0; k < C; ++k) park[k * kResNT + tid] = PP[k * RS + tid];
+    }
+    double f1 = 0, f2 = 0, f3 = 0;
+    if (careful) gs_lds3<LOGC, RS, kResNT, 3, true>(SS, PP, tid, lo_g, lastl, xN, dh, f1, f2, f3);
+    else gs_lds3<LOGC, RS, kResNT, 3, false>(SS, PP, tid, lo_g, lastl, xN, dh, f1, f2, f3);
+    if (!active) { f1 = 0; f2 = 0; f3 = 0; }
+    for (int off = 32; off > 0; off >>= 1) { f1 += __shfl_xor(f1, off); f2 += __shfl_xor(f2, off); f3 += __shfl_xor(f3, off); }
+    __syncthreads();                                           // the pass's stores are visible
+    if ((tid & 63) == 0 && active) { red[tid >> 6] = f1; red[4 + (tid >> 6)] = f2; red[8 + (tid >> 6)] = f3; }
+    // what the neighbours (and, at the hand-over, the coarse workgroup) need of this stretch
+    auto publish = [&]() {
+        if (tid < Y::HN) res_store(res_mine(R, kResXTail + tid), PP[Y::off(Y::N - Y::HN + tid)]);
+        if (tid < Y::NRP) res_store(res_mine(R, kResXHead + tid), PP[Y::off(tid)]);
+        if (tid == kResXS0 - 256) res_store(res_mine(R, kResXS0), SS[Y::off(0)]);
+        if constexpr (LOGC > 2) {
+            if (to_shared && tid >= 128 && tid - 128 < Yc::HN) {
+                // the tail of the next level's source: PoissonSolver::Restrict on nodes that lie inside this stretch
+                const int jc = Yc::N - Yc::HN + (tid - 128), j = 2 * jc;
+                res_store(res_mine(R, kResXSrc + tid - 128),
+                          res_restrict_value(SS[Y::off(j)], PP[Y::off(j - 1)], PP[Y::off(j)], PP[Y::off(j + 1)], D.lv[l + 1].d));
+            }
+        }
+        if (to_coarse && active) {
+            // the first level of the coarse workgroup: this stretch's part of its source goes to global memory (the exchange
+            // that follows is fenced); the node under the boundary to the left neighbour is the coarse workgroup's
+            const Lvl Lk = D.lv[l + 1];
+#pragma unroll
+            for (int k = 0; k < C / 2; ++k) {
+                if (tid == 0 && k == 0) continue;
+                const int j = 2 * (tid * (C / 2) + k);
+                const int ic = (R.m * Y::N) / 2 + tid * (C / 2) + k;
+                A.src[Lk.off + addr(Lk, ic)] = res_restrict_value(SS[Y::off(j)], PP[Y::off(j - 1)], PP[Y::off(j)], PP[Y::off(j + 1)], Lk.d);
+            }
+        }
+    };
+    RPROF_ADD(0, l);
+    { RPROF_T0();
+    publish();
+    __syncthreads();                                           // red[] written
+    RPROF_ADD(1, l); }
+    const double s1 = (red[0] + red[1]), s2 = (red[4] + red[5]), s3 = (red[8] + red[9]);
+    double tot[4], r0, r1, cb[4];
+    const int ns = to_shared ? Yc::HN : 0;
+    { RPROF_T0();
+    if (to_coarse) res_exchange<true>(A, R, s1, s2, s3, 0.0, Y::HN, ns, Y::NRP, 0, red, tot, r0, r1, cb);
+    else res_exchange<false>(A, R, s1, s2, s3, 0.0, Y::HN, ns, Y::NRP, 0, red, tot, r0, r1, cb);
+    RPROF_ADD(2, l); }
+    const double e1 = sqrt(tot[0]), e2 = sqrt(tot[1]), e3 = sqrt(tot[2]);
+    const int K = (e1 < errorMin) ? 1 : ((e2 < errorMin) ? 2 : 3);
+    if (K < 3) {
+        // the reference stops after sweep K: back to the old values (the halos have not been touched yet), the same pass
+        // storing sweep K's values, and the exchange once more
+        RPROF_T0();
+        if (active) {
+#pragma unroll
+            for (int k = 0; k < C; ++k) PP[k * RS + tid] = park[k * kResNT + tid];
+        }
+        __syncthreads();
+        if (K == 1) gs_lds3<LOGC, RS, kResNT, 1, true>(SS, PP, tid, lo_g, lastl, xN, dh, f1, f2, f3);
+        else gs_lds3<LOGC, RS, kResNT, 2, true>(SS, PP, tid, lo_g, lastl, xN, dh, f1, f2, f3);
+        __syncthreads();
+        publish();
+        if (to_coarse) res_exchange<true>(A, R, 0.0, 0.0, 0.0, 0.0, Y::HN, ns, Y::NRP, 0, red, tot, r0, r1, cb);
+        else res_exchange<false>(A, R, 0.0, 0.0, 0.0, 0.0, Y::HN, ns, Y::NRP, 0, red, tot, r0, r1, cb);
+        RPROF_ADD(7, l);
+    }
+    // the neighbours' new values go into the halos
+    { RPROF_T0();
+    if (R.m > 0) {
+        if (tid < Y::HN) PP[Y::off(-Y::HN + tid)] = r0;
+        if constexpr (LOGC > 2) {
+            if (to_shared && tid >= 128 && tid - 128 < Yc::HN) res_ss(R, l + 1)[Yc::off(-Yc::HN + tid - 128)] = r0;
+        }
+    }
+    if (R.m < kResG - 1 && tid < Y::NRP) PP[Y::off(Y::N + tid)] = r1;
+    __syncthreads();
+    RPROF_ADD(3, l); }
+    *nsweeps += K;
+    return K == 1 ? e1 : (K == 2 ? e2 : e3);
+}
+
+// The coarse workgroup's part in a member visit: it follows the exchange(s) to take the same decisions; at the hand-over it
+// completes the source of its first level (the nodes under the members' boundaries) and marks it for a zero-Phi stage-in.
+__device__ __forceinline__ double res_visit_passive(const MgDesc& D, Atom& A, Res& R, const int l, const double errorMin, const bool down,
+                                                    double* red, long* nsweeps)
+{
+    const bool to_coarse = down && (l + 1 == R.kres);
+    const int logC = R.logC0 - l;
+    const int C = 1 << logC;
+    const int hn = ((kWarm3 + 3 + C - 1) / C) * C;
+    double tot[4], r0, r1, cb[4];
+    RPROF_T0();
+    if (to_coarse) res_exchange<true>(A, R, 0.0, 0.0, 0.0, 0.0, 0, 0, 0, hn, red, tot, r0, r1, cb);
+    else res_exchange<false>(A, R, 0.0, 0.0, 0.0, 0.0, 0, 0, 0, 0, red, tot, r0, r1, cb);
+    RPROF_ADD(0, l);
+    const double e1 = sqrt(tot[0]), e2 = sqrt(tot[1]), e3 = sqrt(tot[2]);
+    const int K = (e1 < errorMin) ? 1 : ((e2 < errorMin) ? 2 : 3);
+    if (K < 3) {
+        if (to_coarse) res_exchange<true>(A, R, 0.0, 0.0, 0.0, 0.0, 0, 0, 0, hn, red, tot, r0, r1, cb);
+        else res_exchange<false>(A, R, 0.0, 0.0, 0.0, 0.0, 0, 0, 0, 0, red, tot, r0, r1, cb);
+    }
+    if (to_coarse) {
+        const Lvl Lk = D.lv[l + 1];
+        const int tid = threadIdx.x;
+        const int per = (kResNT << logC) / 2;                  // coarse nodes per member
+        if (tid > 64 && tid < 64 + kResG) {
+            const int m = tid - 64;
+            A.src[Lk.off + addr(Lk, m * per)] = res_restrict_value(cb[3], cb[0], cb[1], cb[2], Lk.d);
+        }
+        if (tid == 0) { A.src[Lk.off + addr(Lk, 0)] = 0; A.src[Lk.off + addr(Lk, Lk.n - 1)] = 0; }
+        A.pend_z = l + 1;
+        __syncthreads();
+    }
+    *nsweeps += 0;      // the members count the sweeps of the shared levels
+    return K == 1 ? e1 : (K == 2 ? e2 : e3);
+}
+
+// PoissonSolver::Restrict from shared level lc-1 (LOGC nodes per lane) to shared level lc on the member's stretch: own nodes and the
+// nodes behind it; the nodes in front of it arrived with the last exchange.  Phi of the coarse level starts from zero everywhere.
+template <int LOGC>
+__device__ __forceinline__ void res_restrict_local(const MgDesc& D, Res& R, const int lc)
+{
+    using Yf = ResLay<LOGC>;
+    using Yc = ResLay<LOGC - 1>;
+    const double* __restrict__ Pf = res_pp(R, lc - 1);
+    const double* __restrict__ Sf = res_ss(R, lc - 1);
+    double* __restrict__ Pc = res_pp(R, lc);
+    double* __restrict__ Sc = res_ss(R, lc);
+    const double dc = D.lv[lc].d;
+    const int tid = threadIdx.x, t = tid & (kResNT - 1), half = tid >> 7;
+#pragma unroll
+    for (int kk = 0; kk < Yc::C / 2; ++kk) {
+        const int k = half * (Yc::C / 2) + kk;
+        const int jc = t * Yc::C + k, j = 2 * jc;
+        double sv = res_restrict_value(Sf[Yf::off(j)], Pf[Yf::off(j - 1)], Pf[Yf::off(j)], Pf[Yf::off(j + 1)], dc);
+        if (R.m == 0 && jc == 0) sv = 0;                       // coarse node 0
+        Sc[k * Yc::RS + t] = sv;
+        Pc[k * Yc::RS + t] = 0;
+    }
+    // behind the stretch (for the last member only the level's last node: source 0)
+    if (tid < Yc::NRS) {
+        const int jc = Yc::N + tid, j = 2 * jc;
+        double sv = 0;
+        if (R.m < kResG - 1) sv = res_restrict_value(Sf[Yf::off(j)], Pf[Yf::off(j - 1)], Pf[Yf::off(j)], Pf[Yf::off(j + 1)], dc);
+        Sc[Yc::off(jc)] = sv;
+    }
+    if (tid < Yc::C) Pc[Yc::off(Yc::N + tid)] = 0;
+    for (int i = tid; i < Yc::HN; i += kThreads) Pc[Yc::off(-Yc::HN + i)] = 0;
+    __syncthreads();
+}
+
+// PoissonSolver::Prolong (PoissonSolver.cpp:110-123) into shared level lf (LOGC nodes per lane) on the member's stretch and its halos.
+// coarse(i): Phi of coarse node i RELATIVE to the member's first coarse node.
+template <int LOGC, typename CF>
+__device__ __forceinline__ void res_prolong(Res& R, const int lf, CF coarse)
+{
+    using Y = ResLay<LOGC>;
+    double* __restrict__ Pf = res_pp(R, lf);
+    const int tid = threadIdx.x, t = tid & (kResNT - 1), half = tid >> 7;
+    auto corr = [&](int j) -> double {                         // fine node j relative to the stretch
+        if ((j & 1) == 0) return coarse(j >> 1);
+        return 0.5 * (coarse((j - 1) >> 1) + coarse((j + 1) >> 1));
+    };
+#pragma unroll 4
+    for (int kk = 0; kk < Y::C / 2; ++kk) {
+        const int k = half * (Y::C / 2) + kk;
+        Pf[k * Y::RS + t] += corr(t * Y::C + k);
+    }
+    if (R.m > 0) for (int i = tid; i < Y::HN; i += kThreads) Pf[Y::off(-Y::HN + i)] += corr(-Y::HN + i);
+    if (tid < Y::NRP && (R.m < kResG - 1 || tid == 0)) Pf[Y::off(Y::N + tid)] += corr(Y::N + tid);
+    __syncthreads();
+}
+
+// shared levels of a member at the start of a solve (PoissonSolver.h:55-74, PoissonSolver.cpp:80-103): Phi = 0, Source_l[p] =
+// 4 Source_{l-1}[2p] = 4^l Source_0[2^l p] (exact scalings) on own nodes and halos, straight from the density
+template <int LOGC>
+__device__ __forceinline__ void res_init_level(const MgDesc& D, Atom& A, Res& R, const int l, const double* __restrict__ rho,
+                                               const double* __restrict__ r, const double* __restrict__ psrc, const int src_all)
+{
+    using Y = ResLay<LOGC>;
+    double* PP = res_pp(R, l);
+    double* SS = res_ss(R, l);
+    const int n = D.lv[l].n, N0 = D.lv[0].n;
+    const int a = R.m * Y::N;
+    const Lvl L0 = D.lv[0];
+    for (int idx = threadIdx.x; idx < Y::C * Y::RS; idx += kThreads) {
+        const int row = idx / Y::RS, col = idx % Y::RS - Y::H;
+        const int i = a + col * Y::C + row;                    // node of level l
+        double sv = 0;
+        if (l == 0) {
+            if (i >= 0 && i < N0) {
+                sv = r[i];
+                if (src_all || (i > 0 && i < N0 - 1)) sv *= psrc[i] * rho[i];
+                // level 0 of the global storage: the source for the unit hooks (dfta_poisson_full_cycle repeats the cycle on it)
+                if (col >= 0 && col < kResNT) A.src[L0.off + addr(L0, i)] = sv;
+                else if (i == N0 - 1) A.src[L0.off + addr(L0, i)] = sv;
+            }
+        } else if (i > 0 && i < n - 1) {
+            const int i0 = i << l;
+            sv = r[i0];
+            sv *= psrc[i0] * rho[i0];
+            for (int q = 0; q < l; ++q) sv = 4 * sv;
+        }
+        PP[row * Y::RS + col] = 0;
+        SS[row * Y::RS + col] = sv;
+    }
+}
+
+// the coarse workgroup's levels at the start of a solve
+__device__ __forceinline__ void res_init_coarse(const MgDesc& D, Atom& A, const Res& R, const double* __restrict__ rho,
+                                                const double* __restrict__ r, const double* __restrict__ psrc, const double lowB, const double highB)
+{
+    A.cur = 0;
+    for (int l = R.kres; l < D.levels; ++l) {
+        const Lvl L = D.lv[l];
+        for (int idx = threadIdx.x; idx < L.n; idx += kThreads) {
+            const int p = node_of(L, idx);
+            double sv = 0;
+            if (p > 0 && p < L.n - 1) {
+                const int i0 = p << l;
+                sv = r[i0];
+                sv *= psrc[i0] * rho[i0];
+                for (int q = 0; q < l; ++q) sv = 4 * sv;
+            }
+            A.src_of(L)[idx] = sv;
+            A.cur_phi(l, L)[idx] = 0;
+        }
+    }
+    __syncthreads();
+    const int cl = D.levels - 1;
+    if (threadIdx.x == 0) {
+        double* Pc = A.cur_phi(cl, D.lv[cl]);
+        Pc[addr(D.lv[cl], 0)] = lowB;
+        Pc[addr(D.lv[cl], D.lv[cl].n - 1)] = highB;
+    }
+    __syncthreads();
+}
+
+#define DFTA_RES_LEVEL(lc, CALL)                     \
+    switch (lc) {                                    \
+        case 5: { constexpr int LC = 5; CALL; } break; \
+        case 4: { constexpr int LC = 4; CALL; } break; \
+        case 3: { constexpr int LC = 3; CALL; } break; \
+        default: { constexpr int LC = 2; CALL; } break; \
+    }
+
+// PoissonSolver::FullCycle (PoissonSolver.h:89-124) for both roles of a resident group: the leg structure of run_cycles, every
+// operation carried out by whoever owns the level (members: levels < kres, coarse workgroup: the others), the two roles meeting
+// in the exchanges of the members' visits and at the hand-over from the first coarse level back to the last shared one.
+__device__ __forceinline__ double res_cycles(const MgDesc& D, Atom& A, Res& R, const int max_vcycles, const double errorMin,
+                                             const double errorMinLast, double* red, Counters& c)
+{
+    const int last = D.levels - 1, kres = R.kres;
+    const int nramp = D.levels - 2 > 0 ? D.levels - 2 : 0;
+    const bool coarse = R.role == 1;
+    double err = 0;
+    bool cs_skip = false;
+    for (int step = 0;; ++step) {
+        int from, to, iterno = 3;
+        double emin = errorMin;
+        bool vleg_down = false;
+        if (step == 0) { from = to = last; iterno = 15; }
+        else if (step <= 2 * nramp) {
+            const int q = (step - 1) >> 1;
+            const int i = D.levels - 2 - q;
+            if ((step - 1) & 1) { from = i; to = last; } else { from = last; to = i; }
+        } else if (step == 2 * nramp + 1) { from = last; to = 0; emin = errorMinLast; }
+        else {
+            emin = errorMinLast;
+            if ((step - (2 * nramp + 2)) & 1) { from = last; to = 0; vleg_down = true; } else { from = 0; to = last; }
+        }
+        const int dir = (from > to) ? -1 : 1;
+        err = 1E10;
+        if (!(dir < 0 && from == to)) {
+            int first_lvl = (dir > 0) ? from : from - 1;
+            if (cs_skip) { first_lvl = D.cs_top - 1; cs_skip = false; }
+            for (int lvl = first_lvl;; lvl += dir) {
+                if (D.cs_top > 0 && dir > 0 && lvl == D.cs_top && lvl > from && to == last && step > 2 * nramp + 1) {
+                    if (coarse) {
+                        RPROF_T0();
+                        long nsw = 0;
+                        coarse_section_enter(D, A);
+                        __syncthreads();
+                        if (threadIdx.x < 64) coarse_section(D, A, emin, iterno, &nsw);
+                        if (threadIdx.x == 0) red[17] = static_cast<double>(nsw);
+                        __syncthreads();
+                        c.sweeps += static_cast<long>(red[17]);
+                        coarse_section_leave(D, A);
+                        __syncthreads();
+                        RPROF_ADD(3, 0);
+                    }
+                    cs_skip = true;
+                    break;
+                }
+                // transfer into level lvl
+                { RPROF_T0();
+                if (dir > 0) {
+                    if (lvl > from) {                                          // Restrict(lvl): fine lvl-1 -> coarse lvl
+                        if (lvl < kres) { if (!coarse) { DFTA_RES_LEVEL(R.logC0 - (lvl - 1), (res_restrict_local<(LC > 2 ? LC : 3)>(D, R, lvl))) } }
+                        else if (lvl > kres) { if (coarse) do_restrict(D, A, lvl, true); }
+                        // lvl == kres: the members have written the source during their visit of level kres-1
+                    }
+                } else {                                                       // Prolong: coarse lvl+1 -> fine lvl
+                    if (lvl + 1 < kres) {
+                        if (!coarse) {
+                            DFTA_RES_LEVEL(R.logC0 - lvl, ({
+                                using Yc = ResLay<(LC > 2 ? LC - 1 : 2)>;
+                                const double* Pc = res_pp(R, lvl + 1);
+                                res_prolong<(LC > 2 ? LC : 3)>(R, lvl, [&](int i) { return Pc[Yc::off(i)]; });
+                            }))
+                        }
+                    } else if (lvl + 1 == kres) {
+                        // hand-over: the coarse workgroup has written the first coarse level back to its current global copy
+                        double tot[4], r0, r1, cb[4];
+                        res_exchange<true>(A, R, 0.0, 0.0, 0.0, coarse ? static_cast<double>((A.cur >> kres) & 1u) : 0.0, 0, 0, 0, 0, red, tot, r0, r1, cb);
+                        if (!coarse) {
+                            const Lvl Lk = D.lv[kres];
+                            const double* __restrict__ Pg = ((tot[3] != 0.0) ? A.phi1 : A.phi0) + Lk.off;
+                            DFTA_RES_LEVEL(R.logC0 - lvl, ({
+                                using Y = ResLay<LC>;
+                                const int a_c = (R.m * Y::N) / 2;
+                                const int nck = Lk.n;
+                                res_prolong<LC>(R, lvl, [&](int i) { const int ic = a_c + i; return (ic >= 0 && ic < nck) ? Pg[addr(Lk, ic)] : 0.0; });
+                            }))
+                        }
+                    } else if (coarse) do_prolong(D, A, lvl + 1, true);
+                }
+                RPROF_ADD(dir > 0 ? 4 : ((lvl + 1 == kres) ? 6 : 5), lvl); }
+                // IterateGaussSeidel(lvl)
+                if (lvl < kres) {
+                    const bool down = dir > 0 && lvl < to;
+                    if (coarse) err = res_visit_passive(D, A, R, lvl, emin, down, red, &c.sweeps);
+                    else { DFTA_RES_LEVEL(R.logC0 - lvl, (err = res_visit<LC>(D, A, R, lvl, emin, down, red, &c.sweeps))) }
+                } else if (coarse) {
+                    RPROF_T0();
+                    err = iterate_gs(D, A, lvl, emin, iterno, red, &c.sweeps);
+                    RPROF_ADD(2, lvl - kres);
+                }
+                if (lvl == to) break;
+            }
+        }
+        if (vleg_down) {
+            ++c.vcycles;
+            if (err < errorMinLast || c.vcycles >= max_vcycles) break;
+        }
+    }
+    return err;
+}
+
+// SolvePoissonNonUniform (PoissonSolver.h:51-81) by a resident group: kResWG blocks per atom
+__global__ __launch_bounds__(kThreads) void k_poisson_solve_res(const MgDesc* __restrict__ Dp, double* __restrict__ phi0, double* __restrict__ phi1,
+                                                                double* __restrict__ src, const int* __restrict__ Z,
+                                                                const double* __restrict__ density, const double* __restrict__ r,
+                                                                const double* __restrict__ psrc, double* __restrict__ U,
+                                                                int* __restrict__ vcycles, double* __restrict__ errs,
+                                                                unsigned long long* __restrict__ total_vcycles,
+                                                                unsigned* __restrict__ group_ctr, double* __restrict__ res_slots,
+                                                                const int* __restrict__ skip, int fault, int src_all)
+{
+    __shared__ double red[32];
+    __shared__ double shm[3 * kSeqCap + 2 * kStageArr];
+    const MgDesc& D = *Dp;
+    const int a = blockIdx.x / kResWG, g = blockIdx.x % kResWG;
+    if (skip && skip[a]) return;
+    if (fault && g == kResG - 1) return;                           // fault injection (tests): this member never arrives
+    Atom A;
+    A.phi0 = phi0 + (size_t)a * D.per_atom;
+    A.phi1 = phi1 + (size_t)a * D.per_atom;
+    A.src = src + (size_t)a * D.per_atom;
+    A.lds = shm;
+    A.stage = shm + 3 * kSeqCap;
+    A.cur = 0;
+    A.G = 1;                       // the code of the non-shared levels runs in the coarse workgroup alone
+    A.g = (g == kResG) ? 0 : 1;
+    A.ctr = group_ctr + a;
+    A.bar = 0;
+    A.part = nullptr; A.fslot = nullptr; A.xchg = nullptr;
+    A.fseq = 0;
+    A.pend = 0; A.pend_r = 0; A.pend_z = 0;
+    A.spin_max = D.spin_max;
+    A.gave_up = false;
+    Res R;
+    R.role = (g == kResG) ? 1 : 0;
+    R.m = g;
+    R.kres = D.res_kres;
+    R.logC0 = D.res_logC0;
+    R.xs = res_slots + (size_t)a * res_slot_doubles();
+    R.xp = R.xs + (size_t)3 * kResWG * 4;
+    R.seq = 0;
+#ifdef DFTA_POISSON_PROF
+    __shared__ unsigned long long prof_acc[64];
+    if (threadIdx.x < 64) prof_acc[threadIdx.x] = 0;
+    R.prof = prof_acc;
+    __syncthreads();
+#endif
+    R.shm = shm;
+    {
+        int at = 0;
+#pragma unroll
+        for (int l = 0; l < kResMaxShared; ++l) {
+            const int lc = R.logC0 - l;
+            const int C = 1 << (lc > 0 ? lc : 0);
+            const int H = (kWarm3 + 3 + C - 1) / C, RS = H + kResNT + 1;
+            R.pat[l] = at + H;
+            R.sat[l] = at + C * RS + H;
+            if (l < R.kres) at += 2 * C * RS;
+        }
+    }
+    const int N = D.lv[0].n;
+    const double* rho = density + (size_t)a * N;
+    Counters c{0, 0};
+    if (R.role == 0) {
+        for (int l = 0; l < R.kres; ++l) { DFTA_RES_LEVEL(R.logC0 - l, (res_init_level<LC>(D, A, R, l, rho, r, psrc, src_all))) }
+        __syncthreads();
+    } else {
+        res_init_coarse(D, A, R, rho, r, psrc, 0.0, (double)Z[a]);
+    }
+    const double err = res_cycles(D, A, R, 100, 1E-3, 1E-14, red, c);      // FullCycle(1E-3, 1E-14), PoissonSolver.h:78
+    if (R.role == 0) {
+        // U = PhiLevels[0] (PoissonSolver.h:80); also into level 0 of the global storage (copy 0) for the unit hooks
+        const Lvl L0 = D.lv[0];
+        DFTA_RES_LEVEL(R.logC0, ({
+            using Y = ResLay<LC>;
+            const double* P = res_pp(R, 0);
+            const int a0 = R.m * Y::N;
+            for (int j = threadIdx.x; j < Y::N; j += kThreads) {
+                const double v = P[Y::off(j)];
+                U[(size_t)a * N + a0 + j] = v;
+                A.phi0[L0.off + addr(L0, a0 + j)] = v;
+            }
+            if (R.m == kResG - 1 && threadIdx.x == 0) {
+                const double v = P[Y::off(Y::N)];
+                U[(size_t)a * N + N - 1] = v;
+                A.phi0[L0.off + addr(L0, N - 1)] = v;
+            }
+        }))
+    } else if (threadIdx.x == 0) {
+        if (vcycles) vcycles[a] = (int)c.vcycles;
+        if (errs) errs[a] = err;
+        if (total_vcycles) atomicAdd(total_vcycles, (unsigned long long)c.vcycles);
+    }
+#ifdef DFTA_POISSON_PROF
+    __syncthreads();
+    if (a == 0 && (R.role == 1 || R.m == 0) && threadIdx.x < 64) g_rprof[R.role * 64 + threadIdx.x] += prof_acc[threadIdx.x];
+#endif
+}
+
 // SolvePoissonNonUniform (PoissonSolver.h:51-81): one block per atom
 __global__ __launch_bounds__(kThreads) void k_poisson_solve(const MgDesc* __restrict__ Dp, double* __restrict__ phi0, double* __restrict__ phi1,
                                                             double* __restrict__ src, const int* __restrict__ Z,
@@ -1921,6 +2592,7 @@ __global__ __launch_bounds__(kThreads) void k_poisson_solve(const MgDesc* __rest
     A.fseq = 0;
     A.pend = 0;
     A.pend_r = 0;
+    A.pend_z = 0;
     A.spin_max = D.spin_max;
     A.gave_up = false;
     const Lvl L0 = D.lv[0];
@@ -1973,6 +2645,7 @@ __global__ __launch_bounds__(kThreads) void k_unit(const MgDesc* __restrict__ Dp
     A.fseq = 0;
     A.pend = 0;
     A.pend_r = 0;
+    A.pend_z = 0;
     A.spin_max = D.spin_max;
     A.gave_up = false;
     A.cur = 0;
@@ -2053,6 +2726,9 @@ struct dfta_poisson {
     int aborts = 0;                 // solves that had to be repeated
     int fault = 0;                  // $DFTA_FAULT_POISSON_MEMBER (tests): the last member of every group never arrives
     bool plain_launch = false;      // groups started with an ordinary launch instead of a cooperative one (profilers, see poisson_create_impl)
+    bool resident = false;          // k_poisson_solve_res: kResWG workgroups per atom, the shared levels live in the members' LDS
+    double* d_res_slots = nullptr;  // per atom: res_slot_doubles() exchange slots (sentinel-filled before every launch)
+    bool grouped() const { return D.G > 1 || resident; }
 };
 
 static int poisson_create_impl(dfta_ctx* ctx, const dfta_grid* g, int batch, int force_logG, dfta_poisson** out);
@@ -2081,6 +2757,30 @@ int dfta_poisson_solve_launch(dfta_poisson* p, const int* dZ, const double* dDen
     if (p->degraded) return dfta_poisson_solve_launch(p->fallback, dZ, dDensity, dU, dVcycles, dErr, dSkip);
     DFTA_HIP(ctx, hipMemsetAsync(p->d_group_ctr, 0, sizeof(unsigned) * p->batch, ctx->stream));
     DFTA_HIP(ctx, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(p->d_group_part), 0x7FF8DEAD, (size_t)p->batch * group_part_doubles(p->D.G) * 2, ctx->stream));   // group_sum_fast's sentinel
+    if (p->resident) {
+        DFTA_HIP(ctx, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(p->d_res_slots), 0x7FF8DEAD, (size_t)p->batch * res_slot_doubles() * 2, ctx->stream));
+        const MgDesc* a0 = p->d_desc;
+        const double *a_r = p->g->d_rsrc, *a_psrc = p->g->d_psrc;
+        int fault = p->fault, src_all = p->g->uniform;
+        if (p->plain_launch) {
+            hipLaunchKernelGGL(k_poisson_solve_res, dim3(p->batch * kResWG), dim3(kThreads), 0, ctx->stream, a0, p->d_phi0, p->d_phi1, p->d_src, dZ,
+                               dDensity, a_r, a_psrc, dU, dVcycles, dErr, p->d_total_vcycles, p->d_group_ctr, p->d_res_slots, dSkip, fault, src_all);
+            DFTA_CHECK_LAUNCH(ctx);
+            return DFTA_OK;
+        }
+        void* args[] = {&a0, &p->d_phi0, &p->d_phi1, &p->d_src, &dZ, &dDensity, &a_r, &a_psrc, &dU, &dVcycles, &dErr, &p->d_total_vcycles,
+                        &p->d_group_ctr, &p->d_res_slots, &dSkip, &fault, &src_all};
+        const hipError_t e = hipLaunchCooperativeKernel(reinterpret_cast<const void*>(k_poisson_solve_res), dim3(p->batch * kResWG), dim3(kThreads),
+                                                        args, 0, ctx->stream);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            int rc = degrade(p);
+            if (rc) return rc;
+            ++p->aborts;
+            return dfta_poisson_solve_launch(p->fallback, dZ, dDensity, dU, dVcycles, dErr, dSkip);
+        }
+        return DFTA_OK;
+    }
     if (p->D.G == 1) {
         hipLaunchKernelGGL(k_poisson_solve, dim3(p->batch), dim3(kThreads), 0, ctx->stream, p->d_desc, p->d_phi0, p->d_phi1, p->d_src, dZ,
                            dDensity, p->g->d_rsrc, p->g->d_psrc, dU, dVcycles, dErr, p->d_total_vcycles, p->d_group_ctr, p->d_group_part,
@@ -2117,14 +2817,15 @@ int dfta_poisson_solve_launch(dfta_poisson* p, const int* dZ, const double* dDen
 static int check_groups(dfta_poisson* p)
 {
     dfta_ctx* ctx = p->ctx;
-    if (p->D.G == 1 || p->degraded) return DFTA_OK;
+    if (!p->grouped() || p->degraded) return DFTA_OK;
     std::vector<unsigned> h(p->batch);
     DFTA_HIP(ctx, hipMemcpyAsync(h.data(), p->d_group_ctr, sizeof(unsigned) * p->batch, hipMemcpyDeviceToHost, ctx->stream));
     DFTA_HIP(ctx, hipStreamSynchronize(ctx->stream));
     for (unsigned v : h)
         if (v & 0x80000000u) {
+            const int G = p->resident ? kResWG : p->D.G;
             snprintf(ctx->err, sizeof(ctx->err), "poisson: a group of %d workgroups lost a member at a barrier (the %d workgroups of "
-                     "the launch were not all resident)", p->D.G, p->batch * p->D.G);
+                     "the launch were not all resident)", G, p->batch * G);
             return DFTA_ERR_HIP;
         }
     return DFTA_OK;
@@ -2136,7 +2837,7 @@ int dfta_poisson_finish(dfta_poisson* p, const int* dZ, const double* dDensity, 
                         const int* dSkip)
 {
     dfta_ctx* ctx = p->ctx;
-    if (p->D.G == 1 || p->degraded) { DFTA_HIP(ctx, hipStreamSynchronize(ctx->stream)); return DFTA_OK; }
+    if (!p->grouped() || p->degraded) { DFTA_HIP(ctx, hipStreamSynchronize(ctx->stream)); return DFTA_OK; }
     if (check_groups(p) == DFTA_OK) return DFTA_OK;
     ++p->aborts;
     DFTA_HIP(ctx, hipMemsetAsync(p->d_total_vcycles, 0, sizeof(unsigned long long), ctx->stream));   // the aborted solve's count
@@ -2164,7 +2865,7 @@ int dfta_poisson_take_vcycles(dfta_poisson* p, unsigned long long* out)   // rea
 int dfta_poisson_group_state(const dfta_poisson* p, int* G, int* degraded, int* aborts)
 {
     if (!p) return DFTA_ERR_INVALID;
-    if (G) *G = p->D.G;
+    if (G) *G = p->resident ? kResWG : p->D.G;
     if (degraded) *degraded = p->degraded ? 1 : 0;
     if (aborts) *aborts = p->aborts;
     return DFTA_OK;
@@ -2202,6 +2903,27 @@ static int poisson_create_impl(dfta_ctx* ctx, const dfta_grid* g, int batch, int
     }
     if (force_logG >= 0) logG = force_logG;
     if (const char* e = getenv("DFTA_FAULT_POISSON_MEMBER")) p->fault = atoi(e) != 0;
+    // Resident group (k_poisson_solve_res): where the batch would get 16 workgroups per atom and level 0 gives every lane of
+    // kResG x kResNT lanes 4 .. 32 nodes (16385 .. 131073 nodes); $DFTA_POISSON_RES = 0 / 1 switches it off / on (for batches
+    // up to 7 atoms), a forced group size (DFTA_POISSON_GROUP, force_logG) selects the staged groups above
+    int res_kres = 0, res_logC0 = 0;
+    {
+        bool want = logG == 4 && force_logG < 0 && !getenv("DFTA_POISSON_GROUP");
+        if (const char* e = getenv("DFTA_POISSON_RES")) want = atoi(e) != 0 && force_logG < 0 && batch * kResWG <= 256;
+        const int lanes = kResG * kResNT;
+        if (want && (g->N - 1) % lanes == 0) {
+            const int C0 = (g->N - 1) / lanes;
+            int lc = 0;
+            while ((1 << lc) < C0) ++lc;
+            if ((1 << lc) == C0 && lc >= 2 && lc <= 5 && g->levels >= lc + 4) { res_logC0 = lc; res_kres = lc - 1; }
+        }
+        if (res_kres > 0) {
+            int per_cu = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_poisson_solve_res, kThreads, 0) != hipSuccess) per_cu = 0;
+            if (batch * kResWG > per_cu * ctx->num_cu) res_kres = 0;
+        }
+        if (res_kres > 0) { logG = 0; p->resident = true; }
+    }
     // rocprofiler-sdk (ROCm 7.2) crashes in an exit handler of a process that has made a cooperative launch -- after its
     // output is written, but the profiled command returns 139.  Under the profiler (rocprofv3 exports ROCP_TOOL_LIBRARIES), or
     // when DFTA_POISSON_PLAIN_LAUNCH is set, the groups are therefore started with an ordinary launch: same kernel, same
@@ -2225,6 +2947,8 @@ static int poisson_create_impl(dfta_ctx* ctx, const dfta_grid* g, int batch, int
     D.logG = logG;
     D.nofold = getenv("DFTA_POISSON_NOFOLD") ? 1 : 0;
     D.fuse3 = getenv("DFTA_POISSON_NOFUSE3") ? 0 : 1;
+    D.res_kres = res_kres;
+    D.res_logC0 = res_logC0;
     D.G = 1 << logG;
     long off = kPad, soff = 0;
     double d = g->delta;                       // PoissonSolver.cpp:21-26 (0 on a uniform grid: PoissonSolver(levels), DFTAtom.cpp:89)
@@ -2286,6 +3010,7 @@ static int poisson_create_impl(dfta_ctx* ctx, const dfta_grid* g, int batch, int
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->d_total_vcycles), sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->d_group_ctr), sizeof(unsigned) * batch);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->d_group_part), sizeof(double) * (size_t)batch * group_part_doubles(D.G));
+    if (e == hipSuccess && p->resident) e = hipMalloc(reinterpret_cast<void**>(&p->d_res_slots), sizeof(double) * (size_t)batch * res_slot_doubles());
     if (e == hipSuccess) e = hipMemsetAsync(p->d_phi0, 0, tot * sizeof(double), ctx->stream);
     if (e == hipSuccess) e = hipMemsetAsync(p->d_phi1, 0, tot * sizeof(double), ctx->stream);
     if (e == hipSuccess) e = hipMemsetAsync(p->d_src, 0, tot * sizeof(double), ctx->stream);
@@ -2329,9 +3054,23 @@ void dfta_poisson_destroy(dfta_poisson* p)
             unsigned long long z[8 * 24] = {0};
             (void)hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof(z));
         }
+        unsigned long long hr[2 * 8 * 8];
+        if (p->resident && hipMemcpyFromSymbol(hr, HIP_SYMBOL(g_rprof), sizeof(hr)) == hipSuccess) {
+            const char* mn[8] = {"pass    ", "publish ", "exchange", "commit  ", "restrict", "prolong ", "handover", "redo    "};
+            const char* cn[8] = {"passive ", "-       ", "iterate ", "coarsesc", "restrict", "prolong ", "handover", "-       "};
+            for (int role = 0; role < 2; ++role)
+                for (int c = 0; c < 8; ++c) {
+                    unsigned long long t = 0;
+                    fprintf(stderr, "[res prof] %s %s:", role ? "coarse wg" : "member 0 ", role ? cn[c] : mn[c]);
+                    for (int l = 0; l < 8; ++l) { fprintf(stderr, " %llu", hr[(role * 8 + c) * 8 + l]); t += hr[(role * 8 + c) * 8 + l]; }
+                    fprintf(stderr, "  = %llu\n", t);
+                }
+            unsigned long long zz[2 * 8 * 8] = {0};
+            (void)hipMemcpyToSymbol(HIP_SYMBOL(g_rprof), zz, sizeof(zz));
+        }
     }
 #endif
-    void* ptrs[] = {p->d_phi0, p->d_phi1, p->d_src, p->d_cur, p->d_total_vcycles, p->d_desc, p->d_group_ctr, p->d_group_part};
+    void* ptrs[] = {p->d_phi0, p->d_phi1, p->d_src, p->d_cur, p->d_total_vcycles, p->d_desc, p->d_group_ctr, p->d_group_part, p->d_res_slots};
     for (void* q : ptrs) if (q) (void)hipFree(q);
     delete p;
 }
