@@ -61,6 +61,7 @@ struct MgDesc {
     int levels;
     int G;           // workgroups per atom (power of two); 1: the whole solve runs in one workgroup
     int logG;
+    int dbg;         // $DFTA_POISSON_DBG, measurements only (results are garbage): 1 = the coarse workgroup skips its sweeps, 2 = the members skip their passes, 4 = no restriction / prolongation on the shared levels
     int res_kres;    // > 0: resident group (k_poisson_solve_res): levels 0 .. res_kres-1 live in the members' LDS; the level layout is that of G = 1
     int res_logC0;   // log2(nodes per lane) of level 0 in a member's stretch (kResG members x kResNT lanes)
     int fuse3;    // visits of three sweeps on staged levels of one workgroup run as ONE fused pass (gs_lds3); 0: $DFTA_POISSON_NOFUSE3
@@ -592,6 +593,16 @@ __device__ __forceinline__ double gs_lds(const double* __restrict__ SSbase, doub
 // behind the chunk of lane NT-1 are rows 0..2 of column NT (a right halo column) unless `last_lane`: then the chunk ends at the
 // level's last node, whose value is xN.  Returns the lane's shares of the three sums of dPhi^2.
 constexpr int kWarm3 = 112;
+// gs_point2 with the right neighbour given as yp = 2 xp as well (stages 2 and 3 of the fused pass, which take it from the stage in
+// front of them): halving commutes with every rounding involved -- fl(xp - x) = fl(yp - y) / 2, fl(t1 + xp) = fma(yp, 0.5, t1),
+// dh fl(xp - x) = (dh / 2) fl(yp - y) -- so the result is gs_point2(s, y, yp / 2, dh) bit for bit, one instruction less.
+__device__ __forceinline__ double gs_point2y(double s, double y, double yp, double dh2)
+{
+    const double t1 = __builtin_fma(y, 0.5, s);
+    const double u = yp - y;
+    const double a = __builtin_fma(yp, 0.5, t1);
+    return a - dh2 * u;
+}
 template <int LOGC, int RS, int NT, int KST, bool CAREFUL>
 __device__ __forceinline__ void gs_lds3(const double* __restrict__ SSbase, double* __restrict__ PPbase, const int tid, const int lo_g,
                                         const bool last_lane, const double xN, const double dh, double& e1, double& e2, double& e3)
@@ -606,9 +617,10 @@ __device__ __forceinline__ void gs_lds3(const double* __restrict__ SSbase, doubl
     asm volatile("" : "+v"(ps), "+v"(pp));
     auto off = [](int r) constexpr -> int { return (r & Cm1) * RS + (r >> LOGC); };       // any r (arithmetic shift = floor)
     const int neg_lo = -lo_g;
+    const double dh2 = 0.5 * dh;
     const double Y0 = 2.0 * PPbase[0];          // node 0 of the level (meaningful where a restart can happen at all)
-    double a1 = 0, a2 = 0, a3 = 0;
-    double y1 = 0, y2 = 0, y3 = 0, sA = 0, sB = 0, o0 = 0, x1p = 0, x2p = 0;
+    double a1 = 0, a2 = 0, a3 = 0;              // a2, a3 are accumulated on doubled differences: four times the sums (exactly)
+    double y1 = 0, y2 = 0, y3 = 0, sA = 0, sB = 0, o0 = 0, y1p = 0, y2p = 0;
     double xr0 = 0, xr1 = 0, xr2 = 0, sr0 = 0, sr1 = 0;
     double ax[kH], as[kH], bx[kH], bv[kH];
     // loads of the batch of 8 steps whose stage-1 nodes are lo + r0 .. lo + r0 + 7 (r0 a multiple of 8): S at the node, old Phi at
@@ -632,17 +644,15 @@ __device__ __forceinline__ void gs_lds3(const double* __restrict__ SSbase, doubl
             X[kH - 1] = *bw;
         }
     };
-    // warm-up batch: recurrences only
+    // warm-up batch: recurrences only (15 instructions per step)
     auto warm = [&](const double (&X)[kH], const double (&SV)[kH], const int r0) {
 #pragma unroll
         for (int q = 0; q < kH; ++q) {
             double t = gs_point2(SV[q], y1, X[q], dh);
             if (CAREFUL && ((q & (C < kH ? Cm1 : kH - 1)) == 0)) t = (r0 + q == neg_lo) ? Y0 : t;           // stage 1 stands on node 0
-            const double x1 = 0.5 * t;
-            double u = gs_point2(sA, y2, x1, dh);
+            double u = gs_point2y(sA, y2, t, dh2);
             if (CAREFUL && (((q - 1) & (C < kH ? Cm1 : kH - 1)) == 0)) u = (r0 + q - 1 == neg_lo) ? Y0 : u;
-            const double x2 = 0.5 * u;
-            double v = gs_point2(sB, y3, x2, dh);
+            double v = gs_point2y(sB, y3, u, dh2);
             if (CAREFUL && (((q - 2) & (C < kH ? Cm1 : kH - 1)) == 0)) v = (r0 + q - 2 == neg_lo) ? Y0 : v;
             y1 = t; y2 = u; y3 = v;
             sB = sA; sA = SV[q];
@@ -659,22 +669,19 @@ __device__ __forceinline__ void gs_lds3(const double* __restrict__ SSbase, doubl
             const double xn = (q == nq - 1) ? ((r0 + nq == C) ? xr0 : X[q]) : X[q];
             double t = gs_point2(SV[q], y1, xn, dh);
             if (CAREFUL && first && q == 0) t = (lo_g == 0) ? Y0 : t;
-            const double x1 = 0.5 * t;
-            { const double d = o0 - x1; a1 = __builtin_fma(d, d, a1); }
-            double u = gs_point2(sA, y2, x1, dh);
+            { const double d = __builtin_fma(t, -0.5, o0); a1 = __builtin_fma(d, d, a1); }
+            double u = gs_point2y(sA, y2, t, dh2);
             if (CAREFUL && first && q == 1) u = (lo_g == 0) ? Y0 : u;
-            const double x2 = 0.5 * u;
-            if (!(first && q == 0)) { const double d = x1p - x2; a2 = __builtin_fma(d, d, a2); }
-            double v = gs_point2(sB, y3, x2, dh);
+            if (!(first && q == 0)) { const double d = y1p - u; a2 = __builtin_fma(d, d, a2); }
+            double v = gs_point2y(sB, y3, u, dh2);
             if (CAREFUL && first && q == 2) v = (lo_g == 0) ? Y0 : v;
-            const double x3 = 0.5 * v;
-            if (!(first && q < 2)) { const double d = x2p - x3; a3 = __builtin_fma(d, d, a3); }
-            if (KST == 1) po[q * RS] = x1;
-            if (KST == 2 && !(first && q == 0)) po[(q - 1) * RS] = x2;
-            if (KST == 3 && !(first && q < 2)) po[(q - 2) * RS] = x3;
+            if (!(first && q < 2)) { const double d = y2p - v; a3 = __builtin_fma(d, d, a3); }
+            if (KST == 1) po[q * RS] = 0.5 * t;
+            if (KST == 2 && !(first && q == 0)) po[(q - 1) * RS] = 0.5 * u;
+            if (KST == 3 && !(first && q < 2)) po[(q - 2) * RS] = 0.5 * v;
             y1 = t; y2 = u; y3 = v;
             sB = sA; sA = SV[q];
-            o0 = xn; x1p = x1; x2p = x2;
+            o0 = xn; y1p = t; y2p = u;
         }
     };
     if (active) {
@@ -689,7 +696,7 @@ __device__ __forceinline__ void gs_lds3(const double* __restrict__ SSbase, doubl
             __builtin_amdgcn_sched_barrier(0);
             warm(bx, bv, r0 + kH);
         }
-        x1p = 0.5 * y1; x2p = 0.5 * y2;
+        y1p = y1; y2p = y2;
         // old values behind the chunk: the right neighbour overwrites them after the barrier
         xr0 = last_lane ? xN : pp[off(C)];
         xr1 = pp[off(C + 1)]; xr2 = pp[off(C + 2)];
@@ -717,30 +724,24 @@ __device__ __forceinline__ void gs_lds3(const double* __restrict__ SSbase, doubl
             const double Y_N = 2.0 * xN;
             double t = gs_point2(sr0, y1, xr1, dh);
             t = last_lane ? Y_N : t;
-            double x1 = 0.5 * t;
-            double u = gs_point2(sA, y2, x1, dh);
-            double x2 = 0.5 * u;
-            { const double d = x1p - x2; a2 = __builtin_fma(d, d, a2); }
-            if (KST == 2) pp[Cm1 * RS] = x2;
+            double u = gs_point2y(sA, y2, t, dh2);
+            { const double d = y1p - u; a2 = __builtin_fma(d, d, a2); }
+            if (KST == 2) pp[Cm1 * RS] = 0.5 * u;
             if (KST == 3) {
-                double v = gs_point2(sB, y3, x2, dh);
-                double x3 = 0.5 * v;
-                { const double d = x2p - x3; a3 = __builtin_fma(d, d, a3); }
-                pp[(C - 2) * RS] = x3;
-                y1 = t; y2 = u; y3 = v; sB = sA; sA = sr0; x2p = x2;
+                double v = gs_point2y(sB, y3, u, dh2);
+                { const double d = y2p - v; a3 = __builtin_fma(d, d, a3); }
+                pp[(C - 2) * RS] = 0.5 * v;
+                y1 = t; y2 = u; y3 = v; sB = sA; sA = sr0; y2p = u;
                 t = gs_point2(sr1, y1, xr2, dh);
-                x1 = 0.5 * t;
-                u = gs_point2(sA, y2, x1, dh);
+                u = gs_point2y(sA, y2, t, dh2);
                 u = last_lane ? Y_N : u;
-                x2 = 0.5 * u;
-                v = gs_point2(sB, y3, x2, dh);
-                x3 = 0.5 * v;
-                { const double d = x2p - x3; a3 = __builtin_fma(d, d, a3); }
-                pp[Cm1 * RS] = x3;
+                v = gs_point2y(sB, y3, u, dh2);
+                { const double d = y2p - v; a3 = __builtin_fma(d, d, a3); }
+                pp[Cm1 * RS] = 0.5 * v;
             }
         }
     }
-    e1 = a1; e2 = a2; e3 = a3;
+    e1 = a1; e2 = 0.25 * a2; e3 = 0.25 * a3;
 }
 
 // One sweep of an LDS-resident level by ONE thread, in the reference's order.  The loads of a batch (right neighbours,
@@ -1911,7 +1912,7 @@ __device__ __forceinline__ double run_cycles(const MgDesc& D, Atom& A, int first
 // of the next level's source, so that restriction and prolongation are local (PoissonSolver.cpp:110-157 on own nodes and
 // halos).  One more workgroup per atom, the coarse workgroup, runs the levels below (<= 8193 nodes) with the code above and
 // meets the members at the two hand-overs of a cycle, through the global arrays of the first coarse level.
-#ifdef DFTA_POISSON_PROF
+#ifdef DFTA_POISSON_RPROF
 __device__ unsigned long long g_rprof[2 * 8 * 8];    // [role][category][level & 7], ticks of member 0 / of the coarse workgroup of atom 0
 #define RPROF_T0() const long long rprof_t0 = clock64()
 #define RPROF_ADD(cat, lvl) do { if (threadIdx.x == 0) R.prof[(cat) * 8 + ((lvl) & 7)] += clock64() - rprof_t0; } while (0)   /* LDS: a global read-modify-write costs microseconds */
@@ -1954,11 +1955,28 @@ struct Res {
     double* xs;               // [3][kResWG][4] sums
     double* xp;               // [3][kResWG][kResX] payload
     unsigned seq;             // exchanges so far
-#ifdef DFTA_POISSON_PROF
+#ifdef DFTA_POISSON_RPROF
     unsigned long long* prof; // [8][8] ticks per category and level, in LDS
 #endif
 };
 
+// a value that is the same in every lane (read from LDS after a barrier), moved to scalar registers: what is derived from it --
+// the decisions of the cycle -- then stays scalar, and the loops that depend on it keep their state out of the vector registers
+__device__ __forceinline__ double res_uniform(const double x)
+{
+    const long long b = __builtin_bit_cast(long long, x);
+    const int lo = __builtin_amdgcn_readfirstlane(static_cast<int>(b));
+    const int hi = __builtin_amdgcn_readfirstlane(static_cast<int>(b >> 32));
+    return __builtin_bit_cast(double, (static_cast<long long>(hi) << 32) | static_cast<unsigned>(lo));
+}
+// the lane id behind an optimisation barrier: the per-lane addresses of an operation are computed where it runs.  (Hoisted out of
+// the cycle loop -- dozens of inlined operations -- they would be live across everything and spill to scratch memory.)
+__device__ __forceinline__ int res_tid()
+{
+    int t = threadIdx.x;
+    asm volatile("" : "+v"(t));
+    return t;
+}
 __device__ __forceinline__ double* res_pp(const Res& R, const int l)
 {
     return R.shm + (l == 0 ? R.pat[0] : (l == 1 ? R.pat[1] : (l == 2 ? R.pat[2] : R.pat[3])));
@@ -1990,7 +2008,7 @@ __device__ __forceinline__ void res_exchange(Atom& A, Res& R, const double m0, c
                                              double (&tot)[4], double& r0, double& r1, double (&cb)[4])
 {
     const unsigned s = R.seq++;
-    const int b = s % 3u, tid = threadIdx.x;
+    const int b = s % 3u, tid = res_tid();
     const int me = R.role ? kResG : R.m;
     double* slots = R.xs + (size_t)b * kResWG * 4;
     const double* pay = R.xp + (size_t)b * kResWG * kResX;
@@ -2063,7 +2081,7 @@ __device__ __forceinline__ void res_exchange(Atom& A, Res& R, const double m0, c
         }
     }
     __syncthreads();
-    tot[0] = red[20]; tot[1] = red[21]; tot[2] = red[22]; tot[3] = red[23];
+    tot[0] = res_uniform(red[20]); tot[1] = res_uniform(red[21]); tot[2] = res_uniform(red[22]); tot[3] = res_uniform(red[23]);
     // everybody has published exchange s, i.e. has read what it needed of exchange s-1: this participant's part of that buffer
     // is reset (by the threads that will store into it again in exchange s+2)
     {
@@ -2094,7 +2112,7 @@ __device__ __forceinline__ double res_visit(const MgDesc& D, Atom& A, Res& R, co
     constexpr int C = Y::C, RS = Y::RS;
     const Lvl L = D.lv[l];
     const double dh = L.d * 0.5;
-    const int tid = threadIdx.x;
+    const int tid = res_tid();
     double* PP = res_pp(R, l);
     double* SS = res_ss(R, l);
     const bool active = tid < kResNT;
@@ -2113,7 +2131,8 @@ __device__ __forceinline__ double res_visit(const MgDesc& D, Atom& A, Res& R, co
         for (int k = 0; k < C; ++k) park[k * kResNT + tid] = PP[k * RS + tid];
     }
     double f1 = 0, f2 = 0, f3 = 0;
-    if (careful) gs_lds3<LOGC, RS, kResNT, 3, true>(SS, PP, tid, lo_g, lastl, xN, dh, f1, f2, f3);
+    if (D.dbg & 2) { f1 = 1; f2 = 1; f3 = 1; }
+    else if (careful) gs_lds3<LOGC, RS, kResNT, 3, true>(SS, PP, tid, lo_g, lastl, xN, dh, f1, f2, f3);
     else gs_lds3<LOGC, RS, kResNT, 3, false>(SS, PP, tid, lo_g, lastl, xN, dh, f1, f2, f3);
     if (!active) { f1 = 0; f2 = 0; f3 = 0; }
     for (int off = 32; off > 0; off >>= 1) { f1 += __shfl_xor(f1, off); f2 += __shfl_xor(f2, off); f3 += __shfl_xor(f3, off); }
@@ -2213,7 +2232,7 @@ __device__ __forceinline__ double res_visit_passive(const MgDesc& D, Atom& A, Re
     }
     if (to_coarse) {
         const Lvl Lk = D.lv[l + 1];
-        const int tid = threadIdx.x;
+        const int tid = res_tid();
         const int per = (kResNT << logC) / 2;                  // coarse nodes per member
         if (tid > 64 && tid < 64 + kResG) {
             const int m = tid - 64;
@@ -2239,7 +2258,7 @@ __device__ __forceinline__ void res_restrict_local(const MgDesc& D, Res& R, cons
     double* __restrict__ Pc = res_pp(R, lc);
     double* __restrict__ Sc = res_ss(R, lc);
     const double dc = D.lv[lc].d;
-    const int tid = threadIdx.x, t = tid & (kResNT - 1), half = tid >> 7;
+    const int tid = res_tid(), t = tid & (kResNT - 1), half = tid >> 7;
 #pragma unroll
     for (int kk = 0; kk < Yc::C / 2; ++kk) {
         const int k = half * (Yc::C / 2) + kk;
@@ -2268,7 +2287,7 @@ __device__ __forceinline__ void res_prolong(Res& R, const int lf, CF coarse)
 {
     using Y = ResLay<LOGC>;
     double* __restrict__ Pf = res_pp(R, lf);
-    const int tid = threadIdx.x, t = tid & (kResNT - 1), half = tid >> 7;
+    const int tid = res_tid(), t = tid & (kResNT - 1), half = tid >> 7;
     auto corr = [&](int j) -> double {                         // fine node j relative to the stretch
         if ((j & 1) == 0) return coarse(j >> 1);
         return 0.5 * (coarse((j - 1) >> 1) + coarse((j + 1) >> 1));
@@ -2388,7 +2407,7 @@ __device__ __forceinline__ double res_cycles(const MgDesc& D, Atom& A, Res& R, c
             if (cs_skip) { first_lvl = D.cs_top - 1; cs_skip = false; }
             for (int lvl = first_lvl;; lvl += dir) {
                 if (D.cs_top > 0 && dir > 0 && lvl == D.cs_top && lvl > from && to == last && step > 2 * nramp + 1) {
-                    if (coarse) {
+                    if (coarse && !(D.dbg & 1)) {
                         RPROF_T0();
                         long nsw = 0;
                         coarse_section_enter(D, A);
@@ -2396,7 +2415,7 @@ __device__ __forceinline__ double res_cycles(const MgDesc& D, Atom& A, Res& R, c
                         if (threadIdx.x < 64) coarse_section(D, A, emin, iterno, &nsw);
                         if (threadIdx.x == 0) red[17] = static_cast<double>(nsw);
                         __syncthreads();
-                        c.sweeps += static_cast<long>(red[17]);
+                        c.sweeps += static_cast<long>(res_uniform(red[17]));
                         coarse_section_leave(D, A);
                         __syncthreads();
                         RPROF_ADD(3, 0);
@@ -2408,13 +2427,13 @@ __device__ __forceinline__ double res_cycles(const MgDesc& D, Atom& A, Res& R, c
                 { RPROF_T0();
                 if (dir > 0) {
                     if (lvl > from) {                                          // Restrict(lvl): fine lvl-1 -> coarse lvl
-                        if (lvl < kres) { if (!coarse) { DFTA_RES_LEVEL(R.logC0 - (lvl - 1), (res_restrict_local<(LC > 2 ? LC : 3)>(D, R, lvl))) } }
+                        if (lvl < kres) { if (!coarse && !(D.dbg & 4)) { DFTA_RES_LEVEL(R.logC0 - (lvl - 1), (res_restrict_local<(LC > 2 ? LC : 3)>(D, R, lvl))) } }
                         else if (lvl > kres) { if (coarse) do_restrict(D, A, lvl, true); }
                         // lvl == kres: the members have written the source during their visit of level kres-1
                     }
                 } else {                                                       // Prolong: coarse lvl+1 -> fine lvl
                     if (lvl + 1 < kres) {
-                        if (!coarse) {
+                        if (!coarse && !(D.dbg & 4)) {
                             DFTA_RES_LEVEL(R.logC0 - lvl, ({
                                 using Yc = ResLay<(LC > 2 ? LC - 1 : 2)>;
                                 const double* Pc = res_pp(R, lvl + 1);
@@ -2443,9 +2462,9 @@ __device__ __forceinline__ double res_cycles(const MgDesc& D, Atom& A, Res& R, c
                     const bool down = dir > 0 && lvl < to;
                     if (coarse) err = res_visit_passive(D, A, R, lvl, emin, down, red, &c.sweeps);
                     else { DFTA_RES_LEVEL(R.logC0 - lvl, (err = res_visit<LC>(D, A, R, lvl, emin, down, red, &c.sweeps))) }
-                } else if (coarse) {
+                } else if (coarse && !(D.dbg & 1)) {
                     RPROF_T0();
-                    err = iterate_gs(D, A, lvl, emin, iterno, red, &c.sweeps);
+                    err = res_uniform(iterate_gs(D, A, lvl, emin, iterno, red, &c.sweeps));
                     RPROF_ADD(2, lvl - kres);
                 }
                 if (lvl == to) break;
@@ -2499,7 +2518,7 @@ __global__ __launch_bounds__(kThreads) void k_poisson_solve_res(const MgDesc* __
     R.xs = res_slots + (size_t)a * res_slot_doubles();
     R.xp = R.xs + (size_t)3 * kResWG * 4;
     R.seq = 0;
-#ifdef DFTA_POISSON_PROF
+#ifdef DFTA_POISSON_RPROF
     __shared__ unsigned long long prof_acc[64];
     if (threadIdx.x < 64) prof_acc[threadIdx.x] = 0;
     R.prof = prof_acc;
@@ -2551,7 +2570,7 @@ __global__ __launch_bounds__(kThreads) void k_poisson_solve_res(const MgDesc* __
         if (errs) errs[a] = err;
         if (total_vcycles) atomicAdd(total_vcycles, (unsigned long long)c.vcycles);
     }
-#ifdef DFTA_POISSON_PROF
+#ifdef DFTA_POISSON_RPROF
     __syncthreads();
     if (a == 0 && (R.role == 1 || R.m == 0) && threadIdx.x < 64) g_rprof[R.role * 64 + threadIdx.x] += prof_acc[threadIdx.x];
 #endif
@@ -2947,6 +2966,7 @@ static int poisson_create_impl(dfta_ctx* ctx, const dfta_grid* g, int batch, int
     D.logG = logG;
     D.nofold = getenv("DFTA_POISSON_NOFOLD") ? 1 : 0;
     D.fuse3 = getenv("DFTA_POISSON_NOFUSE3") ? 0 : 1;
+    D.dbg = getenv("DFTA_POISSON_DBG") ? atoi(getenv("DFTA_POISSON_DBG")) : 0;
     D.res_kres = res_kres;
     D.res_logC0 = res_logC0;
     D.G = 1 << logG;
@@ -3054,6 +3074,10 @@ void dfta_poisson_destroy(dfta_poisson* p)
             unsigned long long z[8 * 24] = {0};
             (void)hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof(z));
         }
+    }
+#endif
+#ifdef DFTA_POISSON_RPROF
+    {
         unsigned long long hr[2 * 8 * 8];
         if (p->resident && hipMemcpyFromSymbol(hr, HIP_SYMBOL(g_rprof), sizeof(hr)) == hipSuccess) {
             const char* mn[8] = {"pass    ", "publish ", "exchange", "commit  ", "restrict", "prolong ", "handover", "redo    "};
