@@ -20,6 +20,7 @@ SWEEP_COUNT, SWEEP_ZERO = 0, 1
 SWEEP_KERNEL_AUTO, SWEEP_KERNEL_FUSED, SWEEP_KERNEL_PIPELINED = 0, 1, 2
 BOUNDARY_DEVICE, BOUNDARY_HOST = 0, 1
 LEVELS_CHAINED, LEVELS_BATCHED = 0, 1
+POISSON_DEFAULT, POISSON_EXACT, POISSON_TOLERANCE = -1, 0, 1    # dfta_poisson_create_ex / dfta_scf_options::poisson_mode
 INT_TRAPEZOID, INT_SIMPSON13, INT_SIMPSON38, INT_BOOLE, INT_ROMBERG = range(5)
 XC_VWN, XC_CHACHIYO, XC_CHACHIYO_IMPROVED = range(3)
 AUFBAU_REFERENCE, AUFBAU_TRANSITION_METALS = range(2)
@@ -49,7 +50,7 @@ class Energies(C.Structure):
 
 
 class ScfOptions(C.Structure):
-    _fields_ = [("integrator", C.c_int), ("functional", C.c_int), ("aufbau", C.c_int)]
+    _fields_ = [("integrator", C.c_int), ("functional", C.c_int), ("aufbau", C.c_int), ("poisson_mode", C.c_int)]
 
 
 class StepStats(C.Structure):
@@ -119,6 +120,8 @@ SIGNATURES = {
     "dfta_chachiyo_lda": (C.c_int, [vp, C.c_int, c_dp, C.c_size_t, c_dp, c_dp]),
     "dfta_split_spin": (C.c_int, [C.c_int, c_ip, c_ip, c_ip, c_ip, c_ip, c_ip, c_ip, c_ip, C.c_int]),
     "dfta_ctx_measure_hbm": (C.c_int, [vp, C.c_size_t, C.c_int, c_dp, c_dp]),
+    "dfta_poisson_create_ex": (C.c_int, [vp, vp, C.c_int, C.c_int, C.POINTER(vp)]),
+    "dfta_poisson_mode": (C.c_int, [vp]),
 }
 
 _lib = None
@@ -305,11 +308,15 @@ def integrate(ctx, rule, delta, values):
 class Poisson:
     """DFT::PoissonSolver for a batch of atoms on one grid (dfta_poisson)."""
 
-    def __init__(self, ctx, grid, batch=1):
+    def __init__(self, ctx, grid, batch=1, mode=POISSON_DEFAULT):
         self.ctx, self.grid, self.batch = ctx, grid, batch
         h = vp()
-        ctx.check(ctx.lib.dfta_poisson_create(ctx.h, grid.h, batch, C.byref(h)))
+        if mode == POISSON_DEFAULT:
+            ctx.check(ctx.lib.dfta_poisson_create(ctx.h, grid.h, batch, C.byref(h)))
+        else:
+            ctx.check(ctx.lib.dfta_poisson_create_ex(ctx.h, grid.h, batch, int(mode), C.byref(h)))
         self.h = h
+        self.mode = ctx.lib.dfta_poisson_mode(h)
 
     def solve(self, Z, density):
         """SolvePoissonNonUniform: density (batch x N) -> U (batch x N), vcycles, err."""
@@ -400,13 +407,13 @@ class Scf:
     """Device-resident SCF state of a batch of atoms (dfta_scf): the body of CalculateNonUniformLDA/LSDA."""
 
     def __init__(self, ctx, grid, Z, lsda=False, alpha=0.5, levels_mode=LEVELS_BATCHED, tree_depth=0, integrator=INT_SIMPSON38,
-                 functional=XC_VWN, aufbau=AUFBAU_REFERENCE):
+                 functional=XC_VWN, aufbau=AUFBAU_REFERENCE, poisson_mode=POISSON_DEFAULT):
         self.ctx, self.grid = ctx, grid
         self.Z = _i32(np.atleast_1d(Z))
         self.natoms = len(self.Z)
         self.lsda = bool(lsda)
         h = vp()
-        opt = ScfOptions(integrator, functional, aufbau)
+        opt = ScfOptions(integrator, functional, aufbau, poisson_mode)
         ctx.check(ctx.lib.dfta_scf_create_ex(ctx.h, grid.h, int(self.lsda), self.natoms, _ip(self.Z), alpha, levels_mode,
                                              tree_depth, C.cast(C.byref(opt), vp), C.byref(h)))
         self.h = h

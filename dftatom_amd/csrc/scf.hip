@@ -261,8 +261,9 @@ int dfta_scf_create_ex(dfta_ctx* ctx, const dfta_grid* g, int lsda, int natoms, 
     if (!ctx || !g || !out) return DFTA_ERR_INVALID;
     DFTA_ENTER(ctx);
     DFTA_REQUIRE(ctx, natoms >= 1 && Z && alpha >= 0 && alpha <= 1, "scf arguments");
-    dfta_scf_options opt = {DFTA_INT_SIMPSON38, DFTA_XC_VWN, DFTA_AUFBAU_REFERENCE};
+    dfta_scf_options opt = {DFTA_INT_SIMPSON38, DFTA_XC_VWN, DFTA_AUFBAU_REFERENCE, -1};
     if (options) opt = *options;
+    DFTA_REQUIRE(ctx, opt.poisson_mode >= -1 && opt.poisson_mode <= DFTA_POISSON_TOLERANCE, "poisson mode");
     DFTA_REQUIRE(ctx, dfta_integral_shape_ok(opt.integrator, g->N), "integration rule / grid size");
     DFTA_REQUIRE(ctx, opt.functional >= DFTA_XC_VWN && opt.functional <= DFTA_XC_CHACHIYO_IMPROVED, "functional");
     DFTA_REQUIRE(ctx, opt.functional == DFTA_XC_VWN || !lsda, "the Chachiyo functional is LDA only (ExcCor.h)");
@@ -308,7 +309,7 @@ int dfta_scf_create_ex(dfta_ctx* ctx, const dfta_grid* g, int lsda, int natoms, 
     for (size_t k = 0; k < specs.size(); ++k) s->h_job_bottom[k] = s->h_bottom0[specs[k].v];
     int rc = s->solver.setup(ctx, g, levels_mode, tree_depth, s->nV, specs);
     if (rc) { dfta_scf_destroy(s); return rc; }
-    rc = dfta_poisson_create(ctx, g, natoms, &s->poisson);
+    rc = opt.poisson_mode < 0 ? dfta_poisson_create(ctx, g, natoms, &s->poisson) : dfta_poisson_create_ex(ctx, g, natoms, opt.poisson_mode, &s->poisson);
     if (rc) { dfta_scf_destroy(s); return rc; }
 
     hipStream_t st = ctx->stream;

@@ -16,14 +16,15 @@ def subshell_count(Z):
     return len(get_subshells(Z))
 
 
-# SCF steps until the stop test |dE/E| < 1e-11 held in two consecutive steps (or the cap of 100, DFTAtom.cpp:396), Z = 1..86,
+# SCF steps until the stop test |dE/E| < 1e-11 held in two consecutive steps (or the cap of 100, DFTAtom.cpp:396), Z = 1..118,
 # LDA, 131073 nodes, mixing 0.5: what the compiled reference took (tests/golden/periodic_table_L17.json).  The stop step is
 # round-off noise in its last digits, but which atoms are slow (open shells: up to the cap) is not.
 EXPECTED_STEPS = (100, 100, 81, 68, 100, 64, 51, 100, 65, 38, 100, 30, 36, 57, 100, 44, 100, 68, 44, 68,
                   31, 64, 66, 51, 100, 76, 99, 41, 100, 100, 59, 42, 55, 78, 100, 89, 100, 34, 43, 100,
                   95, 31, 100, 56, 97, 100, 49, 83, 100, 44, 32, 88, 97, 81, 100, 35, 62, 65, 42, 93,
                   51, 77, 34, 27, 42, 76, 63, 100, 100, 100, 100, 35, 100, 47, 69, 100, 67, 31, 33, 100,
-                  60, 100, 32, 58, 27, 35)
+                  60, 100, 32, 58, 27, 35, 100, 45, 85, 100, 100, 31, 62, 95, 35, 61, 46, 100, 45, 39,
+                  100, 100, 92, 95, 51, 30, 93, 100, 45, 100, 100, 95, 100, 100, 77, 36, 75, 60)
 
 
 def expected_steps(Z):

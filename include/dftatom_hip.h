@@ -161,6 +161,15 @@ int dfta_solve_levels(dfta_ctx* ctx, const dfta_grid* g, int mode, int tree_dept
  * Replaces DFT::PoissonSolver (PoissonSolver.h:15-171, PoissonSolver.cpp).  `batch` independent atoms are
  * solved concurrently, one workgroup per atom. */
 int  dfta_poisson_create(dfta_ctx* ctx, const dfta_grid* g, int batch, dfta_poisson** out);  /* PoissonSolver.cpp:8-27 */
+/* Smoother mode.  EXACT (default): every Gauss-Seidel sweep (PoissonSolver.cpp:40-64) equals the reference's sequential sweep bit
+ * for bit (lanes start 96 / 112 nodes early).  TOLERANCE (opt-in): 32-node warm-ups -- a lane's start value then
+ * carries ~1e-9 of the change its start node undergoes in that sweep; the cycle converges to the same discrete solution and
+ * round-off floor (gates: U within 1e-10 Z of the reference's, SCF energies 1e-9 relative), at about 60 % of the time.
+ * dfta_poisson_create takes the mode from $DFTA_POISSON_MODE (= tolerance), default EXACT. */
+#define DFTA_POISSON_EXACT     0
+#define DFTA_POISSON_TOLERANCE 1
+int  dfta_poisson_create_ex(dfta_ctx* ctx, const dfta_grid* g, int batch, int mode, dfta_poisson** out);
+int  dfta_poisson_mode(const dfta_poisson* p);
 void dfta_poisson_destroy(dfta_poisson* p);
 /* SolvePoissonNonUniform (PoissonSolver.h:51-81): density batch*N (host) -> U batch*N (host).
  * vcycles_out/err_out (optional, per atom): V-cycles executed (<=100) and last ||dPhi||_2. */
@@ -244,6 +253,7 @@ typedef struct dfta_scf_options {
     int integrator;   /* DFTA_INT_*: quadrature of the energy integrals and of the normalisation (default SIMPSON38) */
     int functional;   /* DFTA_XC_*                                                                                */
     int aufbau;       /* DFTA_AUFBAU_*                                                                            */
+    int poisson_mode; /* DFTA_POISSON_EXACT (0, default) / DFTA_POISSON_TOLERANCE; -1: as dfta_poisson_create ($DFTA_POISSON_MODE) */
 } dfta_scf_options;
 int  dfta_scf_create_ex(dfta_ctx* ctx, const dfta_grid* g, int lsda, int natoms, const int* Z, double alpha, int levels_mode,
                         int tree_depth, const dfta_scf_options* options, dfta_scf** out);

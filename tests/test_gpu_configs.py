@@ -170,15 +170,29 @@ def test_periodic_table_batch_vs_reference(ctx, grid17):
         ref = table[str(z)]
         c = {}
         _check_converged(en[k].as_list(), scf.levels(k, 0)["E"], ref["last"], "Z=%d" % z, c, lv_abs=None)
-        worst.append((c["etot"], c["comp"], c["lv"], z))
-        # Final-state gates.  Both runs end where Etotal has stopped moving (or at the cap); Etotal is variational (second
-        # order in what is left of the density error), its components and the eigenvalues are first order, and the two runs
-        # end at different steps of the same jitter: Etotal 3e-9 relative (1e-9 where both runs met the stop test),
-        # components 2e-8 relative, eigenvalues 1e-6 Ha + 1e-10 |E| (observed: 1.8e-9 / 1.1e-8 / 4.9e-7).
-        assert c["etot"] <= (1e-9 if (ref["finished"] and fin[k]) else 3e-9), (z, c)
-        assert c["comp"] <= 2e-8 and c["lv"] <= 1e-6, (z, c)
-        for key in ("lv", "etot", "comp"):
-            conv[key] = max(conv.get(key, 0.0), c[key])
+        worst.append((c["etot"], c["comp"], c["lv"], z, bool(ref["finished"] and fin[k])))
+    # Final-state gates.  Both runs end where Etotal has stopped moving (or at the cap); Etotal is variational (second order in
+    # what is left of the density error), its components and the eigenvalues are first order, and the two runs end at different
+    # steps of the same jitter.  Gates = about twice the observed maxima (asserted below, printed with the summary):
+    #   Z = 1..86   (BASELINE config 4): Etotal 3e-9 relative (1e-9 where both runs met the stop test; observed 1.8e-9 / 6e-10),
+    #               components 2e-8 (1.1e-8), eigenvalues 1e-6 Ha + 1e-10 |E| (4.9e-7)
+    #   Z = 87..118 (round 3; ten of these atoms never meet the reference's stop test within its 100 steps and still move by
+    #               ~1e-6 Ha per step at the cap): Etotal 3e-9, components 3e-8 (1.2e-8), eigenvalues 8e-6 Ha (3.7e-6, Z = 111)
+    for lo, hi, g_et, g_etf, g_comp, g_lv in ((1, 86, 3e-9, 1e-9, 2e-8, 1e-6), (87, 118, 3e-9, 1e-9, 3e-8, 8e-6)):
+        grp = [w for w in worst if lo <= w[3] <= hi]
+        if not grp:
+            continue
+        m_et = max(w[0] for w in grp)
+        m_etf = max([w[0] for w in grp if w[4]] or [0.0])
+        m_comp = max(w[1] for w in grp)
+        m_lv = max(w[2] for w in grp)
+        print("  final states Z = %d..%d: Etotal %.2e (both finished: %.2e), components %.2e, eigenvalue excess %.2e Ha; worst eigenvalue at Z=%d"
+              % (lo, min(hi, Zs[-1]), m_et, m_etf, m_comp, m_lv, max(grp, key=lambda w: w[2])[3]))
+        assert m_et <= g_et and m_etf <= g_etf, (lo, hi, m_et, m_etf)
+        assert m_comp <= g_comp and m_lv <= g_lv, (lo, hi, m_comp, m_lv)
+    for c_et, c_comp, c_lv, z, _ in worst:
+        for key, v in (("lv", c_lv), ("etot", c_et), ("comp", c_comp)):
+            conv[key] = max(conv.get(key, 0.0), v)
     fin_ref = np.array([table[str(z)]["finished"] for z in Zs])
     print("periodic table: %d atoms in one batch, %d steps of the batch; Finished here %d, in the reference %d (both %d)"
           % (len(Zs), nsteps, int(fin.sum()), int(fin_ref.sum()), int((fin_ref & fin.astype(bool)).sum())))
@@ -238,7 +252,7 @@ def test_l20_poisson_vs_reference(ctx, grid20):
     assert vc[0] == 100
     # staged / unstaged and group variants agree bit for bit at this size too
     ref = U[0].view(np.int64)
-    for var in ({"DFTA_POISSON_GROUP": "0"}, {"DFTA_POISSON_NOSTAGE": "1"}):
+    for var in ({"DFTA_POISSON_GROUP": "0"}, {"DFTA_POISSON_NOSTAGE": "1"}, {"DFTA_POISSON_GROUP": "3"}, {"DFTA_POISSON_GROUP": "2"}):
         old = {k: os.environ.get(k) for k in var}
         os.environ.update(var)
         try:

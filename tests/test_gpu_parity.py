@@ -172,7 +172,14 @@ def test_level_solver_chained_vs_golden(ctx, grid14, golden, pname, Z, sweep_ker
     V = _pots(grid14)[pname]
     lv = D.get_subshells(Z)
     res = D.solve_levels(ctx, grid14, V, lv, -float(Z) * Z - 1.0, mode=D.LEVELS_CHAINED)
-    assert np.max(np.abs(res["E"] - data[f"levels_{pname}_E"])) <= 1e-10
+    # BASELINE.md section 3 asks for |dE| <= 2e-12 from identical V.  The bisection takes the reference's decisions (the sweep
+    # counts below are equal), but the two start values of every sweep are exp() of the DEVICE library here and of the host's libm
+    # in the reference (glibc picks an FMA build of exp at run time: not reproducible on the device); a one-ulp start value flips
+    # the sign of u(0) for trial energies inside the round-off band of a level (profiles/r02c_noise_band.txt: up to 7e-12 |E| wide),
+    # so E moves inside that band.  Asserted: twice the observed maximum, and at most the band.
+    dE = np.abs(res["E"] - data[f"levels_{pname}_E"])
+    print("chained level driver %s: max |dE| %.2e Ha, max |dE| / |E| %.2e" % (pname, dE.max(), np.max(dE / np.abs(res["E"]))))
+    assert np.max(dE) <= 2e-11 and np.all(dE <= 8e-12 * np.abs(res["E"]) + 2e-12)
     arr = O.levels_array(lv)
     nd = np.zeros(g.N)
     Eel, Bot = C.c_double(0), C.c_double(-float(Z) * Z - 1.0)
@@ -313,8 +320,15 @@ def test_vwn_vs_golden(ctx, golden):
     data, _ = golden
     n = data["vwn_n"]
 
+    worst = [0.0]
+
     def close(a, b):
-        return np.all(np.abs(a - b) <= 1e-9 * np.abs(b) + 1e-300) and np.array_equal(np.isnan(a), np.isnan(b))
+        # device pow / log / atan against the host's libm: observed maximum 7e-11 relative (asserted at 2e-10: about twice that, plus head room
+        # for another ROCm's device library; xc.hip keeps the reference's operation order, so nothing else differs)
+        m = np.abs(b) > 0
+        if m.any():
+            worst[0] = max(worst[0], float(np.max(np.abs(a[m] - b[m]) / np.abs(b[m]))))
+        return np.all(np.abs(a - b) <= 2e-10 * np.abs(b) + 1e-300) and np.array_equal(np.isnan(a), np.isnan(b))
 
     v, e = D.vwn_lda(ctx, n)
     assert close(v, data["vwn_vexc"]) and close(e, data["vwn_eexcdif"])
@@ -323,6 +337,7 @@ def test_vwn_vs_golden(ctx, golden):
         na, nb, res, va, vb, ee = data[f"vwn_lsda_z{zeta}"]
         r, a, b, x = D.vwn_lsda(ctx, na, nb)
         assert close(r, res) and close(a, va) and close(b, vb) and close(x, ee), zeta
+    print("VWN LDA / LSDA vs reference: max relative difference %.2e" % worst[0])
 
 
 def _oracle_steps(mode, Z, L, d, R, n, chained):
@@ -576,7 +591,9 @@ def test_full_size_radon_to_convergence_vs_reference(ctx, grid17):
     want_lv = np.array([x[1] for x in rn["last"]["levels"]])
     assert lv["converged"].all()
     # eigenvalues carry the same floor through 1/r (core levels most): 2e-7 Ha is 6e-11 of the 1s level
-    assert np.all(np.abs(lv["E"] - want_lv) <= 2e-7 + 1e-9 * np.abs(want_lv))
+    dlv = np.abs(lv["E"] - want_lv)
+    print("Rn converged: eigenvalue excess over 1e-10 |E|: %.2e Ha" % float(np.max(dlv - 1e-10 * np.abs(want_lv))))
+    assert np.all(dlv <= 2e-7 + 1e-10 * np.abs(want_lv))                # the gate of tests/test_gpu_configs.py
     for a, b in zip(scf.energies()[0][0].as_list(), rn["last"]["energies"]):
         assert abs(a - b) <= 2e-9 * abs(b)
     # the predictions pay off as the SCF settles: fewer bisection rounds per step at the end than at the start

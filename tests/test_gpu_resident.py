@@ -1,0 +1,177 @@
+"""GPU suite (-m gpu): the resident multigrid groups (k_poisson_solve_res: 32 member workgroups keep their stretch of every
+shared level in LDS, one fused three-sweep pass and one exchange per visit, a coarse workgroup below) and the opt-in tolerance
+mode of the smoother.
+
+EXACT mode (default): U, the V-cycle count and the last error norm are the bits of the one-workgroup solve -- which equals the
+reference's PoissonSolver (tests/test_gpu_parity.py, test_oracle_vs_ref.py) -- for every grid the resident layout serves
+(16385 .. 131073 nodes: 1 .. 4 shared levels), for Z = 1 (the cycle stops early: the visits' stop-after-one-sweep path) to 86,
+for batches of 1 .. 4 atoms, run after run (the exchange slots are validated by content, never by timing), and through a whole
+SCF.  TOLERANCE mode: U within 1e-9 Z of the exact solve (observed 3.5e-10 Z: the 100-cycle end state is a round-off floor that
+any perturbation of the iteration shifts by that much -- the reference moves by as much under FMA contraction,
+test_oracle_golden.py::test_reference_rounding_sensitivity_of_scf_steps), SCF energies within 1e-9 relative and eigenvalues within
+1e-8 Ha + 2e-9 |E| of the reference's golden values.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import dftatom_amd as D                 # noqa: E402
+from golden.make_golden import GRIDS    # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+KNOBS = ("DFTA_POISSON_GROUP", "DFTA_POISSON_RES", "DFTA_POISSON_MODE", "DFTA_POISSON_NOFUSE3")
+
+
+@pytest.fixture(scope="module")
+def ctx(torch_first):
+    c = D.Context(0)
+    yield c
+    c.close()
+
+
+class env:
+    def __init__(self, **kv):
+        self.kv = kv
+
+    def __enter__(self):
+        self.old = {k: os.environ.get(k) for k in KNOBS}
+        for k in KNOBS:
+            os.environ.pop(k, None)
+        os.environ.update(self.kv)
+
+    def __exit__(self, *a):
+        for k, v in self.old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def _solve(ctx, grid, Zs, rho, mode=D.POISSON_DEFAULT, **kv):
+    with env(**kv):
+        ps = D.Poisson(ctx, grid, len(Zs), mode)
+        U, vc, err = ps.solve(Zs, rho)
+        info = ps.group_info()
+        ps.close()
+    return U, vc, err, info
+
+
+@pytest.mark.parametrize("L,delta,R", [(14, 5e-4, 25.0), (15, 2.5e-4, 30.0), (16, 2e-4, 40.0), (17, 1e-4, 50.0)])
+def test_resident_groups_return_the_one_workgroup_bits(ctx, L, delta, R):
+    grid = D.Grid(ctx, L, delta, R)
+    rr = grid.r()
+    for Zs in ([86], [1], [18, 2], [2, 54, 86, 7]):
+        rho = np.stack([z * (1.0 + 0.3 * k) ** 3 * np.exp(-2 * (1.0 + 0.3 * k) * rr) / np.pi for k, z in enumerate(Zs)])
+        U1, vc1, e1, i1 = _solve(ctx, grid, Zs, rho, DFTA_POISSON_GROUP="0", DFTA_POISSON_NOFUSE3="1")
+        Ur, vcr, er, ir = _solve(ctx, grid, Zs, rho)
+        assert i1[0] == 1 and ir == (33, False, 0), (i1, ir)          # one workgroup per atom vs 32 members + coarse workgroup
+        assert np.array_equal(Ur.view(np.int64), U1.view(np.int64)), (L, Zs)
+        # (the last error norm is a sum of squares taken in another order: it may differ in its last bit, never in a decision)
+        assert np.array_equal(vcr, vc1) and np.all(np.abs(er - e1) <= 1e-14 * np.abs(e1)), (L, Zs, vcr, vc1, er, e1)
+    grid.close()
+
+
+def test_resident_groups_are_deterministic(ctx):
+    """He at 16385 nodes: one shared level, short passes, the cycle stops early -- exchanges follow each other within microseconds.
+    Thirty SCF steps twice: every step's U and V-cycle count identical, and identical to the one-workgroup solver's."""
+    L, d, R = GRIDS["L14"]
+    grid = D.Grid(ctx, L, d, R)
+    runs = []
+    for kv in ({}, {}, {"DFTA_POISSON_GROUP": "0"}):
+        with env(**kv):
+            scf = D.Scf(ctx, grid, [2], lsda=False)
+            tr = []
+            for _ in range(30):
+                st = scf.step()
+                tr.append((st.vcycles, scf.array(5, 0).copy(), scf.energies()[0][0].Etotal))
+            runs.append((scf.poisson_info()[0], tr))
+            scf.close()
+    assert runs[0][0] == 33 and runs[1][0] == 33 and runs[2][0] == 1
+    for k in range(30):
+        for other in (1, 2):
+            assert runs[0][1][k][0] == runs[other][1][k][0], (k, other)
+            assert np.array_equal(runs[0][1][k][1].view(np.int64), runs[other][1][k][1].view(np.int64)), (k, other)
+            assert runs[0][1][k][2] == runs[other][1][k][2]
+    grid.close()
+
+
+def test_resident_lost_member_is_detected(ctx):
+    L, d, R = GRIDS["L17"]
+    grid = D.Grid(ctx, L, d, R)
+    rr = grid.r()
+    rho = (86 * np.exp(-2 * rr) / np.pi)[None, :]
+    U0, vc0, _, info0 = _solve(ctx, grid, [86], rho)
+    assert info0 == (33, False, 0)
+    with env(DFTA_FAULT_POISSON_MEMBER="1"):
+        os.environ["DFTA_FAULT_POISSON_MEMBER"] = "1"
+        try:
+            ps = D.Poisson(ctx, grid, 1)
+            U1, vc1, _ = ps.solve([86], rho)
+            assert ps.group_info() == (33, True, 1)
+            ps.close()
+        finally:
+            os.environ.pop("DFTA_FAULT_POISSON_MEMBER", None)
+    assert np.array_equal(U0.view(np.int64), U1.view(np.int64)) and np.array_equal(vc0, vc1)
+    grid.close()
+
+
+@pytest.mark.parametrize("kv", [{}, {"DFTA_POISSON_RES": "0"}, {"DFTA_POISSON_GROUP": "0"}, {"DFTA_POISSON_GROUP": "2"}])
+def test_tolerance_mode_poisson(ctx, kv):
+    """opt-in 32-node warm-ups, every flavour of the solver: U within 1e-9 Z of the exact mode's (= the reference's) solution"""
+    L, d, R = GRIDS["L17"]
+    grid = D.Grid(ctx, L, d, R)
+    rr = grid.r()
+    worst = 0.0
+    for Z in (1, 18, 86):
+        rho = (Z * np.exp(-2 * rr) / np.pi)[None, :]
+        Ue, vce, _, _ = _solve(ctx, grid, [Z], rho, D.POISSON_EXACT, **kv)
+        Ut, vct, _, _ = _solve(ctx, grid, [Z], rho, D.POISSON_TOLERANCE, **kv)
+        dU = float(np.max(np.abs(Ue - Ut))) / Z
+        worst = max(worst, dU)
+        assert dU <= 1e-9, (Z, dU)
+        # (where the cycle count is decided by the 1e-14 test -- small Z -- it is decided by round-off: not compared)
+        assert 1 <= int(vct[0]) <= 100
+        assert np.max(np.abs(Ut[0] - Z * (1 - (1 + rr) * np.exp(-2 * rr)))) < 3e-7 * Z     # analytic Hartree potential of 1s
+    print("tolerance mode %s: max |dU| / Z = %.2e" % (kv, worst))
+    grid.close()
+
+
+@pytest.mark.parametrize("lsda", [False, True])
+def test_tolerance_mode_radon_steps_vs_reference(ctx, lsda):
+    """BASELINE configs[1] / [2] in tolerance mode against the compiled reference's golden steps: energies 1e-9 relative,
+    eigenvalues 1e-8 Ha + 2e-9 |E| (the gate of every step that has been through a Poisson solve, test_gpu_configs.py)"""
+    L, d, R = GRIDS["L17"]
+    grid = D.Grid(ctx, L, d, R)
+    gold = json.load(open(os.path.join(HERE, "golden", "rn_end_to_end.json")))["Rn_LSDA_L17" if lsda else "Rn_LDA_L17"]
+    scf = D.Scf(ctx, grid, [86], lsda=lsda, levels_mode=D.LEVELS_CHAINED, poisson_mode=D.POISSON_TOLERANCE)
+    worst_e, worst_l = 0.0, 0.0
+    for key in ("first", "second"):
+        scf.step()
+        want = gold[key]
+        en = scf.energies()[0][0].as_list()
+        lv = np.concatenate([scf.levels(0, 0)["E"]] + ([scf.levels(0, 1)["E"]] if lsda else []))
+        wl = np.array([x[1] for x in want["levels"]])
+        de = max(abs(a - b) / abs(b) for a, b in zip(en, want["energies"]))
+        dl = np.abs(lv - wl)
+        worst_e = max(worst_e, de)
+        worst_l = max(worst_l, float(np.max(dl / np.abs(wl))))
+        assert de <= 1e-9, (key, de)
+        assert np.all(dl <= 1e-8 + 2e-9 * np.abs(wl)), (key, dl.max())
+    # and to the end of the recorded trajectory: Etotal of every step
+    traj = np.array(gold["etotal_all"])
+    scf2 = D.Scf(ctx, grid, [86], lsda=lsda, poisson_mode=D.POISSON_TOLERANCE)
+    got = []
+    for _ in range(len(traj)):
+        scf2.step(want_stats=False)
+        got.append(scf2.energies()[0][0].Etotal)
+    rel = np.abs(np.array(got) - traj) / np.abs(traj)
+    print("tolerance mode Rn %s: steps 0/1 energies %.2e rel, eigenvalues %.2e |E|; trajectory (%d steps) %.2e"
+          % ("LSDA" if lsda else "LDA", worst_e, worst_l, len(traj), rel.max()))
+    assert rel.max() <= 1e-9
+    scf.close()
+    scf2.close()
+    grid.close()
