@@ -42,7 +42,8 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s (spec); the attainable figure is measured
+HBM_MEASURED = {"copy": None, "triad": None}   # live by a copy / triad kernel of the library (dfta_ctx_measure_hbm) at the start of the run
 NUMEROV_BYTES_PER_POINT = 8    # one fp64 V_i per traversed grid point per trial
 POISSON_BYTES_PER_VCYCLE = {14: 6162448, 17: 49285736, 20: 394267840}   # SURVEY.md section 8(d), every pass counted
 # fp64 VALU issue: one wave64 instruction per SIMD every 1.86 ns (profiles/microbench/issue_rate.hip), 256 CUs x 4 SIMDs
@@ -101,12 +102,28 @@ def cpu_model():
     return "unknown"
 
 
+def physical_cores():
+    """distinct (package, core) pairs of /proc/cpuinfo; falls back to the logical CPU count"""
+    try:
+        cores, phys = set(), None
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("physical id"):
+                phys = ln.split(":", 1)[1].strip()
+            elif ln.startswith("core id"):
+                cores.add((phys, ln.split(":", 1)[1].strip()))
+        if cores:
+            return len(cores)
+    except OSError:
+        pass
+    return os.cpu_count() or 1
+
+
 def cpu_baseline(levels, lsda, steps):
     """The oracle (plain-C restatement of the reference) timed on this host, in child processes."""
     nproc = os.cpu_count() or 1
     one, _ = _spawn_cpu(levels, lsda, steps, False, 1)
     tab, _ = _spawn_cpu(levels, lsda, steps, True, 1)
-    nall = min(nproc, 64)
+    nall = max(1, min(physical_cores(), len(os.sched_getaffinity(0))))     # every physical core this process may use
     allc, wall = _spawn_cpu(levels, lsda, steps, False, nall)
     o, t = one[0], tab[0]
     assert abs(o["etotal"] - t["etotal"]) == 0.0                     # the table variant is bit-identical
@@ -120,8 +137,11 @@ def cpu_baseline(levels, lsda, steps):
                               "note": "r_i and exp(2 i delta) looked up instead of re-evaluated per point; results bit-identical"},
             "all_cores": {"value": sum(x["sweeps"] for x in allc) / max(x["seconds"] for x in allc), "unit": "sweeps/s", "cores": nall,
                           "vcycles_per_s": sum(x["vcycles"] for x in allc) / max(x["seconds"] for x in allc),
-                          "note": "%d independent replicas of the same run, one process per core (atoms are the parallel axis of the "
-                                  "reference's algorithm; the reference itself is single-threaded), %d steps each, slowest replica's time"
+                          "physical_cores": physical_cores(),
+                          "note": "%d independent replicas of the same run, one process per physical core (atoms are the parallel axis of the "
+                                  "reference's algorithm; the reference itself is single-threaded), %d steps each, slowest replica's time. "
+                                  "Inside one atom only the level loop parallelises (15 subshells, ~77 %% of a step; the multigrid is a serial "
+                                  "recurrence): at most ~3.5x per atom by Amdahl, so replicas are the all-core figure that favours the CPU"
                                   % (nall, steps)}}
 
 
@@ -157,8 +177,9 @@ def pmc_traffic(kernel):
 # ---------------------------------------------------------------------------------------------------------------
 # one measured workload
 # ---------------------------------------------------------------------------------------------------------------
-def run_workload(D, ctx, grid, levels, atoms, lsda, steps, warmup, tree_depth, barrier, torch, after_steps=None):
-    scf = D.Scf(ctx, grid, [86] * atoms, lsda=lsda, alpha=0.5, levels_mode=D.LEVELS_BATCHED, tree_depth=tree_depth)
+def run_workload(D, ctx, grid, levels, atoms, lsda, steps, warmup, tree_depth, barrier, torch, after_steps=None, poisson_mode=None):
+    scf = D.Scf(ctx, grid, [86] * atoms, lsda=lsda, alpha=0.5, levels_mode=D.LEVELS_BATCHED, tree_depth=tree_depth,
+                poisson_mode=D.POISSON_EXACT if poisson_mode is None else poisson_mode)
     for _ in range(warmup):
         scf.step()
     barrier()
@@ -219,10 +240,20 @@ def kernel_figures(tot, levels, N, atoms):
             "achieved": b_ps / t_ps / 1e9 if t_ps else None, "frac": b_ps / t_ps / 1e9 / HBM_PEAK_GBS if t_ps else None,
             "bytes_per_launch": b_ps / psolves, "vcycles_per_s": tot["vcycles"] / t_ps if t_ps else None,
             "workgroups": atoms * tot["poisson_G"],
-            "binding_resource": "latency of the ordered Gauss-Seidel recurrence: %d atom(s) x %d workgroups of 256 lanes on 256 CUs, every sweep "
-                                "%d+95 dependent steps" % (atoms, tot["poisson_G"], max(1, (N - 1) // (256 * tot["poisson_G"]))),
+            "binding_resource": ("latency of the ordered Gauss-Seidel recurrence: %d atom(s) x %d workgroups on 256 CUs; " % (atoms, tot["poisson_G"])) +
+                                ("resident group: 32 members x 128 lanes keep the four finest levels in LDS (one fused 3-sweep pass of 112+C+2 dependent "
+                                 "steps and one exchange per visit), a coarse workgroup runs the 13 levels below" if tot["poisson_G"] == 33 else
+                                 "every sweep %d+95 dependent steps" % max(1, (N - 1) // (256 * tot["poisson_G"]))),
             "note": "algorithmic bytes per V-cycle with every pass counted (GS 24 B/pt x 3 sweeps per visit, restrict, prolong: SURVEY 8d); the "
                     "level storage of one atom (6.3 MB at 17 levels) stays in LDS / L2, so HBM is not what this kernel waits for"}
+    for d in (sweep, pois):
+        d["peak_measured"] = HBM_MEASURED["copy"]
+        d["peak_note"] = "peak = 8 TB/s HBM3E spec; peak_measured = copy kernel of this library on this device in this run (GB/s)"
+    if HBM_MEASURED["copy"]:
+        pois["frac_measured"] = pois["achieved"] / HBM_MEASURED["copy"] if pois["achieved"] else None
+        sweep["frac_issued_measured"] = sweep["achieved_issued"] / HBM_MEASURED["copy"] if sweep["achieved_issued"] else None
+        sweep["frac_reference_equivalent_measured"] = (sweep["achieved_reference_equivalent"] / HBM_MEASURED["copy"]
+                                                       if sweep["achieved_reference_equivalent"] else None)
     return sweep, pois
 
 
@@ -230,9 +261,12 @@ def summarize(tot, levels, N, atoms, lsda, world, delta, rmax):
     sweep, pois = kernel_figures(tot, levels, N, atoms)
     return {"workload": "Rn Z=86 %s, %d multigrid levels (%d pts), delta=%g, Rmax=%g, mixing 0.5, %d atom(s)/GPU, un-chained clamped brackets, "
                         "tree depth %d" % ("LSDA" if lsda else "LDA", levels, N, delta, rmax, atoms, tot["tree_depth"]),
-            "sweeps_per_s": tot["sweeps_reference"] / tot["elapsed"], "sweeps_executed_per_s": tot["sweeps_reference_executed"] / tot["elapsed"],
+            "sweeps_executed_per_s": tot["sweeps_reference_executed"] / tot["elapsed"],
+            "sweeps_reference_equivalent_per_s": tot["sweeps_reference"] / tot["elapsed"],
+            "issued_per_useful": tot["sweeps_issued"] / max(tot["sweeps_reference_executed"], 1),
             "sweeps_issued_per_s": tot["sweeps_issued"] / tot["elapsed"], "vcycles_per_s": tot["vcycles"] / tot["elapsed"],
-            "ms_per_step": 1e3 * tot["elapsed"] / tot["steps"], "steps": tot["steps"], "rounds_per_step": tot["rounds"] / tot["steps"],
+            "ms_per_step": 1e3 * tot["elapsed"] / tot["steps"], "ms_per_atom_step": 1e3 * tot["elapsed"] / tot["steps"] / atoms,
+            "steps": tot["steps"], "rounds_per_step": tot["rounds"] / tot["steps"], "poisson_workgroups_per_atom": tot["poisson_G"],
             "phase_ms_per_step": {"levels": tot["ms_levels"] / tot["steps"], "poisson": tot["ms_poisson"] / tot["steps"],
                                   "tail": tot["ms_tail"] / tot["steps"], "hip_event_total": tot["ev_ms"] / tot["steps"]},
             "kernels": {"sweep": sweep, "poisson": pois}}
@@ -301,6 +335,11 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     ctx = D.Context(dev_index, stream)
     grid = D.Grid(ctx, args.levels, delta, rmax)
+    if rank == 0:
+        try:
+            HBM_MEASURED["copy"], HBM_MEASURED["triad"] = ctx.measure_hbm(1 << 27, 5)      # 3 x 1 GiB arrays, a few ms
+        except Exception:
+            pass
     records = torch.zeros((args.atoms, D.RECORD_DOUBLES), dtype=torch.float64, device="cuda")
 
     def barrier():
@@ -340,6 +379,9 @@ def main():
                 "achieved": dominant["achieved"] if dominant is pois else dominant["achieved_reference_equivalent"],
                 "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": dominant["frac"] if dominant is pois else dominant["frac_reference_equivalent"],
+                "peak_measured": HBM_MEASURED["copy"], "peak_measured_triad": HBM_MEASURED["triad"],
+                "frac_measured": ((dominant["achieved"] if dominant is pois else dominant["achieved_reference_equivalent"]) / HBM_MEASURED["copy"]
+                                  if HBM_MEASURED["copy"] else None),
                 "traffic": traffic, "traffic_source": ttag,
                 "bytes_per_launch": dominant["bytes_per_launch"] if dominant is pois else dominant["bytes_per_launch_reference_equivalent"],
                 "avg_launch_ms": dominant["avg_launch_ms"], "launches": dominant["launches"],
@@ -348,8 +390,9 @@ def main():
                 "note": "dominant kernel of the timed region by HIP-event time; achieved = algorithmic bytes of SURVEY 8d per launch / average "
                         "launch duration; see `kernels` for both hot kernels (the sweep kernel also on issued bytes and against its VALU-issue ceiling)"}
         out = {
-            "metric": "numerov_sweeps_per_s (reference-equivalent, whole SCF step; Rn Z=86 @ %d pts)" % grid.N,
-            "value": ref_all / elapsed,
+            "metric": "numerov_sweeps_per_s (executed sweeps of the reference's bisection path, whole SCF step; Rn Z=86 @ %d pts)" % grid.N,
+            "value": exe_all / elapsed,
+            "value_reference_equivalent": ref_all / elapsed,
             "unit": "sweeps/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -365,9 +408,9 @@ def main():
                                                                            delta, rmax, args.atoms, tot["tree_depth"]),
                        "atoms_per_gpu": args.atoms, "parallelism": "replicas x%d" % world},
             "scf_step_ms": 1e3 * elapsed / args.steps,
-            "sweeps_reference_definition": "every SolveSchrodinger* call of the reference's LoopOverLevels for these steps (CountNodes + "
-                                           "SolutionInZero + Match); sweeps_executed_per_s leaves out the CountNodes calls of node-less levels' "
-                                           "second bisection, which are decided without integrating",
+            "value_definition": "value = sweeps on the reference's bisection path that are actually integrated here (CountNodes + SolutionInZero + "
+                                "Match) / whole-step wall time; value_reference_equivalent also counts the ~52 CountNodes calls per node-less level's "
+                                "second bisection that the reference integrates and this path decides without integrating (+9 %)",
             "sweeps_executed_per_s": exe_all / elapsed,
             "sweeps_issued_per_s": issued_all / elapsed,
             "poisson_vcycles_per_s": vc_all / elapsed,
@@ -381,21 +424,34 @@ def main():
             "kernels": {"sweep": sweep, "poisson": pois},
         }
         if world == 1 and not args.no_extras:
-            # further measured workloads with the same per-kernel figures: a machine-filling batch, LSDA (BASELINE config 3) and
-            # the 1 048 577-node stress of config 5 (one atom and a batch of 16); a few seconds each
+            # further measured workloads with the same per-kernel figures (>= 10 timed steps after >= 5 warm-up steps wherever a step
+            # is short enough): the opt-in tolerance mode of the multigrid smoother, LSDA (BASELINE config 3), machine-filling
+            # batches of Rn atoms, and the 1 048 577-node stress of config 5 (one atom and a batch of 16); a few seconds each
             extra = {}
-            for name, lv, atoms, lsda, st, wu in (("batch256_lda", args.levels, 256, False, 3, 1), ("rn_lsda", args.levels, 1, True, 3, 2),
-                                                  ("rn_lsda_l20", 20, 1, True, 2, 1), ("rn_lsda_l20_batch16", 20, 16, True, 2, 1)):
+            for name, lv, atoms, lsda, st, wu, pm in (("rn_lda_tolerance_mode", args.levels, 1, False, 10, 5, D.POISSON_TOLERANCE),
+                                                      ("rn_lsda", args.levels, 1, True, 10, 5, None),
+                                                      ("rn_lsda_tolerance_mode", args.levels, 1, True, 10, 5, D.POISSON_TOLERANCE),
+                                                      ("batch256_lda", args.levels, 256, False, 10, 5, None),
+                                                      ("batch1024_lda", args.levels, 1024, False, 4, 2, None),
+                                                      ("rn_lsda_l20", 20, 1, True, 3, 2, None), ("rn_lsda_l20_batch16", 20, 16, True, 2, 1, None)):
                 if lv == args.levels:
                     g2, d2, r2 = grid, delta, rmax
                 else:
                     d2, r2 = GRIDS[lv]
                     g2 = D.Grid(ctx, lv, d2, r2)
-                s2, t2 = run_workload(D, ctx, g2, lv, atoms, lsda, st, wu, 0, barrier, torch)
+                s2, t2 = run_workload(D, ctx, g2, lv, atoms, lsda, st, wu, 0, barrier, torch, poisson_mode=pm)
                 s2.close()
                 extra[name] = summarize(t2, lv, g2.N, atoms, lsda, world, d2, r2)
+                extra[name]["poisson_mode"] = "tolerance" if pm == D.POISSON_TOLERANCE else "exact"
+                extra[name]["warmup"] = wu
                 if g2 is not grid:
                     g2.close()
+            try:
+                sys.path.insert(0, os.path.join(ROOT, "profiles"))
+                import dense_k_sweep
+                extra["dense_k_sweeps"] = dense_k_sweep.run(D, ctx, grid, HBM_PEAK_GBS, HBM_MEASURED["copy"])
+            except Exception as e:                      # the isolated sweep-kernel benchmark must not cost the line
+                extra["dense_k_sweeps"] = {"error": repr(e)}
             out["extra"] = extra
         if world == 1 and not args.no_cpu:      # rank 0 at N = 1 only: the other ranks of a larger job would sit at the final barrier
             out["cpu_baseline"] = cpu_baseline(args.levels, args.lsda, args.cpu_steps)

@@ -128,7 +128,7 @@ namespace mg_exact {
 // Tolerance mode (opt-in, DFTA_POISSON_TOLERANCE): the same kernels with 32-node warm-ups.  A lane's start value then carries
 // 0.52^32 ~ 1e-9 of the change its start node undergoes in that sweep -- a perturbation of the ITERATION, not of its fixed point:
 // the cycle still converges to the solution of the same discrete equations, to the same round-off floor (tests: U within
-// 1e-10 Z of the reference's, SCF energies within 1e-9), but a sweep is no longer the sequential sweep bit for bit.
+// 2e-9 Z of the exact solve, SCF energies within 1e-9 of the reference's), but a sweep is no longer the sequential sweep bit for bit.
 namespace mg_tol {
 #define DFTA_MG_KWARM 32
 #define DFTA_MG_KWARM3 32

@@ -24,7 +24,7 @@ __global__ __launch_bounds__(128) void k_integrate(const double* __restrict__ va
 
 // Attainable HBM bandwidth of this device: the second denominator of every roofline figure (SURVEY.md 8d asks for the spec
 // figure AND a stream measurement on the box).  Plain grid-stride kernels, 16 bytes per lane and access, buffers far larger
-// than the 256 MB Infinity Cache.
+// than the 256 MB Infinity Cache; launch shape from profiles/microbench/hbm_stream.hip (results_r03.txt).
 __global__ __launch_bounds__(256) void k_stream_copy(const double2* __restrict__ a, double2* __restrict__ c, size_t n2)
 {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -54,7 +54,7 @@ extern "C" int dfta_ctx_measure_hbm(dfta_ctx* ctx, size_t doubles_per_array, int
     DFTA_HIP(ctx, hipMemsetAsync(A.p, 0, n * sizeof(double), st));
     DFTA_HIP(ctx, hipMemsetAsync(B.p, 0, n * sizeof(double), st));
     DFTA_HIP(ctx, hipMemsetAsync(Cc.p, 0, n * sizeof(double), st));
-    const int blocks = ctx->num_cu * 8;
+    const int blocks = ctx->num_cu * 4;       // the best shape of profiles/microbench/hbm_stream.hip on MI355X: 5.5 TB/s copy
     double best[2] = {0, 0};
     for (int which = 0; which < 2; ++which) {
         for (int r = 0; r < reps + 1; ++r) {            // first repetition: warm-up

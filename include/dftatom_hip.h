@@ -164,7 +164,8 @@ int  dfta_poisson_create(dfta_ctx* ctx, const dfta_grid* g, int batch, dfta_pois
 /* Smoother mode.  EXACT (default): every Gauss-Seidel sweep (PoissonSolver.cpp:40-64) equals the reference's sequential sweep bit
  * for bit (lanes start 96 / 112 nodes early).  TOLERANCE (opt-in): 32-node warm-ups -- a lane's start value then
  * carries ~1e-9 of the change its start node undergoes in that sweep; the cycle converges to the same discrete solution and
- * round-off floor (gates: U within 1e-10 Z of the reference's, SCF energies 1e-9 relative), at about 60 % of the time.
+ * round-off floor (gates: U within 2e-9 Z of the exact solve -- observed 4e-10 .. 9e-10 Z, what the reference itself moves by
+ * under FMA contraction --, SCF energies 1e-9 relative, eigenvalues 1e-8 Ha + 2e-9 |E|), at about 75 % of the time.
  * dfta_poisson_create takes the mode from $DFTA_POISSON_MODE (= tolerance), default EXACT. */
 #define DFTA_POISSON_EXACT     0
 #define DFTA_POISSON_TOLERANCE 1

