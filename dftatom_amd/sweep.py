@@ -1,9 +1,9 @@
 """Host-side sharding of independent atoms over ranks (periodic-table sweep, BASELINE.json config 4).
 
 Atoms are independent SCF problems: there is no exchange during the solve.  Ranks get a
-static longest-processing-time partition (cost ~ subshells x expected SCF steps: Numerov jobs over the atom's run) and
-the only collective is one all_gather of fixed-size result records (RECORD_DOUBLES doubles per atom) at
-the end.  The same code runs over RCCL (backend "nccl", GPU tensors) and, in the CPU tests, over gloo.
+static partition that balances the predicted wall time of the shards (critical path = steps of the slowest atom x the
+latency floor of a step, plus work = subshells x expected SCF steps) and the only collective is one all_gather of
+fixed-size result records (RECORD_DOUBLES doubles per atom) at the end.  The same code runs over RCCL (backend "nccl", GPU tensors) and, in the CPU tests, over gloo.
 """
 import numpy as np
 
@@ -37,16 +37,45 @@ def atom_cost(Z):
     return subshell_count(Z) * expected_steps(Z)
 
 
+# Time model of one shard (measured on MI355X, profiles/r03_periodic_table_predicted_scaling.json): a step of a batch costs a
+# latency floor -- the level search's rounds and the multigrid's dependent sweeps take what they take for one atom or ten -- plus
+# a per-job share once the batch fills the machine:  t_step(batch) = STEP_FLOOR_MS + JOB_MS x (subshells of the atoms still running).
+# A shard runs until its slowest atom stops, so  T(shard) = STEP_FLOOR_MS x max(steps) + JOB_MS x sum(subshells x steps):
+# the first term is the critical path (what a by-work partition ignores), the second the work.
+STEP_FLOOR_MS = 68.0      # fitted to the emulated 1- and 8-rank sweeps of profiles/r03_periodic_table_predicted_scaling.json
+JOB_MS = 0.46             # (32.3 s on one GPU, 10.0 s for an eighth of the table)
+
+
+def shard_time_ms(Zs):
+    """predicted wall time of one rank that advances the atoms Zs together until each has stopped (see the model above)"""
+    if not Zs:
+        return 0.0
+    return STEP_FLOOR_MS * max(expected_steps(z) for z in Zs) + JOB_MS * sum(atom_cost(z) for z in Zs)
+
+
 def partition_atoms(Zs, world_size, cost=None):
-    """Static LPT assignment: returns a list (per rank) of lists of Z, deterministic on every rank."""
-    cost = cost or atom_cost
-    order = sorted(Zs, key=lambda z: (-cost(z), z))
-    loads = [0] * world_size
+    """Static assignment of atoms to ranks, deterministic on every rank: returns a list (per rank) of lists of Z.
+
+    Default (cost=None): greedy on the PREDICTED SHARD TIME (critical path + work, shard_time_ms): atoms in order of decreasing step
+    count, each to the rank whose predicted time grows least / stays smallest.  Long runners (the atoms that hit the reference's
+    100-step cap) therefore land together on as few ranks as the work balance allows -- their late steps keep some batch width and
+    the other ranks finish early instead of every rank idling through 100 latency-bound steps -- while the work term keeps the
+    ranks balanced.  cost=callable: plain longest-processing-time on that additive cost (round 2's subshells x steps)."""
+    if cost is not None:
+        order = sorted(Zs, key=lambda z: (-cost(z), z))
+        loads = [0] * world_size
+        shards = [[] for _ in range(world_size)]
+        for z in order:
+            r = min(range(world_size), key=lambda k: (loads[k], k))
+            shards[r].append(z)
+            loads[r] += cost(z)
+        return [sorted(s) for s in shards]
+    order = sorted(Zs, key=lambda z: (-expected_steps(z), -atom_cost(z), z))
     shards = [[] for _ in range(world_size)]
     for z in order:
-        r = min(range(world_size), key=lambda k: (loads[k], k))
-        shards[r].append(z)
-        loads[r] += cost(z)
+        best = min(range(world_size), key=lambda k: (max(shard_time_ms(shards[j] + ([z] if j == k else [])) for j in range(world_size)),
+                                                     shard_time_ms(shards[k] + [z]), k))
+        shards[best].append(z)
     return [sorted(s) for s in shards]
 
 

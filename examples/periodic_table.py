@@ -28,6 +28,12 @@ def main():
     ap.add_argument("--levels", type=int, default=17)
     ap.add_argument("--max-steps", type=int, default=100, help="the reference's cap (DFTAtom.cpp:396)")
     ap.add_argument("--out", default="")
+    ap.add_argument("--partition", choices=("model", "work"), default="model",
+                    help="model: balance the predicted shard times (critical path + work, dftatom_amd.sweep); work: LPT on subshells x steps")
+    ap.add_argument("--emulate-ranks", type=int, default=0,
+                    help="one GPU, no launcher: run each of the N shards of an N-rank sweep alone, one after the other, and report the "
+                         "per-shard wall times; their maximum PREDICTS the N-GPU wall time (shards never interact; the only collective "
+                         "is a gather of 64 doubles per atom)")
     args = ap.parse_args()
 
     import torch
@@ -52,8 +58,45 @@ def main():
     grid = D.Grid(ctx, args.levels, delta, rmax)
 
     Zs = list(range(args.zmin, args.zmax + 1))
-    mine = sweep.partition_atoms(Zs, world)[rank]
-    cap = max(len(s) for s in sweep.partition_atoms(Zs, world))
+    cost = sweep.atom_cost if args.partition == "work" else None
+    if args.emulate_ranks > 0:
+        # the N shards of an N-rank sweep, one at a time on this GPU
+        assert world == 1, "--emulate-ranks runs without a launcher"
+        N = args.emulate_ranks
+        shards = sweep.partition_atoms(Zs, N, cost=cost)
+        rows = []
+        for r, zs in enumerate(shards):
+            t0 = time.time()
+            scf = D.Scf(ctx, grid, zs, lsda=False)
+            steps = 0
+            while steps < args.max_steps:
+                scf.step(want_stats=False)
+                steps += 1
+                _, fin = scf.energies()
+                if fin.all():
+                    break
+            ctx.synchronize()
+            dt = time.time() - t0
+            en, fin = scf.energies()
+            scf.close()
+            rows.append({"rank": r, "atoms": zs, "steps": steps, "seconds": dt, "finished": int(fin.sum()),
+                         "predicted_seconds_model": sweep.shard_time_ms(zs) / 1e3,
+                         "etotal": {int(z): en[k].Etotal for k, z in enumerate(zs)}})
+            print("shard %d/%d: %2d atoms, %3d steps, %.2f s (model %.2f s)" % (r, N, len(zs), steps, dt, rows[-1]["predicted_seconds_model"]), flush=True)
+        pred = max(x["seconds"] for x in rows)
+        res = {"emulated_ranks": N, "partition": args.partition, "levels": args.levels, "zmin": args.zmin, "zmax": args.zmax,
+               "predicted_n_gpu_seconds": pred, "sum_of_shard_seconds": sum(x["seconds"] for x in rows), "shards": rows,
+               "note": "PREDICTION from one GPU: every shard run alone; max over shards = wall time of an N-rank sweep up to the final "
+                       "all_gather of 64 doubles per atom (microseconds)"}
+        print("emulated %d ranks: predicted wall time %.2f s (slowest shard), sum of shards %.2f s" % (N, pred, res["sum_of_shard_seconds"]))
+        if args.out:
+            with open(args.out, "w") as f:
+                json.dump(res, f, indent=1)
+        grid.close()
+        ctx.close()
+        return
+    mine = sweep.partition_atoms(Zs, world, cost=cost)[rank]
+    cap = max(len(s) for s in sweep.partition_atoms(Zs, world, cost=cost))
     t0 = time.time()
     scf = D.Scf(ctx, grid, mine, lsda=False)
     steps = 0

@@ -13,18 +13,29 @@ from dftatom_amd import sweep
 
 def test_partition_is_balanced_and_complete():
     Zs = list(range(1, 87))
+    assert sum(sweep.subshell_count(z) for z in Zs) == 814
     for world in (1, 2, 4, 8):
-        shards = sweep.partition_atoms(Zs, world)
+        # by work (subshells x expected SCF steps): LPT keeps the ranks within one atom's cost of each other
+        shards = sweep.partition_atoms(Zs, world, cost=sweep.atom_cost)
         assert sorted(z for s in shards for z in s) == Zs
-        assert sum(sweep.subshell_count(z) for z in Zs) == 814
-        # cost of an atom = Numerov jobs per step x expected SCF steps: LPT keeps the ranks within
-        # one atom's cost of each other
         loads = [sum(sweep.atom_cost(z) for z in s) for s in shards]
         assert max(loads) - min(loads) <= max(sweep.atom_cost(z) for z in Zs)
         assert max(loads) <= 1.03 * sum(loads) / world + 1
         by_jobs = sweep.partition_atoms(Zs, world, cost=sweep.subshell_count)     # the round-1 weight is still available
         assert sorted(z for s in by_jobs for z in s) == Zs
+        # default: balance of the PREDICTED SHARD TIMES (critical path + work): complete, and never predicted slower than by-work LPT
+        model = sweep.partition_atoms(Zs, world)
+        assert sorted(z for s in model for z in s) == Zs
+        t_model = max(sweep.shard_time_ms(s) for s in model)
+        t_work = max(sweep.shard_time_ms(s) for s in shards)
+        assert t_model <= 1.02 * t_work, (world, t_model, t_work)
     assert sweep.partition_atoms(Zs, 8) == sweep.partition_atoms(Zs, 8)   # deterministic on every rank
+    # a sweep without cap-hitting atoms on every rank: the model keeps the long runners together so that the other ranks finish early
+    some = [2, 10, 18, 36, 54, 86, 3, 4, 6, 7, 12, 13]
+    parts = sweep.partition_atoms(some, 4)
+    assert sorted(z for s in parts for z in s) == sorted(some)
+    # the Z = 87..118 extension of the table (round 3)
+    assert sweep.expected_steps(118) == 60 and sweep.expected_steps(87) == 100 and sweep.expected_steps(119) == 100
 
 
 def _worker(rank, world, port, q):
