@@ -3,7 +3,7 @@
 // L2 classes (Numerov, PoissonSolver, VWNExchCor, Integral, AufbauPrinciple):
 //   * dftatom_amd/compat/DFTAtom.cpp -- the device-resident SCF (dfta_scf_*): one launch sequence per step, state in HBM;
 //     it defines the four entry points (and Run / levelsMode / integrator below) and never needs the private helpers;
-//   * the reference's own DFTAtom.cpp, compiled unmodified against these headers (tests/test_ref_l3_compiles.py,
+//   * the reference's own DFTAtom.cpp, compiled unmodified against these headers (tests/test_ref_l3.py,
 //     INTEGRATION.md): its LoopOverLevels / LocateInterval / Normalize* then drive the HIP kernels call by call.
 // Both write the reference's console text to std::cout, so the wxWidgets front end (DFTAtomFrame.cpp:185-198) links
 // against either unchanged.

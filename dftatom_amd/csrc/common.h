@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -59,6 +60,34 @@ struct dfta_device_guard {
 
 #define DFTA_CHECK_LAUNCH(ctx) DFTA_HIP(ctx, hipGetLastError())
 
+// Debug / measurement knobs: ONE environment variable, DFTA_DEBUG, a comma-separated list of NAME or NAME=VALUE entries (names
+// as listed in DESIGN.md section 9, e.g. DFTA_DEBUG="POISSON_GROUP=3,POISSON_NOFOLD,LEVELS_STATIC").  dfta_knob("NAME") returns
+// the value ("" for a bare NAME), or nullptr when the knob is not set.  For scripts written before round 3 a separate variable
+// DFTA_<NAME> is still honoured as an alias.  Knobs never change results (the tests prove it for each), only how they are computed.
+static inline const char* dfta_knob(const char* name)
+{
+    static thread_local char val[128];
+    if (const char* all = getenv("DFTA_DEBUG")) {
+        const size_t n = strlen(name);
+        for (const char* p = all; *p;) {
+            const char* e = strchr(p, ',');
+            const size_t len = e ? static_cast<size_t>(e - p) : strlen(p);
+            if (len >= n && strncmp(p, name, n) == 0 && (len == n || p[n] == '=')) {
+                const size_t vl = len == n ? 0 : len - n - 1;
+                const size_t c = vl < sizeof(val) - 1 ? vl : sizeof(val) - 1;
+                memcpy(val, p + n + (len == n ? 0 : 1), c);
+                val[c] = 0;
+                return val;
+            }
+            if (!e) break;
+            p = e + 1;
+        }
+    }
+    char alias[160];
+    snprintf(alias, sizeof(alias), "DFTA_%s", name);
+    return getenv(alias);
+}
+
 #define DFTA_REQUIRE(ctx, cond, msg)                                               \
     do {                                                                           \
         if (!(cond)) {                                                             \
@@ -66,6 +95,50 @@ struct dfta_device_guard {
             return DFTA_ERR_INVALID;                                               \
         }                                                                          \
     } while (0)
+
+// roctx ranges (tracing counterpart) around the phases of an SCF step -- level-search rounds, the multigrid
+// solve, the XC + integrals tail -- so that a rocprofv3 --marker-trace timeline shows them.  libroctx64 is looked up at run time,
+// only under a profiler (rocprofv3 exports ROCP_TOOL_LIBRARIES) or with the ROCTX knob: no link-time dependency, no cost otherwise.
+#include <dlfcn.h>
+struct dfta_range {
+    typedef int (*push_t)(const char*);
+    typedef int (*pop_t)();
+    static void resolve(push_t& push, pop_t& pop)
+    {
+        static push_t s_push = nullptr;
+        static pop_t s_pop = nullptr;
+        static bool tried = false;
+        if (!tried) {
+            tried = true;
+            if (getenv("ROCP_TOOL_LIBRARIES") || dfta_knob("ROCTX")) {
+                void* h = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+                if (!h) h = dlopen("libroctx64.so.4", RTLD_NOW | RTLD_GLOBAL);
+                if (!h) h = dlopen("/opt/rocm/lib/libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+                if (h) {
+                    s_push = reinterpret_cast<push_t>(dlsym(h, "roctxRangePushA"));
+                    s_pop = reinterpret_cast<pop_t>(dlsym(h, "roctxRangePop"));
+                }
+            }
+        }
+        push = s_push; pop = s_pop;
+    }
+    bool on = false;
+    explicit dfta_range(const char* name)
+    {
+        push_t push; pop_t pop;
+        resolve(push, pop);
+        if (push && pop) { push(name); on = true; }
+    }
+    ~dfta_range()
+    {
+        if (!on) return;
+        push_t push; pop_t pop;
+        resolve(push, pop);
+        if (pop) pop();
+    }
+    dfta_range(const dfta_range&) = delete;
+    dfta_range& operator=(const dfta_range&) = delete;
+};
 
 // Device-resident tables of one logarithmic grid r_i = Rp (exp(i delta) - 1), i = 0..N-1.
 // All exp() values are produced on the host with libm in the reference's expression order

@@ -40,7 +40,7 @@ int dfta_ctx_create(int device, void* hip_stream, dfta_ctx** out)
         c->own_stream = true;
     }
     if (hipEventCreate(&c->ev[0]) != hipSuccess || hipEventCreate(&c->ev[1]) != hipSuccess) { delete c; return DFTA_ERR_NO_DEVICE; }
-    if (const char* e = getenv("DFTA_SWEEP_KERNEL"))
+    if (const char* e = dfta_knob("SWEEP_KERNEL"))
         c->sweep_kernel = !strcmp(e, "fused") ? DFTA_SWEEP_FUSED : (!strcmp(e, "pipe") ? DFTA_SWEEP_PIPELINED : DFTA_SWEEP_AUTO);
     *out = c;
     return DFTA_OK;

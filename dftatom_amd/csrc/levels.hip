@@ -909,17 +909,17 @@ int LevelSolver::setup(dfta_ctx* c, const dfta_grid* grid, int mode_, int tree_d
 {
     release();
     ctx = c; g = grid; mode = mode_; nV = nV_;
-    use_prediction = getenv("DFTA_LEVELS_NOPREDICT") == nullptr;   // measurements / tests: every spine and scout off
+    use_prediction = dfta_knob("LEVELS_NOPREDICT") == nullptr;   // measurements / tests: every spine and scout off
     {   // tuning of the predictions (never of a result): the defaults, or what the environment says, every time a solver is made
         double v[3] = {1e-11, 16e-12, 1.5e-11}, k = 0.25;
-        if (const char* e = getenv("DFTA_LEVELS_NOISE")) sscanf(e, "%lf,%lf,%lf", &v[0], &v[1], &v[2]);   // "rel,abs,secant" of the noise band
-        if (const char* e = getenv("DFTA_LEVELS_SECANT_KAPPA")) k = atof(e);                                // trust in the parabolic correction
+        if (const char* e = dfta_knob("LEVELS_NOISE")) sscanf(e, "%lf,%lf,%lf", &v[0], &v[1], &v[2]);   // "rel,abs,secant" of the noise band
+        if (const char* e = dfta_knob("LEVELS_SECANT_KAPPA")) k = atof(e);                                // trust in the parabolic correction
         (void)hipMemcpyToSymbol(HIP_SYMBOL(g_noise_rel), &v[0], sizeof(double));
         (void)hipMemcpyToSymbol(HIP_SYMBOL(g_noise_abs), &v[1], sizeof(double));
         (void)hipMemcpyToSymbol(HIP_SYMBOL(g_secant_noise), &v[2], sizeof(double));
         (void)hipMemcpyToSymbol(HIP_SYMBOL(g_secant_kappa), &k, sizeof(double));
     }
-    debug_rounds = getenv("DFTA_DEBUG_ROUNDS") ? atoi(getenv("DFTA_DEBUG_ROUNDS")) : 0;
+    debug_rounds = dfta_knob("DEBUG_ROUNDS") ? atoi(dfta_knob("DEBUG_ROUNDS")) : 0;
     njobs = static_cast<int>(specs.size());
     if (njobs == 0) return DFTA_OK;
     const int N = g->N;
@@ -954,10 +954,10 @@ int LevelSolver::setup(dfta_ctx* c, const dfta_grid* grid, int mode_, int tree_d
     ntrials = static_cast<long>(njobs) * tpj;
     // latency mode (the pipelined kernel's regime: at most ~1.5 passes of one block per compute unit): the slots of a
     // round are re-allotted among the active jobs (k_allot); the budget is one full pass at least
-    dynamic = (tree_depth <= 0) && njobs <= 64 && ntrials / 64 <= 384 && getenv("DFTA_LEVELS_STATIC") == nullptr;
+    dynamic = (tree_depth <= 0) && njobs <= 64 && ntrials / 64 <= 384 && dfta_knob("LEVELS_STATIC") == nullptr;
     if (dynamic) {
         long blocks = std::max(ctx->num_cu, 1);
-        if (const char* e = getenv("DFTA_LEVELS_BUDGET_BLOCKS")) blocks = std::max(64, atoi(e));     // measurements
+        if (const char* e = dfta_knob("LEVELS_BUDGET_BLOCKS")) blocks = std::max(64, atoi(e));     // measurements
         ntrials = std::max<long>(ntrials, 64L * blocks);
     }
     nwaves = static_cast<int>(ntrials / 64);
@@ -1121,6 +1121,7 @@ int LevelSolver::run(const double* dV, const double* job_bottom, int run_mode, d
     float ms_sweep = 0;
     const int max_rounds = 4096;
     while (rounds < max_rounds) {
+        dfta_range r_round("dfta: level-search round (expand, sweeps, scout, walk, plan)");
         hipLaunchKernelGGL(k_expand, dim3((unsigned)((ntrials + 255) / 256)), dim3(256), 0, st, d_jobs, d_wave_job, (int)ntrials, g->d_r, N, g->delta,
                            g->far_arg_threshold, d_E, d_limit, d_start, d_us, d_us1, d_wave_kind, d_counters, g->uniform, g->Rmax, g->h);
         DFTA_CHECK_LAUNCH(ctx);

@@ -322,7 +322,7 @@ int dfta_poisson_create_ex(dfta_ctx* ctx, const dfta_grid* g, int batch, int mod
 int dfta_poisson_create(dfta_ctx* ctx, const dfta_grid* g, int batch, dfta_poisson** out)
 {
     // $DFTA_POISSON_MODE = tolerance: measurements and tests of the opt-in mode through callers that do not pass a mode
-    const char* e = getenv("DFTA_POISSON_MODE");
+    const char* e = dfta_knob("POISSON_MODE");
     return dfta_poisson_create_ex(ctx, g, batch, (e && e[0] == 't') ? DFTA_POISSON_TOLERANCE : DFTA_POISSON_EXACT, out);
 }
 
@@ -346,19 +346,19 @@ static int poisson_create_impl(dfta_ctx* ctx, const dfta_grid* g, int batch, int
     // (measured: G = 16 wins up to 4 atoms; beyond that the barriers of 16 members on a nearly full chip cost more than the
     // shorter chunks save)
     int logG = batch <= 4 ? 4 : (batch <= 32 ? 3 : (batch <= 64 ? 2 : (batch <= 128 ? 1 : 0)));
-    if (const char* e = getenv("DFTA_POISSON_GROUP")) {      // measurements: force log2 of the group size
+    if (const char* e = dfta_knob("POISSON_GROUP")) {      // measurements: force log2 of the group size
         const int v = atoi(e);
         if (v >= 0 && v <= 4 && (batch << v) <= 256) logG = v;
     }
     if (force_logG >= 0) logG = force_logG;
-    if (const char* e = getenv("DFTA_FAULT_POISSON_MEMBER")) p->fault = atoi(e) != 0;
+    if (const char* e = dfta_knob("FAULT_POISSON_MEMBER")) p->fault = atoi(e) != 0;
     // Resident group (k_poisson_solve_res): where the batch would get 16 workgroups per atom and level 0 gives every lane of
     // kResG x kResNT lanes 4 .. 32 nodes (16385 .. 131073 nodes); $DFTA_POISSON_RES = 0 / 1 switches it off / on (for batches
     // up to 7 atoms), a forced group size (DFTA_POISSON_GROUP, force_logG) selects the staged groups above
     int res_kres = 0, res_logC0 = 0;
     {
-        bool want = logG == 4 && force_logG < 0 && !getenv("DFTA_POISSON_GROUP") && !getenv("DFTA_POISSON_NOSTAGE");   // (the hand-over needs the first coarse level staged)
-        if (const char* e = getenv("DFTA_POISSON_RES")) want = atoi(e) != 0 && force_logG < 0 && batch * kResWG <= 256 && !getenv("DFTA_POISSON_NOSTAGE");
+        bool want = logG == 4 && force_logG < 0 && !dfta_knob("POISSON_GROUP") && !dfta_knob("POISSON_NOSTAGE");   // (the hand-over needs the first coarse level staged)
+        if (const char* e = dfta_knob("POISSON_RES")) want = atoi(e) != 0 && force_logG < 0 && batch * kResWG <= 256 && !dfta_knob("POISSON_NOSTAGE");
         const int lanes = kResG * kResNT;
         if (want && (g->N - 1) % lanes == 0) {
             const int C0 = (g->N - 1) / lanes;
@@ -378,7 +378,7 @@ static int poisson_create_impl(dfta_ctx* ctx, const dfta_grid* g, int batch, int
     // when DFTA_POISSON_PLAIN_LAUNCH is set, the groups are therefore started with an ordinary launch: same kernel, same
     // results and timing; co-residency then rests on the occupancy query of this function, the bounded spins and the abort
     // flag (dfta_poisson_finish) as in round 1.
-    p->plain_launch = getenv("DFTA_POISSON_PLAIN_LAUNCH") != nullptr || getenv("ROCP_TOOL_LIBRARIES") != nullptr;
+    p->plain_launch = dfta_knob("POISSON_PLAIN_LAUNCH") != nullptr || getenv("ROCP_TOOL_LIBRARIES") != nullptr;
     D.spin_max = p->fault ? (1 << 12) : (1 << 23);
     {
         // every workgroup of the launch must be resident at once (the members wait for each other)
@@ -394,9 +394,9 @@ static int poisson_create_impl(dfta_ctx* ctx, const dfta_grid* g, int batch, int
     }
     if (D.kcoop == 0) logG = 0;
     D.logG = logG;
-    D.nofold = getenv("DFTA_POISSON_NOFOLD") ? 1 : 0;
-    D.fuse3 = getenv("DFTA_POISSON_NOFUSE3") ? 0 : 1;
-    D.dbg = getenv("DFTA_POISSON_DBG") ? atoi(getenv("DFTA_POISSON_DBG")) : 0;
+    D.nofold = dfta_knob("POISSON_NOFOLD") ? 1 : 0;
+    D.fuse3 = dfta_knob("POISSON_NOFUSE3") ? 0 : 1;
+    D.dbg = dfta_knob("POISSON_DBG") ? atoi(dfta_knob("POISSON_DBG")) : 0;
     D.res_kres = res_kres;
     D.res_logC0 = res_logC0;
     D.G = 1 << logG;
@@ -412,11 +412,11 @@ static int poisson_create_impl(dfta_ctx* ctx, const dfta_grid* g, int batch, int
         if (n < kSeqBelow) { L.seq = 1; L.logT = 0; L.logC = lg; L.soff = soff; soff += n; }
         else {
             L.seq = 0; L.logT = std::min(lg, l < D.kcoop ? 8 + logG : 8); L.logC = lg - L.logT; L.soff = -1;
-            if (!getenv("DFTA_POISSON_NOSTAGE")) {
-                if (l >= D.kcoop && n <= kWaveMaxN && n >= 129 && !getenv("DFTA_POISSON_NOSTAGE_WAVE")) L.stage = 3;
+            if (!dfta_knob("POISSON_NOSTAGE")) {
+                if (l >= D.kcoop && n <= kWaveMaxN && n >= 129 && !dfta_knob("POISSON_NOSTAGE_WAVE")) L.stage = 3;
                 else if (l >= D.kcoop && L.logT == 8 && L.logC <= kStageMaxLogC) L.stage = 1;
                 else if (l < D.kcoop && D.G > 1 && L.logT == 8 + logG && L.logC >= 2 && L.logC <= kStageMaxLogC &&
-                         !getenv("DFTA_POISSON_NOSTAGE_SHARED")) L.stage = 2;
+                         !dfta_knob("POISSON_NOSTAGE_SHARED")) L.stage = 2;
             }
         }
         off += n;
@@ -426,7 +426,7 @@ static int poisson_create_impl(dfta_ctx* ctx, const dfta_grid* g, int batch, int
     D.per_atom = off;
     // coarse section: from the first one-wave level down, if everything below is one-wave or sequential and fits the staging memory
     D.cs_top = -1;
-    if (!getenv("DFTA_POISSON_NOCOARSE")) {
+    if (!dfta_knob("POISSON_NOCOARSE")) {
         int top = -1;
         for (int l = 1; l < D.levels; ++l)
             if (D.lv[l].stage == 3) { top = l; break; }

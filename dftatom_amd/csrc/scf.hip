@@ -350,7 +350,7 @@ int dfta_scf_create_ex(dfta_ctx* ctx, const dfta_grid* g, int lsda, int natoms, 
     unsigned long long dummy;
     rc = dfta_poisson_take_vcycles(s->poisson, &dummy);
     if (rc) { dfta_scf_destroy(s); return rc; }
-    s->debug_levels = getenv("DFTA_DEBUG_LEVELS") != nullptr;
+    s->debug_levels = dfta_knob("DEBUG_LEVELS") != nullptr;
     s->h_frozen.assign(specs.size(), 0);
     *out = s;
     return DFTA_OK;
@@ -380,8 +380,10 @@ int dfta_scf_step(dfta_scf* s, dfta_step_stats* stats)
         for (int k = as.job_off; k < as.job_end; ++k) s->h_frozen[k] = as.finished ? 1 : 0;
         any_frozen = any_frozen || as.finished;
     }
+    dfta_range* r_levels = new dfta_range("dfta: level search (LoopOverLevels: all subshells of the batch)");
     int rc = s->solver.run(s->d_V, s->h_job_bottom.data(), run_mode, s->d_newDensity, stats ? &ls : nullptr,
                            any_frozen ? s->h_frozen.data() : nullptr);
+    delete r_levels;
     if (rc) return rc;
     {
         std::vector<dfta::Job>& jobs = s->h_jobs;
@@ -402,13 +404,17 @@ int dfta_scf_step(dfta_scf* s, dfta_step_stats* stats)
                        s->d_dA, s->d_dB, s->d_fin);
     DFTA_CHECK_LAUNCH(ctx);
     DFTA_HIP(ctx, hipEventRecord(s->ev[1], st));
-    rc = dfta_poisson_solve_launch(s->poisson, s->d_Z, s->d_density, s->d_U, nullptr, nullptr, s->d_fin);
-    if (rc) return rc;
-    DFTA_HIP(ctx, hipEventRecord(s->ev[2], st));   // ev[1]..ev[2] brackets exactly the persistent multigrid kernel
-    // synchronises and inspects the group barriers' abort flag on EVERY step; an aborted solve is repeated with one
-    // workgroup per atom before anything reads U
-    rc = dfta_poisson_finish(s->poisson, s->d_Z, s->d_density, s->d_U, nullptr, nullptr, s->d_fin);
-    if (rc) return rc;
+    {
+        dfta_range r_poisson("dfta: multigrid Poisson solve (FullCycle)");
+        rc = dfta_poisson_solve_launch(s->poisson, s->d_Z, s->d_density, s->d_U, nullptr, nullptr, s->d_fin);
+        if (rc) return rc;
+        DFTA_HIP(ctx, hipEventRecord(s->ev[2], st));   // ev[1]..ev[2] brackets exactly the persistent multigrid kernel
+        // synchronises and inspects the group barriers' abort flag on EVERY step; an aborted solve is repeated with one
+        // workgroup per atom before anything reads U
+        rc = dfta_poisson_finish(s->poisson, s->d_Z, s->d_density, s->d_U, nullptr, nullptr, s->d_fin);
+        if (rc) return rc;
+    }
+    dfta_range r_tail("dfta: XC + integrands + ordered integrals + energies");
     rc = scf_xc(s);
     if (rc) return rc;
     hipLaunchKernelGGL(k_tail, grid, block, 0, st, s->d_atoms, s->lsda, N, g->d_r, g->d_cnst, s->d_density, s->d_dA, s->d_dB, s->d_U,
