@@ -150,7 +150,8 @@ def cpu_baseline(levels, lsda, steps):
 # ---------------------------------------------------------------------------------------------------------------
 def source_sha():
     h = hashlib.sha256()
-    for f in sorted(glob.glob(os.path.join(ROOT, "dftatom_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "dftatom_amd", "csrc", "*.h"))):
+    src = os.path.join(ROOT, "dftatom_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(src, "*.hip")) + glob.glob(os.path.join(src, "*.h")) + glob.glob(os.path.join(src, "*.inc"))):
         h.update(open(f, "rb").read())
     return h.hexdigest()[:16]
 
@@ -160,7 +161,8 @@ def pmc_traffic(kernel):
     (profiles/*_hbm_traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate passes; FETCH_SIZE doubled as
     MI355X_MICROARCH.md prescribes for gfx950).  bench.py cannot run the profiler on itself: the number is the measured one of
     that profile, returned with its tag -- and withheld (null) when the kernels' sources have changed since it was taken."""
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.json")), key=os.path.getmtime)
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*default_hbm_traffic.json")), key=os.path.getmtime) or \
+        sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.json")), key=os.path.getmtime)    # the default workload's passes
     if not files:
         return None, None
     try:
@@ -235,7 +237,8 @@ def kernel_figures(tot, levels, N, atoms):
     t_ps = tot["ms_poisson"] * 1e-3
     b_ps = POISSON_BYTES_PER_VCYCLE.get(levels, 376 * N) * tot["vcycles"]
     psolves = max(tot["steps"], 1)
-    pois = {"kernel": "k_poisson_solve (persistent multigrid: FMG ramp + 100 V-cycles per launch)", "bound": "hbm", "peak": HBM_PEAK_GBS,
+    pois = {"kernel": ("k_poisson_solve_res" if tot["poisson_G"] == 33 else "k_poisson_solve") + " (persistent multigrid: FMG ramp + 100 V-cycles per launch)",
+            "bound": "hbm", "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "launches": psolves, "avg_launch_ms": tot["ms_poisson"] / psolves,
             "achieved": b_ps / t_ps / 1e9 if t_ps else None, "frac": b_ps / t_ps / 1e9 / HBM_PEAK_GBS if t_ps else None,
             "bytes_per_launch": b_ps / psolves, "vcycles_per_s": tot["vcycles"] / t_ps if t_ps else None,
@@ -283,6 +286,7 @@ def main():
     ap.add_argument("--atoms", type=int, default=1, help="identical Rn atoms advanced together per GPU")
     ap.add_argument("--levels", type=int, default=17)
     ap.add_argument("--lsda", action="store_true")
+    ap.add_argument("--tolerance", action="store_true", help="the multigrid smoother's opt-in tolerance mode (DFTA_POISSON_TOLERANCE) for the headline workload")
     ap.add_argument("--tree-depth", type=int, default=0)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra workloads (256-atom batch, LSDA, 1 048 577 nodes)")
@@ -355,7 +359,8 @@ def main():
             gathered = [torch.empty_like(mine) for _ in range(world)]
             dist.all_gather(gathered, mine)
 
-    scf, tot = run_workload(D, ctx, grid, args.levels, args.atoms, args.lsda, args.steps, args.warmup, args.tree_depth, barrier, torch, gather)
+    scf, tot = run_workload(D, ctx, grid, args.levels, args.atoms, args.lsda, args.steps, args.warmup, args.tree_depth, barrier, torch, gather,
+                            poisson_mode=D.POISSON_TOLERANCE if args.tolerance else D.POISSON_EXACT)
     elapsed = tot["elapsed"]
     # max over ranks of the elapsed time, sums of the work
     if world > 1:
@@ -373,7 +378,8 @@ def main():
         ncu, devname = ctx.device_info()
         sweep, pois = kernel_figures(tot, args.levels, grid.N, args.atoms)
         dominant = pois if tot["ms_poisson"] >= tot["ms_sweep_kernels"] else sweep
-        dkey = "k_poisson_solve" if dominant is pois else ("k_sweep_pipe" if "k_sweep_pipe" in sweep["kernel"] else "k_sweep")
+        dkey = ("k_poisson_solve_res" if tot["poisson_G"] == 33 else "k_poisson_solve") if dominant is pois else \
+            ("k_sweep_pipe" if "k_sweep_pipe" in sweep["kernel"] else "k_sweep")
         traffic, ttag = pmc_traffic(dkey)
         roof = {"bound": "hbm", "kernel": dominant["kernel"],
                 "achieved": dominant["achieved"] if dominant is pois else dominant["achieved_reference_equivalent"],
@@ -406,7 +412,8 @@ def main():
             "config": {"workload": "Rn Z=86 %s, %d multigrid levels (%d pts), delta=%g, Rmax=%g, mixing 0.5, %d atom(s)/GPU, "
                                    "un-chained clamped brackets, tree depth %d" % ("LSDA" if args.lsda else "LDA", args.levels, grid.N,
                                                                            delta, rmax, args.atoms, tot["tree_depth"]),
-                       "atoms_per_gpu": args.atoms, "parallelism": "replicas x%d" % world},
+                       "atoms_per_gpu": args.atoms, "parallelism": "replicas x%d" % world,
+                       "poisson_mode": "tolerance" if args.tolerance else "exact"},
             "scf_step_ms": 1e3 * elapsed / args.steps,
             "value_definition": "value = sweeps on the reference's bisection path that are actually integrated here (CountNodes + SolutionInZero + "
                                 "Match) / whole-step wall time; value_reference_equivalent also counts the ~52 CountNodes calls per node-less level's "

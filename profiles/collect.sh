@@ -1,18 +1,31 @@
 #!/bin/bash
 # Collect the rocprofv3 evidence behind bench.py's roofline numbers (run on the MI355X box, e.g.
-#   gpurun --timeout 1500 -- 'bash profiles/collect.sh r01'
-# ).  Three separate passes of the SAME command: kernel trace + stats, then the two HBM-side PMC counters
-# (FETCH_SIZE and WRITE_SIZE do not fit one pass; --pmc is never combined with sys/runtime traces).
-# Raw output goes to gpurun_out/<tag>_*/ (scratch); profiles/summarize.py turns it into the committed summaries.
+#   gpurun --timeout 2400 -- 'bash profiles/collect.sh r03'
+# ) for the headline workload AND the throughput workloads the README quotes.  Per workload four separate passes of the SAME
+# command: kernel trace + stats, the two HBM-side PMC counters (FETCH_SIZE and WRITE_SIZE do not fit one pass; --pmc is never
+# combined with sys/runtime traces), and the SQ counters.  The profiled program comes directly after `--` (python3 bench.py ...).
+# Raw output goes to gpurun_out/<tag>_<workload>/ (scratch); profiles/summarize.py turns it into the committed summaries
+#   profiles/<tag>_<workload>_{bench_kernel_stats.csv, bench_under_rocprof.json, hbm_traffic.json, sq_counters.json}.
 set -u
-TAG=${1:-r01}
-ARGS=${2:-"--steps 3 --warmup 1 --no-cpu --no-extras"}
+TAG=${1:-r03}
+ONLY=${2:-}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-OUT=gpurun_out/${TAG}
-mkdir -p "$OUT"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o bench -- python3 bench.py $ARGS > "$OUT/bench_under_rocprof.json" 2> "$OUT/trace.err"
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/fetch" -o bench -- python3 bench.py $ARGS > /dev/null 2> "$OUT/fetch.err"
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/write" -o bench -- python3 bench.py $ARGS > /dev/null 2> "$OUT/write.err"
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY --kernel-trace --output-format csv -d "$OUT/sq" -o bench -- python3 bench.py $ARGS > /dev/null 2> "$OUT/sq.err"
-python3 profiles/summarize.py "$OUT" "$TAG" "$ARGS"
-ls -la "$OUT" "$OUT"/*/ 2>/dev/null | head -40
+run_one() {
+    local name=$1; shift
+    local ARGS="$*"
+    if [ -n "$ONLY" ] && [ "$ONLY" != "$name" ]; then return; fi
+    local OUT=gpurun_out/${TAG}_${name}
+    mkdir -p "$OUT"
+    rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o bench -- python3 bench.py $ARGS > "$OUT/bench_under_rocprof.json" 2> "$OUT/trace.err"
+    rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/fetch" -o bench -- python3 bench.py $ARGS > /dev/null 2> "$OUT/fetch.err"
+    rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/write" -o bench -- python3 bench.py $ARGS > /dev/null 2> "$OUT/write.err"
+    rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY --kernel-trace --output-format csv -d "$OUT/sq" -o bench -- python3 bench.py $ARGS > /dev/null 2> "$OUT/sq.err"
+    python3 profiles/summarize.py "$OUT" "${TAG}_${name}" "$ARGS"
+    tail -2 "$OUT/trace.err"
+}
+run_one default      --steps 5 --warmup 2 --no-cpu --no-extras
+run_one tolerance    --steps 5 --warmup 2 --no-cpu --no-extras --tolerance
+run_one rn_lsda      --lsda --steps 5 --warmup 2 --no-cpu --no-extras
+run_one batch256     --atoms 256 --steps 3 --warmup 1 --no-cpu --no-extras
+run_one l20_batch16  --levels 20 --atoms 16 --lsda --steps 2 --warmup 1 --no-cpu --no-extras
+ls profiles | grep "^${TAG}_" | head -40
