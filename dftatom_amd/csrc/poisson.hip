@@ -97,9 +97,12 @@ __device__ __forceinline__ int node_of(const Lvl& L, int idx)
 // 6 times per V-cycle by a single lane and would otherwise pay a global-memory round trip per node.
 constexpr unsigned long long kFastSentinel = 0x7FF8DEAD7FF8DEADull;
 constexpr int kXchg = 128;       // doubles per member and buffer of the boundary exchange (<= 96 halo nodes; the first node in the last one)
-// per atom: [6 G + 2] partial sums of the members and the published state, [3 G] slots of the fast sum, [3 G kXchg] boundary
+// per atom: [6 G + 2] partial sums of the members and the published state, [kGrpBuf G] slots of the fast sum, [kGrpBuf G kXchg] boundary
 // nodes exchanged between neighbours in the middle of a staged visit
-__host__ __device__ constexpr size_t group_part_doubles(int G) { return (size_t)9 * G + 2 + (size_t)3 * G * kXchg; }
+// fast-sum slots and boundary-exchange buffers rotate over kGrpBuf sets (round 3: 8, was 3): a member resets its part of the set half a
+// rotation away, so that a reset has several exchanges to land before the slot is used again (see kResBuf below)
+constexpr unsigned kGrpBuf = 8;
+__host__ __device__ constexpr size_t group_part_doubles(int G) { return (size_t)(6 + kGrpBuf) * G + 2 + (size_t)kGrpBuf * G * kXchg; }
 
 constexpr int kResNT = 128;                    // sweeping lanes of a member (its first two waves; all four move data)
 constexpr int kResG = 32;                      // members per atom
@@ -352,12 +355,14 @@ static int poisson_create_impl(dfta_ctx* ctx, const dfta_grid* g, int batch, int
     }
     if (force_logG >= 0) logG = force_logG;
     if (const char* e = dfta_knob("FAULT_POISSON_MEMBER")) p->fault = atoi(e) != 0;
-    // Resident group (k_poisson_solve_res): where the batch would get 16 workgroups per atom and level 0 gives every lane of
-    // kResG x kResNT lanes 4 .. 32 nodes (16385 .. 131073 nodes); $DFTA_POISSON_RES = 0 / 1 switches it off / on (for batches
-    // up to 7 atoms), a forced group size (DFTA_POISSON_GROUP, force_logG) selects the staged groups above
+    // Resident group (k_poisson_solve_res): where the batch leaves 33 compute units per atom (up to 7 atoms) and level 0 gives every
+    // lane of kResG x kResNT lanes 4 .. 32 nodes (16385 .. 131073 nodes); the knob POISSON_RES = 0 / 1 switches it off / on, a forced
+    // group size (POISSON_GROUP, force_logG) selects the staged groups above
     int res_kres = 0, res_logC0 = 0;
     {
-        bool want = logG == 4 && force_logG < 0 && !dfta_knob("POISSON_GROUP") && !dfta_knob("POISSON_NOSTAGE");   // (the hand-over needs the first coarse level staged)
+        // every atom of the batch gets its 33 workgroups at once: up to 7 atoms on 256 compute units (measured: 28.6 .. 29.0 ms per
+        // 131073-node solve for 5 .. 7 atoms against 46 .. 48 ms with staged groups of 8)
+        bool want = batch * kResWG <= ctx->num_cu && force_logG < 0 && !dfta_knob("POISSON_GROUP") && !dfta_knob("POISSON_NOSTAGE");   // (the hand-over needs the first coarse level staged)
         if (const char* e = dfta_knob("POISSON_RES")) want = atoi(e) != 0 && force_logG < 0 && batch * kResWG <= 256 && !dfta_knob("POISSON_NOSTAGE");
         const int lanes = kResG * kResNT;
         if (want && (g->N - 1) % lanes == 0) {

@@ -5,7 +5,7 @@ mode of the smoother.
 EXACT mode (default): U, the V-cycle count and the last error norm are the bits of the one-workgroup solve -- which equals the
 reference's PoissonSolver (tests/test_gpu_parity.py, test_oracle_vs_ref.py) -- for every grid the resident layout serves
 (16385 .. 131073 nodes: 1 .. 4 shared levels), for Z = 1 (the cycle stops early: the visits' stop-after-one-sweep path) to 86,
-for batches of 1 .. 4 atoms, run after run (the exchange slots are validated by content, never by timing), and through a whole
+for batches of 1 .. 7 atoms (33 workgroups each on 256 compute units), run after run (the exchange slots are validated by content, never by timing), and through a whole
 SCF.  TOLERANCE mode: U within 2e-9 Z of the exact solve (observed 9.1e-10 Z at Z = 1, 3.5e-10 Z at Z = 86: the end state of the cycle is a round-off floor that
 any perturbation of the iteration shifts by that much -- the reference moves by as much under FMA contraction,
 test_oracle_golden.py::test_reference_rounding_sensitivity_of_scf_steps), SCF energies of the first steps within 1e-9 relative
@@ -66,7 +66,7 @@ def _solve(ctx, grid, Zs, rho, mode=D.POISSON_DEFAULT, **kv):
 def test_resident_groups_return_the_one_workgroup_bits(ctx, L, delta, R):
     grid = D.Grid(ctx, L, delta, R)
     rr = grid.r()
-    for Zs in ([86], [1], [18, 2], [2, 54, 86, 7]):
+    for Zs in ([86], [1], [18, 2], [2, 54, 86, 7], [86, 36, 18, 10, 2, 1, 54]):
         rho = np.stack([z * (1.0 + 0.3 * k) ** 3 * np.exp(-2 * (1.0 + 0.3 * k) * rr) / np.pi for k, z in enumerate(Zs)])
         U1, vc1, e1, i1 = _solve(ctx, grid, Zs, rho, DFTA_POISSON_GROUP="0", DFTA_POISSON_NOFUSE3="1")
         Ur, vcr, er, ir = _solve(ctx, grid, Zs, rho)
