@@ -100,6 +100,12 @@ struct LevelSolver {
     double* d_slot_min = nullptr;   // per table slot: min_i Veff_l(i)
     double2* d_bounds = nullptr;    // per table slot: fast-division range bounds (numerov.hip)
     hipEvent_t ev[2] = {nullptr, nullptr};
+    // Early match solves (latency mode): a level whose search has ended is matched on a second stream while the remaining levels'
+    // last rounds run -- the outer levels, whose outward streams are the long ones, end a round or two before the core levels.
+    hipStream_t st2 = nullptr;
+    hipEvent_t ev_walk = nullptr, ev_early = nullptr;
+    int *d_jmatched = nullptr, *d_jstart_keep = nullptr;
+    bool early_match = false;
 
     LevelSolver() = default;
     LevelSolver(const LevelSolver&) = delete;

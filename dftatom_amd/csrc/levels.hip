@@ -877,6 +877,28 @@ __global__ void k_store_match(dfta::Job* __restrict__ jobs, int njobs, const int
     }
 }
 
+// early match solves: of the jobs whose cut-off indices were just computed, keep those whose search has ended and that have not been
+// matched yet (the others get -1: skipped by k_match); remember the kept ones' cut-off index for the statistics and the final passes
+__global__ void k_mask_ready(const dfta::Job* __restrict__ jobs, int njobs, int* __restrict__ jstart, int* __restrict__ matched,
+                             int* __restrict__ jstart_keep)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= njobs) return;
+    const bool ready = jobs[k].phase == PH_DONE && !jobs[k].frozen && !matched[k];
+    if (ready) { matched[k] = 1; jstart_keep[k] = jstart[k]; }
+    else jstart[k] = -1;
+}
+// the final pass: every job that is neither frozen nor matched already
+__global__ void k_mask_rest(const dfta::Job* __restrict__ jobs, int njobs, int* __restrict__ jstart, const int* __restrict__ matched,
+                            int* __restrict__ jstart_keep)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= njobs) return;
+    if (jobs[k].frozen) { jstart[k] = -1; jstart_keep[k] = -1; }
+    else if (matched[k]) jstart[k] = -1;
+    else jstart_keep[k] = jstart[k];
+}
+
 // frozen jobs are skipped by the match / normalise kernels: their cut-off index is replaced by -1
 __global__ void k_mask_frozen(const dfta::Job* __restrict__ jobs, int njobs, int* __restrict__ jstart)
 {
@@ -896,6 +918,12 @@ void LevelSolver::release()
                     d_u0, d_phi, d_istop, d_trip, d_wave_job, d_wave_kind, d_wave_slot, d_wave_first, d_wave_cnt, d_counters, d_Psi, d_Q, d_jE, d_jslot, d_jl,
                     d_jstart, d_jus, d_jus1, d_jmp, d_slot_min, d_bounds};
     for (void* p : ptrs) if (p) (void)hipFree(p);
+    if (d_jmatched) (void)hipFree(d_jmatched);
+    if (d_jstart_keep) (void)hipFree(d_jstart_keep);
+    d_jmatched = nullptr; d_jstart_keep = nullptr;
+    if (st2) { (void)hipStreamDestroy(st2); st2 = nullptr; }
+    if (ev_walk) { (void)hipEventDestroy(ev_walk); ev_walk = nullptr; }
+    if (ev_early) { (void)hipEventDestroy(ev_early); ev_early = nullptr; }
     for (hipEvent_t& e : ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
     d_jobs = nullptr; d_chain_off = nullptr; d_chain_off_b = nullptr; d_v_off = nullptr; d_slot_v = nullptr; d_slot_l = nullptr; d_tab = nullptr;
     d_E = nullptr; d_limit = nullptr; d_start = nullptr; d_us = nullptr; d_us1 = nullptr; d_count = nullptr; d_u0 = nullptr; d_phi = nullptr; d_istop = nullptr; d_trip = nullptr;
@@ -961,6 +989,7 @@ int LevelSolver::setup(dfta_ctx* c, const dfta_grid* grid, int mode_, int tree_d
         ntrials = std::max<long>(ntrials, 64L * blocks);
     }
     nwaves = static_cast<int>(ntrials / 64);
+    early_match = dynamic && !g->uniform && dfta_knob("LEVELS_NOEARLYMATCH") == nullptr;
 
     // table slots: one per distinct (v, l)
     std::vector<int> slot_v, slot_l;
@@ -1005,6 +1034,12 @@ int LevelSolver::setup(dfta_ctx* c, const dfta_grid* grid, int mode_, int tree_d
     ALLOC(d_Psi, double, (size_t)njobs * N);
     ALLOC(d_Q, double, (size_t)njobs * N);
     ALLOC(d_jE, double, njobs); ALLOC(d_jslot, int, njobs); ALLOC(d_jl, int, njobs); ALLOC(d_jstart, int, njobs);
+    ALLOC(d_jmatched, int, njobs); ALLOC(d_jstart_keep, int, njobs);
+    if (early_match) {
+        DFTA_HIP(ctx, hipStreamCreateWithFlags(&st2, hipStreamNonBlocking));
+        DFTA_HIP(ctx, hipEventCreateWithFlags(&ev_walk, hipEventDisableTiming));
+        DFTA_HIP(ctx, hipEventCreateWithFlags(&ev_early, hipEventDisableTiming));
+    }
     ALLOC(d_jus, double, njobs); ALLOC(d_jus1, double, njobs); ALLOC(d_jmp, int, njobs);
     ALLOC(d_slot_min, double, nslots);
     ALLOC(d_bounds, double2, (size_t)nslots * dfta_bounds_stride(g));
@@ -1092,6 +1127,7 @@ int LevelSolver::run(const double* dV, const double* job_bottom, int run_mode, d
     }
     DFTA_HIP(ctx, hipMemcpyAsync(d_jobs, jobs.data(), sizeof(Job) * njobs, hipMemcpyHostToDevice, st));
     DFTA_HIP(ctx, hipMemsetAsync(d_counters, 0, sizeof(unsigned long long) * 4, st));
+    DFTA_HIP(ctx, hipMemsetAsync(d_jmatched, 0, sizeof(int) * njobs, st));
     if (nfrozen == njobs) {            // nothing to solve: Psi, density contributions and job records stand
         DFTA_HIP(ctx, hipStreamSynchronize(st));      // `jobs` is the source of the copy above
         if (stats) *stats = LevelStats();
@@ -1120,6 +1156,8 @@ int LevelSolver::run(const double* dV, const double* job_bottom, int run_mode, d
     int rounds = 0;
     float ms_sweep = 0;
     const int max_rounds = 4096;
+    int done_seen = nfrozen;
+    bool early_pending = false;
     while (rounds < max_rounds) {
         dfta_range r_round("dfta: level-search round (expand, sweeps, scout, walk, plan)");
         hipLaunchKernelGGL(k_expand, dim3((unsigned)((ntrials + 255) / 256)), dim3(256), 0, st, d_jobs, d_wave_job, (int)ntrials, g->d_r, N, g->delta,
@@ -1136,11 +1174,30 @@ int LevelSolver::run(const double* dV, const double* job_bottom, int run_mode, d
         DFTA_HIP(ctx, hipMemsetAsync(d_ndone, 0, sizeof(int), st));
         hipLaunchKernelGGL(k_walk, dim3((run_chains + 63) / 64), dim3(64), 0, st, d_jobs, d_chains, run_chains, d_count, d_u0, d_phi, d_istop, stats ? d_trip : nullptr, d_tab, N, d_ndone);
         DFTA_CHECK_LAUNCH(ctx);
+        if (early_match) DFTA_HIP(ctx, hipEventRecord(ev_walk, st));
         rc = plan();
         if (rc) return rc;
         int ndone = 0;
         DFTA_HIP(ctx, hipMemcpyAsync(&ndone, d_ndone, sizeof(int), hipMemcpyDeviceToHost, st));
         DFTA_HIP(ctx, hipStreamSynchronize(st));
+        if (early_match && ndone > done_seen && ndone < njobs) {
+            // some levels have their eigenvalue while others still search: their match solves start now, on the second stream,
+            // under the next round's sweeps (two waves and 8 KB of LDS per level fit next to a sweep block)
+            done_seen = ndone;
+            DFTA_HIP(ctx, hipStreamWaitEvent(st2, ev_walk, 0));
+            ctx->stream = st2;                       // the launch helpers below use the context's stream
+            int erc = DFTA_OK;
+            hipLaunchKernelGGL(k_job_energies, dim3((njobs + 63) / 64), dim3(64), 0, st2, d_jobs, njobs, d_jE, d_jslot, d_jl);
+            erc = dfta_launch_boundary(ctx, g, d_jE, njobs, d_jstart, d_jus, d_jus1, 1, d_jl, d_Q);
+            if (!erc) {
+                hipLaunchKernelGGL(k_mask_ready, dim3((njobs + 63) / 64), dim3(64), 0, st2, d_jobs, njobs, d_jstart, d_jmatched, d_jstart_keep);
+                erc = dfta_launch_match(ctx, g, njobs, d_tab, d_jslot, d_jE, d_jstart, d_jus, d_jus1, d_jl, d_Psi, d_Q, d_jmp, d_bounds, d_Q);
+            }
+            ctx->stream = st;
+            if (erc) return erc;
+            DFTA_HIP(ctx, hipEventRecord(ev_early, st2));
+            early_pending = true;
+        }
         if (stats) {
             float ms = 0;
             DFTA_HIP(ctx, hipEventElapsedTime(&ms, ev[0], ev[1]));
@@ -1175,21 +1232,22 @@ int LevelSolver::run(const double* dV, const double* job_bottom, int run_mode, d
     }
     if (rounds >= max_rounds) { snprintf(ctx->err, sizeof(ctx->err), "level solver did not terminate"); return DFTA_ERR_NOT_CONVERGED; }
 
-    // wavefunctions: match, normalise, accumulate
+    // wavefunctions: match (the levels that were not matched while the others searched), normalise, accumulate
+    if (early_pending) DFTA_HIP(ctx, hipStreamWaitEvent(st, ev_early, 0));       // the early solves use the same per-job scratch arrays
     hipLaunchKernelGGL(k_job_energies, dim3((njobs + 63) / 64), dim3(64), 0, st, d_jobs, njobs, d_jE, d_jslot, d_jl);
     DFTA_CHECK_LAUNCH(ctx);
     rc = dfta_launch_boundary(ctx, g, d_jE, njobs, d_jstart, d_jus, d_jus1, 1, d_jl, d_Q /* uniform: start value at the first node, one per job */);
     if (rc) return rc;
-    if (nfrozen) {
-        hipLaunchKernelGGL(k_mask_frozen, dim3((njobs + 63) / 64), dim3(64), 0, st, d_jobs, njobs, d_jstart);
-        DFTA_CHECK_LAUNCH(ctx);
-    }
+    // cut-off index -1 = skipped by k_match: frozen jobs (the result of their last solve stands) and jobs matched already;
+    // d_jstart_keep: the cut-off index of every job that was matched in this run (-1: frozen)
+    hipLaunchKernelGGL(k_mask_rest, dim3((njobs + 63) / 64), dim3(64), 0, st, d_jobs, njobs, d_jstart, d_jmatched, d_jstart_keep);
+    DFTA_CHECK_LAUNCH(ctx);
     rc = dfta_launch_match(ctx, g, njobs, d_tab, d_jslot, d_jE, d_jstart, d_jus, d_jus1, d_jl, d_Psi, d_Q, d_jmp, g->uniform ? nullptr : d_bounds,
                            d_Q);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_store_match, dim3((njobs + 63) / 64), dim3(64), 0, st, d_jobs, njobs, d_jmp, d_jstart);
+    hipLaunchKernelGGL(k_store_match, dim3((njobs + 63) / 64), dim3(64), 0, st, d_jobs, njobs, d_jmp, d_jstart_keep);
     DFTA_CHECK_LAUNCH(ctx);
-    hipLaunchKernelGGL(k_normalize, dim3(njobs), dim3(kNormThreads), 0, st, d_Psi, d_Q, N, g->d_eh, g->d_cnst, nfrozen ? d_jstart : nullptr, g->uniform ? g->h : 1.0, integ_rule);
+    hipLaunchKernelGGL(k_normalize, dim3(njobs), dim3(kNormThreads), 0, st, d_Psi, d_Q, N, g->d_eh, g->d_cnst, nfrozen ? d_jstart_keep : nullptr, g->uniform ? g->h : 1.0, integ_rule);
     DFTA_CHECK_LAUNCH(ctx);
     if (dNewDensity) {
         hipLaunchKernelGGL(k_accumulate_density, dim3(std::min(256, (N + 255) / 256), nV), dim3(256), 0, st, d_Psi, d_jobs, d_v_off,
