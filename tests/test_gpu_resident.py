@@ -101,6 +101,30 @@ def test_resident_groups_are_deterministic(ctx):
     grid.close()
 
 
+def test_resident_groups_are_deterministic_radon(ctx):
+    """Rn at 131073 nodes (four shared levels, the hand-over to the coarse workgroup twice per V-cycle) and a batch of three
+    different atoms: 10 SCF steps, twice with resident groups and once with one workgroup per atom -- U of every step identical."""
+    L, d, R = GRIDS["L17"]
+    grid = D.Grid(ctx, L, d, R)
+    for Zs in ([86], [86, 30, 7]):
+        runs = []
+        for kv in ({}, {}, {"DFTA_POISSON_GROUP": "0"}):
+            with env(**kv):
+                scf = D.Scf(ctx, grid, Zs, lsda=False)
+                tr = []
+                for _ in range(10):
+                    scf.step(want_stats=False)
+                    tr.append([scf.array(5, a).copy() for a in range(len(Zs))])
+                runs.append((scf.poisson_info()[0], tr))
+                scf.close()
+        assert runs[0][0] == 33 and runs[2][0] == 1
+        for k in range(10):
+            for a in range(len(Zs)):
+                for other in (1, 2):
+                    assert np.array_equal(runs[0][1][k][a].view(np.int64), runs[other][1][k][a].view(np.int64)), (Zs, k, a, other)
+    grid.close()
+
+
 def test_resident_lost_member_is_detected(ctx):
     L, d, R = GRIDS["L17"]
     grid = D.Grid(ctx, L, d, R)
