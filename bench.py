@@ -57,14 +57,19 @@ GRIDS = {14: (5e-4, 25.0), 17: (1e-4, 50.0), 20: (1.25e-5, 50.0)}
 # ---------------------------------------------------------------------------------------------------------------
 # CPU baseline: the oracle (test infrastructure, used here as the measured CPU leg only)
 # ---------------------------------------------------------------------------------------------------------------
-def cpu_worker(levels, lsda, steps, tables):
-    """runs in its own process: `steps` SCF steps of Rn on the oracle, prints one JSON line"""
+def cpu_worker(levels, lsda, steps, tables, threads=1):
+    """runs in its own process: `steps` SCF steps of Rn on the oracle, prints one JSON line.  threads > 1: the level-parallel
+    variant (un-chained clamped brackets -- the GPU path's mode -- one OpenMP thread per level, oracle/libdfta_oracle_omp.so)"""
+    if threads > 1:
+        os.environ["DFTA_ORACLE_OMP"] = "1"
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import _oracle as O
     delta, rmax = GRIDS.get(levels, (1e-4, 50.0))
     o = O.oracle()
+    if threads > 1:
+        o.dfo_set_level_threads(threads)
     t0 = time.time()
-    s = o.dfo_scf_create(int(lsda), 86, levels, 0.5, rmax, delta, 1)
+    s = o.dfo_scf_create(int(lsda), 86, levels, 0.5, rmax, delta, 3 if threads > 1 else 1)
     t_setup = time.time() - t0
     if tables:
         o.dfo_tables_enable(C.byref(s.contents.g))
@@ -84,8 +89,8 @@ def cpu_worker(levels, lsda, steps, tables):
     print(json.dumps({"sweeps": sweeps, "seconds": dt, "vcycles": vc, "setup_s": t_setup, "etotal": e.Etotal}))
 
 
-def _spawn_cpu(levels, lsda, steps, tables, n):
-    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-worker", str(levels), str(int(lsda)), str(steps), str(int(tables))]
+def _spawn_cpu(levels, lsda, steps, tables, n, threads=1):
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-worker", str(levels), str(int(lsda)), str(steps), str(int(tables)), str(threads)]
     t0 = time.time()
     procs = [subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True) for _ in range(n)]
     outs = [json.loads(p.communicate()[0].strip().splitlines()[-1]) for p in procs]
@@ -125,6 +130,8 @@ def cpu_baseline(levels, lsda, steps):
     tab, _ = _spawn_cpu(levels, lsda, steps, True, 1)
     nall = max(1, min(physical_cores(), len(os.sched_getaffinity(0))))     # every physical core this process may use
     allc, wall = _spawn_cpu(levels, lsda, steps, False, nall)
+    nlev = 15                                                              # Rn: 15 subshells per spin
+    par, _ = _spawn_cpu(levels, lsda, steps, False, 1, threads=nlev)       # one thread per level, one atom
     o, t = one[0], tab[0]
     assert abs(o["etotal"] - t["etotal"]) == 0.0                     # the table variant is bit-identical
     tag = "Rn %s @ %d levels" % ("LSDA" if lsda else "LDA", levels)
@@ -135,6 +142,11 @@ def cpu_baseline(levels, lsda, steps):
             "cpu_model": cpu_model(), "nproc": nproc,
             "table_variant": {"value": t["sweeps"] / t["seconds"], "unit": "sweeps/s", "cores": 1, "ms_per_step": 1e3 * t["seconds"] / steps,
                               "note": "r_i and exp(2 i delta) looked up instead of re-evaluated per point; results bit-identical"},
+            "level_parallel": {"value": par[0]["sweeps"] / par[0]["seconds"], "unit": "sweeps/s", "cores": nlev,
+                               "ms_per_step": 1e3 * par[0]["seconds"] / steps,
+                               "note": "ONE atom, the levels of a spin on %d OpenMP threads (un-chained clamped brackets: the GPU path's mode; "
+                                       "bit-identical to its serial form), multigrid / XC / integrals serial: the per-atom latency a CPU can reach "
+                                       "(SURVEY 8d ii)" % nlev},
             "all_cores": {"value": sum(x["sweeps"] for x in allc) / max(x["seconds"] for x in allc), "unit": "sweeps/s", "cores": nall,
                           "vcycles_per_s": sum(x["vcycles"] for x in allc) / max(x["seconds"] for x in allc),
                           "physical_cores": physical_cores(),
@@ -277,7 +289,7 @@ def summarize(tot, levels, N, atoms, lsda, world, delta, rmax):
 
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "--cpu-worker":
-        cpu_worker(int(sys.argv[2]), bool(int(sys.argv[3])), int(sys.argv[4]), bool(int(sys.argv[5])))
+        cpu_worker(int(sys.argv[2]), bool(int(sys.argv[3])), int(sys.argv[4]), bool(int(sys.argv[5])), int(sys.argv[6]) if len(sys.argv) > 6 else 1)
         return
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)

@@ -408,13 +408,54 @@ int dfo_loop_over_levels(const dfo_grid* g, const double* V, dfo_level* levels, 
     return reallyConverged;
 }
 
+/* Level-parallel CPU baseline (SURVEY.md section 8d ii: "one thread per level"): in the un-chained clamped mode (chained == 3,
+ * what the GPU path runs) the levels are independent, so each is solved by its own call of dfo_loop_over_levels with ONE level into
+ * its own density buffer (0 + x is exact), and the buffers are added in level order afterwards -- bit for bit the serial result.
+ * Threads only when the library is built with -fopenmp (oracle/Makefile: libdfta_oracle_omp.so) and dfo_set_level_threads(n > 1). */
+static int g_level_threads = 1;
+void dfo_set_level_threads(int n) { g_level_threads = n > 1 ? n : 1; }
+int dfo_get_level_threads(void)
+{
+#ifdef _OPENMP
+    return g_level_threads;
+#else
+    return 1;
+#endif
+}
+
+static int dfo_loop_over_levels_parallel(const dfo_grid* g, const double* V, dfo_level* levels, int nlevels,
+                                         double* newDensity, double* Eelectronic, double Bottom0)
+{
+    const int n = g->N;
+    double* all = (double*)calloc((size_t)nlevels * (size_t)n, sizeof(double));
+    double* eel = (double*)calloc((size_t)nlevels, sizeof(double));
+    int* cv = (int*)calloc((size_t)nlevels, sizeof(int));
+#ifdef _OPENMP
+#pragma omp parallel for num_threads(g_level_threads) schedule(dynamic, 1)
+#endif
+    for (int k = 0; k < nlevels; ++k) {
+        double bot = Bottom0;
+        cv[k] = dfo_loop_over_levels(g, V, &levels[k], 1, all + (size_t)k * n, &eel[k], &bot, 3, NULL);
+    }
+    int conv = 1;
+    for (int k = 0; k < nlevels; ++k) {
+        const double* t = all + (size_t)k * n;
+        for (int i = 0; i < n - 1; ++i) newDensity[i] += t[i];
+        *Eelectronic += eel[k];
+        if (!cv[k]) conv = 0;
+    }
+    free(all); free(eel); free(cv);
+    return conv;
+}
+
 int dfo_calculate_density(const dfo_grid* g, const double* V, dfo_level* levels, int nlevels,
                           double* density, double alpha, double* newDensity, double* Eelectronic,
                           double BottomEnergy, int chained, const double* hints)   /* DFTAtom.cpp:328-343 */
 {
     const double oneMinusAlpha = 1. - alpha;
-    const int conv = dfo_loop_over_levels(g, V, levels, nlevels, newDensity, Eelectronic,
-                                          &BottomEnergy, chained, hints);
+    const int conv = (chained == 3 && g_level_threads > 1)
+                         ? dfo_loop_over_levels_parallel(g, V, levels, nlevels, newDensity, Eelectronic, BottomEnergy)
+                         : dfo_loop_over_levels(g, V, levels, nlevels, newDensity, Eelectronic, &BottomEnergy, chained, hints);
     for (int i = 1; i < g->N; ++i) {
         const double position = g->Rp * (exp(i * g->delta) - 1.);
         newDensity[i] /= fourM_PI * position * position;

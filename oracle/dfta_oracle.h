@@ -80,6 +80,9 @@ void dfo_normalize_nonuniform(const dfo_grid* g, double* Psi);       /* DFTAtom.
 int  dfo_loop_over_levels(const dfo_grid* g, const double* V, dfo_level* levels, int nlevels,
                           double* newDensity, double* Eelectronic, double* BottomEnergy,
                           int chained, const double* hints);         /* DFTAtom.cpp:493-563 */
+/* level-parallel variant of the un-chained clamped mode (bench.py's CPU baseline): see dfta_oracle.c */
+void dfo_set_level_threads(int n);
+int  dfo_get_level_threads(void);
 int  dfo_calculate_density(const dfo_grid* g, const double* V, dfo_level* levels, int nlevels,
                            double* density, double alpha, double* newDensity,
                            double* Eelectronic, double BottomEnergy, int chained,

@@ -9,7 +9,9 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
-ORACLE_SO = os.path.join(ORACLE_DIR, "libdfta_oracle.so")
+# DFTA_ORACLE_OMP=1 (bench.py's level-parallel CPU leg, tests/test_oracle_golden.py): the same source built with -fopenmp
+ORACLE_OMP = os.environ.get("DFTA_ORACLE_OMP") == "1"
+ORACLE_SO = os.path.join(ORACLE_DIR, "libdfta_oracle_omp.so" if ORACLE_OMP else "libdfta_oracle.so")
 REF_SO = os.path.join(ORACLE_DIR, "_ref", "libdfta_ref.so")
 
 c_dp = C.POINTER(C.c_double)
@@ -67,7 +69,7 @@ def build_oracle(force=False):
     """Compile oracle/libdfta_oracle.so (gcc) and, if /root/reference exists, oracle/_ref."""
     if force or not os.path.exists(ORACLE_SO) or \
             os.path.getmtime(ORACLE_SO) < os.path.getmtime(os.path.join(ORACLE_DIR, "dfta_oracle.c")):
-        subprocess.check_call(["make", "-C", ORACLE_DIR, "libdfta_oracle.so"], stdout=subprocess.DEVNULL)
+        subprocess.check_call(["make", "-C", ORACLE_DIR, os.path.basename(ORACLE_SO)], stdout=subprocess.DEVNULL)
     if os.path.isdir("/root/reference/DFTAtom"):
         subprocess.check_call(["make", "-C", ORACLE_DIR, "ref"], stdout=subprocess.DEVNULL)
 
@@ -86,6 +88,8 @@ def oracle():
     G = C.POINTER(Grid)
     sig = {
         "dfo_num_nodes": (C.c_int, [C.c_int]),
+        "dfo_set_level_threads": (None, [C.c_int]),
+        "dfo_get_level_threads": (C.c_int, []),
         "dfo_grid_init": (None, [G, C.c_int, C.c_double, C.c_double]),
         "dfo_position": (C.c_double, [G, C.c_long]),
         "dfo_tables_enable": (None, [G]),
