@@ -346,9 +346,9 @@ static int poisson_create_impl(dfta_ctx* ctx, const dfta_grid* g, int batch, int
     // units idle the fine levels of every atom are shared by a group of G workgroups (all of them must be resident:
     // batch * G <= 256 CUs).  A level is shared when every lane of the group still owns >= 8 nodes (>= 4 for G = 16: the
     // same four levels at 131073 nodes, with 32 nodes per lane on the finest one -- the most that is staged in LDS).
-    // (measured: G = 16 wins up to 4 atoms; beyond that the barriers of 16 members on a nearly full chip cost more than the
-    // shorter chunks save)
-    int logG = batch <= 4 ? 4 : (batch <= 32 ? 3 : (batch <= 64 ? 2 : (batch <= 128 ? 1 : 0)));
+    // round 3, re-measured with the fused visits in place (131073 nodes, ms per solve): 8 atoms 39.8 (G = 16) / 48.7 (8); 12: 42.4 / 50.5;
+    // 16: 45.0 / 51.4; 32: 59.2 (8) / 71.6 (4); 64: 99.6 (4) / 124 (2) / 149 (1); 96: 150 (2) / 156 (1); 128: 184 (2) / 171 (1)
+    int logG = batch <= 16 ? 4 : (batch <= 32 ? 3 : (batch <= 64 ? 2 : (batch <= 96 ? 1 : 0)));
     if (const char* e = dfta_knob("POISSON_GROUP")) {      // measurements: force log2 of the group size
         const int v = atoi(e);
         if (v >= 0 && v <= 4 && (batch << v) <= 256) logG = v;
