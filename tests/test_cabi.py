@@ -92,3 +92,25 @@ def test_aufbau_transition_metal_option():
                 assert "5s" not in tm
         else:
             assert ref == tm, Z
+
+
+def test_transition_metal_aufbau_option():
+    """dfta_get_subshells_ex(..., DFTA_AUFBAU_TRANSITION_METALS): the reference's unwired AdjustForTransitionMetals
+    (AufbauPrinciple.h:78-99: the d shell takes one electron from the s shell above it for Cr, Cu, Nb, Mo, Ru, Rh, Ag, Pt, Au; two for
+    Pd) as an option -- the textbook ground-state configurations, every electron accounted for, and no change for the other atoms
+    (host code: no device needed)."""
+    import dftatom_amd as D
+    lab = "spdf"
+
+    def cfg(Z, a):
+        return " ".join("%d%s%d" % (n + 1, lab[l], o) for n, l, o in D.get_subshells(Z, a))
+
+    want = {24: "3d5 4s1", 29: "3d10 4s1", 41: "4d4 5s1", 42: "4d5 5s1", 44: "4d7 5s1", 45: "4d8 5s1", 46: "4p6 4d10", 47: "4d10 5s1",
+            78: "5d9 6s1", 79: "5d10 6s1"}
+    for Z in range(1, 119):
+        ref, tm = cfg(Z, D.AUFBAU_REFERENCE), cfg(Z, D.AUFBAU_TRANSITION_METALS)
+        assert sum(o for _, _, o in D.get_subshells(Z, D.AUFBAU_TRANSITION_METALS)) == Z
+        if Z in want:
+            assert tm.endswith(want[Z]) and tm != ref, (Z, tm)
+        else:
+            assert tm == ref, (Z, tm, ref)
