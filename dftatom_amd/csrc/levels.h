@@ -93,6 +93,10 @@ struct LevelSolver {
     int *d_limit = nullptr, *d_start = nullptr, *d_count = nullptr, *d_istop = nullptr, *d_trip = nullptr;
     int *d_wave_kind = nullptr, *d_wave_slot = nullptr, *d_wave_first = nullptr, *d_wave_cnt = nullptr, *d_wave_job = nullptr;
     bool dynamic = false;          // trial slots re-allotted among the active jobs every round (few jobs: latency mode)
+    // packed rounds (batches): the trials of a round laid out job after job inside their (table slot, kind) group by k_pack
+    bool packed = false;
+    int pack_dmin = 3, pack_dmax = 12, pack_lanes_small = 0, pack_dsmall = 3, pack_lanes_large = 0;
+    int *d_lane_job = nullptr, *d_slot_off = nullptr, *d_slot_jobs = nullptr, *d_gsz = nullptr, *d_goff = nullptr, *d_pack_out = nullptr;
     unsigned long long* d_counters = nullptr;   // [0] issued trials, [1] traversed points, [2] scratch
     double *d_Psi = nullptr, *d_Q = nullptr;     // njobs*N each
     double *d_jE = nullptr, *d_jus = nullptr, *d_jus1 = nullptr;

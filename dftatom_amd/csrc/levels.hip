@@ -71,7 +71,7 @@ __device__ __forceinline__ bool pred_bit(const dfta::Job& j, int ph, int k)
 }
 
 // ---- expand: trial energies of the current round of every job, plus their far boundary values ----------------------
-__global__ __launch_bounds__(256) void k_expand(const dfta::Job* __restrict__ jobs, const int* __restrict__ wave_job, int ntrials, const double* __restrict__ r,
+__global__ __launch_bounds__(256) void k_expand(const dfta::Job* __restrict__ jobs, const int* __restrict__ wave_job, int wshift, int ntrials, const double* __restrict__ r,
                                                 int N, double delta, double far_thr, double* __restrict__ E,
                                                 int* __restrict__ limit, int* __restrict__ start, double* __restrict__ us,
                                                 double* __restrict__ us1, int* __restrict__ wave_kind,
@@ -79,8 +79,8 @@ __global__ __launch_bounds__(256) void k_expand(const dfta::Job* __restrict__ jo
 {
     const int gt = blockIdx.x * blockDim.x + threadIdx.x;
     if (gt >= ntrials) return;       // ntrials is a multiple of 64: whole waves leave
-    const int job = wave_job[gt >> 6];
-    if (job < 0) {                    // a block of 64 slots that no job owns this round
+    const int job = wave_job[gt >> wshift];   // one entry per 64-trial block (wshift 6) or per trial (packed rounds: wshift 0)
+    if (job < 0) {                    // slots that no job owns this round
         E[gt] = 0; limit[gt] = 0; start[gt] = 0;
         if ((gt & 63) == 0) wave_kind[gt >> 6] = DFTA_SWEEP_ZERO;
         return;
@@ -617,13 +617,13 @@ __global__ void k_walk(dfta::Job* __restrict__ jobs, const int* __restrict__ cha
 }
 
 // spines of the next round, after every walk of this one (a job reads its sibling's first-bisection result)
-__global__ void k_plan(dfta::Job* __restrict__ jobs, int njobs, int nopredict)
+__global__ void k_plan(dfta::Job* __restrict__ jobs, int njobs, int nopredict, int tpj_override)
 {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= njobs) return;
     dfta::Job j = jobs[k];
     if (j.phase != PH_TOP && j.phase != PH_BOTTOM && j.phase != PH_ZERO) return;
-    const int tpj = j.tcap;
+    const int tpj = tpj_override > 0 ? tpj_override : j.tcap;   // packed rounds: "with room to spare", k_pack cuts it to size
     plan_round(j, jobs, tpj);
     if (nopredict) { j.spine = 0; j.capz = tpj; j.use_sp = 0; j.sp_len = 0; j.sp_bits = 0; }     // plain trees only (DFTA_LEVELS_NOPREDICT)
     jobs[k].spine = j.spine;
@@ -631,6 +631,149 @@ __global__ void k_plan(dfta::Job* __restrict__ jobs, int njobs, int nopredict)
     jobs[k].use_sp = j.use_sp;
     jobs[k].sp_bits = j.sp_bits;
     jobs[k].sp_len = j.sp_len;
+}
+
+// ---- packed rounds: many jobs (batches of atoms) -- the trials of a round laid out job after job, no 64-slot block per job ----
+// A 64-trial block of the sweep kernels has ONE table slot (potential, l) and ONE kind (CountNodes / SolutionInZero); its
+// lanes are independent otherwise.  With a block per job (the static layout) a job cannot have fewer than 64 trials, and the
+// work of a step is the number of blocks: a depth-5 tree behind a 10-decision spine integrates 42 trials for 15 decisions
+// and pays for 64.  Here the jobs of a round are grouped by (slot, kind) -- 1s..6s of one atom share a table, 2p..6p the
+// next -- and laid out back to back inside their group, a job taking exactly probe + spine + 2^d - 1 trials; only the end
+// of a group is padded to a block.  The depth d is the same for every job of a round and is chosen from what is still
+// searching: the largest one whose trials fit the launch that fills the machine (latency regime: ~1.5 passes of one block
+// per compute unit, the pipelined kernel; else two waves per SIMD of the fused one), never below dmin.  As jobs finish, the
+// rest get deeper trees.  Which midpoints are integrated changes; the decisions do not (the walk follows the reference's
+// predicates on whatever nodes it finds).
+constexpr int kPackThreads = 1024;
+constexpr int kPackSpineCap = 40;      // decisions of one round's spine (the tree behind it adds d more)
+
+__device__ __forceinline__ bool job_searching(int phase) { return phase == PH_TOP || phase == PH_BOTTOM || phase == PH_ZERO; }
+
+__global__ __launch_bounds__(kPackThreads) void k_pack(dfta::Job* __restrict__ jobs, int njobs, int nslots, const int* __restrict__ slot_off,
+                                                       const int* __restrict__ slot_jobs, int lanes_small, int dsmall, int lanes_large, int dmin, int dmax,
+                                                       int* __restrict__ gsz, int* __restrict__ goff, int* __restrict__ lane_job,
+                                                       int* __restrict__ wave_slot, int* __restrict__ out)
+{
+    __shared__ long long s_sum[kPackThreads / 64];
+    __shared__ int s_cnt[kPackThreads / 64];
+    __shared__ int s_scan[kPackThreads];
+    __shared__ int s_d;
+    const int tid = threadIdx.x;
+    // (1) what is still searching, and how long its spines are
+    long long ss = 0;
+    int a = 0;
+    for (int k = tid; k < njobs; k += kPackThreads) {
+        if (!job_searching(jobs[k].phase)) continue;
+        int S = jobs[k].spine;
+        if (S > kPackSpineCap) { S = kPackSpineCap; jobs[k].spine = S; }
+        ss += S;
+        ++a;
+    }
+    for (int off = 32; off > 0; off >>= 1) { ss += __shfl_xor(ss, off); a += __shfl_xor(a, off); }
+    if ((tid & 63) == 0) { s_sum[tid >> 6] = ss; s_cnt[tid >> 6] = a; }
+    __syncthreads();
+    if (tid == 0) {
+        long long S = 0;
+        long long A = 0;
+        for (int w = 0; w < kPackThreads / 64; ++w) { S += s_sum[w]; A += s_cnt[w]; }
+        auto fit = [&](long long T) { int d = dmin; while (d < dmax && S + (A << (d + 1)) <= T) ++d; return d; };
+        int d = fit(lanes_small);
+        if (d < dsmall) d = fit(lanes_large);
+        s_d = d;
+        out[1] = d;
+        out[2] = (int)A;
+    }
+    __syncthreads();
+    const int d = s_d;
+    // (2) size of every (slot, kind) group, padded to whole blocks
+    for (int s = tid; s < nslots; s += kPackThreads) {
+        int nc = 0, nz = 0;
+        for (int q = slot_off[s]; q < slot_off[s + 1]; ++q) {
+            const int k = slot_jobs[q];
+            const int ph = jobs[k].phase;
+            if (!job_searching(ph)) continue;
+            const int t = jobs[k].spine + (1 << d);
+            if (ph == PH_ZERO) nz += t; else nc += t;
+        }
+        gsz[2 * s] = (nc + 63) & ~63;
+        gsz[2 * s + 1] = (nz + 63) & ~63;
+    }
+    __syncthreads();
+    // (3) exclusive scan of the group sizes: consecutive chunks per thread, scan of the chunk sums in LDS
+    const int n2 = 2 * nslots;
+    const int chunk = (n2 + kPackThreads - 1) / kPackThreads;
+    const int c0 = min(tid * chunk, n2), c1 = min(c0 + chunk, n2);
+    int local = 0;
+    for (int i = c0; i < c1; ++i) local += gsz[i];
+    s_scan[tid] = local;
+    __syncthreads();
+    for (int off = 1; off < kPackThreads; off <<= 1) {
+        const int v = tid >= off ? s_scan[tid - off] : 0;
+        __syncthreads();
+        s_scan[tid] += v;
+        __syncthreads();
+    }
+    int run = s_scan[tid] - local;
+    for (int i = c0; i < c1; ++i) { goff[i] = run; run += gsz[i]; }
+    if (tid == kPackThreads - 1) out[0] = s_scan[tid];       // trials of the round (a multiple of 64)
+    __syncthreads();
+    // (4) the jobs of a group back to back.  What the padding of the group's last block leaves free goes to deeper trees, a
+    // level at a time, to the job with the shallowest tree (among equals: the one furthest behind -- earlier bisection, wider
+    // interval); only what is left after that belongs to nobody.
+    for (int s = tid; s < nslots; s += kPackThreads) {
+        const int q0 = slot_off[s], q1 = slot_off[s + 1];
+        int used[2] = {0, 0};
+        for (int q = q0; q < q1; ++q) {
+            const int k = slot_jobs[q];
+            const int ph = jobs[k].phase;
+            if (!job_searching(ph)) { jobs[k].tbase = 0; jobs[k].tcap = 0; continue; }
+            jobs[k].tcap = d;                                      // depth of the job's tree, for now
+            used[ph == PH_ZERO] += jobs[k].spine + (1 << d);
+        }
+        for (int kind = 0; kind < 2; ++kind) {
+            int room = gsz[2 * s + kind] - used[kind];
+            while (room >= (1 << d)) {
+                int best = -1, bd = 1 << 30, bph = 0;
+                double bw = 0;
+                for (int q = q0; q < q1; ++q) {
+                    const int k = slot_jobs[q];
+                    const int ph = jobs[k].phase;
+                    if (!job_searching(ph) || (ph == PH_ZERO) != (kind == 1)) continue;
+                    const int dj = jobs[k].tcap;
+                    const double w = jobs[k].toe - jobs[k].boe;
+                    if (dj < bd || (dj == bd && (ph < bph || (ph == bph && w > bw)))) { best = k; bd = dj; bph = ph; bw = w; }
+                }
+                if (best < 0 || (1 << bd) > room || bd >= dmax) break;
+                room -= 1 << bd;
+                jobs[best].tcap = bd + 1;
+            }
+        }
+        int c = goff[2 * s], z = goff[2 * s + 1];
+        const int cend = c + gsz[2 * s], zend = z + gsz[2 * s + 1];
+        for (int b = c >> 6; b < (cend >> 6); ++b) wave_slot[b] = s;
+        for (int b = z >> 6; b < (zend >> 6); ++b) wave_slot[b] = s;
+        for (int q = q0; q < q1; ++q) {
+            const int k = slot_jobs[q];
+            const int ph = jobs[k].phase;
+            if (!job_searching(ph)) continue;
+            const int t = jobs[k].spine + (1 << jobs[k].tcap);
+            jobs[k].tcap = t;
+            jobs[k].capz = t;
+            if (ph == PH_ZERO) { jobs[k].tbase = z; z += t; } else { jobs[k].tbase = c; c += t; }
+        }
+        for (; c < cend; ++c) lane_job[c] = -1;
+        for (; z < zend; ++z) lane_job[z] = -1;
+    }
+}
+
+// owner of every trial slot of a packed round (one wave per job)
+__global__ __launch_bounds__(256) void k_pack_lanes(const dfta::Job* __restrict__ jobs, int njobs, int* __restrict__ lane_job)
+{
+    const int k = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (k >= njobs) return;
+    if (!job_searching(jobs[k].phase)) return;
+    const int base = jobs[k].tbase, cap = jobs[k].tcap;
+    for (int i = lane; i < cap; i += 64) lane_job[base + i] = k;
 }
 
 // ---- latency mode: the trial slots of a round are re-allotted among the jobs that are still searching -----------------
@@ -921,6 +1064,7 @@ void LevelSolver::release()
     if (d_jmatched) (void)hipFree(d_jmatched);
     if (d_jstart_keep) (void)hipFree(d_jstart_keep);
     d_jmatched = nullptr; d_jstart_keep = nullptr;
+    for (int** q : {&d_lane_job, &d_slot_off, &d_slot_jobs, &d_gsz, &d_goff, &d_pack_out}) { if (*q) (void)hipFree(*q); *q = nullptr; }
     if (st2) { (void)hipStreamDestroy(st2); st2 = nullptr; }
     if (ev_walk) { (void)hipEventDestroy(ev_walk); ev_walk = nullptr; }
     if (ev_early) { (void)hipEventDestroy(ev_early); ev_early = nullptr; }
@@ -988,26 +1132,59 @@ int LevelSolver::setup(dfta_ctx* c, const dfta_grid* grid, int mode_, int tree_d
         if (const char* e = dfta_knob("LEVELS_BUDGET_BLOCKS")) blocks = std::max(64, atoi(e));     // measurements
         ntrials = std::max<long>(ntrials, 64L * blocks);
     }
-    nwaves = static_cast<int>(ntrials / 64);
-    early_match = dynamic && !g->uniform && dfta_knob("LEVELS_NOEARLYMATCH") == nullptr;
-
+    // packed rounds (k_pack): batches whose static layout would have 64-trial trees (up to 192 jobs it has 128 trials per job and
+    // the upper half scouts the third bisection: measured on a 12-atom shard, 98 jobs, that is worth 1.6 rounds a step, and the
+    // packed layout has no whole blocks of kind ZERO to give to a job that is still counting nodes), unless a depth was asked for
+    {
+        int min_jobs = 193;
+        if (const char* e = dfta_knob("LEVELS_PACK_MIN_JOBS")) min_jobs = atoi(e);              // measurements
+        packed = (tree_depth <= 0) && !dynamic && njobs >= min_jobs && dfta_knob("LEVELS_NOPACK") == nullptr;
+    }
     // table slots: one per distinct (v, l)
     std::vector<int> slot_v, slot_l;
     std::vector<Job> jobs(njobs);
-    for (int k = 0; k < njobs; ++k) {
-        int slot = -1;
-        for (size_t s = 0; s < slot_v.size(); ++s) if (slot_v[s] == specs[k].v && slot_l[s] == specs[k].l) slot = (int)s;
-        if (slot < 0) { slot = (int)slot_v.size(); slot_v.push_back(specs[k].v); slot_l.push_back(specs[k].l); }
-        Job& j = jobs[k];
-        memset(&j, 0, sizeof(Job));
-        j.v = specs[k].v; j.n = specs[k].n; j.l = specs[k].l; j.occ = specs[k].occ; j.nodes = specs[k].n - specs[k].l;
-        j.slot = slot;
+    {
+        std::vector<int> last_of_v(4, -1);          // jobs are ordered by v: only the slots of the current potential can match
+        int cur_v = -1;
+        for (int k = 0; k < njobs; ++k) {
+            if (specs[k].v != cur_v) { cur_v = specs[k].v; std::fill(last_of_v.begin(), last_of_v.end(), -1); }
+            int& slot = last_of_v[specs[k].l];
+            if (slot < 0) { slot = (int)slot_v.size(); slot_v.push_back(specs[k].v); slot_l.push_back(specs[k].l); }
+            Job& j = jobs[k];
+            memset(&j, 0, sizeof(Job));
+            j.v = specs[k].v; j.n = specs[k].n; j.l = specs[k].l; j.occ = specs[k].occ; j.nodes = specs[k].n - specs[k].l;
+            j.slot = slot;
+        }
+        // sibling: the level of the same potential and l with one node less (its end points bracket this one's, plan_round)
+        for (int k = 0, v0 = 0; k < njobs; ++k) {
+            if (jobs[k].v != jobs[v0].v) v0 = k;
+            jobs[k].sib = -1;
+            for (int q = v0; q < njobs && jobs[q].v == jobs[k].v; ++q)
+                if (jobs[q].l == jobs[k].l && jobs[q].nodes == jobs[k].nodes - 1) jobs[k].sib = q;
+        }
     }
     h_jobs_template = jobs;
     nslots = static_cast<int>(slot_v.size());
+    if (packed) {
+        pack_dmin = 3; pack_dmax = 12;
+        pack_lanes_small = std::max(ctx->num_cu, 64) * 64;   // one pass of one block per compute unit: the pipelined kernel's regime
+        pack_dsmall = 3;                                     // ... as long as that leaves every job a tree of this depth
+        pack_lanes_large = 131072;                   // two waves per SIMD of the fused kernel
+        if (const char* e = dfta_knob("LEVELS_PACK_DMIN")) pack_dmin = std::min(std::max(atoi(e), 1), 8);
+        if (const char* e = dfta_knob("LEVELS_PACK_LANES")) pack_lanes_large = std::max(4096, atoi(e));
+        if (const char* e = dfta_knob("LEVELS_PACK_LANES_SMALL")) pack_lanes_small = std::max(4096, atoi(e));
+        if (const char* e = dfta_knob("LEVELS_PACK_DSMALL")) pack_dsmall = atoi(e);
+        depth = pack_dmin;
+        tpj = 0;                                     // no fixed share: k_pack lays the trials of a round out
+        ntrials = std::max<long>(std::max(pack_lanes_large, pack_lanes_small), static_cast<long>(njobs) * (kPackSpineCap + (1L << pack_dmin))) + 128L * nslots;
+        ntrials = (ntrials + 63) & ~63L;
+    }
+    nwaves = static_cast<int>(ntrials / 64);
+    early_match = dynamic && !g->uniform && dfta_knob("LEVELS_NOEARLYMATCH") == nullptr;
+
     std::vector<int> wave_slot(nwaves), wave_first(nwaves), wave_cnt(nwaves, 64), wave_job(nwaves);
     for (int w = 0; w < nwaves; ++w) {
-        const int q = (w * 64) / tpj;
+        const int q = packed ? njobs : (w * 64) / tpj;
         wave_job[w] = q < njobs ? q : -1;
         wave_slot[w] = q < njobs ? jobs[q].slot : 0;
         wave_first[w] = w * 64;
@@ -1030,6 +1207,19 @@ int LevelSolver::setup(dfta_ctx* c, const dfta_grid* grid, int mode_, int tree_d
     ALLOC(d_wave_first, int, nwaves); UPLOAD(d_wave_first, wave_first);
     ALLOC(d_wave_cnt, int, nwaves); UPLOAD(d_wave_cnt, wave_cnt);
     ALLOC(d_wave_job, int, nwaves); UPLOAD(d_wave_job, wave_job);
+    if (packed) {
+        std::vector<int> slot_off(nslots + 1, 0), slot_jobs(njobs);
+        for (int k = 0; k < njobs; ++k) slot_off[jobs[k].slot + 1]++;
+        for (int q = 0; q < nslots; ++q) slot_off[q + 1] += slot_off[q];
+        std::vector<int> fill(slot_off.begin(), slot_off.end() - 1);
+        for (int k = 0; k < njobs; ++k) slot_jobs[fill[jobs[k].slot]++] = k;
+        ALLOC(d_slot_off, int, nslots + 1); UPLOAD(d_slot_off, slot_off);
+        ALLOC(d_slot_jobs, int, njobs); UPLOAD(d_slot_jobs, slot_jobs);
+        ALLOC(d_gsz, int, 2 * nslots); ALLOC(d_goff, int, 2 * nslots);
+        ALLOC(d_lane_job, int, ntrials);
+        ALLOC(d_pack_out, int, 4);
+        DFTA_HIP(ctx, hipStreamSynchronize(st));     // the vectors above are the sources of the copies
+    }
     ALLOC(d_counters, unsigned long long, 4);
     ALLOC(d_Psi, double, (size_t)njobs * N);
     ALLOC(d_Q, double, (size_t)njobs * N);
@@ -1081,8 +1271,8 @@ int LevelSolver::run(const double* dV, const double* job_bottom, int run_mode, d
             continue;
         }
         j.frozen = 0;
-        j.tbase = k * tpj;
-        j.tcap = tpj;
+        j.tbase = packed ? 0 : k * tpj;      // packed rounds: k_pack lays the trials out
+        j.tcap = packed ? 0 : tpj;
         j.bottom0 = job_bottom[k];
         const bool first = (k == 0 || jobs[k].v != jobs[k - 1].v);
         if (!chained || first) { j.phase = PH_TOP; j.toe = 50; j.boe = j.bottom0; }   // DFTAtom.cpp:499
@@ -1119,9 +1309,6 @@ int LevelSolver::run(const double* dV, const double* job_bottom, int run_mode, d
         j.use_sp = 0;
         j.sp_len = 0;
         j.sp_bits = 0;
-        j.sib = -1;
-        for (int q = 0; q < njobs; ++q)
-            if (jobs[q].v == j.v && jobs[q].l == j.l && jobs[q].nodes == j.nodes - 1) j.sib = q;
         j.spine = 0;           // planned on the device (k_plan below), after the bottoms have been clamped
         j.phase_done = 0;
     }
@@ -1146,12 +1333,27 @@ int LevelSolver::run(const double* dV, const double* job_bottom, int run_mode, d
         if (dynamic)
             hipLaunchKernelGGL(k_allot, dim3(1), dim3(64), 0, st, d_jobs, njobs, (int)ntrials, use_prediction ? 0 : 1, d_wave_job, d_wave_slot);
         else
-            hipLaunchKernelGGL(k_plan, dim3((njobs + 63) / 64), dim3(64), 0, st, d_jobs, njobs, use_prediction ? 0 : 1);
+            hipLaunchKernelGGL(k_plan, dim3((njobs + 63) / 64), dim3(64), 0, st, d_jobs, njobs, use_prediction ? 0 : 1, packed ? (1 << 14) : 0);
         DFTA_CHECK_LAUNCH(ctx);
+        if (packed) {
+            hipLaunchKernelGGL(k_pack, dim3(1), dim3(kPackThreads), 0, st, d_jobs, njobs, nslots, d_slot_off, d_slot_jobs, pack_lanes_small,
+                               pack_dsmall, pack_lanes_large, pack_dmin, pack_dmax, d_gsz, d_goff, d_lane_job, d_wave_slot, d_pack_out);
+            DFTA_CHECK_LAUNCH(ctx);
+            hipLaunchKernelGGL(k_pack_lanes, dim3((njobs + 3) / 4), dim3(256), 0, st, d_jobs, njobs, d_lane_job);
+            DFTA_CHECK_LAUNCH(ctx);
+        }
         return DFTA_OK;
     };
     rc = plan();
     if (rc) return rc;
+    // trials of the coming round: the whole static / latency-mode layout, or what k_pack has just laid out
+    long round_trials = ntrials;
+    int pack_out[4] = {0, 0, 0, 0};
+    if (packed) {
+        DFTA_HIP(ctx, hipMemcpyAsync(pack_out, d_pack_out, sizeof(pack_out), hipMemcpyDeviceToHost, st));
+        DFTA_HIP(ctx, hipStreamSynchronize(st));
+        round_trials = pack_out[0];
+    }
     int* d_ndone = reinterpret_cast<int*>(d_counters + 2);
     int rounds = 0;
     float ms_sweep = 0;
@@ -1160,17 +1362,22 @@ int LevelSolver::run(const double* dV, const double* job_bottom, int run_mode, d
     bool early_pending = false;
     while (rounds < max_rounds) {
         dfta_range r_round("dfta: level-search round (expand, sweeps, scout, walk, plan)");
-        hipLaunchKernelGGL(k_expand, dim3((unsigned)((ntrials + 255) / 256)), dim3(256), 0, st, d_jobs, d_wave_job, (int)ntrials, g->d_r, N, g->delta,
-                           g->far_arg_threshold, d_E, d_limit, d_start, d_us, d_us1, d_wave_kind, d_counters, g->uniform, g->Rmax, g->h);
+        if (round_trials <= 0 || round_trials > ntrials) { snprintf(ctx->err, sizeof(ctx->err), "level solver: packed round of %ld trials (room for %ld)", round_trials, ntrials); return DFTA_ERR_HIP; }
+        const int round_waves = static_cast<int>(round_trials / 64);
+        hipLaunchKernelGGL(k_expand, dim3((unsigned)((round_trials + 255) / 256)), dim3(256), 0, st, d_jobs, packed ? d_lane_job : d_wave_job, packed ? 0 : 6,
+                           (int)round_trials, g->d_r, N, g->delta, g->far_arg_threshold, d_E, d_limit, d_start, d_us, d_us1, d_wave_kind, d_counters, g->uniform,
+                           g->Rmax, g->h);
         DFTA_CHECK_LAUNCH(ctx);
         if (stats) DFTA_HIP(ctx, hipEventRecord(ev[0], st));
-        rc = dfta_launch_sweep(ctx, g, DFTA_SWEEP_COUNT, d_wave_kind, nwaves, d_tab, d_wave_slot, d_wave_first, d_wave_cnt, d_E,
+        rc = dfta_launch_sweep(ctx, g, DFTA_SWEEP_COUNT, d_wave_kind, round_waves, d_tab, d_wave_slot, d_wave_first, d_wave_cnt, d_E,
                                d_limit, d_start, d_us, d_us1, d_count, d_u0, stats ? d_trip : nullptr, stats ? d_counters + 1 : nullptr, g->uniform ? nullptr : d_bounds, d_phi,
                                d_istop, d_slot_l);
         if (rc) return rc;
         if (stats) DFTA_HIP(ctx, hipEventRecord(ev[1], st));
-        hipLaunchKernelGGL(k_scout, dim3(njobs), dim3(64), 0, st, d_jobs, d_E, d_start, d_u0);
-        DFTA_CHECK_LAUNCH(ctx);
+        if (!packed) {          // packed rounds have no scouts (capz == tcap)
+            hipLaunchKernelGGL(k_scout, dim3(njobs), dim3(64), 0, st, d_jobs, d_E, d_start, d_u0);
+            DFTA_CHECK_LAUNCH(ctx);
+        }
         DFTA_HIP(ctx, hipMemsetAsync(d_ndone, 0, sizeof(int), st));
         hipLaunchKernelGGL(k_walk, dim3((run_chains + 63) / 64), dim3(64), 0, st, d_jobs, d_chains, run_chains, d_count, d_u0, d_phi, d_istop, stats ? d_trip : nullptr, d_tab, N, d_ndone);
         DFTA_CHECK_LAUNCH(ctx);
@@ -1179,7 +1386,10 @@ int LevelSolver::run(const double* dV, const double* job_bottom, int run_mode, d
         if (rc) return rc;
         int ndone = 0;
         DFTA_HIP(ctx, hipMemcpyAsync(&ndone, d_ndone, sizeof(int), hipMemcpyDeviceToHost, st));
+        if (packed) DFTA_HIP(ctx, hipMemcpyAsync(pack_out, d_pack_out, sizeof(pack_out), hipMemcpyDeviceToHost, st));
         DFTA_HIP(ctx, hipStreamSynchronize(st));
+        const long this_round = round_trials;
+        if (packed) round_trials = pack_out[0];
         if (early_match && ndone > done_seen && ndone < njobs) {
             // some levels have their eigenvalue while others still search: their match solves start now, on the second stream,
             // under the next round's sweeps (two waves and 8 KB of LDS per level fit next to a sweep block)
@@ -1202,6 +1412,8 @@ int LevelSolver::run(const double* dV, const double* job_bottom, int run_mode, d
             float ms = 0;
             DFTA_HIP(ctx, hipEventElapsedTime(&ms, ev[0], ev[1]));
             ms_sweep += ms;
+            if (debug_rounds && packed)
+                fprintf(stderr, "   packed round %d: %ld trials in %.3f ms; next: %d trials, depth %d, %d jobs searching\n", rounds + 1, this_round, ms, pack_out[0], pack_out[1], pack_out[2]);
         }
         ++rounds;
         if (debug_rounds) {      // per-round census of the jobs (phase/decisions taken), stderr

@@ -3,7 +3,9 @@
   * an atom that has met the reference's stop test (DFTAtom.cpp:474-479) is frozen: every atom of a batch ends in the
     state of ITS OWN last step -- energies, eigenvalues, step count -- bit for bit what a run of that atom alone gives;
   * the Poisson solver's groups of workgroups: a lost member (fault injection) is detected after the solve, the solve
-    is repeated with one workgroup per atom in the same process and returns the same bits.
+    is repeated with one workgroup per atom in the same process and returns the same bits;
+  * packed rounds of the level search (batches: the trials of a round laid out job after job inside their (potential, l, kind)
+    group instead of a 64-trial block per job) take the reference's decisions: bit-identical to the static layout, fewer trials.
 """
 import os
 
@@ -125,4 +127,60 @@ def test_lost_group_member_is_detected_and_solve_repeated(ctx):
     scf_ok.step(want_stats=False)
     assert scf_ok.energies()[0][0].as_list() == e_bad
     scf_ok.close()
+    grid.close()
+
+
+def _with_debug(knobs, fn):
+    old = os.environ.get("DFTA_DEBUG")
+    if knobs:
+        os.environ["DFTA_DEBUG"] = knobs
+    else:
+        os.environ.pop("DFTA_DEBUG", None)
+    try:
+        return fn()
+    finally:
+        if old is None:
+            os.environ.pop("DFTA_DEBUG", None)
+        else:
+            os.environ["DFTA_DEBUG"] = old
+
+
+@pytest.mark.parametrize("lsda", [False, True])
+def test_packed_rounds_take_the_same_decisions(ctx, lsda):
+    """Z = 1..40 (230 jobs; LSDA 460) on the 16385-node grid, six SCF steps (the first one on the reference's chained path, the
+    history spines from the third on): packed rounds -- default depth rule, shallow and deep floors, a small and a large launch
+    target -- against one 64-trial block per job: energies, eigenvalues, potentials and the reference-equivalent sweep counts
+    are the same bits; with small trees the packed layout integrates fewer trials for them."""
+    L, d, R = GRIDS["L14"]
+    grid = D.Grid(ctx, L, d, R)
+    Zs = list(range(1, 41))
+
+    def run():
+        scf = D.Scf(ctx, grid, Zs, lsda=lsda)
+        out, issued = [], 0
+        for _ in range(6):
+            st = scf.step()
+            en, _ = scf.energies()
+            out.append(([e.as_list() for e in en],
+                        [scf.levels(a, sp)["E"].copy() for a in range(len(Zs)) for sp in range(2 if lsda else 1)],
+                        int(st.sweeps_reference), int(st.sweeps_reference_executed)))
+            issued += int(st.sweeps_issued)
+        pot = scf.array(3, len(Zs) - 1).copy()
+        info = (scf.tree_depth, scf.trials_per_round)
+        scf.close()
+        return out, pot, issued, info
+
+    ref, pot_ref, issued_static, info_static = _with_debug("LEVELS_NOPACK", run)
+    for knobs in ("", "LEVELS_PACK_DMIN=1", "LEVELS_PACK_DMIN=6", "LEVELS_PACK_DSMALL=20,LEVELS_PACK_LANES=8192",
+                  "LEVELS_PACK_LANES_SMALL=65536"):
+        got, pot, issued, info = _with_debug(knobs, run)
+        assert info != info_static, knobs                          # the packed layout really ran
+        for k, (x, y) in enumerate(zip(ref, got)):
+            assert x[0] == y[0], (knobs, k)
+            for a, b in zip(x[1], y[1]):
+                assert np.array_equal(a.view(np.int64), b.view(np.int64)), (knobs, k)
+            assert x[2:] == y[2:], (knobs, k)
+        assert np.array_equal(pot.view(np.int64), pot_ref.view(np.int64)), knobs
+        if "LEVELS_PACK_LANES=8192" in knobs:                      # depth 3 plus whatever fills the groups' last blocks
+            assert issued < issued_static, (issued, issued_static)
     grid.close()
