@@ -216,6 +216,8 @@ def run_workload(D, ctx, grid, levels, atoms, lsda, steps, warmup, tree_depth, b
     tot["steps"] = steps
     tot["trials_per_round"] = scf.trials_per_round
     tot["tree_depth"] = scf.tree_depth
+    tot["levels_layout"] = {0: "one block of 2^depth trials per job", 1: "latency mode (slots re-allotted every round)",
+                            2: "packed rounds (depth chosen per round, floor = tree depth)", 3: "latency mode over the live jobs"}.get(int(st.levels_layout), "?")
     tot["poisson_G"] = scf.poisson_info()[0]
     tot["energies"] = scf.energies()[0][0].as_list()
     return scf, tot
@@ -275,7 +277,7 @@ def kernel_figures(tot, levels, N, atoms):
 def summarize(tot, levels, N, atoms, lsda, world, delta, rmax):
     sweep, pois = kernel_figures(tot, levels, N, atoms)
     return {"workload": "Rn Z=86 %s, %d multigrid levels (%d pts), delta=%g, Rmax=%g, mixing 0.5, %d atom(s)/GPU, un-chained clamped brackets, "
-                        "tree depth %d" % ("LSDA" if lsda else "LDA", levels, N, delta, rmax, atoms, tot["tree_depth"]),
+                        "tree depth %d, %s" % ("LSDA" if lsda else "LDA", levels, N, delta, rmax, atoms, tot["tree_depth"], tot["levels_layout"]),
             "sweeps_executed_per_s": tot["sweeps_reference_executed"] / tot["elapsed"],
             "sweeps_reference_equivalent_per_s": tot["sweeps_reference"] / tot["elapsed"],
             "issued_per_useful": tot["sweeps_issued"] / max(tot["sweeps_reference_executed"], 1),
@@ -422,8 +424,8 @@ def main():
             "dtype": "f64",
             "data": "synthetic (reference's flat start density, SCF iterations %d..%d)" % (args.warmup, args.warmup + args.steps - 1),
             "config": {"workload": "Rn Z=86 %s, %d multigrid levels (%d pts), delta=%g, Rmax=%g, mixing 0.5, %d atom(s)/GPU, "
-                                   "un-chained clamped brackets, tree depth %d" % ("LSDA" if args.lsda else "LDA", args.levels, grid.N,
-                                                                           delta, rmax, args.atoms, tot["tree_depth"]),
+                                   "un-chained clamped brackets, tree depth %d, %s" % ("LSDA" if args.lsda else "LDA", args.levels, grid.N,
+                                                                           delta, rmax, args.atoms, tot["tree_depth"], tot["levels_layout"]),
                        "atoms_per_gpu": args.atoms, "parallelism": "replicas x%d" % world,
                        "poisson_mode": "tolerance" if args.tolerance else "exact"},
             "scf_step_ms": 1e3 * elapsed / args.steps,

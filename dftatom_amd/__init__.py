@@ -57,7 +57,8 @@ class StepStats(C.Structure):
     _fields_ = [("sweeps_issued", C.c_long), ("sweeps_reference", C.c_long), ("points_traversed", C.c_long),
                 ("vcycles", C.c_long), ("rounds", C.c_int), ("ms_levels", C.c_float), ("ms_poisson", C.c_float),
                 ("ms_tail", C.c_float), ("ms_sweep_kernels", C.c_float), ("ms_poisson_kernel", C.c_float),
-                ("sweeps_reference_executed", C.c_long), ("points_reference", C.c_long)]
+                ("sweeps_reference_executed", C.c_long), ("points_reference", C.c_long),
+                ("levels_layout", C.c_int), ("poisson_groups", C.c_int)]
 
 
 # every symbol include/dftatom_hip.h declares: name -> (restype, argtypes)

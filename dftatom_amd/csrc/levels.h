@@ -73,6 +73,7 @@ struct LevelStats {
     long sweeps_issued = 0;
     long points_traversed = 0;
     float ms_sweep = 0;          // HIP-event time summed over the sweep launches
+    int layout = 0;              // 0 static blocks, 1 latency mode, 2 packed rounds, 3 latency mode over the live jobs of a batch
 };
 
 struct LevelSolver {
@@ -93,6 +94,11 @@ struct LevelSolver {
     int *d_limit = nullptr, *d_start = nullptr, *d_count = nullptr, *d_istop = nullptr, *d_trip = nullptr;
     int *d_wave_kind = nullptr, *d_wave_slot = nullptr, *d_wave_first = nullptr, *d_wave_cnt = nullptr, *d_wave_job = nullptr;
     bool dynamic = false;          // trial slots re-allotted among the active jobs every round (few jobs: latency mode)
+    // a static / packed solver whose live jobs have dropped to <= 64 (frozen atoms) runs its rounds in latency mode (k_allot over d_live)
+    bool can_switch = false, tables_dirty = false;
+    long static_trials = 0, budget_trials = 0;
+    int* d_live = nullptr;
+    std::vector<int> h_wave_job, h_wave_slot;
     // packed rounds (batches): the trials of a round laid out job after job inside their (table slot, kind) group by k_pack
     bool packed = false;
     int pack_dmin = 3, pack_dmax = 12, pack_lanes_small = 0, pack_dsmall = 3, pack_lanes_large = 0;

@@ -795,14 +795,18 @@ __device__ __forceinline__ int decisions_left(const dfta::Job& j)
 }
 
 __global__ __launch_bounds__(64) void k_allot(dfta::Job* __restrict__ jobs, int njobs, int budget, int nopredict, int* __restrict__ wave_job,
-                                              int* __restrict__ wave_slot)
+                                              int* __restrict__ wave_slot, const int* __restrict__ live)
 {
-    __shared__ int s_S[64], s_base[64], s_cap[64];
+    // `live` (may be null): the njobs <= 64 jobs of a larger list that are still to be solved (the rest are frozen: finished atoms
+    // of an SCF batch); lane k then stands for job live[k]
+    __shared__ int s_S[64], s_base[64], s_cap[64], s_id[64];
     const int k = threadIdx.x;            // njobs <= 64 in this mode
+    const int kk = (live && k < njobs) ? live[k] : k;
+    s_id[k] = kk;
     bool act = false;
     int S = 0, r = 0, sc = 0, rem = 0, left = 0;
     if (k < njobs) {
-        dfta::Job j = jobs[k];
+        dfta::Job j = jobs[kk];
         act = (j.phase == PH_TOP || j.phase == PH_BOTTOM || j.phase == PH_ZERO);
         if (act) {
             plan_round(j, jobs, 1 << 14);                      // what would it do with room to spare?
@@ -887,32 +891,32 @@ __global__ __launch_bounds__(64) void k_allot(dfta::Job* __restrict__ jobs, int 
         }
     }
     // the block table of the round, by all lanes (a lone thread pays a memory round trip per entry)
-    const int my_slot = k < njobs ? jobs[k].slot : 0;
+    const int my_slot = k < njobs ? jobs[kk].slot : 0;
     s_S[k] = my_slot;                                          // (the spine lengths are not needed any more)
     __syncthreads();
     for (int w = k; w < (budget >> 6); w += 64) {
         int q = -1;
         for (int t = 0; t < njobs; ++t)
             if (w * 64 >= s_base[t] && w * 64 < s_base[t] + s_cap[t]) q = t;
-        wave_job[w] = q;
+        wave_job[w] = q >= 0 ? s_id[q] : -1;
         wave_slot[w] = q >= 0 ? s_S[q] : 0;
     }
-    if (k < njobs) { jobs[k].tbase = s_base[k]; jobs[k].tcap = s_cap[k]; }
+    if (k < njobs) { jobs[kk].tbase = s_base[k]; jobs[kk].tcap = s_cap[k]; }
     if (k < njobs && act) {                                    // the plan for the slots the job really got
-        dfta::Job j = jobs[k];
+        dfta::Job j = jobs[kk];
         j.tbase = s_base[k];
         j.tcap = s_cap[k];
         if (j.tcap < 128) {                                    // nothing left for it this round (cannot happen while budget >= 128 njobs)
-            jobs[k].spine = 0; jobs[k].capz = j.tcap; jobs[k].use_sp = 0; jobs[k].sp_bits = 0; jobs[k].sp_len = 0;
+            jobs[kk].spine = 0; jobs[kk].capz = j.tcap; jobs[kk].use_sp = 0; jobs[kk].sp_bits = 0; jobs[kk].sp_len = 0;
             return;
         }
         plan_round(j, jobs, j.tcap);
         if (nopredict) { j.spine = 0; j.capz = j.tcap; j.use_sp = 0; j.sp_len = 0; j.sp_bits = 0; }
-        jobs[k].spine = j.spine;
-        jobs[k].capz = j.capz;
-        jobs[k].use_sp = j.use_sp;
-        jobs[k].sp_bits = j.sp_bits;
-        jobs[k].sp_len = j.sp_len;
+        jobs[kk].spine = j.spine;
+        jobs[kk].capz = j.capz;
+        jobs[kk].use_sp = j.use_sp;
+        jobs[kk].sp_bits = j.sp_bits;
+        jobs[kk].sp_len = j.sp_len;
     }
 }
 
@@ -1064,7 +1068,7 @@ void LevelSolver::release()
     if (d_jmatched) (void)hipFree(d_jmatched);
     if (d_jstart_keep) (void)hipFree(d_jstart_keep);
     d_jmatched = nullptr; d_jstart_keep = nullptr;
-    for (int** q : {&d_lane_job, &d_slot_off, &d_slot_jobs, &d_gsz, &d_goff, &d_pack_out}) { if (*q) (void)hipFree(*q); *q = nullptr; }
+    for (int** q : {&d_lane_job, &d_slot_off, &d_slot_jobs, &d_gsz, &d_goff, &d_pack_out, &d_live}) { if (*q) (void)hipFree(*q); *q = nullptr; }
     if (st2) { (void)hipStreamDestroy(st2); st2 = nullptr; }
     if (ev_walk) { (void)hipEventDestroy(ev_walk); ev_walk = nullptr; }
     if (ev_early) { (void)hipEventDestroy(ev_early); ev_early = nullptr; }
@@ -1127,11 +1131,17 @@ int LevelSolver::setup(dfta_ctx* c, const dfta_grid* grid, int mode_, int tree_d
     // latency mode (the pipelined kernel's regime: at most ~1.5 passes of one block per compute unit): the slots of a
     // round are re-allotted among the active jobs (k_allot); the budget is one full pass at least
     dynamic = (tree_depth <= 0) && njobs <= 64 && ntrials / 64 <= 384 && dfta_knob("LEVELS_STATIC") == nullptr;
-    if (dynamic) {
+    static_trials = ntrials;
+    // A larger job list whose atoms finish one by one (SCF batches: finished atoms are frozen) ends up in that regime too: once at
+    // most 64 jobs are live, run() hands the rounds to k_allot through the list of live jobs (room for one pass is kept for it).
+    can_switch = (tree_depth <= 0) && !dynamic && mode == DFTA_LEVELS_BATCHED && dfta_knob("LEVELS_STATIC") == nullptr && dfta_knob("LEVELS_NOSWITCH") == nullptr;
+    if (dynamic || can_switch) {
         long blocks = std::max(ctx->num_cu, 1);
         if (const char* e = dfta_knob("LEVELS_BUDGET_BLOCKS")) blocks = std::max(64, atoi(e));     // measurements
-        ntrials = std::max<long>(ntrials, 64L * blocks);
+        budget_trials = 64L * blocks;
+        ntrials = std::max<long>(ntrials, budget_trials);
     }
+    if (dynamic) budget_trials = ntrials;
     // packed rounds (k_pack): batches whose static layout would have 64-trial trees (up to 192 jobs it has 128 trials per job and
     // the upper half scouts the third bisection: measured on a 12-atom shard, 98 jobs, that is worth 1.6 rounds a step, and the
     // packed layout has no whole blocks of kind ZERO to give to a job that is still counting nodes), unless a depth was asked for
@@ -1180,7 +1190,7 @@ int LevelSolver::setup(dfta_ctx* c, const dfta_grid* grid, int mode_, int tree_d
         ntrials = (ntrials + 63) & ~63L;
     }
     nwaves = static_cast<int>(ntrials / 64);
-    early_match = dynamic && !g->uniform && dfta_knob("LEVELS_NOEARLYMATCH") == nullptr;
+    early_match = (dynamic || can_switch) && !g->uniform && dfta_knob("LEVELS_NOEARLYMATCH") == nullptr;
 
     std::vector<int> wave_slot(nwaves), wave_first(nwaves), wave_cnt(nwaves, 64), wave_job(nwaves);
     for (int w = 0; w < nwaves; ++w) {
@@ -1189,6 +1199,9 @@ int LevelSolver::setup(dfta_ctx* c, const dfta_grid* grid, int mode_, int tree_d
         wave_slot[w] = q < njobs ? jobs[q].slot : 0;
         wave_first[w] = w * 64;
     }
+    h_wave_job = wave_job;
+    h_wave_slot = wave_slot;
+    tables_dirty = false;
 
     hipStream_t st = ctx->stream;
 #define ALLOC(ptr, type, count) DFTA_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ptr), sizeof(type) * (size_t)(count)))
@@ -1221,6 +1234,7 @@ int LevelSolver::setup(dfta_ctx* c, const dfta_grid* grid, int mode_, int tree_d
         DFTA_HIP(ctx, hipStreamSynchronize(st));     // the vectors above are the sources of the copies
     }
     ALLOC(d_counters, unsigned long long, 4);
+    if (can_switch) ALLOC(d_live, int, 64);
     ALLOC(d_Psi, double, (size_t)njobs * N);
     ALLOC(d_Q, double, (size_t)njobs * N);
     ALLOC(d_jE, double, njobs); ALLOC(d_jslot, int, njobs); ALLOC(d_jl, int, njobs); ALLOC(d_jstart, int, njobs);
@@ -1259,6 +1273,22 @@ int LevelSolver::run(const double* dV, const double* job_bottom, int run_mode, d
     const int run_chains = chained ? nchains_chained : njobs;
     std::vector<Job> jobs = h_jobs_template;
     int nfrozen = 0;
+    // this run's layout: the solver's own, or -- a batch most of whose atoms have finished -- latency mode over the live jobs
+    std::vector<int> live;
+    if (frozen && h_last.size() == jobs.size())
+        for (int k = 0; k < njobs; ++k) if (!frozen[k]) live.push_back(k);
+    const bool sw = can_switch && !chained && frozen && h_last.size() == jobs.size() && !live.empty() && live.size() <= 64;
+    const bool dyn = dynamic || sw;
+    const bool pk = packed && !sw;
+    const bool early = early_match && dyn;
+    if (sw) {
+        DFTA_HIP(ctx, hipMemcpyAsync(d_live, live.data(), sizeof(int) * live.size(), hipMemcpyHostToDevice, st));
+        tables_dirty = true;
+    } else if (tables_dirty) {           // back from latency mode: the solver's own block tables
+        DFTA_HIP(ctx, hipMemcpyAsync(d_wave_job, h_wave_job.data(), sizeof(int) * h_wave_job.size(), hipMemcpyHostToDevice, st));
+        DFTA_HIP(ctx, hipMemcpyAsync(d_wave_slot, h_wave_slot.data(), sizeof(int) * h_wave_slot.size(), hipMemcpyHostToDevice, st));
+        tables_dirty = false;
+    }
     for (int k = 0; k < njobs; ++k) {
         Job& j = jobs[k];
         if (frozen && frozen[k] && h_last.size() == jobs.size()) {
@@ -1271,8 +1301,8 @@ int LevelSolver::run(const double* dV, const double* job_bottom, int run_mode, d
             continue;
         }
         j.frozen = 0;
-        j.tbase = packed ? 0 : k * tpj;      // packed rounds: k_pack lays the trials out
-        j.tcap = packed ? 0 : tpj;
+        j.tbase = (pk || sw) ? 0 : k * tpj;      // packed rounds: k_pack lays the trials out (latency mode: k_allot)
+        j.tcap = (pk || sw) ? 0 : tpj;
         j.bottom0 = job_bottom[k];
         const bool first = (k == 0 || jobs[k].v != jobs[k - 1].v);
         if (!chained || first) { j.phase = PH_TOP; j.toe = 50; j.boe = j.bottom0; }   // DFTAtom.cpp:499
@@ -1330,12 +1360,13 @@ int LevelSolver::run(const double* dV, const double* job_bottom, int run_mode, d
     }
 
     auto plan = [&]() -> int {          // spines (and, in latency mode, the slots) of the next round
-        if (dynamic)
-            hipLaunchKernelGGL(k_allot, dim3(1), dim3(64), 0, st, d_jobs, njobs, (int)ntrials, use_prediction ? 0 : 1, d_wave_job, d_wave_slot);
+        if (dyn)
+            hipLaunchKernelGGL(k_allot, dim3(1), dim3(64), 0, st, d_jobs, sw ? (int)live.size() : njobs, (int)budget_trials, use_prediction ? 0 : 1, d_wave_job,
+                               d_wave_slot, sw ? d_live : nullptr);
         else
-            hipLaunchKernelGGL(k_plan, dim3((njobs + 63) / 64), dim3(64), 0, st, d_jobs, njobs, use_prediction ? 0 : 1, packed ? (1 << 14) : 0);
+            hipLaunchKernelGGL(k_plan, dim3((njobs + 63) / 64), dim3(64), 0, st, d_jobs, njobs, use_prediction ? 0 : 1, pk ? (1 << 14) : 0);
         DFTA_CHECK_LAUNCH(ctx);
-        if (packed) {
+        if (pk) {
             hipLaunchKernelGGL(k_pack, dim3(1), dim3(kPackThreads), 0, st, d_jobs, njobs, nslots, d_slot_off, d_slot_jobs, pack_lanes_small,
                                pack_dsmall, pack_lanes_large, pack_dmin, pack_dmax, d_gsz, d_goff, d_lane_job, d_wave_slot, d_pack_out);
             DFTA_CHECK_LAUNCH(ctx);
@@ -1347,9 +1378,9 @@ int LevelSolver::run(const double* dV, const double* job_bottom, int run_mode, d
     rc = plan();
     if (rc) return rc;
     // trials of the coming round: the whole static / latency-mode layout, or what k_pack has just laid out
-    long round_trials = ntrials;
+    long round_trials = dyn ? budget_trials : static_trials;
     int pack_out[4] = {0, 0, 0, 0};
-    if (packed) {
+    if (pk) {
         DFTA_HIP(ctx, hipMemcpyAsync(pack_out, d_pack_out, sizeof(pack_out), hipMemcpyDeviceToHost, st));
         DFTA_HIP(ctx, hipStreamSynchronize(st));
         round_trials = pack_out[0];
@@ -1364,7 +1395,7 @@ int LevelSolver::run(const double* dV, const double* job_bottom, int run_mode, d
         dfta_range r_round("dfta: level-search round (expand, sweeps, scout, walk, plan)");
         if (round_trials <= 0 || round_trials > ntrials) { snprintf(ctx->err, sizeof(ctx->err), "level solver: packed round of %ld trials (room for %ld)", round_trials, ntrials); return DFTA_ERR_HIP; }
         const int round_waves = static_cast<int>(round_trials / 64);
-        hipLaunchKernelGGL(k_expand, dim3((unsigned)((round_trials + 255) / 256)), dim3(256), 0, st, d_jobs, packed ? d_lane_job : d_wave_job, packed ? 0 : 6,
+        hipLaunchKernelGGL(k_expand, dim3((unsigned)((round_trials + 255) / 256)), dim3(256), 0, st, d_jobs, pk ? d_lane_job : d_wave_job, pk ? 0 : 6,
                            (int)round_trials, g->d_r, N, g->delta, g->far_arg_threshold, d_E, d_limit, d_start, d_us, d_us1, d_wave_kind, d_counters, g->uniform,
                            g->Rmax, g->h);
         DFTA_CHECK_LAUNCH(ctx);
@@ -1374,23 +1405,23 @@ int LevelSolver::run(const double* dV, const double* job_bottom, int run_mode, d
                                d_istop, d_slot_l);
         if (rc) return rc;
         if (stats) DFTA_HIP(ctx, hipEventRecord(ev[1], st));
-        if (!packed) {          // packed rounds have no scouts (capz == tcap)
+        if (!pk) {          // packed rounds have no scouts (capz == tcap)
             hipLaunchKernelGGL(k_scout, dim3(njobs), dim3(64), 0, st, d_jobs, d_E, d_start, d_u0);
             DFTA_CHECK_LAUNCH(ctx);
         }
         DFTA_HIP(ctx, hipMemsetAsync(d_ndone, 0, sizeof(int), st));
         hipLaunchKernelGGL(k_walk, dim3((run_chains + 63) / 64), dim3(64), 0, st, d_jobs, d_chains, run_chains, d_count, d_u0, d_phi, d_istop, stats ? d_trip : nullptr, d_tab, N, d_ndone);
         DFTA_CHECK_LAUNCH(ctx);
-        if (early_match) DFTA_HIP(ctx, hipEventRecord(ev_walk, st));
+        if (early) DFTA_HIP(ctx, hipEventRecord(ev_walk, st));
         rc = plan();
         if (rc) return rc;
         int ndone = 0;
         DFTA_HIP(ctx, hipMemcpyAsync(&ndone, d_ndone, sizeof(int), hipMemcpyDeviceToHost, st));
-        if (packed) DFTA_HIP(ctx, hipMemcpyAsync(pack_out, d_pack_out, sizeof(pack_out), hipMemcpyDeviceToHost, st));
+        if (pk) DFTA_HIP(ctx, hipMemcpyAsync(pack_out, d_pack_out, sizeof(pack_out), hipMemcpyDeviceToHost, st));
         DFTA_HIP(ctx, hipStreamSynchronize(st));
         const long this_round = round_trials;
-        if (packed) round_trials = pack_out[0];
-        if (early_match && ndone > done_seen && ndone < njobs) {
+        if (pk) round_trials = pack_out[0];
+        if (early && ndone > done_seen && ndone < njobs) {
             // some levels have their eigenvalue while others still search: their match solves start now, on the second stream,
             // under the next round's sweeps (two waves and 8 KB of LDS per level fit next to a sweep block)
             done_seen = ndone;
@@ -1412,7 +1443,7 @@ int LevelSolver::run(const double* dV, const double* job_bottom, int run_mode, d
             float ms = 0;
             DFTA_HIP(ctx, hipEventElapsedTime(&ms, ev[0], ev[1]));
             ms_sweep += ms;
-            if (debug_rounds && packed)
+            if (debug_rounds && pk)
                 fprintf(stderr, "   packed round %d: %ld trials in %.3f ms; next: %d trials, depth %d, %d jobs searching\n", rounds + 1, this_round, ms, pack_out[0], pack_out[1], pack_out[2]);
         }
         ++rounds;
@@ -1474,6 +1505,7 @@ int LevelSolver::run(const double* dV, const double* job_bottom, int run_mode, d
         stats->sweeps_issued = static_cast<long>(cnt[0]) + 2L * (njobs - nfrozen);    // + inward/outward halves of the match solve
         stats->points_traversed = static_cast<long>(cnt[1]);
         stats->ms_sweep = ms_sweep;
+        stats->layout = sw ? 3 : (dynamic ? 1 : (pk ? 2 : 0));
     }
     return DFTA_OK;
 }

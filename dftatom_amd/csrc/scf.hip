@@ -200,6 +200,8 @@ __global__ void k_energies(AtomState* __restrict__ atoms, int natoms, const dfta
 
 }  // namespace
 
+constexpr int kLiveAtoms = 7;
+
 struct dfta_scf {
     dfta_ctx* ctx = nullptr;
     const dfta_grid* g = nullptr;
@@ -207,6 +209,13 @@ struct dfta_scf {
     double alpha = 0.5;
     dfta::LevelSolver solver;
     dfta_poisson* poisson = nullptr;
+    // The last few live atoms of a larger batch (the others have finished and are frozen) are solved by a second solver for
+    // kLiveAtoms atoms -- the size at which the multigrid's resident groups apply (28 ms per solve where the staged groups of a
+    // 10 .. 30-atom batch take 40 .. 55) -- on gathered copies of their densities; the results are the same bits.
+    dfta_poisson* poisson_live = nullptr;
+    bool live_tried = false;
+    int* d_liveZ = nullptr;               // kLiveAtoms charges, then kLiveAtoms skip flags
+    double *d_liveRho = nullptr, *d_liveU = nullptr;
     std::vector<AtomState> h_atoms;
     std::vector<double> h_bottom0;        // per potential: -Z^2-1 (DFTAtom.cpp:407)
     std::vector<double> h_job_bottom;     // per job: bracket start of the next level solve
@@ -246,6 +255,8 @@ void dfta_scf_destroy(dfta_scf* s)
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (hipEvent_t e : s->ev) if (e) (void)hipEventDestroy(e);
     if (s->poisson) dfta_poisson_destroy(s->poisson);
+    if (s->poisson_live) dfta_poisson_destroy(s->poisson_live);
+    for (void* p : {(void*)s->d_liveZ, (void*)s->d_liveRho, (void*)s->d_liveU}) if (p) (void)hipFree(p);
     delete s;
 }
 
@@ -404,15 +415,59 @@ int dfta_scf_step(dfta_scf* s, dfta_step_stats* stats)
                        s->d_dA, s->d_dB, s->d_fin);
     DFTA_CHECK_LAUNCH(ctx);
     DFTA_HIP(ctx, hipEventRecord(s->ev[1], st));
+    // live atoms of this step (finished ones are frozen, see above)
+    std::vector<int> live_atoms;
+    for (int a = 0; a < natoms; ++a) if (!s->h_atoms[a].finished) live_atoms.push_back(a);
+    bool use_live = natoms > kLiveAtoms && !live_atoms.empty() && (int)live_atoms.size() <= kLiveAtoms;
+    if (use_live && !s->live_tried) {
+        s->live_tried = true;
+        if (dfta_knob("SCF_NOLIVE") == nullptr) {
+            dfta_poisson* pl = nullptr;
+            int G = 0;
+            rc = dfta_poisson_create_ex(ctx, g, kLiveAtoms, dfta_poisson_mode(s->poisson), &pl);
+            if (rc) return rc;
+            dfta_poisson_group_state(pl, &G, nullptr, nullptr);
+            int Gbig = 0;
+            dfta_poisson_group_state(s->poisson, &Gbig, nullptr, nullptr);
+            if (G > Gbig) {                    // resident groups (or at least larger staged ones) are to be had
+                s->poisson_live = pl;
+                DFTA_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&s->d_liveZ), sizeof(int) * 2 * kLiveAtoms));
+                DFTA_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&s->d_liveRho), sizeof(double) * (size_t)kLiveAtoms * N));
+                DFTA_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&s->d_liveU), sizeof(double) * (size_t)kLiveAtoms * N));
+            } else {
+                dfta_poisson_destroy(pl);
+            }
+        }
+    }
+    use_live = use_live && s->poisson_live != nullptr;
+    int h_liveZ[2 * kLiveAtoms];
+    if (use_live) {
+        for (int i = 0; i < kLiveAtoms; ++i) {
+            const bool on = i < (int)live_atoms.size();
+            h_liveZ[i] = on ? s->h_atoms[live_atoms[i]].Z : 1;
+            h_liveZ[kLiveAtoms + i] = on ? 0 : 1;
+        }
+        DFTA_HIP(ctx, hipMemcpyAsync(s->d_liveZ, h_liveZ, sizeof(h_liveZ), hipMemcpyHostToDevice, st));
+        for (size_t i = 0; i < live_atoms.size(); ++i)
+            DFTA_HIP(ctx, hipMemcpyAsync(s->d_liveRho + i * N, s->d_density + (size_t)live_atoms[i] * N, sizeof(double) * N, hipMemcpyDeviceToDevice, st));
+    }
     {
         dfta_range r_poisson("dfta: multigrid Poisson solve (FullCycle)");
-        rc = dfta_poisson_solve_launch(s->poisson, s->d_Z, s->d_density, s->d_U, nullptr, nullptr, s->d_fin);
+        dfta_poisson* ps = use_live ? s->poisson_live : s->poisson;
+        const int* pZ = use_live ? s->d_liveZ : s->d_Z;
+        const double* pRho = use_live ? s->d_liveRho : s->d_density;
+        double* pU = use_live ? s->d_liveU : s->d_U;
+        const int* pSkip = use_live ? s->d_liveZ + kLiveAtoms : s->d_fin;
+        rc = dfta_poisson_solve_launch(ps, pZ, pRho, pU, nullptr, nullptr, pSkip);
         if (rc) return rc;
         DFTA_HIP(ctx, hipEventRecord(s->ev[2], st));   // ev[1]..ev[2] brackets exactly the persistent multigrid kernel
         // synchronises and inspects the group barriers' abort flag on EVERY step; an aborted solve is repeated with one
         // workgroup per atom before anything reads U
-        rc = dfta_poisson_finish(s->poisson, s->d_Z, s->d_density, s->d_U, nullptr, nullptr, s->d_fin);
+        rc = dfta_poisson_finish(ps, pZ, pRho, pU, nullptr, nullptr, pSkip);
         if (rc) return rc;
+        if (use_live)
+            for (size_t i = 0; i < live_atoms.size(); ++i)
+                DFTA_HIP(ctx, hipMemcpyAsync(s->d_U + (size_t)live_atoms[i] * N, s->d_liveU + i * N, sizeof(double) * N, hipMemcpyDeviceToDevice, st));
     }
     dfta_range r_tail("dfta: XC + integrands + ordered integrals + energies");
     rc = scf_xc(s);
@@ -439,6 +494,8 @@ int dfta_scf_step(dfta_scf* s, dfta_step_stats* stats)
         stats->ms_poisson_kernel = stats->ms_poisson;
         stats->ms_sweep_kernels = ls.ms_sweep;
         stats->rounds = ls.rounds;
+        stats->levels_layout = ls.layout;
+        dfta_poisson_group_state(use_live ? s->poisson_live : s->poisson, &stats->poisson_groups, nullptr, nullptr);
         stats->sweeps_issued = ls.sweeps_issued;
         stats->points_traversed = ls.points_traversed;
         long ref = 0;
@@ -454,6 +511,12 @@ int dfta_scf_step(dfta_scf* s, dfta_step_stats* stats)
         unsigned long long vc = 0;
         rc = dfta_poisson_take_vcycles(s->poisson, &vc);
         if (rc) return rc;
+        if (s->poisson_live) {
+            unsigned long long vl = 0;
+            rc = dfta_poisson_take_vcycles(s->poisson_live, &vl);
+            if (rc) return rc;
+            vc += vl;
+        }
         stats->vcycles = (long)vc;
     }
     return DFTA_OK;

@@ -5,7 +5,9 @@
   * the Poisson solver's groups of workgroups: a lost member (fault injection) is detected after the solve, the solve
     is repeated with one workgroup per atom in the same process and returns the same bits;
   * packed rounds of the level search (batches: the trials of a round laid out job after job inside their (potential, l, kind)
-    group instead of a 64-trial block per job) take the reference's decisions: bit-identical to the static layout, fewer trials.
+    group instead of a 64-trial block per job) take the reference's decisions: bit-identical to the static layout, fewer trials;
+  * a batch most of whose atoms have finished hands its last <= 64 jobs to the latency-mode allotment and its last <= 7 atoms to
+    the multigrid's resident groups: same bits as each atom alone and as the batch without the switches.
 """
 import os
 
@@ -183,4 +185,52 @@ def test_packed_rounds_take_the_same_decisions(ctx, lsda):
         assert np.array_equal(pot.view(np.int64), pot_ref.view(np.int64)), knobs
         if "LEVELS_PACK_LANES=8192" in knobs:                      # depth 3 plus whatever fills the groups' last blocks
             assert issued < issued_static, (issued, issued_static)
+    grid.close()
+
+
+def test_last_live_atoms_switch_layouts_and_keep_the_bits(ctx):
+    """Kr x 5, Ar x 4, Ne x 3, He (72 jobs, 13 atoms) on the 16385-node grid, run until all have finished.  While everything is
+    live the level search runs static blocks and the multigrid staged groups; once only the Kr atoms are left (40 jobs, 5 atoms)
+    the step statistics report latency mode over the live jobs (layout 3) and the 33-workgroup resident groups.  Energies,
+    eigenvalues, potentials and step counts equal each atom's own run and the same batch with both switches off."""
+    L, d, R = GRIDS["L14"]
+    grid = D.Grid(ctx, L, d, R)
+    Zs = [36] * 5 + [18] * 4 + [10] * 3 + [2]
+
+    def run_batch():
+        scf = D.Scf(ctx, grid, Zs, lsda=False)
+        seen, steps = [], 0
+        while steps < 100:
+            st = scf.step()
+            steps += 1
+            seen.append((int(st.levels_layout), int(st.poisson_groups)))
+            _, fin = scf.energies()
+            if fin.all():
+                break
+        en, _ = scf.energies()
+        out = ([e.as_list() for e in en], [scf.levels(a, 0)["E"].copy() for a in range(len(Zs))],
+               [scf.array(3, a).copy() for a in range(len(Zs))], steps)
+        scf.close()
+        return out, seen
+
+    got, seen = run_batch()
+    assert seen[0][0] == 0 and seen[0][1] < 33, seen[:3]               # 72 jobs: static blocks; 13 atoms: staged groups
+    assert (3, 33) in seen, sorted(set(seen))                           # ... and the switched layouts at the end
+    plain, seen_plain = _with_debug("LEVELS_NOSWITCH,SCF_NOLIVE", run_batch)
+    assert all(x[0] == 0 and x[1] < 33 for x in seen_plain), sorted(set(seen_plain))
+    assert got[0] == plain[0] and got[3] == plain[3]
+    for a in range(len(Zs)):
+        assert np.array_equal(got[1][a].view(np.int64), plain[1][a].view(np.int64)), a
+        assert np.array_equal(got[2][a].view(np.int64), plain[2][a].view(np.int64)), a
+    alone = {}
+    for Z in sorted(set(Zs)):
+        one = D.Scf(ctx, grid, [Z], lsda=False)
+        n1 = _run_to_end(one)
+        alone[Z] = (one.energies()[0][0].as_list(), one.levels(0, 0)["E"].copy(), one.array(3, 0).copy(), n1)
+        one.close()
+    for a, Z in enumerate(Zs):
+        assert got[0][a] == alone[Z][0], (a, Z)
+        assert np.array_equal(got[1][a].view(np.int64), alone[Z][1].view(np.int64)), (a, Z)
+        assert np.array_equal(got[2][a].view(np.int64), alone[Z][2].view(np.int64)), (a, Z)
+    assert got[3] == max(v[3] for v in alone.values())
     grid.close()
