@@ -42,8 +42,8 @@ def atom_cost(Z):
 # a per-job share once the batch fills the machine:  t_step(batch) = STEP_FLOOR_MS + JOB_MS x (subshells of the atoms still running).
 # A shard runs until its slowest atom stops, so  T(shard) = STEP_FLOOR_MS x max(steps) + JOB_MS x sum(subshells x steps):
 # the first term is the critical path (what a by-work partition ignores), the second the work.
-STEP_FLOOR_MS = 68.0      # fitted to the emulated 1- and 8-rank sweeps of profiles/r03_periodic_table_predicted_scaling.json
-JOB_MS = 0.46             # (32.3 s on one GPU, 10.0 s for an eighth of the table)
+STEP_FLOOR_MS = 64.0      # least squares over the 15 shards of the emulated 1-, 2-, 4- and 8-rank sweeps of
+JOB_MS = 0.30             # profiles/r03_periodic_table_predicted_scaling.json (22.6 s on one GPU, 7.8 .. 9.1 s for an eighth of the table)
 
 
 def shard_time_ms(Zs):
