@@ -28,6 +28,28 @@ def test_header_symbols_are_exported_and_bound():
     assert sorted(D.SIGNATURES) == names
 
 
+def test_struct_layouts_match_the_header():
+    """the four plain structs that cross the boundary: the ctypes mirrors have the header's fields, in its order, with its types"""
+    src = open(os.path.join(ROOT, "include", "dftatom_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    ctype = {"long": C.c_long, "int": C.c_int, "float": C.c_float, "double": C.c_double}
+    mirrors = {"dfta_level_result": D.LevelResult, "dfta_energies": D.Energies, "dfta_step_stats": D.StepStats,
+               "dfta_scf_options": D.ScfOptions}
+    found = {}
+    for body, name in re.findall(r"typedef\s+struct\s+\w+\s*\{(.*?)\}\s*(\w+)\s*;", src, flags=re.S):
+        fields = []
+        for decl in body.split(";"):
+            decl = decl.strip()
+            if not decl:
+                continue
+            t, rest = decl.split(None, 1)
+            fields += [(n.strip(), ctype[t]) for n in rest.split(",")]
+        found[name] = fields
+    assert sorted(found) == sorted(mirrors)
+    for name, cls in mirrors.items():
+        assert [(n, t) for n, t in cls._fields_] == found[name], name
+
+
 def test_signatures_cite_reference():
     """every block of the header names the reference interface it replaces (file:line)"""
     src = open(os.path.join(ROOT, "include", "dftatom_hip.h")).read()

@@ -234,3 +234,28 @@ def test_last_live_atoms_switch_layouts_and_keep_the_bits(ctx):
         assert np.array_equal(got[2][a].view(np.int64), alone[Z][2].view(np.int64)), (a, Z)
     assert got[3] == max(v[3] for v in alone.values())
     grid.close()
+
+
+def test_packed_rounds_on_the_uniform_grid(ctx):
+    """the reference's uniform-grid functor (Numerov.h:16-70) under packed rounds: Z = 1..30 x 2 (288 jobs) on 16385 uniform nodes up to
+    r = 25, three steps, against one block per job"""
+    grid = D.Grid(ctx, 14, None, 25.0)
+    Zs = list(range(1, 31)) * 2
+
+    def run():
+        scf = D.Scf(ctx, grid, Zs, lsda=False)
+        out = []
+        for _ in range(3):
+            st = scf.step()
+            out.append(([e.as_list() for e in scf.energies()[0]], [scf.levels(a, 0)["E"].copy() for a in range(len(Zs))], int(st.levels_layout)))
+        scf.close()
+        return out
+
+    ref = _with_debug("LEVELS_NOPACK", run)
+    got = _with_debug("", run)
+    assert ref[-1][2] == 0 and got[-1][2] == 2, (ref[-1][2], got[-1][2])
+    for k, (x, y) in enumerate(zip(ref, got)):
+        assert x[0] == y[0], k
+        for a, b in zip(x[1], y[1]):
+            assert np.array_equal(a.view(np.int64), b.view(np.int64)), k
+    grid.close()
