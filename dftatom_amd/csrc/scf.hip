@@ -200,7 +200,22 @@ __global__ void k_energies(AtomState* __restrict__ atoms, int natoms, const dfta
 
 }  // namespace
 
-constexpr int kLiveAtoms = 7;
+// rows idx[y] of src -> row y of dst, and back (the live atoms of a batch, see dfta_scf::live_solver)
+__global__ void k_gather_rows(const double* __restrict__ src, const int* __restrict__ idx, int N, double* __restrict__ dst)
+{
+    const double* s = src + (size_t)idx[blockIdx.y] * N;
+    double* d = dst + (size_t)blockIdx.y * N;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) d[i] = s[i];
+}
+__global__ void k_scatter_rows(const double* __restrict__ src, const int* __restrict__ idx, int N, double* __restrict__ dst)
+{
+    const double* s = src + (size_t)blockIdx.y * N;
+    double* d = dst + (size_t)idx[blockIdx.y] * N;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) d[i] = s[i];
+}
+
+constexpr int kLiveClasses = 4;
+constexpr int kLiveClassAtoms[kLiveClasses] = {7, 16, 32, 64};
 
 struct dfta_scf {
     dfta_ctx* ctx = nullptr;
@@ -209,12 +224,14 @@ struct dfta_scf {
     double alpha = 0.5;
     dfta::LevelSolver solver;
     dfta_poisson* poisson = nullptr;
-    // The last few live atoms of a larger batch (the others have finished and are frozen) are solved by a second solver for
-    // kLiveAtoms atoms -- the size at which the multigrid's resident groups apply (28 ms per solve where the staged groups of a
-    // 10 .. 30-atom batch take 40 .. 55) -- on gathered copies of their densities; the results are the same bits.
-    dfta_poisson* poisson_live = nullptr;
-    bool live_tried = false;
-    int* d_liveZ = nullptr;               // kLiveAtoms charges, then kLiveAtoms skip flags
+    // Finished atoms are frozen, and the multigrid's workgroups per atom are a function of the batch size (1 for > 96 atoms ... 16 for
+    // <= 16, the resident groups' 33 for <= 7): once the LIVE atoms of a batch fit a smaller size class, their solve goes to a second
+    // solver made for that class, on gathered copies of their densities (results scattered back; the same bits -- every grouping of
+    // the multigrid is bit-identical to one workgroup per atom).
+    struct LiveSolver { dfta_poisson* p = nullptr; int G = 0; bool tried = false; };
+    LiveSolver live_solver[kLiveClasses];
+    int live_cap = 0;                     // atoms the gather buffers hold
+    int* d_liveZ = nullptr;               // live_cap charges, live_cap skip flags, live_cap atom indices
     double *d_liveRho = nullptr, *d_liveU = nullptr;
     std::vector<AtomState> h_atoms;
     std::vector<double> h_bottom0;        // per potential: -Z^2-1 (DFTAtom.cpp:407)
@@ -255,7 +272,7 @@ void dfta_scf_destroy(dfta_scf* s)
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (hipEvent_t e : s->ev) if (e) (void)hipEventDestroy(e);
     if (s->poisson) dfta_poisson_destroy(s->poisson);
-    if (s->poisson_live) dfta_poisson_destroy(s->poisson_live);
+    for (auto& ls : s->live_solver) if (ls.p) dfta_poisson_destroy(ls.p);
     for (void* p : {(void*)s->d_liveZ, (void*)s->d_liveRho, (void*)s->d_liveU}) if (p) (void)hipFree(p);
     delete s;
 }
@@ -415,49 +432,60 @@ int dfta_scf_step(dfta_scf* s, dfta_step_stats* stats)
                        s->d_dA, s->d_dB, s->d_fin);
     DFTA_CHECK_LAUNCH(ctx);
     DFTA_HIP(ctx, hipEventRecord(s->ev[1], st));
-    // live atoms of this step (finished ones are frozen, see above)
+    // live atoms of this step (finished ones are frozen, see above) and the solver of their size class
     std::vector<int> live_atoms;
     for (int a = 0; a < natoms; ++a) if (!s->h_atoms[a].finished) live_atoms.push_back(a);
-    bool use_live = natoms > kLiveAtoms && !live_atoms.empty() && (int)live_atoms.size() <= kLiveAtoms;
-    if (use_live && !s->live_tried) {
-        s->live_tried = true;
-        if (dfta_knob("SCF_NOLIVE") == nullptr) {
-            dfta_poisson* pl = nullptr;
-            int G = 0;
-            rc = dfta_poisson_create_ex(ctx, g, kLiveAtoms, dfta_poisson_mode(s->poisson), &pl);
-            if (rc) return rc;
-            dfta_poisson_group_state(pl, &G, nullptr, nullptr);
-            int Gbig = 0;
-            dfta_poisson_group_state(s->poisson, &Gbig, nullptr, nullptr);
-            if (G > Gbig) {                    // resident groups (or at least larger staged ones) are to be had
-                s->poisson_live = pl;
-                DFTA_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&s->d_liveZ), sizeof(int) * 2 * kLiveAtoms));
-                DFTA_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&s->d_liveRho), sizeof(double) * (size_t)kLiveAtoms * N));
-                DFTA_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&s->d_liveU), sizeof(double) * (size_t)kLiveAtoms * N));
-            } else {
-                dfta_poisson_destroy(pl);
+    const int nlive = static_cast<int>(live_atoms.size());
+    dfta_poisson* pl = nullptr;
+    int cls_atoms = 0;
+    if (nlive > 0 && dfta_knob("SCF_NOLIVE") == nullptr) {
+        for (int c = 0; c < kLiveClasses && !pl; ++c) {
+            if (kLiveClassAtoms[c] < nlive) continue;
+            if (kLiveClassAtoms[c] >= natoms) break;              // the batch's own solver is of that class already
+            dfta_scf::LiveSolver& ls = s->live_solver[c];
+            if (!ls.tried) {
+                ls.tried = true;
+                int Gbig = 0;
+                dfta_poisson_group_state(s->poisson, &Gbig, nullptr, nullptr);
+                rc = dfta_poisson_create_ex(ctx, g, kLiveClassAtoms[c], dfta_poisson_mode(s->poisson), &ls.p);
+                if (rc) return rc;
+                dfta_poisson_group_state(ls.p, &ls.G, nullptr, nullptr);
+                if (ls.G <= Gbig) { dfta_poisson_destroy(ls.p); ls.p = nullptr; }     // nothing to gain on this grid
             }
+            if (ls.p) { pl = ls.p; cls_atoms = kLiveClassAtoms[c]; }
+            break;                                                  // the smallest class that holds the live atoms, or the batch's solver
         }
     }
-    use_live = use_live && s->poisson_live != nullptr;
-    int h_liveZ[2 * kLiveAtoms];
+    const bool use_live = pl != nullptr;
+    std::vector<int> h_live;
     if (use_live) {
-        for (int i = 0; i < kLiveAtoms; ++i) {
-            const bool on = i < (int)live_atoms.size();
-            h_liveZ[i] = on ? s->h_atoms[live_atoms[i]].Z : 1;
-            h_liveZ[kLiveAtoms + i] = on ? 0 : 1;
+        if (s->live_cap < cls_atoms) {
+            for (void* q : {(void*)s->d_liveZ, (void*)s->d_liveRho, (void*)s->d_liveU}) if (q) (void)hipFree(q);
+            s->d_liveZ = nullptr; s->d_liveRho = nullptr; s->d_liveU = nullptr;
+            DFTA_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&s->d_liveZ), sizeof(int) * 3 * cls_atoms));
+            DFTA_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&s->d_liveRho), sizeof(double) * (size_t)cls_atoms * N));
+            DFTA_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&s->d_liveU), sizeof(double) * (size_t)cls_atoms * N));
+            s->live_cap = cls_atoms;
         }
-        DFTA_HIP(ctx, hipMemcpyAsync(s->d_liveZ, h_liveZ, sizeof(h_liveZ), hipMemcpyHostToDevice, st));
-        for (size_t i = 0; i < live_atoms.size(); ++i)
-            DFTA_HIP(ctx, hipMemcpyAsync(s->d_liveRho + i * N, s->d_density + (size_t)live_atoms[i] * N, sizeof(double) * N, hipMemcpyDeviceToDevice, st));
+        const int cap = s->live_cap;
+        h_live.assign(3 * cap, 0);
+        for (int i = 0; i < cap; ++i) {
+            const bool on = i < nlive;
+            h_live[i] = on ? s->h_atoms[live_atoms[i]].Z : 1;
+            h_live[cap + i] = on ? 0 : 1;
+            h_live[2 * cap + i] = on ? live_atoms[i] : 0;
+        }
+        DFTA_HIP(ctx, hipMemcpyAsync(s->d_liveZ, h_live.data(), sizeof(int) * h_live.size(), hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(k_gather_rows, dim3(std::min(256, (N + 255) / 256), nlive), dim3(256), 0, st, s->d_density, s->d_liveZ + 2 * cap, N, s->d_liveRho);
+        DFTA_CHECK_LAUNCH(ctx);
     }
     {
         dfta_range r_poisson("dfta: multigrid Poisson solve (FullCycle)");
-        dfta_poisson* ps = use_live ? s->poisson_live : s->poisson;
+        dfta_poisson* ps = use_live ? pl : s->poisson;
         const int* pZ = use_live ? s->d_liveZ : s->d_Z;
         const double* pRho = use_live ? s->d_liveRho : s->d_density;
         double* pU = use_live ? s->d_liveU : s->d_U;
-        const int* pSkip = use_live ? s->d_liveZ + kLiveAtoms : s->d_fin;
+        const int* pSkip = use_live ? s->d_liveZ + s->live_cap : s->d_fin;
         rc = dfta_poisson_solve_launch(ps, pZ, pRho, pU, nullptr, nullptr, pSkip);
         if (rc) return rc;
         DFTA_HIP(ctx, hipEventRecord(s->ev[2], st));   // ev[1]..ev[2] brackets exactly the persistent multigrid kernel
@@ -465,9 +493,10 @@ int dfta_scf_step(dfta_scf* s, dfta_step_stats* stats)
         // workgroup per atom before anything reads U
         rc = dfta_poisson_finish(ps, pZ, pRho, pU, nullptr, nullptr, pSkip);
         if (rc) return rc;
-        if (use_live)
-            for (size_t i = 0; i < live_atoms.size(); ++i)
-                DFTA_HIP(ctx, hipMemcpyAsync(s->d_U + (size_t)live_atoms[i] * N, s->d_liveU + i * N, sizeof(double) * N, hipMemcpyDeviceToDevice, st));
+        if (use_live) {
+            hipLaunchKernelGGL(k_scatter_rows, dim3(std::min(256, (N + 255) / 256), nlive), dim3(256), 0, st, s->d_liveU, s->d_liveZ + 2 * s->live_cap, N, s->d_U);
+            DFTA_CHECK_LAUNCH(ctx);
+        }
     }
     dfta_range r_tail("dfta: XC + integrands + ordered integrals + energies");
     rc = scf_xc(s);
@@ -495,7 +524,7 @@ int dfta_scf_step(dfta_scf* s, dfta_step_stats* stats)
         stats->ms_sweep_kernels = ls.ms_sweep;
         stats->rounds = ls.rounds;
         stats->levels_layout = ls.layout;
-        dfta_poisson_group_state(use_live ? s->poisson_live : s->poisson, &stats->poisson_groups, nullptr, nullptr);
+        dfta_poisson_group_state(use_live ? pl : s->poisson, &stats->poisson_groups, nullptr, nullptr);
         stats->sweeps_issued = ls.sweeps_issued;
         stats->points_traversed = ls.points_traversed;
         long ref = 0;
@@ -511,9 +540,9 @@ int dfta_scf_step(dfta_scf* s, dfta_step_stats* stats)
         unsigned long long vc = 0;
         rc = dfta_poisson_take_vcycles(s->poisson, &vc);
         if (rc) return rc;
-        if (s->poisson_live) {
+        for (auto& ls : s->live_solver) if (ls.p) {
             unsigned long long vl = 0;
-            rc = dfta_poisson_take_vcycles(s->poisson_live, &vl);
+            rc = dfta_poisson_take_vcycles(ls.p, &vl);
             if (rc) return rc;
             vc += vl;
         }

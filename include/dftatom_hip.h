@@ -245,8 +245,9 @@ typedef struct dfta_step_stats {
     int    levels_layout;        /* trial layout of this step's level search: 0 one block of 2^depth trials per job, 1 latency mode
                                     (slots re-allotted every round, <= 64 jobs), 2 packed rounds (batches), 3 latency mode over the
                                     live jobs of a batch most of whose atoms have finished -- never changes a result */
-    int    poisson_groups;       /* workgroups per atom of the multigrid solve of this step (33: resident groups; a batch whose
-                                    live atoms have dropped to <= 7 is solved by a second, 7-atom solver) */
+    int    poisson_groups;       /* workgroups per atom of the multigrid solve of this step (33: resident groups); the live atoms of
+                                    a batch are solved by a solver of their size class (64 / 32 / 16 / 7 atoms) once that is smaller
+                                    than the batch's own */
 } dfta_step_stats;
 
 int  dfta_scf_create(dfta_ctx* ctx, const dfta_grid* g, int lsda, int natoms, const int* Z,

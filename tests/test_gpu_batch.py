@@ -188,14 +188,17 @@ def test_packed_rounds_take_the_same_decisions(ctx, lsda):
     grid.close()
 
 
-def test_last_live_atoms_switch_layouts_and_keep_the_bits(ctx):
-    """Kr x 5, Ar x 4, Ne x 3, He (72 jobs, 13 atoms) on the 16385-node grid, run until all have finished.  While everything is
-    live the level search runs static blocks and the multigrid staged groups; once only the Kr atoms are left (40 jobs, 5 atoms)
-    the step statistics report latency mode over the live jobs (layout 3) and the 33-workgroup resident groups.  Energies,
-    eigenvalues, potentials and step counts equal each atom's own run and the same batch with both switches off."""
+@pytest.mark.parametrize("Zs,groups", [([36] * 5 + [18] * 4 + [10] * 3 + [2], [16, 33]),
+                                       ([36] * 5 + [18] * 6 + [10] * 6 + [2] * 3, [8, 16, 33])])
+def test_last_live_atoms_switch_layouts_and_keep_the_bits(ctx, Zs, groups):
+    """Kr x 5, Ar x 4, Ne x 3, He (72 jobs, 13 atoms) and Kr x 5, Ar x 6, Ne x 6, He x 3 (91 jobs, 20 atoms) on the 16385-node grid, run
+    until all have finished.  While everything is live the level search runs static blocks and the multigrid the staged groups of the
+    batch size (16 / 8 workgroups per atom); as atoms finish the live ones move to the solver of their size class (20 atoms: 16
+    workgroups once <= 16 are live) and, once one element is left (<= 6 atoms, <= 40 jobs), the step statistics report latency mode
+    over the live jobs (layout 3) and the 33-workgroup resident groups.  Energies, eigenvalues, potentials and step counts equal each
+    atom's own run and the same batch with both switches off."""
     L, d, R = GRIDS["L14"]
     grid = D.Grid(ctx, L, d, R)
-    Zs = [36] * 5 + [18] * 4 + [10] * 3 + [2]
 
     def run_batch():
         scf = D.Scf(ctx, grid, Zs, lsda=False)
@@ -214,10 +217,11 @@ def test_last_live_atoms_switch_layouts_and_keep_the_bits(ctx):
         return out, seen
 
     got, seen = run_batch()
-    assert seen[0][0] == 0 and seen[0][1] < 33, seen[:3]               # 72 jobs: static blocks; 13 atoms: staged groups
+    assert seen[0] == (0, groups[0]), seen[:3]                          # static blocks; staged groups of the batch size
     assert (3, 33) in seen, sorted(set(seen))                           # ... and the switched layouts at the end
+    assert sorted(set(g for _, g in seen)) == groups, sorted(set(seen))
     plain, seen_plain = _with_debug("LEVELS_NOSWITCH,SCF_NOLIVE", run_batch)
-    assert all(x[0] == 0 and x[1] < 33 for x in seen_plain), sorted(set(seen_plain))
+    assert set(seen_plain) == {(0, groups[0])}, sorted(set(seen_plain))
     assert got[0] == plain[0] and got[3] == plain[3]
     for a in range(len(Zs)):
         assert np.array_equal(got[1][a].view(np.int64), plain[1][a].view(np.int64)), a
