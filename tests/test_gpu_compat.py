@@ -160,3 +160,12 @@ def test_periodic_table_two_ranks_equal_one_rank(tmp_path):
     for x, y in zip(a["atoms"], b["atoms"]):
         assert x == y, (x, y)
     assert all(x["finished"] for x in a["atoms"])
+
+
+def test_graft_entry_smoke_runs():
+    """the driver's smoke(): one small invocation of the hot path on cuda:0 through the C ABI, checked against the oracle"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("graft_entry", os.path.join(ROOT, "__graft_entry__.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    mod.smoke()
