@@ -307,6 +307,30 @@ def test_l20_radon_lsda_steps_vs_reference(ctx, grid20):
     scf.close()
 
 
+def test_l20_batch_layouts_agree(ctx, grid20):
+    """BASELINE config 5's batch-of-atoms form (bench.py: rn_lsda_l20_batch16): 8 Rn atoms LSDA at 1 048 577 nodes -- 240 jobs: packed
+    rounds of the level search, 16 multigrid workgroups per atom -- two SCF steps; every copy of the atom gets the single atom's
+    energies and eigenvalues bit for bit (latency-mode level search, one atom's multigrid groups), and the packed layout reports
+    itself in the step statistics."""
+    one = D.Scf(ctx, grid20, [86], lsda=True)
+    for _ in range(2):
+        st1 = one.step()
+    ref_e = one.energies()[0][0].as_list()
+    ref_lv = [one.levels(0, sp)["E"].copy() for sp in range(2)]
+    assert int(st1.levels_layout) == 1
+    one.close()
+    b = D.Scf(ctx, grid20, [86] * 8, lsda=True)
+    for _ in range(2):
+        st = b.step()
+    assert int(st.levels_layout) == 2 and b.njobs == 240
+    en, _ = b.energies()
+    for a in range(8):
+        assert en[a].as_list() == ref_e, a
+        for sp in range(2):
+            assert np.array_equal(b.levels(a, sp)["E"].view(np.int64), ref_lv[sp].view(np.int64)), (a, sp)
+    b.close()
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # README.md:30-52
 # ---------------------------------------------------------------------------------------------------------------
