@@ -40,7 +40,7 @@ constexpr int kSeqBelow = 129;   // levels with n < 129 nodes: one lane, sequent
 constexpr int kWaveMaxN = 1025;  // staged levels up to this size are swept by the first wave alone (64 lanes: a quarter of the LDS traffic per warm-up step)
 constexpr int kSeqCap = 144;     // LDS doubles per array for the sequential levels (65+33+17+9+5+3 = 132)
 constexpr int kPF = 8;           // register prefetch depth of the chunked sweep
-constexpr int kFuseMinLogC = 9;  // fuse the three sweeps of a level visit when every lane owns >= 512 nodes
+constexpr int kFuseMinLogC = 6;  // fuse the three sweeps of a visit of a global-memory level when every lane owns >= 64 nodes (knob POISSON_FUSE_MIN_LOGC)
 constexpr int kStageMaxLogC = 5;   // chunked levels with <= 32 nodes per lane are swept from a copy in LDS (Phi, S)
 constexpr int kStagePad = 128;     // one workgroup: doubles in front of each staged array (warm-up reads of the first lanes)
 constexpr int kStageH = 24;        // group members: halo columns in front of every staged row (>= 96/C lanes, C >= 4)
@@ -66,6 +66,7 @@ struct MgDesc {
     int dbg;         // $DFTA_POISSON_DBG, measurements only (results are garbage): 1 = the coarse workgroup skips its sweeps, 2 = the members skip their passes, 4 = no restriction / prolongation on the shared levels
     int res_kres;    // > 0: resident group (k_poisson_solve_res): levels 0 .. res_kres-1 live in the members' LDS; the level layout is that of G = 1
     int res_logC0;   // log2(nodes per lane) of level 0 in a member's stretch (kResG members x kResNT lanes)
+    int fuse_min_logc;   // global-memory levels of one workgroup: fused visits (gs_fused3) from this many nodes per lane on
     int fuse3;    // visits of three sweeps on staged levels of one workgroup run as ONE fused pass (gs_lds3); 0: $DFTA_POISSON_NOFUSE3
     int nofold;   // DFTA_POISSON_NOFOLD: restriction / prolongation as separate passes even where they could be folded into a staged copy-in
     int kcoop;       // levels 0 .. kcoop-1 are swept by all G workgroups together (256 G lanes), the others by workgroup 0
@@ -401,6 +402,8 @@ static int poisson_create_impl(dfta_ctx* ctx, const dfta_grid* g, int batch, int
     D.logG = logG;
     D.nofold = dfta_knob("POISSON_NOFOLD") ? 1 : 0;
     D.fuse3 = dfta_knob("POISSON_NOFUSE3") ? 0 : 1;
+    D.fuse_min_logc = kFuseMinLogC;
+    if (const char* e = dfta_knob("POISSON_FUSE_MIN_LOGC")) D.fuse_min_logc = std::max(kFuseMinLogC, atoi(e));   // measurements (99: never; staged levels -- <= 32 nodes per lane -- have their own fused pass)
     D.dbg = dfta_knob("POISSON_DBG") ? atoi(dfta_knob("POISSON_DBG")) : 0;
     D.res_kres = res_kres;
     D.res_logC0 = res_logC0;

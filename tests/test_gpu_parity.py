@@ -645,6 +645,38 @@ def test_iterate_gs_fused_equals_single_sweeps(ctx):
         assert nsw == 1 and np.array_equal(a.get_level(lvl)[0], b.get_level(lvl)[0]), lvl
     a.close()
     b.close()
+    # one workgroup per atom (batches of more than 96 atoms): levels 0..3 (512 ... 64 nodes per lane) stay in global memory and a
+    # visit is ONE out-of-place fused pass (gs_fused3, all three stages started 112 nodes ahead); stops after one and after two sweeps
+    old = os.environ.get("DFTA_DEBUG")
+    os.environ["DFTA_DEBUG"] = "POISSON_GROUP=0"
+    try:
+        a, b = D.Poisson(ctx, grid, 1), D.Poisson(ctx, grid, 1)
+    finally:
+        if old is None:
+            os.environ.pop("DFTA_DEBUG", None)
+        else:
+            os.environ["DFTA_DEBUG"] = old
+    assert a.group_info()[0] == 1
+    for lvl in (0, 1, 2, 3):
+        n = a.level_size(lvl)
+        phi, src = rng.standard_normal(n), rng.standard_normal(n) * 1e-2
+        for p in (a, b):
+            p.set_level(lvl, phi, src)
+        err_f, nsw = a.iterate_gs(lvl, 0.0, 3)
+        errs = b.gauss_seidel(lvl, 3)
+        assert nsw == 3 and abs(err_f - errs[2]) <= 1e-12 * errs[2], lvl
+        assert np.array_equal(a.get_level(lvl)[0], b.get_level(lvl)[0]), lvl
+        for stop_after in (1, 2):
+            for p in (a, b):
+                p.set_level(lvl, phi, src)
+            emin = 1e30 if stop_after == 1 else 0.5 * (errs[0] + errs[1])
+            assert errs[1] < emin
+            err_k, nsw = a.iterate_gs(lvl, emin, 3)
+            ek = b.gauss_seidel(lvl, stop_after)
+            assert nsw == stop_after and abs(err_k - ek[-1]) <= 1e-12 * ek[-1], (lvl, stop_after)
+            assert np.array_equal(a.get_level(lvl)[0], b.get_level(lvl)[0]), (lvl, stop_after)
+    a.close()
+    b.close()
     grid.close()
 
 
