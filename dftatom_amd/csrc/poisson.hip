@@ -67,6 +67,7 @@ struct MgDesc {
     int res_kres;    // > 0: resident group (k_poisson_solve_res): levels 0 .. res_kres-1 live in the members' LDS; the level layout is that of G = 1
     int res_logC0;   // log2(nodes per lane) of level 0 in a member's stretch (kResG members x kResNT lanes)
     int fuse_min_logc;   // global-memory levels of one workgroup: fused visits (gs_fused3) from this many nodes per lane on
+    int fuse_coop;       // ... and on the levels the G workgroups of an atom share (0: $DFTA_DEBUG POISSON_NOFUSE_COOP)
     int fuse3;    // visits of three sweeps on staged levels of one workgroup run as ONE fused pass (gs_lds3); 0: $DFTA_POISSON_NOFUSE3
     int nofold;   // DFTA_POISSON_NOFOLD: restriction / prolongation as separate passes even where they could be folded into a staged copy-in
     int kcoop;       // levels 0 .. kcoop-1 are swept by all G workgroups together (256 G lanes), the others by workgroup 0
@@ -348,8 +349,10 @@ static int poisson_create_impl(dfta_ctx* ctx, const dfta_grid* g, int batch, int
     // batch * G <= 256 CUs).  A level is shared when every lane of the group still owns >= 8 nodes (>= 4 for G = 16: the
     // same four levels at 131073 nodes, with 32 nodes per lane on the finest one -- the most that is staged in LDS).
     // round 3, re-measured with the fused visits in place (131073 nodes, ms per solve): 8 atoms 39.8 (G = 16) / 48.7 (8); 12: 42.4 / 50.5;
-    // 16: 45.0 / 51.4; 32: 59.2 (8) / 71.6 (4); 64: 99.6 (4) / 124 (2) / 149 (1); 96: 150 (2) / 156 (1); 128: 184 (2) / 171 (1)
-    int logG = batch <= 16 ? 4 : (batch <= 32 ? 3 : (batch <= 64 ? 2 : (batch <= 96 ? 1 : 0)));
+    // 16: 45.0 / 51.4; 32: 59.2 (8) / 71.6 (4); 64: 99.6 (4) / 124 (2) / 149 (1); 96: 150 (2) / 156 (1); 128: 184 (2) / 171 (1).
+    // End of round 3, with fused visits on the global levels too (gs_fused3, also on shared levels): 16 atoms 45.1 (16) / 50.1 (8);
+    // 32: 53.6 (8) / 64.7 (4); 64: 77.3 (4) / 99.5 (2) / 137 (1); 96: 113 (2) / 145 (1); 112: 118 / 154; 128: 129 (2) / 153 (1)
+    int logG = batch <= 16 ? 4 : (batch <= 32 ? 3 : (batch <= 64 ? 2 : ((batch <= 128 && 2 * batch <= std::max(ctx->num_cu, 1)) ? 1 : 0)));
     if (const char* e = dfta_knob("POISSON_GROUP")) {      // measurements: force log2 of the group size
         const int v = atoi(e);
         if (v >= 0 && v <= 4 && (batch << v) <= 256) logG = v;
@@ -403,6 +406,7 @@ static int poisson_create_impl(dfta_ctx* ctx, const dfta_grid* g, int batch, int
     D.nofold = dfta_knob("POISSON_NOFOLD") ? 1 : 0;
     D.fuse3 = dfta_knob("POISSON_NOFUSE3") ? 0 : 1;
     D.fuse_min_logc = kFuseMinLogC;
+    D.fuse_coop = dfta_knob("POISSON_NOFUSE_COOP") ? 0 : 1;
     if (const char* e = dfta_knob("POISSON_FUSE_MIN_LOGC")) D.fuse_min_logc = std::max(kFuseMinLogC, atoi(e));   // measurements (99: never; staged levels -- <= 32 nodes per lane -- have their own fused pass)
     D.dbg = dfta_knob("POISSON_DBG") ? atoi(dfta_knob("POISSON_DBG")) : 0;
     D.res_kres = res_kres;

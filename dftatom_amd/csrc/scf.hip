@@ -214,8 +214,8 @@ __global__ void k_scatter_rows(const double* __restrict__ src, const int* __rest
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) d[i] = s[i];
 }
 
-constexpr int kLiveClasses = 4;
-constexpr int kLiveClassAtoms[kLiveClasses] = {7, 16, 32, 64};
+constexpr int kLiveClasses = 5;
+constexpr int kLiveClassAtoms[kLiveClasses] = {7, 16, 32, 64, 128};
 
 struct dfta_scf {
     dfta_ctx* ctx = nullptr;
@@ -224,7 +224,7 @@ struct dfta_scf {
     double alpha = 0.5;
     dfta::LevelSolver solver;
     dfta_poisson* poisson = nullptr;
-    // Finished atoms are frozen, and the multigrid's workgroups per atom are a function of the batch size (1 for > 96 atoms ... 16 for
+    // Finished atoms are frozen, and the multigrid's workgroups per atom are a function of the batch size (1 for > 128 atoms ... 16 for
     // <= 16, the resident groups' 33 for <= 7): once the LIVE atoms of a batch fit a smaller size class, their solve goes to a second
     // solver made for that class, on gathered copies of their densities (results scattered back; the same bits -- every grouping of
     // the multigrid is bit-identical to one workgroup per atom).

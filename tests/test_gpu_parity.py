@@ -645,7 +645,7 @@ def test_iterate_gs_fused_equals_single_sweeps(ctx):
         assert nsw == 1 and np.array_equal(a.get_level(lvl)[0], b.get_level(lvl)[0]), lvl
     a.close()
     b.close()
-    # one workgroup per atom (batches of more than 96 atoms): levels 0..3 (512 ... 64 nodes per lane) stay in global memory and a
+    # one workgroup per atom (batches of more than 128 atoms): levels 0..3 (512 ... 64 nodes per lane) stay in global memory and a
     # visit is ONE out-of-place fused pass (gs_fused3, all three stages started 112 nodes ahead); stops after one and after two sweeps
     old = os.environ.get("DFTA_DEBUG")
     os.environ["DFTA_DEBUG"] = "POISSON_GROUP=0"
