@@ -145,7 +145,8 @@ def test_resident_lost_member_is_detected(ctx):
     grid.close()
 
 
-@pytest.mark.parametrize("kv", [{}, {"DFTA_POISSON_RES": "0"}, {"DFTA_POISSON_GROUP": "0"}, {"DFTA_POISSON_GROUP": "2"}])
+@pytest.mark.parametrize("kv", [{}, {"DFTA_POISSON_RES": "0"}, {"DFTA_POISSON_GROUP": "0"}, {"DFTA_POISSON_GROUP": "1"}, {"DFTA_POISSON_GROUP": "2"},
+                                {"DFTA_POISSON_GROUP": "3"}])
 def test_tolerance_mode_poisson(ctx, kv):
     """opt-in 32-node warm-ups, every flavour of the solver: U within 2e-9 Z of the exact mode's (= the reference's) solution"""
     L, d, R = GRIDS["L17"]
