@@ -65,6 +65,7 @@ struct Job {
     // Trial slots of the job in the current round: [tbase, tbase + tcap).  Static (k * tpj, tpj) when the launch fills the
     // machine; re-allotted every round by k_allot when a handful of jobs leave compute units idle (levels.hip).
     int tbase, tcap;
+    int n_fixed;                     // iterations of the third bisection counted in n_zero but not integrated: the bisection stood on a fixed point (walk_job)
     long long n_points;              // grid points traversed by the sweeps ON the bisection path (n_count + n_zero executed ones) + the match solve
 };
 

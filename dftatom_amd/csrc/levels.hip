@@ -256,6 +256,7 @@ __device__ __forceinline__ void predict_from_bracket(dfta::Job& j, double lo, do
 // side of a predicted transition (sibling's end point, own top for l = 0), g_secant_noise |E| added to the secant's error bound.
 // Round 1 used 2e-11 / 64e-12 / 3e-11; DFTA_LEVELS_NOISE="rel,abs,secant" overrides (read when a solver is created).
 __device__ double g_noise_rel = 1e-11, g_noise_abs = 16e-12, g_secant_noise = 1.5e-11;
+__device__ int g_fixed_point = 1;      // 0 ($DFTA_DEBUG LEVELS_NOFIXEDPOINT): a third bisection on its fixed point is integrated to the iteration cap (tests)
 // Spine of the job's next round.  `jobs` is read for the sibling only (k_plan runs after every walk of the round).
 __device__ __forceinline__ void plan_round(dfta::Job& j, const dfta::Job* __restrict__ jobs, int tpj)
 {
@@ -485,11 +486,24 @@ __device__ void walk_job(dfta::Job& j, const int* __restrict__ count, const doub
             if (trip) j.n_points += trip[base + h];
             ++j.iter3;
             const bool bit = ((d > 0) == (j.sgnBottom != 0));        // 1: BottomEnergy = E
+            const double hi_was = hi, lo_was = lo;
             if (bit) lo = e; else hi = e;
             c.advance(bit, pred_bit(j, 2, j.phase_done));
             record_bit(j, 2, bit);
             const double ad = fabs(d);
             if (hi - lo < kEnergyErr && !isnan(ad) && ad < 1E15) { conv = true; break; }
+            if (g_fixed_point && hi == hi_was && lo == lo_was) {
+                // A level whose u(0) never gets below 1e15 (or is NaN) keeps the reference bisecting until its 500-iteration cap
+                // (DFTAtom.cpp:517-534) although the interval has long collapsed: once a step leaves (toe, boe) as they were, the
+                // midpoint, its sweep, its sign and the decision repeat unchanged to the end -- a fixed point.  The remaining
+                // iterations are taken here without their sweeps (counted: the reference integrates every one of them); they used to
+                // cost a round per ~7 of them -- 70 rounds, 2.1 s per SCF step at 1 048 577 nodes whenever a level ended that way.
+                const int rest = kMaxIter3 - j.iter3;
+                j.n_zero += rest;
+                j.n_fixed += rest;
+                j.iter3 = kMaxIter3;
+                break;
+            }
         }
         finish_phase(j, 2);
         j.toe = hi;
@@ -1094,6 +1108,8 @@ int LevelSolver::setup(dfta_ctx* c, const dfta_grid* grid, int mode_, int tree_d
         (void)hipMemcpyToSymbol(HIP_SYMBOL(g_noise_abs), &v[1], sizeof(double));
         (void)hipMemcpyToSymbol(HIP_SYMBOL(g_secant_noise), &v[2], sizeof(double));
         (void)hipMemcpyToSymbol(HIP_SYMBOL(g_secant_kappa), &k, sizeof(double));
+        const int fp = dfta_knob("LEVELS_NOFIXEDPOINT") ? 0 : 1;
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_fixed_point), &fp, sizeof(int));
     }
     debug_rounds = dfta_knob("DEBUG_ROUNDS") ? atoi(dfta_knob("DEBUG_ROUNDS")) : 0;
     njobs = static_cast<int>(specs.size());

@@ -533,6 +533,7 @@ int dfta_scf_step(dfta_scf* s, dfta_step_stats* stats)
             ref += j.n_count + j.n_zero + 1;   // + the matched solve of each level
             pts += j.n_points;
             if (j.nodes == 0) skipped += j.cur_len[1];     // the second bisection of a node-less level is pure arithmetic
+            skipped += j.n_fixed;                            // a third bisection on its fixed point (walk_job)
         }
         stats->sweeps_reference = ref;
         stats->sweeps_reference_executed = ref - (long)skipped;

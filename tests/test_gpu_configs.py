@@ -331,6 +331,45 @@ def test_l20_batch_layouts_agree(ctx, grid20):
     b.close()
 
 
+def test_l20_third_bisection_on_its_fixed_point(ctx, grid20):
+    """From the seventh SCF step on, one of Rn's levels at 1 048 577 nodes ends its third bisection with |u(0)| >= 1e15: the reference
+    (DFTAtom.cpp:517-534) then keeps halving an interval that has collapsed until its 500-iteration cap -- the same midpoint, the same
+    sweep, the same decision ~440 times.  The level solver takes those iterations without integrating them once a step leaves the
+    interval unchanged: same energies, eigenvalues, convergence flags and reference-equivalent sweep counts as with every iteration
+    integrated (LEVELS_NOFIXEDPOINT), in 8-12 rounds instead of 70."""
+    def run(knobs):
+        old = os.environ.get("DFTA_DEBUG")
+        if knobs:
+            os.environ["DFTA_DEBUG"] = knobs
+        try:
+            scf = D.Scf(ctx, grid20, [86], lsda=True)
+        finally:
+            if knobs:
+                if old is None:
+                    os.environ.pop("DFTA_DEBUG", None)
+                else:
+                    os.environ["DFTA_DEBUG"] = old
+        rows = []
+        for _ in range(8):
+            st = scf.step()
+            rows.append((scf.energies()[0][0].as_list(), [scf.levels(0, sp)["E"].copy() for sp in range(2)],
+                         [scf.levels(0, sp)["converged"].copy() for sp in range(2)], int(st.sweeps_reference), int(st.sweeps_reference_executed),
+                         int(st.rounds)))
+        scf.close()
+        return rows
+    got, full = run(""), run("LEVELS_NOFIXEDPOINT")
+    hit = False
+    for k, (x, y) in enumerate(zip(got, full)):
+        assert x[0] == y[0] and x[3] == y[3], k
+        for sp in range(2):
+            assert np.array_equal(x[1][sp].view(np.int64), y[1][sp].view(np.int64)) and np.array_equal(x[2][sp], y[2][sp]), (k, sp)
+        assert x[5] <= 20, (k, x[5])
+        if y[5] >= 50:                                   # a step in which a level runs to the iteration cap
+            hit = True
+            assert x[4] <= y[4] - 300 and not (x[2][0].all() and x[2][1].all()), (k, x[4], y[4])
+    assert hit, [r[5] for r in full]
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # README.md:30-52
 # ---------------------------------------------------------------------------------------------------------------
