@@ -447,14 +447,15 @@ def main():
         if world == 1 and not args.no_extras:
             # further measured workloads with the same per-kernel figures (>= 10 timed steps after >= 5 warm-up steps wherever a step
             # is short enough): the opt-in tolerance mode of the multigrid smoother, LSDA (BASELINE config 3), machine-filling
-            # batches of Rn atoms, and the 1 048 577-node stress of config 5 (one atom and a batch of 16); a few seconds each
+            # batches of Rn atoms, and the 1 048 577-node stress of config 5 (one atom and a batch of 16, SCF steps 6.. : from the seventh step
+            # on one level ends its third bisection at the reference's 500-iteration cap in most steps); a few seconds each
             extra = {}
             for name, lv, atoms, lsda, st, wu, pm in (("rn_lda_tolerance_mode", args.levels, 1, False, 10, 5, D.POISSON_TOLERANCE),
                                                       ("rn_lsda", args.levels, 1, True, 10, 5, None),
                                                       ("rn_lsda_tolerance_mode", args.levels, 1, True, 10, 5, D.POISSON_TOLERANCE),
                                                       ("batch256_lda", args.levels, 256, False, 10, 5, None),
                                                       ("batch1024_lda", args.levels, 1024, False, 4, 2, None),
-                                                      ("rn_lsda_l20", 20, 1, True, 3, 2, None), ("rn_lsda_l20_batch16", 20, 16, True, 2, 1, None)):
+                                                      ("rn_lsda_l20", 20, 1, True, 6, 6, None), ("rn_lsda_l20_batch16", 20, 16, True, 4, 6, None)):
                 if lv == args.levels:
                     g2, d2, r2 = grid, delta, rmax
                 else:
