@@ -15,15 +15,16 @@ makes, including the ~52 CountNodes calls per node-less level whose outcome -- "
 integrating; `sweeps_reference_executed` leaves those out) divided by the elapsed time including Poisson / XC / integrals:
 the same quantity the CPU baseline reports.
 
-Objects on the JSON line:
+The ONE line on stdout is compact (< 6 KB: the driver keeps the last 8 KB of stdout; compact_line()); the complete result with every
+kernel object and its notes goes to profiles/bench_full_last.json (and gpurun_out/bench_full_last.json).  On the line:
   roofline       the DOMINANT kernel of the timed region (by HIP-event time): the persistent multigrid kernel or the sweep
-                 kernel; achieved = algorithmic bytes / its HIP-event time, against 8 TB/s
-  kernels        both hot kernels, each with its own figures: the sweep kernel on ISSUED and on REFERENCE-EQUIVALENT bytes
-                 plus its VALU-issue ceiling (the resource that binds it), the multigrid kernel on the 8d bytes
-  extra          (N = 1 only) two more measured workloads, each with the same per-kernel figures: a machine-filling batch of
-                 256 Rn atoms (one workgroup per atom in the multigrid kernel, four waves per SIMD in the sweep kernel) and
-                 Rn LSDA (BASELINE configs[2])
-  cpu_baseline   the oracle on the host: 1 core (how the reference runs), 1 core with tables, and all cores (replicas)
+                 kernel; achieved = algorithmic bytes / its HIP-event time, against 8 TB/s; traffic,
+                 hbm_GBps_counters, frac_counters = rocprofv3 FETCH/WRITE bytes of the committed profile of this workload
+  kernels        both hot kernels, flat: frac (reference's bisection path), frac_issued (every speculative trial), counters
+  extra          (N = 1 only) one flat object per further workload: tolerance mode, Rn LSDA (configs[2]), a 256-atom batch,
+                 1 048 577 nodes x 1 and x 16 atoms (configs[4]); --all-extras: LSDA tolerance, 1024 atoms, dense-K sweeps
+  cpu_baseline   the oracle on the host: 1 core (how the reference runs) + scalars for the table variant, 15 level threads and
+                 one replica per physical core
 
 N > 1 (launched by torch.distributed.run): atoms are independent, so every rank advances its own replica of the batch (weak
 scaling, no data-path collective); the per-atom result records are all_gathered over RCCL once after the last step, inside
@@ -89,12 +90,13 @@ def cpu_worker(levels, lsda, steps, tables, threads=1):
     print(json.dumps({"sweeps": sweeps, "seconds": dt, "vcycles": vc, "setup_s": t_setup, "etotal": e.Etotal}))
 
 
-def _spawn_cpu(levels, lsda, steps, tables, n, threads=1):
+def _start_cpu(levels, lsda, steps, tables, n, threads=1):
     cmd = [sys.executable, os.path.abspath(__file__), "--cpu-worker", str(levels), str(int(lsda)), str(steps), str(int(tables)), str(threads)]
-    t0 = time.time()
-    procs = [subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True) for _ in range(n)]
-    outs = [json.loads(p.communicate()[0].strip().splitlines()[-1]) for p in procs]
-    return outs, time.time() - t0
+    return [subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True) for _ in range(n)]
+
+
+def _join_cpu(procs):
+    return [json.loads(p.communicate()[0].strip().splitlines()[-1]) for p in procs]
 
 
 def cpu_model():
@@ -123,38 +125,51 @@ def physical_cores():
     return os.cpu_count() or 1
 
 
-def cpu_baseline(levels, lsda, steps):
-    """The oracle (plain-C restatement of the reference) timed on this host, in child processes."""
-    nproc = os.cpu_count() or 1
-    one, _ = _spawn_cpu(levels, lsda, steps, False, 1)
-    tab, _ = _spawn_cpu(levels, lsda, steps, True, 1)
-    nall = max(1, min(physical_cores(), len(os.sched_getaffinity(0))))     # every physical core this process may use
-    allc, wall = _spawn_cpu(levels, lsda, steps, False, nall)
+def cpu_baseline_start(levels, lsda, steps):
+    """The oracle (plain-C restatement of the reference) timed on this host, in child processes.  Three variants start at once (1 + 1 + 15
+    threads on a host with far more cores; the GPU extras run meanwhile and need one host thread): 1 core as the reference runs, 1 core with
+    tables, one atom with its levels on 15 OpenMP threads (SURVEY 8d ii).  The all-core replicas run alone afterwards (cpu_baseline_finish)."""
     nlev = 15                                                              # Rn: 15 subshells per spin
-    par, _ = _spawn_cpu(levels, lsda, steps, False, 1, threads=nlev)       # SURVEY 8d (ii): one thread per level, one atom
+    return {"levels": levels, "lsda": lsda, "steps": steps, "nlev": nlev,
+            "one": _start_cpu(levels, lsda, steps, False, 1), "tab": _start_cpu(levels, lsda, steps, True, 1),
+            "par": _start_cpu(levels, lsda, steps, False, 1, threads=nlev)}
+
+
+def cpu_baseline_finish(job, all_cores=True):
+    levels, lsda, steps, nlev = job["levels"], job["lsda"], job["steps"], job["nlev"]
+    nproc = os.cpu_count() or 1
+    one, tab, par = _join_cpu(job["one"]), _join_cpu(job["tab"]), _join_cpu(job["par"])
     o, t = one[0], tab[0]
     assert abs(o["etotal"] - t["etotal"]) == 0.0                     # the table variant is bit-identical
     tag = "Rn %s @ %d levels" % ("LSDA" if lsda else "LDA", levels)
-    return {"value": o["sweeps"] / o["seconds"], "unit": "sweeps/s", "cores": 1, "kind": "port",
-            "sample": "%d SCF steps of %s on the oracle (oracle/dfta_oracle.c, gcc -O2 -ffp-contract=off, 1 thread): %.2f s, %d sweeps, "
-                      "%d V-cycles; setup (flat density + Poisson) %.2f s excluded" % (steps, tag, o["seconds"], o["sweeps"], o["vcycles"], o["setup_s"]),
-            "ms_per_step": 1e3 * o["seconds"] / steps, "vcycles_per_s": o["vcycles"] / o["seconds"],
-            "cpu_model": cpu_model(), "nproc": nproc,
-            "table_variant": {"value": t["sweeps"] / t["seconds"], "unit": "sweeps/s", "cores": 1, "ms_per_step": 1e3 * t["seconds"] / steps,
-                              "note": "r_i and exp(2 i delta) looked up instead of re-evaluated per point; results bit-identical"},
-            "level_parallel": {"value": par[0]["sweeps"] / par[0]["seconds"], "unit": "sweeps/s", "cores": nlev,
-                               "ms_per_step": 1e3 * par[0]["seconds"] / steps,
-                               "note": "ONE atom, the levels of a spin on %d OpenMP threads (un-chained clamped brackets: the GPU path's mode; "
-                                       "bit-identical to its serial form), multigrid / XC / integrals serial: the per-atom latency a CPU can reach "
-                                       "(SURVEY 8d ii)" % nlev},
-            "all_cores": {"value": sum(x["sweeps"] for x in allc) / max(x["seconds"] for x in allc), "unit": "sweeps/s", "cores": nall,
-                          "vcycles_per_s": sum(x["vcycles"] for x in allc) / max(x["seconds"] for x in allc),
-                          "physical_cores": physical_cores(),
-                          "note": "%d independent replicas of the same run, one process per physical core (atoms are the parallel axis of the "
-                                  "reference's algorithm; the reference itself is single-threaded), %d steps each, slowest replica's time. "
-                                  "Inside one atom only the level loop parallelises (15 subshells, ~77 %% of a step; the multigrid is a serial "
-                                  "recurrence): at most ~3.5x per atom by Amdahl, so replicas are the all-core figure that favours the CPU"
-                                  % (nall, steps)}}
+    out = {"value": o["sweeps"] / o["seconds"], "unit": "sweeps/s", "cores": 1, "kind": "port",
+           "sample": "%d SCF steps of %s on the oracle (oracle/dfta_oracle.c, gcc -O2 -ffp-contract=off, 1 thread): %.2f s, %d sweeps, "
+                     "%d V-cycles; setup (flat density + Poisson) %.2f s excluded" % (steps, tag, o["seconds"], o["sweeps"], o["vcycles"], o["setup_s"]),
+           "ms_per_step": 1e3 * o["seconds"] / steps, "vcycles_per_s": o["vcycles"] / o["seconds"],
+           "cpu_model": cpu_model(), "nproc": nproc,
+           "table_variant": {"value": t["sweeps"] / t["seconds"], "unit": "sweeps/s", "cores": 1, "ms_per_step": 1e3 * t["seconds"] / steps,
+                             "note": "r_i and exp(2 i delta) looked up instead of re-evaluated per point; results bit-identical"},
+           "level_parallel": {"value": par[0]["sweeps"] / par[0]["seconds"], "unit": "sweeps/s", "cores": nlev,
+                              "ms_per_step": 1e3 * par[0]["seconds"] / steps,
+                              "note": "ONE atom, the levels of a spin on %d OpenMP threads (un-chained clamped brackets: the GPU path's mode; "
+                                      "bit-identical to its serial form), multigrid / XC / integrals serial: the per-atom latency a CPU can reach "
+                                      "(SURVEY 8d ii)" % nlev}}
+    if all_cores:
+        nall = max(1, min(physical_cores(), len(os.sched_getaffinity(0))))     # every physical core this process may use
+        allc = _join_cpu(_start_cpu(levels, lsda, steps, False, nall))
+        out["all_cores"] = {"value": sum(x["sweeps"] for x in allc) / max(x["seconds"] for x in allc), "unit": "sweeps/s", "cores": nall,
+                            "vcycles_per_s": sum(x["vcycles"] for x in allc) / max(x["seconds"] for x in allc),
+                            "physical_cores": physical_cores(),
+                            "note": "%d independent replicas of the same run, one process per physical core (atoms are the parallel axis of the "
+                                    "reference's algorithm; the reference itself is single-threaded), %d steps each, slowest replica's time. "
+                                    "Inside one atom only the level loop parallelises (15 subshells, ~77 %% of a step; the multigrid is a serial "
+                                    "recurrence): at most ~3.5x per atom by Amdahl, so replicas are the all-core figure that favours the CPU"
+                                    % (nall, steps)}
+    return out
+
+
+def cpu_baseline(levels, lsda, steps, all_cores=True):
+    return cpu_baseline_finish(cpu_baseline_start(levels, lsda, steps), all_cores)
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -168,13 +183,12 @@ def source_sha():
     return h.hexdigest()[:16]
 
 
-def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the newest committed rocprofv3 PMC passes of this same command
-    (profiles/*_hbm_traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate passes; FETCH_SIZE doubled as
+def pmc_traffic(kernel, workload="default"):
+    """HBM bytes per launch of `kernel` from the newest committed rocprofv3 PMC passes of the same workload
+    (profiles/*<workload>_hbm_traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate passes; FETCH_SIZE doubled as
     MI355X_MICROARCH.md prescribes for gfx950).  bench.py cannot run the profiler on itself: the number is the measured one of
     that profile, returned with its tag -- and withheld (null) when the kernels' sources have changed since it was taken."""
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*default_hbm_traffic.json")), key=os.path.getmtime) or \
-        sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.json")), key=os.path.getmtime)    # the default workload's passes
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*%s_hbm_traffic.json" % workload)), key=os.path.getmtime)
     if not files:
         return None, None
     try:
@@ -186,6 +200,17 @@ def pmc_traffic(kernel):
         return float(d["kernels"][kernel]["hbm_bytes_per_launch_fetch_doubled"]), tag
     except Exception:
         return None, None
+
+
+def counter_rate(d, kernel, workload):
+    """adds the counter-based HBM rate of a kernel object: (2 x FETCH_SIZE + WRITE_SIZE) per launch of the committed profile of
+    this workload / the launch time measured in this run.  This -- not the algorithmic figure -- is a bandwidth."""
+    traffic, tag = pmc_traffic(kernel, workload)
+    d["hbm_bytes_per_launch_counters"] = traffic
+    d["counters_profile"] = tag
+    ms = d.get("avg_launch_ms")
+    d["hbm_GBps_counters"] = traffic / (ms * 1e-3) / 1e9 if traffic and ms else None
+    d["frac_counters"] = d["hbm_GBps_counters"] / HBM_PEAK_GBS if d["hbm_GBps_counters"] else None
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -223,8 +248,10 @@ def run_workload(D, ctx, grid, levels, atoms, lsda, steps, warmup, tree_depth, b
     return scf, tot
 
 
-def kernel_figures(tot, levels, N, atoms):
-    """per-kernel roofline figures of a workload (HIP-event times measured inside the library on the launch stream)"""
+def kernel_figures(tot, levels, N, atoms, workload=None):
+    """per-kernel roofline figures of a workload (HIP-event times measured inside the library on the launch stream).
+    `algorithmic_*` = SURVEY 8d bytes / time: a yardstick, NOT a bandwidth (levels resident in LDS / L2 and trials sharing a table row
+    make it exceed what HBM moves); `hbm_GBps_counters` = rocprofv3 FETCH/WRITE bytes of the committed profile of `workload` / time."""
     forced = os.environ.get("DFTA_SWEEP_KERNEL", "")
     piped = forced == "pipe" or (forced != "fused" and tot["trials_per_round"] // 64 <= 768)
     sname = "k_sweep_pipe" if piped else "k_sweep"
@@ -233,49 +260,47 @@ def kernel_figures(tot, levels, N, atoms):
     b_issued = NUMEROV_BYTES_PER_POINT * tot["points_traversed"]
     b_ref = NUMEROV_BYTES_PER_POINT * tot["points_reference"]
     block_points = tot["points_traversed"] / 64.0       # lower bound: 64 live lanes in every block
-    sweep = {"kernel": sname + " (Numerov CountNodes / SolutionInZero sweeps)", "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
+    sweep = {"kernel": sname, "what": "Numerov CountNodes / SolutionInZero sweeps", "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
              "launches": launches, "avg_launch_ms": tot["ms_sweep_kernels"] / launches,
-             "achieved_issued": b_issued / t_sw / 1e9 if t_sw else None, "frac_issued": b_issued / t_sw / 1e9 / HBM_PEAK_GBS if t_sw else None,
-             "achieved_reference_equivalent": b_ref / t_sw / 1e9 if t_sw else None,
-             "frac_reference_equivalent": b_ref / t_sw / 1e9 / HBM_PEAK_GBS if t_sw else None,
-             "bytes_per_launch_issued": b_issued / launches, "bytes_per_launch_reference_equivalent": b_ref / launches,
+             "algorithmic_GBps_issued": b_issued / t_sw / 1e9 if t_sw else None, "frac_issued": b_issued / t_sw / 1e9 / HBM_PEAK_GBS if t_sw else None,
+             "algorithmic_GBps": b_ref / t_sw / 1e9 if t_sw else None,
+             "frac": b_ref / t_sw / 1e9 / HBM_PEAK_GBS if t_sw else None,
+             "bytes_per_launch_issued": b_issued / launches, "bytes_per_launch": b_ref / launches,
              "binding_resource": "fp64 VALU issue of the integrator wave (one block of 64 trials per CU; sequential three-term recurrence)",
              "valu_issue": {"wave_instr_per_block_point": SWEEP_VALU_PER_BLOCK_POINT, "block_points_per_s": block_points / t_sw if t_sw else None,
                             "ceiling_wave_instr_per_s": VALU_WAVE_INSTR_PER_S,
                             "frac": SWEEP_VALU_PER_BLOCK_POINT * block_points / t_sw / VALU_WAVE_INSTR_PER_S if t_sw else None,
                             "ns_per_point_per_block": 1e9 * t_sw / (launches * N) if t_sw else None,
                             "note": "static instruction count from numerov.hip x measured points; profiles/*_sq_counters.json holds SQ_INSTS_VALU"},
-             "note": "8 B per traversed grid point per trial (SURVEY 8d). ISSUED = every trial of the speculative trees; REFERENCE-EQUIVALENT = "
-                     "only the trials on the reference's bisection path (what its sequential loop integrates). The 64 trials of a block share "
-                     "one table row, so physical HBM traffic is far below either figure."}
+             "note": "8 B per traversed grid point per trial (SURVEY 8d). frac = only the trials on the reference's bisection path (what its "
+                     "sequential loop integrates); frac_issued = every trial of the speculative trees. The 64 trials of a block share "
+                     "one table row, so physical HBM traffic (hbm_GBps_counters) is far below either figure."}
     t_ps = tot["ms_poisson"] * 1e-3
     b_ps = POISSON_BYTES_PER_VCYCLE.get(levels, 376 * N) * tot["vcycles"]
     psolves = max(tot["steps"], 1)
-    pois = {"kernel": ("k_poisson_solve_res" if tot["poisson_G"] == 33 else "k_poisson_solve") + " (persistent multigrid: FMG ramp + 100 V-cycles per launch)",
+    pname = "k_poisson_solve_res" if tot["poisson_G"] >= 33 else "k_poisson_solve"
+    pois = {"kernel": pname, "what": "persistent multigrid: FMG ramp + 100 V-cycles per launch",
             "bound": "hbm", "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "launches": psolves, "avg_launch_ms": tot["ms_poisson"] / psolves,
-            "achieved": b_ps / t_ps / 1e9 if t_ps else None, "frac": b_ps / t_ps / 1e9 / HBM_PEAK_GBS if t_ps else None,
+            "algorithmic_GBps": b_ps / t_ps / 1e9 if t_ps else None, "frac": b_ps / t_ps / 1e9 / HBM_PEAK_GBS if t_ps else None,
             "bytes_per_launch": b_ps / psolves, "vcycles_per_s": tot["vcycles"] / t_ps if t_ps else None,
             "workgroups": atoms * tot["poisson_G"],
             "binding_resource": ("latency of the ordered Gauss-Seidel recurrence: %d atom(s) x %d workgroups on 256 CUs; " % (atoms, tot["poisson_G"])) +
-                                ("resident group: 32 members x 128 lanes keep the four finest levels in LDS (one fused 3-sweep pass of 112+C+2 dependent "
-                                 "steps and one exchange per visit), a coarse workgroup runs the 13 levels below" if tot["poisson_G"] == 33 else
+                                ("resident groups keep the finest levels in LDS (one fused 3-sweep pass of 112+C+2 dependent "
+                                 "steps and one exchange per visit), a coarse workgroup runs the levels below" if tot["poisson_G"] >= 33 else
                                  "every sweep %d+95 dependent steps" % max(1, (N - 1) // (256 * tot["poisson_G"]))),
             "note": "algorithmic bytes per V-cycle with every pass counted (GS 24 B/pt x 3 sweeps per visit, restrict, prolong: SURVEY 8d); the "
-                    "level storage of one atom (6.3 MB at 17 levels) stays in LDS / L2, so HBM is not what this kernel waits for"}
-    for d in (sweep, pois):
-        d["peak_measured"] = HBM_MEASURED["copy"]
-        d["peak_note"] = "peak = 8 TB/s HBM3E spec; peak_measured = copy kernel of this library on this device in this run (GB/s)"
-    if HBM_MEASURED["copy"]:
-        pois["frac_measured"] = pois["achieved"] / HBM_MEASURED["copy"] if pois["achieved"] else None
-        sweep["frac_issued_measured"] = sweep["achieved_issued"] / HBM_MEASURED["copy"] if sweep["achieved_issued"] else None
-        sweep["frac_reference_equivalent_measured"] = (sweep["achieved_reference_equivalent"] / HBM_MEASURED["copy"]
-                                                       if sweep["achieved_reference_equivalent"] else None)
+                    "level storage of one atom (6.3 MB at 17 levels) stays in LDS / L2 and fused visits read a level once per three sweeps, so "
+                    "the figure can exceed the HBM peak: hbm_GBps_counters is the bandwidth"}
+    for d, k in ((sweep, sname), (pois, pname)):
+        d["peak_measured_copy"] = HBM_MEASURED["copy"]
+        if workload:
+            counter_rate(d, k, workload)
     return sweep, pois
 
 
-def summarize(tot, levels, N, atoms, lsda, world, delta, rmax):
-    sweep, pois = kernel_figures(tot, levels, N, atoms)
+def summarize(tot, levels, N, atoms, lsda, world, delta, rmax, workload=None):
+    sweep, pois = kernel_figures(tot, levels, N, atoms, workload)
     return {"workload": "Rn Z=86 %s, %d multigrid levels (%d pts), delta=%g, Rmax=%g, mixing 0.5, %d atom(s)/GPU, un-chained clamped brackets, "
                         "tree depth %d, %s" % ("LSDA" if lsda else "LDA", levels, N, delta, rmax, atoms, tot["tree_depth"], tot["levels_layout"]),
             "sweeps_executed_per_s": tot["sweeps_reference_executed"] / tot["elapsed"],
@@ -287,6 +312,96 @@ def summarize(tot, levels, N, atoms, lsda, world, delta, rmax):
             "phase_ms_per_step": {"levels": tot["ms_levels"] / tot["steps"], "poisson": tot["ms_poisson"] / tot["steps"],
                                   "tail": tot["ms_tail"] / tot["steps"], "hip_event_total": tot["ev_ms"] / tot["steps"]},
             "kernels": {"sweep": sweep, "poisson": pois}}
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the ONE line on stdout: compact (the driver keeps the last 8 KB of stdout); everything else goes to a side file
+# ---------------------------------------------------------------------------------------------------------------
+LINE_LIMIT = 6000
+
+
+def _r(x, sig=6):
+    """numbers to `sig` significant digits (the full values are in the side file)"""
+    if isinstance(x, bool) or x is None:
+        return x
+    if isinstance(x, float):
+        return float("%.*g" % (sig, x))
+    return x
+
+
+def _flat_kernel(k, keys):
+    return {a: _r(k.get(a)) for a in keys if a in k}
+
+
+def compact_line(full):
+    """the driver's schema keys + roofline (dominant kernel) + cpu_baseline + one flat object per extra workload.  Pure function of the
+    full result (tests/test_bench_line.py feeds it a canned one)."""
+    sweep_keys = ("kernel", "launches", "avg_launch_ms", "frac", "frac_issued", "bytes_per_launch", "hbm_GBps_counters", "frac_counters")
+    pois_keys = ("kernel", "launches", "avg_launch_ms", "frac", "bytes_per_launch", "vcycles_per_s", "workgroups", "hbm_GBps_counters", "frac_counters")
+    out = {k: _r(full[k]) if not isinstance(full[k], (dict, list)) else full[k]
+           for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+                     "data", "config") if k in full}
+    for k in ("value_reference_equivalent", "sweeps_issued_per_s", "poisson_vcycles_per_s", "poisson_vcycles_per_s_kernel", "rounds_per_step",
+              "device", "compute_units"):
+        if k in full:
+            out[k] = _r(full[k])
+    out["phase_ms_per_step"] = {k: _r(v, 5) for k, v in full.get("phase_ms_per_step", {}).items()}
+    out["etotal_last_step"] = (full.get("energies_last_step") or [None])[0]
+    rf = full["roofline"]
+    out["roofline"] = {k: _r(rf.get(k)) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "frac_issued", "traffic", "bytes_per_launch",
+                                                   "avg_launch_ms", "launches", "hbm_GBps_counters", "frac_counters", "peak_measured_copy",
+                                                   "achieved_is") if k in rf}
+    ks = full.get("kernels", {})
+    out["kernels"] = {"sweep": _flat_kernel(ks.get("sweep", {}), sweep_keys), "poisson": _flat_kernel(ks.get("poisson", {}), pois_keys)}
+    if "cpu_baseline" in full:
+        c = full["cpu_baseline"]
+        out["cpu_baseline"] = {k: _r(c.get(k)) for k in ("value", "unit", "cores", "kind", "ms_per_step", "vcycles_per_s", "cpu_model", "nproc")}
+        out["cpu_baseline"]["sample"] = str(c.get("sample", ""))[:200]
+        for name in ("table_variant", "level_parallel", "all_cores"):
+            if isinstance(c.get(name), dict):
+                out["cpu_baseline"][name + "_value"] = _r(c[name].get("value"))
+                out["cpu_baseline"][name + "_cores"] = c[name].get("cores")
+    if "extra" in full:
+        ex = {}
+        for name, e in full["extra"].items():
+            if "ms_per_step" not in e:
+                ex[name] = {k: _r(v) for k, v in e.items() if not isinstance(v, (dict, list))} or {"see": "side file"}
+                continue
+            k2 = e.get("kernels", {})
+            ex[name] = {"ms_per_step": _r(e["ms_per_step"]), "ms_per_atom_step": _r(e.get("ms_per_atom_step")),
+                        "sweeps_executed_per_s": _r(e.get("sweeps_executed_per_s")), "vcycles_per_s": _r(e.get("vcycles_per_s")),
+                        "issued_per_useful": _r(e.get("issued_per_useful"), 4), "rounds_per_step": _r(e.get("rounds_per_step"), 4),
+                        "sweep_frac": _r(k2.get("sweep", {}).get("frac")), "sweep_frac_issued": _r(k2.get("sweep", {}).get("frac_issued")),
+                        "sweep_frac_counters": _r(k2.get("sweep", {}).get("frac_counters")),
+                        "poisson_ms": _r(k2.get("poisson", {}).get("avg_launch_ms")), "poisson_frac": _r(k2.get("poisson", {}).get("frac")),
+                        "poisson_frac_counters": _r(k2.get("poisson", {}).get("frac_counters")),
+                        "steps": e.get("steps"), "warmup": e.get("warmup")}
+        out["extra"] = ex
+    if full.get("full_result"):
+        out["full_result"] = full["full_result"]
+    line = json.dumps(out)
+    if len(line) > LINE_LIMIT:                 # never lose the line to its own size: drop the optional parts, largest first
+        for k in ("extra", "kernels", "phase_ms_per_step"):
+            out.pop(k, None)
+            line = json.dumps(out)
+            if len(line) <= LINE_LIMIT:
+                break
+    return line
+
+
+def write_full(full):
+    """the complete result (every kernel object with its notes) next to the profiles and, on a gpurun box, under gpurun_out/"""
+    written = []
+    for d in ("profiles", "gpurun_out"):
+        try:
+            os.makedirs(os.path.join(ROOT, d), exist_ok=True)
+            path = os.path.join(ROOT, d, "bench_full_last.json")
+            with open(path, "w") as f:
+                json.dump(full, f, indent=1)
+            written.append(os.path.join(d, "bench_full_last.json"))
+        except OSError:
+            pass
+    return written
 
 
 def main():
@@ -304,6 +419,8 @@ def main():
     ap.add_argument("--tree-depth", type=int, default=0)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra workloads (256-atom batch, LSDA, 1 048 577 nodes)")
+    ap.add_argument("--all-extras", action="store_true", help="also: LSDA in tolerance mode, a 1024-atom batch, the dense-K sweep benchmark")
+    ap.add_argument("--no-cpu-all-cores", action="store_true", help="CPU baseline: skip the one-replica-per-physical-core leg")
     ap.add_argument("--cpu-steps", type=int, default=3)
     args = ap.parse_args()
 
@@ -390,25 +507,29 @@ def main():
 
     if rank == 0:
         ncu, devname = ctx.device_info()
-        sweep, pois = kernel_figures(tot, args.levels, grid.N, args.atoms)
+        wl = None
+        if args.atoms == 1 and args.levels == 17:
+            wl = "tolerance" if args.tolerance and not args.lsda else "rn_lsda" if args.lsda and not args.tolerance else "default" if not args.lsda else None
+        elif args.atoms == 256 and args.levels == 17 and not args.lsda:
+            wl = "batch256"
+        elif args.atoms == 16 and args.levels == 20 and args.lsda:
+            wl = "l20_batch16"
+        sweep, pois = kernel_figures(tot, args.levels, grid.N, args.atoms, wl)
         dominant = pois if tot["ms_poisson"] >= tot["ms_sweep_kernels"] else sweep
-        dkey = ("k_poisson_solve_res" if tot["poisson_G"] == 33 else "k_poisson_solve") if dominant is pois else \
-            ("k_sweep_pipe" if "k_sweep_pipe" in sweep["kernel"] else "k_sweep")
-        traffic, ttag = pmc_traffic(dkey)
         roof = {"bound": "hbm", "kernel": dominant["kernel"],
-                "achieved": dominant["achieved"] if dominant is pois else dominant["achieved_reference_equivalent"],
-                "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": dominant["frac"] if dominant is pois else dominant["frac_reference_equivalent"],
-                "peak_measured": HBM_MEASURED["copy"], "peak_measured_triad": HBM_MEASURED["triad"],
-                "frac_measured": ((dominant["achieved"] if dominant is pois else dominant["achieved_reference_equivalent"]) / HBM_MEASURED["copy"]
-                                  if HBM_MEASURED["copy"] else None),
-                "traffic": traffic, "traffic_source": ttag,
-                "bytes_per_launch": dominant["bytes_per_launch"] if dominant is pois else dominant["bytes_per_launch_reference_equivalent"],
+                "achieved": dominant["algorithmic_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dominant["frac"],
+                "achieved_is": "algorithmic bytes of SURVEY 8d per launch / average launch duration (HIP events on the launch stream)",
+                "traffic": dominant.get("hbm_bytes_per_launch_counters"), "traffic_source": dominant.get("counters_profile"),
+                "hbm_GBps_counters": dominant.get("hbm_GBps_counters"), "frac_counters": dominant.get("frac_counters"),
+                "bytes_per_launch": dominant["bytes_per_launch"],
                 "avg_launch_ms": dominant["avg_launch_ms"], "launches": dominant["launches"],
-                "share_of_step_ms": {"k_poisson_solve": tot["ms_poisson"] / args.steps, "sweep kernel": tot["ms_sweep_kernels"] / args.steps},
+                "peak_measured_copy": HBM_MEASURED["copy"], "peak_measured_triad": HBM_MEASURED["triad"],
+                "share_of_step_ms": {"multigrid kernel": tot["ms_poisson"] / args.steps, "sweep kernel": tot["ms_sweep_kernels"] / args.steps},
                 "binding_resource": dominant["binding_resource"],
-                "note": "dominant kernel of the timed region by HIP-event time; achieved = algorithmic bytes of SURVEY 8d per launch / average "
-                        "launch duration; see `kernels` for both hot kernels (the sweep kernel also on issued bytes and against its VALU-issue ceiling)"}
+                "note": "dominant kernel of the timed region by HIP-event time; see `kernels` for both hot kernels (the sweep kernel also on "
+                        "issued bytes and against its VALU-issue ceiling)"}
+        if dominant is sweep:
+            roof["frac_issued"] = sweep["frac_issued"]
         out = {
             "metric": "numerov_sweeps_per_s (executed sweeps of the reference's bisection path, whole SCF step; Rn Z=86 @ %d pts)" % grid.N,
             "value": exe_all / elapsed,
@@ -423,9 +544,8 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic (reference's flat start density, SCF iterations %d..%d)" % (args.warmup, args.warmup + args.steps - 1),
-            "config": {"workload": "Rn Z=86 %s, %d multigrid levels (%d pts), delta=%g, Rmax=%g, mixing 0.5, %d atom(s)/GPU, "
-                                   "un-chained clamped brackets, tree depth %d, %s" % ("LSDA" if args.lsda else "LDA", args.levels, grid.N,
-                                                                           delta, rmax, args.atoms, tot["tree_depth"], tot["levels_layout"]),
+            "config": {"workload": "Rn Z=86 %s, %d levels (%d pts), delta=%g, Rmax=%g, mixing 0.5, %d atom(s)/GPU, %s"
+                                   % ("LSDA" if args.lsda else "LDA", args.levels, grid.N, delta, rmax, args.atoms, tot["levels_layout"]),
                        "atoms_per_gpu": args.atoms, "parallelism": "replicas x%d" % world,
                        "poisson_mode": "tolerance" if args.tolerance else "exact"},
             "scf_step_ms": 1e3 * elapsed / args.steps,
@@ -436,7 +556,8 @@ def main():
             "sweeps_issued_per_s": issued_all / elapsed,
             "poisson_vcycles_per_s": vc_all / elapsed,
             "poisson_vcycles_per_s_kernel": pois["vcycles_per_s"],
-            "phase_ms_per_step": {"levels": tot["ms_levels"] / args.steps, "poisson": tot["ms_poisson"] / args.steps,
+            "phase_ms_per_step": {"levels": tot["ms_levels"] / args.steps, "sweep_kernels": tot["ms_sweep_kernels"] / args.steps,
+                                  "poisson": tot["ms_poisson"] / args.steps,
                                   "tail": tot["ms_tail"] / args.steps, "hip_event_total": tot["ev_ms"] / args.steps},
             "rounds_per_step": tot["rounds"] / args.steps,
             "energies_last_step": tot["energies"],
@@ -444,18 +565,24 @@ def main():
             "roofline": roof,
             "kernels": {"sweep": sweep, "poisson": pois},
         }
+        cpu_job = None
+        if world == 1 and not args.no_cpu:      # rank 0 at N = 1 only: the other ranks of a larger job would sit at the final barrier
+            cpu_job = cpu_baseline_start(args.levels, args.lsda, args.cpu_steps)      # child processes on the host cores, next to the extras
         if world == 1 and not args.no_extras:
             # further measured workloads with the same per-kernel figures (>= 10 timed steps after >= 5 warm-up steps wherever a step
-            # is short enough): the opt-in tolerance mode of the multigrid smoother, LSDA (BASELINE config 3), machine-filling
-            # batches of Rn atoms, and the 1 048 577-node stress of config 5 (one atom and a batch of 16, SCF steps 6.. : from the seventh step
-            # on one level ends its third bisection at the reference's 500-iteration cap in most steps); a few seconds each
+            # is short enough): the opt-in tolerance mode of the multigrid smoother, LSDA (BASELINE config 3), a machine-filling
+            # batch of Rn atoms, and the 1 048 577-node stress of config 5 (one atom and a batch of 16, SCF steps 6.. : from the seventh step
+            # on one level ends its third bisection at the reference's 500-iteration cap in most steps); a few seconds each.
+            # --all-extras adds LSDA in tolerance mode, the 1024-atom batch and the dense-K sweep benchmark of SURVEY 8d.
             extra = {}
-            for name, lv, atoms, lsda, st, wu, pm in (("rn_lda_tolerance_mode", args.levels, 1, False, 10, 5, D.POISSON_TOLERANCE),
-                                                      ("rn_lsda", args.levels, 1, True, 10, 5, None),
-                                                      ("rn_lsda_tolerance_mode", args.levels, 1, True, 10, 5, D.POISSON_TOLERANCE),
-                                                      ("batch256_lda", args.levels, 256, False, 10, 5, None),
-                                                      ("batch1024_lda", args.levels, 1024, False, 4, 2, None),
-                                                      ("rn_lsda_l20", 20, 1, True, 6, 6, None), ("rn_lsda_l20_batch16", 20, 16, True, 4, 6, None)):
+            sel = [("rn_lda_tolerance_mode", args.levels, 1, False, 10, 5, D.POISSON_TOLERANCE, "tolerance"),
+                   ("rn_lsda", args.levels, 1, True, 10, 5, None, "rn_lsda"),
+                   ("batch256_lda", args.levels, 256, False, 6, 5, None, "batch256"),
+                   ("rn_lsda_l20", 20, 1, True, 6, 6, None, None), ("rn_lsda_l20_batch16", 20, 16, True, 4, 6, None, "l20_batch16")]
+            if args.all_extras:
+                sel += [("rn_lsda_tolerance_mode", args.levels, 1, True, 10, 5, D.POISSON_TOLERANCE, None),
+                        ("batch1024_lda", args.levels, 1024, False, 4, 2, None, None)]
+            for name, lv, atoms, lsda, st, wu, pm, wl2 in sel:
                 if lv == args.levels:
                     g2, d2, r2 = grid, delta, rmax
                 else:
@@ -463,23 +590,27 @@ def main():
                     g2 = D.Grid(ctx, lv, d2, r2)
                 s2, t2 = run_workload(D, ctx, g2, lv, atoms, lsda, st, wu, 0, barrier, torch, poisson_mode=pm)
                 s2.close()
-                extra[name] = summarize(t2, lv, g2.N, atoms, lsda, world, d2, r2)
+                extra[name] = summarize(t2, lv, g2.N, atoms, lsda, world, d2, r2, wl2 if args.levels == 17 else None)
                 extra[name]["poisson_mode"] = "tolerance" if pm == D.POISSON_TOLERANCE else "exact"
                 extra[name]["warmup"] = wu
                 if g2 is not grid:
                     g2.close()
-            try:
-                sys.path.insert(0, os.path.join(ROOT, "profiles"))
-                import dense_k_sweep
-                extra["dense_k_sweeps"] = dense_k_sweep.run(D, ctx, grid, HBM_PEAK_GBS, HBM_MEASURED["copy"])
-            except Exception as e:                      # the isolated sweep-kernel benchmark must not cost the line
-                extra["dense_k_sweeps"] = {"error": repr(e)}
+            if args.all_extras:
+                try:
+                    sys.path.insert(0, os.path.join(ROOT, "profiles"))
+                    import dense_k_sweep
+                    extra["dense_k_sweeps"] = dense_k_sweep.run(D, ctx, grid, HBM_PEAK_GBS, HBM_MEASURED["copy"])
+                except Exception as e:                      # the isolated sweep-kernel benchmark must not cost the line
+                    extra["dense_k_sweeps"] = {"error": repr(e)}
             out["extra"] = extra
-        if world == 1 and not args.no_cpu:      # rank 0 at N = 1 only: the other ranks of a larger job would sit at the final barrier
-            out["cpu_baseline"] = cpu_baseline(args.levels, args.lsda, args.cpu_steps)
+        if cpu_job is not None:
+            out["cpu_baseline"] = cpu_baseline_finish(cpu_job, not args.no_cpu_all_cores)
         if shared:
             out["data"] += " -- SHARED-GPU TEST MODE (all ranks on device 0, gloo): not a measurement"
-        print(json.dumps(out))
+        out["full_result"] = write_full(out)
+        sys.stdout.flush()
+        print(compact_line(out))
+        sys.stdout.flush()
     grid.close()
     ctx.close()
     if world > 1:

@@ -47,8 +47,8 @@ def main():
                                 "tree_depth": tot["tree_depth"], "poisson_workgroups_per_atom": tot["poisson_G"],
                                 "sweep_kernel": s["kernels"]["sweep"]["kernel"].split(" ")[0],
                                 "sweep_frac_issued": s["kernels"]["sweep"]["frac_issued"],
-                                "sweep_frac_executed_path": s["kernels"]["sweep"]["frac_reference_equivalent"],
-                                "poisson_frac": s["kernels"]["poisson"]["frac"], "poisson_frac_measured": s["kernels"]["poisson"].get("frac_measured"),
+                                "sweep_frac_executed_path": s["kernels"]["sweep"]["frac"],
+                                "poisson_frac_algorithmic": s["kernels"]["poisson"]["frac"],
                                 "wall_s": time.time() - t0}
         sys.stderr.write("B=%d: %.1f ms/step, %.0f sweeps/s, issued/useful %.2f, rounds %.1f\n"
                          % (B, s["ms_per_step"], s["sweeps_executed_per_s"], s["issued_per_useful"], s["rounds_per_step"]))
