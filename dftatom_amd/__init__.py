@@ -20,6 +20,9 @@ SWEEP_COUNT, SWEEP_ZERO = 0, 1
 SWEEP_KERNEL_AUTO, SWEEP_KERNEL_FUSED, SWEEP_KERNEL_PIPELINED = 0, 1, 2
 BOUNDARY_DEVICE, BOUNDARY_HOST = 0, 1
 LEVELS_CHAINED, LEVELS_BATCHED = 0, 1
+LEVELS_SCAN_SWEEPS = 0x10          # OR-ed into the mode of solve_levels: tolerance mode of the sweeps (transfer-matrix scan)
+SWEEPS_EXACT, SWEEPS_TOLERANCE = 0, 1
+ABI_VERSION = 4
 POISSON_DEFAULT, POISSON_EXACT, POISSON_TOLERANCE = -1, 0, 1    # dfta_poisson_create_ex / dfta_scf_options::poisson_mode
 INT_TRAPEZOID, INT_SIMPSON13, INT_SIMPSON38, INT_BOOLE, INT_ROMBERG = range(5)
 XC_VWN, XC_CHACHIYO, XC_CHACHIYO_IMPROVED = range(3)
@@ -50,7 +53,7 @@ class Energies(C.Structure):
 
 
 class ScfOptions(C.Structure):
-    _fields_ = [("integrator", C.c_int), ("functional", C.c_int), ("aufbau", C.c_int), ("poisson_mode", C.c_int)]
+    _fields_ = [("integrator", C.c_int), ("functional", C.c_int), ("aufbau", C.c_int), ("poisson_mode", C.c_int), ("sweep_mode", C.c_int)]
 
 
 class StepStats(C.Structure):
@@ -68,6 +71,7 @@ SIGNATURES = {
     "dfta_ctx_synchronize": (C.c_int, [vp]),
     "dfta_last_error": (C.c_char_p, [vp]),
     "dfta_version": (C.c_char_p, []),
+    "dfta_abi_version": (C.c_int, []),
     "dfta_ctx_device_info": (C.c_int, [vp, c_ip, C.c_char_p, C.c_int]),
     "dfta_ctx_last_kernel_ms": (C.c_int, [vp, C.POINTER(C.c_float)]),
     "dfta_ctx_set_sweep_kernel": (C.c_int, [vp, C.c_int]),
@@ -81,6 +85,7 @@ SIGNATURES = {
     "dfta_num_nodes": (C.c_int, [C.c_int]),
     "dfta_numerov_sweeps": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, c_dp, C.c_int, c_ip, c_ip, c_dp, c_ip,
                                       c_ip, c_dp, c_ip, c_ip]),
+    "dfta_numerov_sweeps_scan": (C.c_int, [vp, vp, C.c_int, C.c_int, c_dp, C.c_int, c_ip, c_ip, c_dp, c_ip, c_ip, c_dp, c_ip, c_ip, c_ip]),
     "dfta_numerov_sweeps_dev": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, C.c_int, c_ip, c_ip, c_ip, vp, vp, vp, vp, vp,
                                           vp, vp, vp, vp]),
     "dfta_numerov_match": (C.c_int, [vp, vp, C.c_int, C.c_int, c_dp, C.c_int, c_ip, c_ip, c_dp, c_dp, c_lp]),
@@ -141,6 +146,9 @@ def load():
         f = getattr(lib, name)       # AttributeError if a declared symbol is not exported
         f.restype = res
         f.argtypes = args
+    if lib.dfta_abi_version() != ABI_VERSION:      # the struct mirrors above grow with the header (no size fields)
+        raise DftaError("%s was built from another version of include/dftatom_hip.h (ABI %d, binding %d): rebuild it"
+                        % (LIB_PATH, lib.dfta_abi_version(), ABI_VERSION))
     _lib = lib
     return lib
 
@@ -249,6 +257,21 @@ def numerov_sweeps(ctx, grid, kind, V, l, E, limit=None, vidx=None, boundary=BOU
     ctx.check(ctx.lib.dfta_numerov_sweeps(ctx.h, grid.h, kind, boundary, V.shape[0], _dp(V), nt, _ip(vi), _ip(l), _dp(E),
                                           _ip(lim), _ip(count), _dp(u0), _ip(start), _ip(trip)))
     return {"count": count, "u0": u0, "start": start, "trip": trip}
+
+
+def numerov_sweeps_scan(ctx, grid, kind, V, l, E, limit=None, vidx=None):
+    """Tolerance mode of the same sweeps (transfer-matrix scan, one workgroup per trial).  Returns dict(count, u0, start, trip, fallback)."""
+    V = _f64(V).reshape(-1, grid.N)
+    l = _i32(l)
+    E = _f64(E)
+    nt = len(E)
+    lim = _i32(limit) if limit is not None else np.zeros(nt, np.int32)
+    vi = _i32(vidx) if vidx is not None else np.zeros(nt, np.int32)
+    count, start, trip, fb = (np.zeros(nt, np.int32) for _ in range(4))
+    u0 = np.zeros(nt)
+    ctx.check(ctx.lib.dfta_numerov_sweeps_scan(ctx.h, grid.h, kind, V.shape[0], _dp(V), nt, _ip(vi), _ip(l), _dp(E), _ip(lim), _ip(count),
+                                               _dp(u0), _ip(start), _ip(trip), _ip(fb)))
+    return {"count": count, "u0": u0, "start": start, "trip": trip, "fallback": fb}
 
 
 def numerov_match(ctx, grid, V, l, E, vidx=None, boundary=BOUNDARY_HOST):
@@ -408,13 +431,13 @@ class Scf:
     """Device-resident SCF state of a batch of atoms (dfta_scf): the body of CalculateNonUniformLDA/LSDA."""
 
     def __init__(self, ctx, grid, Z, lsda=False, alpha=0.5, levels_mode=LEVELS_BATCHED, tree_depth=0, integrator=INT_SIMPSON38,
-                 functional=XC_VWN, aufbau=AUFBAU_REFERENCE, poisson_mode=POISSON_DEFAULT):
+                 functional=XC_VWN, aufbau=AUFBAU_REFERENCE, poisson_mode=POISSON_DEFAULT, sweep_mode=SWEEPS_EXACT):
         self.ctx, self.grid = ctx, grid
         self.Z = _i32(np.atleast_1d(Z))
         self.natoms = len(self.Z)
         self.lsda = bool(lsda)
         h = vp()
-        opt = ScfOptions(integrator, functional, aufbau, poisson_mode)
+        opt = ScfOptions(integrator, functional, aufbau, poisson_mode, sweep_mode)
         ctx.check(ctx.lib.dfta_scf_create_ex(ctx.h, grid.h, int(self.lsda), self.natoms, _ip(self.Z), alpha, levels_mode,
                                              tree_depth, C.cast(C.byref(opt), vp), C.byref(h)))
         self.h = h

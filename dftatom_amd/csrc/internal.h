@@ -25,6 +25,13 @@ int dfta_launch_match(dfta_ctx* ctx, const dfta_grid* g, int ntrials, const doub
                       double* dPsi, double* dQ, int* dMatch, const double2* bounds /* per slot (dfta_bounds_stride), may be null */,
                       const double* dUz = nullptr /* uniform grid: start value at the first node per trial */);
 
+// scan.hip: the tolerance mode of the sweeps (transfer-matrix scan: one workgroup per trial); tabs = nslots * N rows, lane-interleaved
+int dfta_scan_supported(const dfta_grid* g);
+// mm: nslots * 1024 {min, max} of veff per lane segment
+int dfta_launch_scan_build_tab(dfta_ctx* ctx, const dfta_grid* g, double2* tabs, double2* mm, const double* dV, const int* d_slot_v, const int* d_slot_l, int nslots);
+int dfta_launch_scan_sweeps(dfta_ctx* ctx, const dfta_grid* g, int kind, int ntrials, const double2* tabs, const double2* mm, const int* d_trial_slot,
+                            const double* dE, const int* dLimit, int* dCount, double* dU0, int* dStart, int* dTrip, int* dBad);
+
 // reduce.hip: Integral::{Trapezoid,SimpsonOneThird,Simpson38,Boole,Romberg} (Integral.h:11-155) with the reference's
 // sequential summation order, one wave per vector: out[k] = rule(delta, vals + k*stride) for k < nvec
 int dfta_launch_integrate_ordered(dfta_ctx* ctx, int rule /* DFTA_INT_* */, double delta, const double* dVals, int n, int nvec,

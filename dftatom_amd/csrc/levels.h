@@ -117,6 +117,10 @@ struct LevelSolver {
     hipEvent_t ev_walk = nullptr, ev_early = nullptr;
     int *d_jmatched = nullptr, *d_jstart_keep = nullptr;
     bool early_match = false;
+    // Tolerance mode of the sweeps (scan.hip; DFTA_SWEEPS_TOLERANCE, set before setup()): interleaved tables per slot, per-lane {min, max}
+    int sweep_mode = DFTA_SWEEPS_EXACT;
+    double2 *d_stab = nullptr, *d_smm = nullptr;
+    int scan_fallbacks = 0;         // solves the scan handed back to the exact kernels (a trial it could not decide)
 
     LevelSolver() = default;
     LevelSolver(const LevelSolver&) = delete;
@@ -131,3 +135,8 @@ struct LevelSolver {
 };
 
 }  // namespace dfta
+
+// scan.hip: LocateInterval + the u(0) bisection of every chain of jobs by one workgroup each; counters[0] += executed sweeps,
+// counters[1] += traversed points, counters[3] |= 1 when a sweep could not be decided by the scan
+int dfta_launch_scan_levels(dfta_ctx* ctx, const dfta_grid* g, dfta::Job* d_jobs, const int* d_chain_off, int nchains, int chained,
+                            const double2* tabs, const double2* mm, int fixed_point, unsigned long long* d_counters);

@@ -1079,6 +1079,9 @@ void LevelSolver::release()
                     d_u0, d_phi, d_istop, d_trip, d_wave_job, d_wave_kind, d_wave_slot, d_wave_first, d_wave_cnt, d_counters, d_Psi, d_Q, d_jE, d_jslot, d_jl,
                     d_jstart, d_jus, d_jus1, d_jmp, d_slot_min, d_bounds};
     for (void* p : ptrs) if (p) (void)hipFree(p);
+    if (d_stab) (void)hipFree(d_stab);
+    if (d_smm) (void)hipFree(d_smm);
+    d_stab = nullptr; d_smm = nullptr;
     if (d_jmatched) (void)hipFree(d_jmatched);
     if (d_jstart_keep) (void)hipFree(d_jstart_keep);
     d_jmatched = nullptr; d_jstart_keep = nullptr;
@@ -1263,6 +1266,10 @@ int LevelSolver::setup(dfta_ctx* c, const dfta_grid* grid, int mode_, int tree_d
     ALLOC(d_jus, double, njobs); ALLOC(d_jus1, double, njobs); ALLOC(d_jmp, int, njobs);
     ALLOC(d_slot_min, double, nslots);
     ALLOC(d_bounds, double2, (size_t)nslots * dfta_bounds_stride(g));
+    if (sweep_mode == DFTA_SWEEPS_TOLERANCE && dfta_scan_supported(g)) {      // scan.hip: interleaved tables + per-lane {min, max}
+        ALLOC(d_stab, double2, (size_t)nslots * N);
+        ALLOC(d_smm, double2, (size_t)nslots * 1024);
+    }
 #undef ALLOC
 #undef UPLOAD
     DFTA_HIP(ctx, hipEventCreate(&ev[0]));
@@ -1391,23 +1398,52 @@ int LevelSolver::run(const double* dV, const double* job_bottom, int run_mode, d
         }
         return DFTA_OK;
     };
-    rc = plan();
-    if (rc) return rc;
+    // TOLERANCE MODE of the sweeps (scan.hip, opt-in): every level's three bisections by one workgroup, start to end on the device --
+    // no rounds, no speculation.  A sweep the scan cannot decide (non-finite values, f >= 12 in a step row: never seen for the
+    // potential of an SCF) sends the whole solve to the exact kernels below.
+    bool scan = sweep_mode == DFTA_SWEEPS_TOLERANCE && d_stab != nullptr;
+    float ms_scan = 0;
+    if (scan) {
+        rc = dfta_launch_scan_build_tab(ctx, g, d_stab, d_smm, dV, d_slot_v, d_slot_l, nslots);
+        if (rc) return rc;
+        DFTA_HIP(ctx, hipEventRecord(ev[0], st));
+        rc = dfta_launch_scan_levels(ctx, g, d_jobs, d_chains, run_chains, chained ? 1 : 0, d_stab, d_smm, dfta_knob("LEVELS_NOFIXEDPOINT") ? 0 : 1, d_counters);
+        if (rc) return rc;
+        DFTA_HIP(ctx, hipEventRecord(ev[1], st));
+        unsigned long long flag = 0;
+        DFTA_HIP(ctx, hipMemcpyAsync(&flag, d_counters + 3, sizeof(flag), hipMemcpyDeviceToHost, st));
+        DFTA_HIP(ctx, hipStreamSynchronize(st));
+        if (stats) DFTA_HIP(ctx, hipEventElapsedTime(&ms_scan, ev[0], ev[1]));
+        if (flag) {                  // back to the exact kernels with the job records as they were uploaded
+            scan = false;
+            ++scan_fallbacks;
+            DFTA_HIP(ctx, hipMemcpyAsync(d_jobs, jobs.data(), sizeof(Job) * njobs, hipMemcpyHostToDevice, st));
+            DFTA_HIP(ctx, hipMemsetAsync(d_counters, 0, sizeof(unsigned long long) * 4, st));
+            if (!chained && clamp_bottoms) {
+                hipLaunchKernelGGL(k_clamp_bottoms, dim3((njobs + 63) / 64), dim3(64), 0, st, d_jobs, njobs, d_slot_min);
+                DFTA_CHECK_LAUNCH(ctx);
+            }
+        }
+    }
+    if (!scan) {
+        rc = plan();
+        if (rc) return rc;
+    }
     // trials of the coming round: the whole static / latency-mode layout, or what k_pack has just laid out
     long round_trials = dyn ? budget_trials : static_trials;
     int pack_out[4] = {0, 0, 0, 0};
-    if (pk) {
+    if (pk && !scan) {
         DFTA_HIP(ctx, hipMemcpyAsync(pack_out, d_pack_out, sizeof(pack_out), hipMemcpyDeviceToHost, st));
         DFTA_HIP(ctx, hipStreamSynchronize(st));
         round_trials = pack_out[0];
     }
     int* d_ndone = reinterpret_cast<int*>(d_counters + 2);
-    int rounds = 0;
-    float ms_sweep = 0;
+    int rounds = scan ? 1 : 0;
+    float ms_sweep = ms_scan;
     const int max_rounds = 4096;
     int done_seen = nfrozen;
     bool early_pending = false;
-    while (rounds < max_rounds) {
+    while (!scan && rounds < max_rounds) {
         dfta_range r_round("dfta: level-search round (expand, sweeps, scout, walk, plan)");
         if (round_trials <= 0 || round_trials > ntrials) { snprintf(ctx->err, sizeof(ctx->err), "level solver: packed round of %ld trials (room for %ld)", round_trials, ntrials); return DFTA_ERR_HIP; }
         const int round_waves = static_cast<int>(round_trials / 64);
@@ -1521,7 +1557,7 @@ int LevelSolver::run(const double* dV, const double* job_bottom, int run_mode, d
         stats->sweeps_issued = static_cast<long>(cnt[0]) + 2L * (njobs - nfrozen);    // + inward/outward halves of the match solve
         stats->points_traversed = static_cast<long>(cnt[1]);
         stats->ms_sweep = ms_sweep;
-        stats->layout = sw ? 3 : (dynamic ? 1 : (pk ? 2 : 0));
+        stats->layout = scan ? 4 : (sw ? 3 : (dynamic ? 1 : (pk ? 2 : 0)));
     }
     return DFTA_OK;
 }
@@ -1547,11 +1583,15 @@ extern "C" int dfta_solve_levels(dfta_ctx* ctx, const dfta_grid* g, int mode, in
     if (!ctx || !g) return DFTA_ERR_INVALID;
     DFTA_ENTER(ctx);
     DFTA_REQUIRE(ctx, V && bottom0 && n && l && occ && results && nV > 0 && nlevels > 0, "null input");
+    const bool scan_sweeps = (mode & DFTA_LEVELS_SCAN_SWEEPS) != 0;
+    mode &= ~DFTA_LEVELS_SCAN_SWEEPS;
     DFTA_REQUIRE(ctx, mode == DFTA_LEVELS_CHAINED || mode == DFTA_LEVELS_BATCHED, "mode");
+    DFTA_REQUIRE(ctx, !scan_sweeps || dfta_scan_supported(g), "the tolerance mode of the sweeps needs a logarithmic grid of 12 .. 24 multigrid levels");
     const int N = g->N;
     std::vector<dfta::JobSpec> specs(nlevels);
     for (int k = 0; k < nlevels; ++k) specs[k] = {vidx ? vidx[k] : 0, n[k], l[k], occ[k]};
     dfta::LevelSolver solver;
+    solver.sweep_mode = scan_sweeps ? DFTA_SWEEPS_TOLERANCE : DFTA_SWEEPS_EXACT;
     int rc = solver.setup(ctx, g, mode, tree_depth, nV, specs);
     if (rc) { if (rc == DFTA_ERR_INVALID) snprintf(ctx->err, sizeof(ctx->err), "levels must be grouped by potential, l in 0..3"); return rc; }
     hipStream_t st = ctx->stream;

@@ -277,6 +277,8 @@ void dfta_scf_destroy(dfta_scf* s)
     delete s;
 }
 
+int dfta_abi_version(void) { return DFTA_ABI_VERSION; }
+
 int dfta_scf_create(dfta_ctx* ctx, const dfta_grid* g, int lsda, int natoms, const int* Z, double alpha, int levels_mode,
                     int tree_depth, dfta_scf** out)
 {
@@ -289,14 +291,17 @@ int dfta_scf_create_ex(dfta_ctx* ctx, const dfta_grid* g, int lsda, int natoms, 
     if (!ctx || !g || !out) return DFTA_ERR_INVALID;
     DFTA_ENTER(ctx);
     DFTA_REQUIRE(ctx, natoms >= 1 && Z && alpha >= 0 && alpha <= 1, "scf arguments");
-    dfta_scf_options opt = {DFTA_INT_SIMPSON38, DFTA_XC_VWN, DFTA_AUFBAU_REFERENCE, -1};
+    dfta_scf_options opt = {DFTA_INT_SIMPSON38, DFTA_XC_VWN, DFTA_AUFBAU_REFERENCE, -1, DFTA_SWEEPS_EXACT};
     if (options) opt = *options;
     DFTA_REQUIRE(ctx, opt.poisson_mode >= -1 && opt.poisson_mode <= DFTA_POISSON_TOLERANCE, "poisson mode");
     DFTA_REQUIRE(ctx, dfta_integral_shape_ok(opt.integrator, g->N), "integration rule / grid size");
     DFTA_REQUIRE(ctx, opt.functional >= DFTA_XC_VWN && opt.functional <= DFTA_XC_CHACHIYO_IMPROVED, "functional");
     DFTA_REQUIRE(ctx, opt.functional == DFTA_XC_VWN || !lsda, "the Chachiyo functional is LDA only (ExcCor.h)");
     DFTA_REQUIRE(ctx, opt.aufbau == DFTA_AUFBAU_REFERENCE || opt.aufbau == DFTA_AUFBAU_TRANSITION_METALS, "aufbau");
+    DFTA_REQUIRE(ctx, opt.sweep_mode == DFTA_SWEEPS_EXACT || opt.sweep_mode == DFTA_SWEEPS_TOLERANCE, "sweep mode");
+    DFTA_REQUIRE(ctx, opt.sweep_mode == DFTA_SWEEPS_EXACT || dfta_scan_supported(g), "the tolerance mode of the sweeps needs a logarithmic grid of 12 .. 24 multigrid levels");
     dfta_scf* s = new dfta_scf();
+    s->solver.sweep_mode = opt.sweep_mode;
     s->integ_rule = opt.integrator;
     s->solver.integ_rule = opt.integrator;
     s->functional = opt.functional;

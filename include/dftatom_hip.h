@@ -117,6 +117,18 @@ int dfta_numerov_sweeps_dev(dfta_ctx* ctx, const dfta_grid* g, int kind,
                             const int* dStart, const double* dUs, const double* dUs1,   /* NULL -> device boundary */
                             int* dCount, double* dU0, int* dStartOut, int* dTrip);
 
+/* TOLERANCE MODE of the same two sweeps (opt-in; logarithmic grids of 12 .. 24 multigrid levels): the recurrence of Numerov.h:309-321
+ * is linear in w, w_{i-1} = (2 + f_i/(1 - f_i/12)) w_i - w_{i+1}, so ONE trial is integrated by the 1024 lanes of a workgroup as a
+ * transfer-matrix scan (segment products, log-depth combine, a second pass for the sign changes) in ~25 us at 131 073 points instead
+ * of 4 ms as a dependent chain.  Same cut-off index, start values (device exp) and exit rules as above; a different order of roundings:
+ * node counts equal the exact kernels' except inside the round-off band of a count transition (a few 1e-12 |E| wide), u(0) agrees to
+ * ~1e-9 relative away from its zeros.  count_out holds CountNodes' decision value min(count, nodesLimit + 1); trip_out the loop trips up
+ * to the classical-turning-point exit (not the early return at count > nodesLimit).  fallback_out[t] != 0 (optional): the scan met a
+ * non-finite value or f >= 12 -- the exact kernels must decide that trial (never the case for potentials of an SCF). */
+int dfta_numerov_sweeps_scan(dfta_ctx* ctx, const dfta_grid* g, int kind, int nV, const double* V, int ntrials, const int* vidx,
+                             const int* l, const double* E, const int* nodesLimit, int* count_out, double* u0_out,
+                             int* start_out, int* trip_out, int* fallback_out);
+
 /* Numerov<NonUniform>::SolveSchrodingerMatchSolutionCompletely (Numerov.h:403-504) for a batch of
  * (vidx, l, E); Psi_out: ntrials*N doubles; matchPoint_out: ntrials. */
 int dfta_numerov_match(dfta_ctx* ctx, const dfta_grid* g, int boundary, int nV, const double* V,
@@ -137,6 +149,14 @@ int dfta_numerov_match(dfta_ctx* ctx, const dfta_grid* g, int boundary, int nV, 
  *                              the chained path to ~1e-10 relative (tests).  bottom_hint, if given, is used as is. */
 #define DFTA_LEVELS_CHAINED 0
 #define DFTA_LEVELS_BATCHED 1
+/* OR-ed into `mode` of dfta_solve_levels: the TOLERANCE MODE of the sweeps (see dfta_numerov_sweeps_scan).  The same three bisections
+ * with the same midpoints, every trial integrated by the transfer-matrix scan: one workgroup runs LocateInterval and the u(0)
+ * bisection of its level from start to end on the device -- no rounds, no speculation.  Eigenvalues agree with the exact path to the
+ * width of the round-off band of the reference's own predicates (gate 2e-11 |E| + 1e-11 Ha; sweeps_reference counts stay
+ * the reference's except for decisions inside that band).  Grids of 12 .. 24 multigrid levels; dfta_scf_options::sweep_mode for the SCF. */
+#define DFTA_LEVELS_SCAN_SWEEPS 0x10
+#define DFTA_SWEEPS_EXACT     0
+#define DFTA_SWEEPS_TOLERANCE 1
 
 typedef struct dfta_level_result {
     double E;            /* eigenvalue (level.E, DFTAtom.cpp:534)                       */
@@ -261,7 +281,13 @@ typedef struct dfta_scf_options {
     int functional;   /* DFTA_XC_*                                                                                */
     int aufbau;       /* DFTA_AUFBAU_*                                                                            */
     int poisson_mode; /* DFTA_POISSON_EXACT (0, default) / DFTA_POISSON_TOLERANCE; -1: as dfta_poisson_create ($DFTA_POISSON_MODE) */
+    int sweep_mode;   /* DFTA_SWEEPS_EXACT (0, default) / DFTA_SWEEPS_TOLERANCE (scan sweeps, see DFTA_LEVELS_SCAN_SWEEPS)                */
 } dfta_scf_options;
+/* The option and statistics structs grow at the END between versions of this header and carry no size field: zero-initialise them
+ * (every member's 0 is the reference's behaviour) and build against the header of the library you load -- dfta_abi_version()
+ * returns the DFTA_ABI_VERSION the library was built with, for a run-time check. */
+#define DFTA_ABI_VERSION 4
+int  dfta_abi_version(void);
 int  dfta_scf_create_ex(dfta_ctx* ctx, const dfta_grid* g, int lsda, int natoms, const int* Z, double alpha, int levels_mode,
                         int tree_depth, const dfta_scf_options* options, dfta_scf** out);
 void dfta_scf_destroy(dfta_scf* s);
