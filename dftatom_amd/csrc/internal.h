@@ -25,11 +25,19 @@ int dfta_launch_match(dfta_ctx* ctx, const dfta_grid* g, int ntrials, const doub
                       double* dPsi, double* dQ, int* dMatch, const double2* bounds /* per slot (dfta_bounds_stride), may be null */,
                       const double* dUz = nullptr /* uniform grid: start value at the first node per trial */);
 
-// scan.hip: the tolerance mode of the sweeps (transfer-matrix scan: one workgroup per trial); tabs = nslots * N rows, lane-interleaved
+// scan.hip: the tolerance mode of the sweeps (transfer-matrix scan: one workgroup per trial)
+struct dfta_scan_tables {
+    double* tabv = nullptr;    // nslots * N: veff = V + c_l per slot, lane-interleaved (row i = t C + k at k 512 + t, row N-1 at N-1)
+    double2* mm = nullptr;     // nslots * 512: {min, max} of veff over a lane's rows
+    double* Atop = nullptr;    // 513: A = 2 Rp^2 delta^2 exp(2 i delta) of every lane's top row (and of row N-1)
+    double* T = nullptr;       // C: exp(-2 delta (C-1-k))
+    int nslots = 0;
+};
 int dfta_scan_supported(const dfta_grid* g);
-// mm: nslots * 1024 {min, max} of veff per lane segment
-int dfta_launch_scan_build_tab(dfta_ctx* ctx, const dfta_grid* g, double2* tabs, double2* mm, const double* dV, const int* d_slot_v, const int* d_slot_l, int nslots);
-int dfta_launch_scan_sweeps(dfta_ctx* ctx, const dfta_grid* g, int kind, int ntrials, const double2* tabs, const double2* mm, const int* d_trial_slot,
+int dfta_scan_tables_create(dfta_ctx* ctx, const dfta_grid* g, int nslots, dfta_scan_tables* tb);
+void dfta_scan_tables_destroy(dfta_scan_tables* tb);
+int dfta_launch_scan_build_tab(dfta_ctx* ctx, const dfta_grid* g, const dfta_scan_tables& tb, const double* dV, const int* d_slot_v, const int* d_slot_l);
+int dfta_launch_scan_sweeps(dfta_ctx* ctx, const dfta_grid* g, int kind, int ntrials, const dfta_scan_tables& tb, const int* d_trial_slot,
                             const double* dE, const int* dLimit, int* dCount, double* dU0, int* dStart, int* dTrip, int* dBad);
 
 // reduce.hip: Integral::{Trapezoid,SimpsonOneThird,Simpson38,Boole,Romberg} (Integral.h:11-155) with the reference's

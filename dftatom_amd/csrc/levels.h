@@ -3,6 +3,7 @@
 #include <vector>
 
 #include "common.h"
+#include "internal.h"
 
 namespace dfta {
 
@@ -119,7 +120,7 @@ struct LevelSolver {
     bool early_match = false;
     // Tolerance mode of the sweeps (scan.hip; DFTA_SWEEPS_TOLERANCE, set before setup()): interleaved tables per slot, per-lane {min, max}
     int sweep_mode = DFTA_SWEEPS_EXACT;
-    double2 *d_stab = nullptr, *d_smm = nullptr;
+    dfta_scan_tables scan_tb;
     int scan_fallbacks = 0;         // solves the scan handed back to the exact kernels (a trial it could not decide)
 
     LevelSolver() = default;
@@ -139,4 +140,4 @@ struct LevelSolver {
 // scan.hip: LocateInterval + the u(0) bisection of every chain of jobs by one workgroup each; counters[0] += executed sweeps,
 // counters[1] += traversed points, counters[3] |= 1 when a sweep could not be decided by the scan
 int dfta_launch_scan_levels(dfta_ctx* ctx, const dfta_grid* g, dfta::Job* d_jobs, const int* d_chain_off, int nchains, int chained,
-                            const double2* tabs, const double2* mm, int fixed_point, unsigned long long* d_counters);
+                            const dfta_scan_tables& tb, int fixed_point, unsigned long long* d_counters);

@@ -1079,9 +1079,7 @@ void LevelSolver::release()
                     d_u0, d_phi, d_istop, d_trip, d_wave_job, d_wave_kind, d_wave_slot, d_wave_first, d_wave_cnt, d_counters, d_Psi, d_Q, d_jE, d_jslot, d_jl,
                     d_jstart, d_jus, d_jus1, d_jmp, d_slot_min, d_bounds};
     for (void* p : ptrs) if (p) (void)hipFree(p);
-    if (d_stab) (void)hipFree(d_stab);
-    if (d_smm) (void)hipFree(d_smm);
-    d_stab = nullptr; d_smm = nullptr;
+    dfta_scan_tables_destroy(&scan_tb);
     if (d_jmatched) (void)hipFree(d_jmatched);
     if (d_jstart_keep) (void)hipFree(d_jstart_keep);
     d_jmatched = nullptr; d_jstart_keep = nullptr;
@@ -1267,8 +1265,8 @@ int LevelSolver::setup(dfta_ctx* c, const dfta_grid* grid, int mode_, int tree_d
     ALLOC(d_slot_min, double, nslots);
     ALLOC(d_bounds, double2, (size_t)nslots * dfta_bounds_stride(g));
     if (sweep_mode == DFTA_SWEEPS_TOLERANCE && dfta_scan_supported(g)) {      // scan.hip: interleaved tables + per-lane {min, max}
-        ALLOC(d_stab, double2, (size_t)nslots * N);
-        ALLOC(d_smm, double2, (size_t)nslots * 1024);
+        const int trc = dfta_scan_tables_create(ctx, g, nslots, &scan_tb);
+        if (trc) return trc;
     }
 #undef ALLOC
 #undef UPLOAD
@@ -1401,13 +1399,13 @@ int LevelSolver::run(const double* dV, const double* job_bottom, int run_mode, d
     // TOLERANCE MODE of the sweeps (scan.hip, opt-in): every level's three bisections by one workgroup, start to end on the device --
     // no rounds, no speculation.  A sweep the scan cannot decide (non-finite values, f >= 12 in a step row: never seen for the
     // potential of an SCF) sends the whole solve to the exact kernels below.
-    bool scan = sweep_mode == DFTA_SWEEPS_TOLERANCE && d_stab != nullptr;
+    bool scan = sweep_mode == DFTA_SWEEPS_TOLERANCE && scan_tb.tabv != nullptr;
     float ms_scan = 0;
     if (scan) {
-        rc = dfta_launch_scan_build_tab(ctx, g, d_stab, d_smm, dV, d_slot_v, d_slot_l, nslots);
+        rc = dfta_launch_scan_build_tab(ctx, g, scan_tb, dV, d_slot_v, d_slot_l);
         if (rc) return rc;
         DFTA_HIP(ctx, hipEventRecord(ev[0], st));
-        rc = dfta_launch_scan_levels(ctx, g, d_jobs, d_chains, run_chains, chained ? 1 : 0, d_stab, d_smm, dfta_knob("LEVELS_NOFIXEDPOINT") ? 0 : 1, d_counters);
+        rc = dfta_launch_scan_levels(ctx, g, d_jobs, d_chains, run_chains, chained ? 1 : 0, scan_tb, dfta_knob("LEVELS_NOFIXEDPOINT") ? 0 : 1, d_counters);
         if (rc) return rc;
         DFTA_HIP(ctx, hipEventRecord(ev[1], st));
         unsigned long long flag = 0;

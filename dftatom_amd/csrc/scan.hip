@@ -10,18 +10,20 @@
 // is LINEAR in w:  w_{i-1} = (2 + g_i) w_i - w_{i+1},  g_i = f_i / (1 - f_i/12).  In the summed form
 //     D_{i-1} = D_i + g_i w_i,   w_{i-1} = w_i + D_{i-1}          (D_i = w_i - w_{i+1})
 // one step is the 2x2 matrix [[1+g, 1], [g, 1]] acting on (w, D); products of such matrices are associative, so the sweep of ONE
-// trial is spread over the 1024 lanes of a workgroup: lane t multiplies the matrices of its own C = (N-1)/1024 grid points (two
-// independent columns: 2 fma + 2 add per point, g from the table row in 8 instructions), a log-depth scan over the lanes combines
-// the 1024 segment matrices (wave shuffles + one hand-over through LDS), and -- CountNodes only -- a second pass over the segment
-// with the now known incoming (w, D) counts the sign changes.  A 131 073-point sweep takes ~25 us on one compute unit instead of
-// 4 ms as a dependent chain, so the bisections of a level need no speculation: ONE workgroup runs LocateInterval and the
-// u(0) bisection of its level from start to end on the device (k_scan_levels), ~150 sweeps back to back, no host round trips.
-// The summed form carries the slope D separately (no 2w - w' cancellation), which makes it slightly MORE accurate than the
-// reference's own rounding sequence; what differs from the exact kernels is only which way round-off falls.
+// trial is spread over the 512 lanes of a workgroup: lane t multiplies the matrices of its own C = (N-1)/512 grid points (two
+// independent columns: 2 fma + 2 add per point, g from the table row in 7 instructions), a log-depth scan over the lanes combines
+// the 512 segment matrices (wave shuffles + one hand-over through LDS), and -- CountNodes only -- a second pass over the rows of
+// the classically allowed lanes with the now known incoming (w, D) counts the sign changes.  A 131 073-point sweep takes 35 (u(0)) ...
+// 75 us (count) on one compute unit instead of 4 ms as a dependent chain, so the bisections of a level need no speculation: ONE
+// workgroup runs LocateInterval and the u(0) bisection of its level from start to end on the device (k_scan_levels), ~150 sweeps back
+// to back, no host round trips.  What bounds it: fp64 VALU issue of the one compute unit (~20 instructions per row and lane).
+// The summed form carries the slope D as a variable of its own (the reference forms it as 2w - w', a difference of numbers that agree
+// to 3-4 digits): tests/test_scan_precision.py shows it ~1000x closer to the 80-bit eigenvalue than the reference's own double
+// arithmetic -- the gate against the exact kernels (6e-11 |E| + 6e-10 Ha) measures the reference's rounding bias.
 //
-// Table: per slot (potential, l) rows { veff_i, A_i = 2 Rp^2 delta^2 exp(2 i delta) }, f_i = A_i (veff_i - E) + delta^2/4
-// (Numerov.h:96-101), LANE-INTERLEAVED: row i = t C + k is stored at k 1024 + t, so that the 1024 lanes read consecutive
-// addresses at every step (the layout idea of the multigrid levels).
+// Table: per slot (potential, l) the rows veff_i (8 bytes), f_i = A_i (veff_i - E) + delta^2/4 with A_i = 2 Rp^2 delta^2 exp(2 i delta)
+// (Numerov.h:96-101) factored per grid as Atop[t] T[k]; LANE-INTERLEAVED: row i = t C + k is stored at k 512 + t, so that the 512 lanes
+// read consecutive addresses at every step (the layout idea of the multigrid levels).
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -33,16 +35,33 @@
 #include "internal.h"
 #include "levels.h"
 
+#ifdef DFTA_SCAN_PROF
+// -DDFTA_SCAN_PROF: wave 0 accumulates the clock ticks (100 MHz wall clock) spent in the sections of scan_sweep; dfta_debug_scan_prof reads them
+__device__ unsigned long long g_scan_prof[16];
+#define SCAN_TICK(slot) do { if (threadIdx.x == 0) { const unsigned long long now_ = wall_clock64(); atomicAdd(&g_scan_prof[slot], now_ - tick_); tick_ = now_; } } while (0)
+#define SCAN_TICK0() unsigned long long tick_ = wall_clock64()
+#else
+#define SCAN_TICK(slot) do { } while (0)
+#define SCAN_TICK0() do { } while (0)
+#endif
+
 namespace {
 
-constexpr int kT = 1024;          // lanes per trial = threads per workgroup
+constexpr int kLogT = 9;
+constexpr int kT = 1 << kLogT;    // lanes per trial = threads per workgroup: 8 waves, two per SIMD, 256 VGPRs each
 constexpr int kW = kT / 64;       // waves per workgroup
 constexpr double kInv12 = 1. / 12.;
 
+// Tables (device): veff rows lane-interleaved per slot (N doubles: row i = t C + k at k 512 + t, row N-1 at N-1), per slot and lane
+// {min, max} of veff, and per GRID the factors of A_i = 2 Rp^2 delta^2 exp(2 i delta) = Atop[t] T[k]: Atop[t] = A of the lane's top
+// row (Atop[512] = A_{N-1}), T[k] = exp(-2 delta (C-1-k)) -- so that a row costs 8 bytes of L2 traffic, not 16.
 struct ScanGrid {
-    int N, logC;                  // N - 1 = 1024 << logC
+    int N, logC;                  // N - 1 = kT << logC
     double delta, far_thr, c4;    // delta, exp(a) < 1e-200 <=> a < far_thr, delta^2/4
+    double Rp;
     const double* r;              // r_i
+    const double* Atop;           // 1025
+    const double* T;              // C
 };
 
 struct Mat { double a, b, c, d; };   // [[a, b], [c, d]] acting on (w, D)
@@ -59,21 +78,21 @@ __device__ __forceinline__ Mat mat_mul(const Mat& L, const Mat& E)    // L after
 
 __device__ __forceinline__ double shfl_up_d(double v, int off) { return __shfl_up(v, off, 64); }
 
-// g = f / (1 - f/12) = f (1 + x)(1 + x^2)(1 + x^4) + O(x^8), x = f/12.  |x| <= 2^-7 on every grid of BASELINE (f <= (460 delta)^2 at
-// the cut-off) makes the remainder < 2^-56; rows beyond that (large delta; the innermost rows of l = 3, where f -> l(l+1)) are
-// detected per sweep (xmax) and the sweep is repeated with an IEEE division per row
-template <bool DIV>
-__device__ __forceinline__ double g_of(double f, double& xmax)
+// g = f / (1 - f/12) = f (1 + x)(1 + x^2)(1 + x^4) + O(x^8), x = f/12.  Which form a lane uses is decided BEFORE its rows are read, from
+// a bound on |x| over its rows (A <= Atop, veff in [min, max]): V4 for |x| <= 2^-14.5 (x^4 < 2^-58), V8 for |x| <= 2^-7, else an IEEE division.
+enum GVar { V4 = 0, V8 = 1, VDIV = 2 };
+template <int V>
+__device__ __forceinline__ double g_of(double f)
 {
     const double x = f * kInv12;
-    xmax = fmax(xmax, fabs(x));
-    if (DIV) return f / (1. - x);
+    if (V == VDIV) return f / (1. - x);
     const double x2 = x * x;
     const double t1 = fma(f, x, f);
     const double t2 = fma(t1, x2, t1);
+    if (V == V4) return t2;
     return fma(t2, x2 * x2, t2);
 }
-constexpr double kSeriesMax = 0.0078125;
+constexpr double kX4 = 4.3e-5, kX8 = 0.0078125;
 
 // turning-point summary of a stretch of rows in sweep order (descending index); combine(X earlier/higher, Y later/lower)
 struct Turn { int amax, fmax, fbelow; };   // largest allowed index (veff <= E), largest forbidden index, largest forbidden index below amax
@@ -87,179 +106,267 @@ __device__ __forceinline__ Turn turn_combine(const Turn& X, const Turn& Y)
 }
 
 struct ScanShared {
-    Mat wave_tot[kW];
-    Turn wave_turn[kW];
-    int red[kW];
+    Mat wave_tot[2][kW];          // double-buffered by sweep parity: a wave is never two sweeps ahead (every sweep has a barrier)
+    int wave_bad[2][kW];
+    Turn wave_turn[2][kW];
+    int red[2][kW];
 };
 
 struct SweepOut {
     int count;          // COUNT: min(sign changes, limit + 1) (+ the final extrapolated test); the decision value of CountNodes
     int start, iexit;   // cut-off index, index at which CountNodes returned (0: ran to the end)
     double u0;          // ZERO: u_1 (2 + f_1) - u_2 (Numerov.h:398)
-    double w1, w2;      // the last two w of the sweep (indices 1, 2) when it ran to the end
-    int bad;            // a non-finite value or f >= 12 above the innermost row: the exact kernels must decide this trial
+    int bad;            // a non-finite value or f >= 12 in a step row: the exact kernels must decide this trial
 };
 
-__device__ __forceinline__ int block_min_int(int v, ScanShared& sh, int tid)
-{
-    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
-    __syncthreads();
-    if ((tid & 63) == 0) sh.red[tid >> 6] = v;
-    __syncthreads();
-    int m = sh.red[0];
-#pragma unroll
-    for (int w = 1; w < kW; ++w) m = min(m, sh.red[w]);
-    return m;
-}
-__device__ __forceinline__ int block_sum_int(int v, ScanShared& sh, int tid)
-{
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    __syncthreads();
-    if ((tid & 63) == 0) sh.red[tid >> 6] = v;
-    __syncthreads();
-    int m = 0;
-#pragma unroll
-    for (int w = 0; w < kW; ++w) m += sh.red[w];
-    return m;
-}
-
+// i is the same in every lane: the table value comes through the scalar cache
 __device__ __forceinline__ double far_arg_s(const double* __restrict__ r, int i, double s, double delta)
 {
-    return -r[i] * s - static_cast<double>(i) * delta * 0.5;      // Numerov.h:107
+    const int iu = __builtin_amdgcn_readfirstlane(i);
+    return -r[iu] * s - static_cast<double>(iu) * delta * 0.5;      // Numerov.h:107
 }
 
-// GetMaxRadiusIndex (Numerov.h:119-136) for a monotone start value: the smallest index >= 2 whose start value is below 1e-200, N-1 if none
-__device__ int scan_cutoff(const ScanGrid& G, double s, ScanShared& sh, int tid)
+// GetMaxRadiusIndex (Numerov.h:119-136): the start value exp(-r_i sqrt(2|E|) - i delta/2) falls monotonically with i, so the integer
+// bisection returns the smallest index >= 2 whose start value is below 1e-200 (N-1 if none).  Settled on the table values themselves,
+// starting from the cut-off of the previous trial of the bisection (it moves by less than a cell after the first few halvings) or from
+// the root of Rp sq (e^x - 1) + x/2 = -far_thr, x = i delta (Newton's method).  Every lane does the same.
+__device__ int scan_cutoff(const ScanGrid& G, double sq, int hint)
 {
-    const int C = 1 << G.logC;
-    // first the segment: lane tid looks at the LAST index of segment tid
-    const int iend = min(tid * C + C, G.N - 1);
-    int cand = (iend >= 2 && far_arg_s(G.r, iend, s, G.delta) < G.far_thr) ? tid : kT;
-    const int seg = block_min_int(cand, sh, tid);
-    if (seg >= kT) return G.N - 1;
-    // then the index inside (seg C, seg C + C]
-    int best = G.N;
-    for (int k = tid; k < C; k += kT) {
-        const int i = seg * C + 1 + k;
-        if (i >= 2 && far_arg_s(G.r, i, s, G.delta) < G.far_thr) { best = i; break; }     // ascending k: the first hit of this lane
+    auto below = [&](int i) { return far_arg_s(G.r, i, sq, G.delta) < G.far_thr; };
+    auto settle = [&](int i0, int maxsteps, bool& ok) {
+        int n = 0;
+        const bool b1 = i0 > 2 && below(i0 - 1), b0 = i0 >= G.N - 1 || below(i0);     // both table values in flight at once
+        if (!b1 && b0) { ok = true; return i0; }
+        while (n < maxsteps && i0 > 2 && below(i0 - 1)) { --i0; ++n; }
+        while (n < maxsteps && i0 < G.N - 1 && !below(i0)) { ++i0; ++n; }
+        ok = n < maxsteps;
+        return i0;
+    };
+    bool ok = false;
+    int i0 = 0;
+    if (hint >= 2 && hint <= G.N - 1) i0 = settle(hint, 3, ok);
+    if (ok) return i0;
+    const double c = -G.far_thr, a = G.Rp * sq;
+    i0 = G.N - 1;
+    if (a > 0.) {
+        double x = log(c / a + 1.);
+        for (int it = 0; it < 4; ++it) {
+            const double ex = exp(x);
+            x -= (a * (ex - 1.) + 0.5 * x - c) / (a * ex + 0.5);
+        }
+        const double fi = ceil(x / G.delta);
+        i0 = fi < 2. ? 2 : (fi > static_cast<double>(G.N - 1) ? G.N - 1 : static_cast<int>(fi));
     }
-    return block_min_int(best, sh, tid);
+    return settle(i0, 1 << 30, ok);
 }
 
-constexpr int kBatch = 8;
-// rows [klo, khi] of a lane's segment (descending), kBatch table rows in flight
-template <typename F>
-__device__ __forceinline__ void for_rows(const double2* __restrict__ p, int khi, int klo, F&& step)
+// ---- the row loops --------------------------------------------------------------------------------------------------------------
+// pv: the lane's column of the slot's veff table (row k at pv[k << kLogT]); A_k = Atop T[k]; f = A (veff - E) + c4.
+// gam = 1: the row is taken; gam = 0: the state stays as it is (rows of a lane outside [lo, s-1]; exact either way: fma(1, x, y) = x + y)
+struct Pass1 {        // transfer matrix of the rows, two columns
+    Mat M;
+    template <int V> __device__ __forceinline__ void row(double f)
+    {
+        const double g = g_of<V>(f);
+        M.c = fma(g, M.a, M.c); M.a += M.c;
+        M.d = fma(g, M.b, M.d); M.b += M.d;
+    }
+    template <int V> __device__ __forceinline__ void row_gated(double f, double gam)
+    {
+        const double g = gam * g_of<V>(f);
+        M.c = fma(g, M.a, M.c); M.a = fma(gam, M.c, M.a);
+        M.d = fma(g, M.b, M.d); M.b = fma(gam, M.d, M.b);
+    }
+};
+struct Pass2 {        // sign changes of w along the rows, from (w, D); per lane
+    double w, D;
+    int cnt;
+    template <int V> __device__ __forceinline__ void row(double f)
+    {
+        const double g = g_of<V>(f);
+        D = fma(g, w, D);
+        const double wn = w + D;
+        cnt += ((wn > 0.) != (w > 0.));
+        w = wn;
+    }
+    template <int V> __device__ __forceinline__ void row_gated(double f, double gam)
+    {
+        const double g = gam * g_of<V>(f);
+        D = fma(g, w, D);
+        const double wn = fma(gam, D, w);
+        cnt += ((wn > 0.) != (w > 0.));
+        w = wn;
+    }
+};
+struct Pass2W {       // the same for a wave whose lanes all run all their rows: the changes are counted per wave in scalar registers
+    double w, D;
+    unsigned long long prev;
+    int cnt;
+    template <int V> __device__ __forceinline__ void row(double f)
+    {
+        const double g = g_of<V>(f);
+        D = fma(g, w, D);
+        w = w + D;
+        const unsigned long long m = __ballot(w > 0.);
+        cnt += __popcll(m ^ prev);
+        prev = m;
+    }
+    template <int V> __device__ __forceinline__ void row_gated(double f, double) { row<V>(f); }
+};
+
+// rows [klo, khi] of one lane (per-lane bounds), descending, eight rows in flight: small grids (C < 16) and the innermost rows.
+// tabv: the slot's table (wave-uniform pointer), t: the lane's column.
+template <int V, typename P>
+__device__ __forceinline__ void rows_lane(const double* __restrict__ tabv, int t, const double* __restrict__ T, double Atop, int khi, int klo, double E, double c4, P& ps)
 {
     int k = khi;
-    for (; k - (kBatch - 1) >= klo; k -= kBatch) {
-        double2 r[kBatch];
+    for (; k - 7 >= klo; k -= 8) {
+        double v[8], tk[8];
 #pragma unroll
-        for (int j = 0; j < kBatch; ++j) r[j] = p[(size_t)(k - j) << 10];
+        for (int j = 0; j < 8; ++j) { v[j] = tabv[((size_t)(k - j) << kLogT) + t]; tk[j] = T[k - j]; }
 #pragma unroll
-        for (int j = 0; j < kBatch; ++j) step(r[j]);
+        for (int j = 0; j < 8; ++j) ps.template row<V>(fma(Atop * tk[j], v[j] - E, c4));
     }
-    for (; k >= klo; --k) step(p[(size_t)k << 10]);
+    if (k >= klo) {
+        double v[8], tk[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const int kk = k - j >= klo ? k - j : klo; v[j] = tabv[((size_t)kk << kLogT) + t]; tk[j] = T[kk]; }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) if (k - j >= klo) ps.template row<V>(fma(Atop * tk[j], v[j] - E, c4));
+    }
 }
 
-// the innermost rows (index < 16) are always divided: there f -> l(l+1)/i^2 is far outside the series' range
+// all C rows of the wave's lanes (C a multiple of 16), descending, two batches of eight rows in flight; the row pointer and T[k] are
+// wave-uniform (scalar address arithmetic, scalar loads).  PRED: a lane takes only its rows in [klo, khi] (the waves that hold the
+// cut-off, the exit point or the innermost lane) -- by a 0/1 factor, not by branches.
+template <int V, bool PRED, typename P>
+__device__ __forceinline__ void rows_wave(const double* __restrict__ tabv, int t, const double* __restrict__ T, double Atop, int C, int khi, int klo, double E,
+                                          double c4, P& ps)
+{
+    const unsigned tu = static_cast<unsigned>(t);      // uniform row pointer + 32-bit lane offset: the load's own addressing mode
+    auto rowp = [&](int k) { return tabv + ((size_t)(k < 0 ? 0 : k) << kLogT); };
+    double v0[8], v1[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v0[j] = rowp(C - 1 - j)[tu];
+    for (int k = C - 1; k >= 0; k -= 16) {
+        const int ku = __builtin_amdgcn_readfirstlane(k);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v1[j] = rowp(ku - 8 - j)[tu];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const double f = fma(Atop * T[ku - j], v0[j] - E, c4);
+            if (PRED) ps.template row_gated<V>(f, (ku - j <= khi && ku - j >= klo) ? 1. : 0.); else ps.template row<V>(f);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v0[j] = rowp(ku - 16 - j)[tu];       // below row 0 (last turn): row 0 again, unused
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const double f = fma(Atop * T[ku - 8 - j], v1[j] - E, c4);
+            if (PRED) ps.template row_gated<V>(f, (ku - 8 - j <= khi && ku - 8 - j >= klo) ? 1. : 0.); else ps.template row<V>(f);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// the innermost rows (index < 16) are always divided: there f -> l(l+1)/i^2 is far outside the series' range (row 1 of l = 3 has f > 12)
 constexpr int kInnerRows = 16;
 
-// pass 1: the transfer matrix of rows [klo, khi] (two columns), min of f (all rows forbidden <=> fmin >= 0), max |f/12|
-template <bool DIV>
-__device__ __forceinline__ void pass1_rows(const double2* __restrict__ p, int khi, int klo, bool inner, double E, double c4, Mat& M, double& fmin, double& xmax)
+template <int V, typename P>
+__device__ __forceinline__ void run_rows_v(const double* __restrict__ tabv, int t, const double* __restrict__ T, double Atop, int C, int khi, int klo, bool full,
+                                           bool inner, double E, double c4, P& ps)
 {
-    auto step_s = [&](const double2 row) {
-        const double f = fma(row.y, row.x - E, c4);
-        const double g = g_of<DIV>(f, xmax);
-        fmin = fmin < f ? fmin : f;
-        M.c = fma(g, M.a, M.c); M.a += M.c;
-        M.d = fma(g, M.b, M.d); M.b += M.d;
-    };
-    if (!inner || DIV) { for_rows(p, khi, klo, step_s); return; }
-    double xin = 0;
-    auto step_d = [&](const double2 row) {
-        const double f = fma(row.y, row.x - E, c4);
-        const double g = g_of<true>(f, xin);
-        fmin = fmin < f ? fmin : f;
-        M.c = fma(g, M.a, M.c); M.a += M.c;
-        M.d = fma(g, M.b, M.d); M.b += M.d;
-    };
-    if (khi >= kInnerRows) for_rows(p, khi, max(klo, kInnerRows), step_s);
-    if (klo < kInnerRows) for_rows(p, min(khi, kInnerRows - 1), klo, step_d);
+    if (C >= 16) {
+        if (full) rows_wave<V, false>(tabv, t, T, Atop, C, khi, klo, E, c4, ps);
+        else rows_wave<V, true>(tabv, t, T, Atop, C, khi, inner ? max(klo, kInnerRows) : klo, E, c4, ps);
+        if (inner && klo < kInnerRows && khi >= klo) rows_lane<VDIV>(tabv, t, T, Atop, min(khi, kInnerRows - 1), klo, E, c4, ps);
+        return;
+    }
+    if (khi < klo) return;
+    if (inner) rows_lane<VDIV>(tabv, t, T, Atop, khi, klo, E, c4, ps);
+    else rows_lane<V>(tabv, t, T, Atop, khi, klo, E, c4, ps);
 }
 
-// pass 2: sign changes between consecutive w over rows [klo, khi], starting from (w, D)
-template <bool DIV>
-__device__ __forceinline__ int pass2_rows(const double2* __restrict__ p, int khi, int klo, bool inner, double E, double c4, double w, double D)
+// `full` and `var` are wave-uniform
+template <typename P>
+__device__ __forceinline__ void run_rows(const double* __restrict__ tabv, int t, const double* __restrict__ T, double Atop, int C, int khi, int klo, bool full,
+                                         bool inner, int var, double E, double c4, P& ps)
 {
-    int cnt = 0;
-    double xm = 0;
-    auto step_s = [&](const double2 row) {
-        const double f = fma(row.y, row.x - E, c4);
-        const double g = g_of<DIV>(f, xm);
-        D = fma(g, w, D);
-        const double wn = w + D;
-        cnt += ((wn > 0.) != (w > 0.));
-        w = wn;
-    };
-    if (!inner || DIV) { for_rows(p, khi, klo, step_s); return cnt; }
-    auto step_d = [&](const double2 row) {
-        const double f = fma(row.y, row.x - E, c4);
-        const double g = g_of<true>(f, xm);
-        D = fma(g, w, D);
-        const double wn = w + D;
-        cnt += ((wn > 0.) != (w > 0.));
-        w = wn;
-    };
-    if (khi >= kInnerRows) for_rows(p, khi, max(klo, kInnerRows), step_s);
-    if (klo < kInnerRows) for_rows(p, min(khi, kInnerRows - 1), klo, step_d);
-    return cnt;
+    if (var == V4) run_rows_v<V4>(tabv, t, T, Atop, C, khi, klo, full, inner, E, c4, ps);
+    else if (var == V8) run_rows_v<V8>(tabv, t, T, Atop, C, khi, klo, full, inner, E, c4, ps);
+    else run_rows_v<VDIV>(tabv, t, T, Atop, C, khi, klo, full, inner, E, c4, ps);
 }
 
-// One sweep of one trial by the whole workgroup.  KIND: DFTA_SWEEP_COUNT / DFTA_SWEEP_ZERO.  tab: the slot's interleaved table; mm: per
-// lane {min, max} of veff over the lane's rows ({-inf, +inf} when a row is NaN).
+// One sweep of one trial by the whole workgroup.  KIND: DFTA_SWEEP_COUNT / DFTA_SWEEP_ZERO.  tabv: the slot's interleaved veff table;
+// mm: per lane {min, max} of veff over the lane's rows ({-inf, +inf} when a row is NaN).
 template <int KIND>
-__device__ SweepOut scan_sweep(const ScanGrid& G, const double2* __restrict__ tab, const double2* __restrict__ mm, double E, int limit, ScanShared& sh)
+__device__ SweepOut scan_sweep(const ScanGrid& G, const double* __restrict__ tabv, const double2* __restrict__ mm, double E, int limit, ScanShared& sh, unsigned par,
+                               int hint = 0)
 {
     const int tid = threadIdx.x;
     const int t = kT - 1 - tid;                 // segment of this lane: thread order = sweep order (descending index)
     const int C = 1 << G.logC;
     const int lane = tid & 63, wv = tid >> 6;
     SweepOut out;
-    out.count = 0; out.u0 = 0; out.bad = 0; out.iexit = 0; out.w1 = out.w2 = 0;
+    out.count = 0; out.u0 = 0; out.bad = 0; out.iexit = 0;
+    SCAN_TICK0();
     const double sq = sqrt(2. * fabs(E));
-    const int s = scan_cutoff(G, sq, sh, tid);
+    const int s = scan_cutoff(G, sq, hint);
+    SCAN_TICK(0);
     out.start = s;
     const double us = exp(far_arg_s(G.r, s, sq, G.delta));          // GetBoundaryValueFar at the cut-off and one point inside
     const double us1 = exp(far_arg_s(G.r, s - 1, sq, G.delta));
-    auto row_of = [&](int i) -> double2 { return (i == (kT << G.logC)) ? tab[(size_t)kT << G.logC] : tab[((size_t)(i & (C - 1)) << 10) + (i >> G.logC)]; };
-    const double2 rs = row_of(s), rs1 = row_of(s - 1);
-    const double fs = fma(rs.y, rs.x - E, G.c4), fs1 = fma(rs1.y, rs1.x - E, G.c4);
+    auto f_of_row = [&](int ii) -> double {          // ii is the same in every lane: scalar loads
+        const int i = __builtin_amdgcn_readfirstlane(ii);
+        const bool last = (i == (kT << G.logC));
+        const double v = last ? tabv[(size_t)kT << G.logC] : tabv[((size_t)(i & (C - 1)) << kLogT) + (i >> G.logC)];
+        const double A = last ? G.Atop[kT] : G.Atop[i >> G.logC] * G.T[i & (C - 1)];
+        return fma(A, v - E, G.c4);
+    };
+    const double f1 = f_of_row(1), f2 = f_of_row(2);          // for the end of the sweep: in flight from here
+    const double fs = f_of_row(s), fs1 = f_of_row(s - 1);
     const double ws = (1. - kInv12 * fs) * us, ws1 = (1. - kInv12 * fs1) * us1;        // Numerov.h:297,302
     const int ibase = t << G.logC;
-    const double2* p = tab + t;
+    const double Atop = G.Atop[t];
+    const double2 m = mm[t];
+    SCAN_TICK(1);
     // ---- CountNodes: where does the sweep leave through the classical turning point (Numerov.h:337-341)?  The loop index runs over
-    // [1, s-2]; lanes whose rows lie on one side of E answer from {min, max}, the others look at their rows
+    // [1, s-2]; lanes whose rows lie on one side of E answer from {min, max}; the rows of the others are looked at by their whole wave
     int iexit = 0;
     if (KIND == DFTA_SWEEP_COUNT) {
         Turn tu = {-1, -1, -1};
         const int top = min(s - 2, ibase + C - 1), bot = max(1, ibase);
+        int cls = 0;
         if (top >= bot) {
-            const double2 m = mm[t];
-            if (m.x > E) tu.fmax = top;                 // every row forbidden
-            else if (m.y <= E) tu.amax = top;           // every row allowed
-            else {
-                int i = top;
-                for_rows(p, top - ibase, bot - ibase, [&](const double2 row) {
-                    const double tt = row.x - E;
-                    const bool al = tt <= 0., fo = tt > 0.;
-                    tu.amax = (al && tu.amax < 0) ? i : tu.amax;
-                    tu.fbelow = (fo && tu.amax >= 0 && tu.fbelow < 0) ? i : tu.fbelow;
-                    tu.fmax = (fo && tu.fmax < 0) ? i : tu.fmax;
-                    --i;
-                });
+            if (m.x > E) { tu.fmax = top; cls = 1; }         // every row forbidden
+            else if (m.y <= E) { tu.amax = top; cls = 2; }   // every row allowed
+            else cls = 3;
+        }
+        unsigned long long mixed = __ballot(cls == 3);
+        while (mixed) {
+            const int src = __ffsll(static_cast<long long>(mixed)) - 1;
+            mixed &= mixed - 1;
+            const int ts = kT - 1 - ((tid & ~63) + src), ib = ts << G.logC;
+            const int tp = __shfl(top, src, 64), bt = __shfl(bot, src, 64);
+            Turn acc = {-1, -1, -1};
+            for (int base = (tp - ib) & ~63; base >= 0 && ib + base + 63 >= bt; base -= 64) {
+                const int k = base + lane, i = ib + k;
+                const bool valid = k < C && i <= tp && i >= bt;
+                const double tt = valid ? tabv[((size_t)k << kLogT) + ts] - E : 0.;
+                const unsigned long long Am = __ballot(valid && tt <= 0.), Fm = __ballot(valid && tt > 0.);
+                Turn ch = {-1, -1, -1};
+                if (Am) {
+                    const int ba = 63 - __clzll(static_cast<long long>(Am));
+                    ch.amax = ib + base + ba;
+                    const unsigned long long below = ba ? (Fm & ((1ull << ba) - 1ull)) : 0ull;
+                    if (below) ch.fbelow = ib + base + 63 - __clzll(static_cast<long long>(below));
+                }
+                if (Fm) ch.fmax = ib + base + 63 - __clzll(static_cast<long long>(Fm));
+                acc = turn_combine(acc, ch);
             }
+            if (lane == src) tu = acc;
         }
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {     // inclusive scan of the summaries: lane 63 ends up with the wave's
@@ -267,32 +374,34 @@ __device__ SweepOut scan_sweep(const ScanGrid& G, const double2* __restrict__ ta
             X.amax = __shfl_up(tu.amax, off, 64); X.fmax = __shfl_up(tu.fmax, off, 64); X.fbelow = __shfl_up(tu.fbelow, off, 64);
             if (lane >= off) tu = turn_combine(X, tu);
         }
+        if (lane == 63) sh.wave_turn[par][wv] = tu;
         __syncthreads();
-        if (lane == 63) sh.wave_turn[wv] = tu;
-        __syncthreads();
-        Turn all = sh.wave_turn[0];
+        Turn all = sh.wave_turn[par][0];
 #pragma unroll
-        for (int q = 1; q < kW; ++q) all = turn_combine(all, sh.wave_turn[q]);
+        for (int q = 1; q < kW; ++q) all = turn_combine(all, sh.wave_turn[par][q]);
         iexit = all.fbelow >= 0 ? all.fbelow : 0;       // the first forbidden index below the first allowed one; 0: none
     }
     out.iexit = iexit;
+    SCAN_TICK(2);
     // ---- pass 1: the segment's transfer matrix (two columns) over its step rows in [lo, s-1]; step i maps (w_i, D_i) to (w_{i-1}, D_{i-1})
     const int lo = max(iexit + 1, 2), hi = s - 1;
     const int khi = min(hi - ibase, C - 1), klo = max(lo - ibase, 0);
-    Mat M = {1., 0., 0., 1.};
-    double fmin = 1., xmax = 0.;
     const bool inner = (t == 0);                     // the lane that owns the innermost rows
-    if (khi >= klo) pass1_rows<false>(p, khi, klo, inner, E, G.c4, M, fmin, xmax);
-    const bool use_div = __syncthreads_or(xmax > kSeriesMax) != 0;
-    double xall = xmax;
-    if (use_div) {                                   // a row outside the series' range somewhere: all lanes again, with the division
-        M.a = 1.; M.b = 0.; M.c = 0.; M.d = 1.;
-        fmin = 1.; xall = 0.;
-        if (khi >= klo) pass1_rows<true>(p, khi, klo, inner, E, G.c4, M, fmin, xall);
-    }
-    // f >= 12 in a step row (d <= 0: u and w differ in sign) is left to the exact kernels.  (The series rows have |x| <= 2^-7, the
-    // inner rows of pass1_rows<false> keep their own maximum: row 1 of l = 3 has f > 12 by construction and is no step row.)
-    int bad = !(xall < 1.);
+    const bool covered = (khi == C - 1) && (klo == 0) && !inner;
+    const bool full = __all(covered) != 0;
+    // which form of g: from the bound |f| <= Atop max(|min - E|, |max - E|) + c4 over the lane's rows
+    const double xb = (Atop * fmax(fabs(m.x - E), fabs(m.y - E)) + G.c4) * kInv12;
+    const int myvar = xb <= kX4 ? V4 : (xb <= kX8 ? V8 : VDIV);
+    const bool has_rows = khi >= klo;
+    int var = V4;
+    if (__any(has_rows && !inner && myvar != V4)) var = __any(has_rows && !inner && myvar == VDIV) ? VDIV : V8;
+    // f >= 12 in a step row (d <= 0: u and w differ in sign) is left to the exact kernels; the innermost lane looks at its rows itself
+    int bad = has_rows && !inner && !(xb < 1.);
+    Pass1 p1;
+    p1.M.a = 1.; p1.M.b = 0.; p1.M.c = 0.; p1.M.d = 1.;
+    if (__any(has_rows)) run_rows(tabv, t, G.T, Atop, C, khi, klo, full, inner, var, E, G.c4, p1);
+    const Mat M = p1.M;
+    SCAN_TICK(3);
     // ---- combine: inclusive scan of the matrices in thread order (wave shuffles, then the 16 wave totals through LDS)
     Mat P = M;
 #pragma unroll
@@ -301,17 +410,22 @@ __device__ SweepOut scan_sweep(const ScanGrid& G, const double2* __restrict__ ta
         Ee.a = shfl_up_d(P.a, off); Ee.b = shfl_up_d(P.b, off); Ee.c = shfl_up_d(P.c, off); Ee.d = shfl_up_d(P.d, off);
         if (lane >= off) P = mat_mul(P, Ee);
     }
-    if (lane == 63) sh.wave_tot[wv] = P;
+    const int wbad = __any(bad) != 0;
+    if (lane == 63) { sh.wave_tot[par][wv] = P; sh.wave_bad[par][wv] = wbad; }
+    SCAN_TICK(4);
     __syncthreads();
+    SCAN_TICK(5);
     // incoming state of this wave, and the final state of the sweep
     double w_in = ws1, D_in = ws1 - ws;
     double w_fin, D_fin;
+    int anybad = 0;
     {
         double w = ws1, D = ws1 - ws;
 #pragma unroll
         for (int q = 0; q < kW; ++q) {
             if (q == wv) { w_in = w; D_in = D; }
-            const Mat Wq = sh.wave_tot[q];
+            const Mat Wq = sh.wave_tot[par][q];
+            anybad |= sh.wave_bad[par][q];
             const double w2 = fma(Wq.a, w, Wq.b * D), D2 = fma(Wq.c, w, Wq.d * D);
             w = w2; D = D2;
         }
@@ -324,58 +438,71 @@ __device__ SweepOut scan_sweep(const ScanGrid& G, const double2* __restrict__ ta
         const double w2 = fma(X.a, w_in, X.b * D_in), D2 = fma(X.c, w_in, X.d * D_in);
         w_in = w2; D_in = D2;
     }
-    bad |= !(fabs(w_fin) < INFINITY) || !(fabs(D_fin) < INFINITY);
-    // u_1, u_2 and the extrapolation to the origin (Numerov.h:343-346,398) when the sweep ran to the end: the final state is
+    anybad |= !(fabs(w_fin) < INFINITY) || !(fabs(D_fin) < INFINITY);
+    // u_1, u_2 and the extrapolation to the origin (Numerov.h:343-346,398) when the sweep ran to index 1: the final state is
     // (w_1, w_1 - w_2).  Row 1 of l = 3 has f > 12 (d < 0): these last values are divided exactly
     double u1 = 0, u2 = 0;
     if (iexit <= 1) {
-        const double2 r1 = row_of(1), r2 = row_of(2);
-        const double f1 = fma(r1.y, r1.x - E, G.c4), f2 = fma(r2.y, r2.x - E, G.c4);
-        out.w1 = w_fin; out.w2 = w_fin - D_fin;
-        u1 = out.w1 / (1. - kInv12 * f1); u2 = out.w2 / (1. - kInv12 * f2);
+        anybad |= !(f2 < 12.);
+        u1 = w_fin / (1. - kInv12 * f1); u2 = (w_fin - D_fin) / (1. - kInv12 * f2);
         out.u0 = u1 * (2. + f1) - u2;
     }
+    SCAN_TICK(6);
     if (KIND == DFTA_SWEEP_COUNT) {
         // ---- pass 2: sign changes between w_i and w_{i-1} for the step rows i in [lo2, s-1] (u has the sign of w there: d > 0; the
-        // comparison of step 2, u_2 against u_1, is taken from the divided values below).  A lane whose rows are all forbidden (g >= 0:
+        // comparison of step 2, u_2 against u_1, is taken from the divided values above).  A lane whose rows are all forbidden (g >= 0:
         // w'' = g w keeps |w| convex) crosses zero at most once: its count is the sign change between its two ends, known from M.
         const int lo2 = max(lo, 3);
         const int klo2 = max(lo2 - ibase, 0);
         int cnt = 0;
-        if (khi >= klo2) {
-            if (fmin >= 0. && klo2 == klo) {
-                const double w_out = fma(M.a, w_in, M.b * D_in);
-                cnt = (w_out > 0.) != (w_in > 0.);
-            } else {
-                cnt = use_div ? pass2_rows<true>(p, khi, klo2, inner, E, G.c4, w_in, D_in) : pass2_rows<false>(p, khi, klo2, inner, E, G.c4, w_in, D_in);
+        const bool rows2 = khi >= klo2;
+        const bool convex = rows2 && (m.x >= E) && klo2 == klo && !inner;     // veff >= E on every row: f >= c4 > 0
+        if (convex) {
+            const double w_out = fma(M.a, w_in, M.b * D_in);
+            cnt = (w_out > 0.) != (w_in > 0.);
+        }
+        const bool need = rows2 && !convex;
+        if (__any(need)) {
+            if (full && C >= 16 && klo2 == klo) {          // every lane of the wave runs all its rows: per-wave count (the convex lanes' rows included)
+                Pass2W p2;
+                p2.w = w_in; p2.D = D_in; p2.cnt = 0; p2.prev = __ballot(w_in > 0.);
+                run_rows(tabv, t, G.T, Atop, C, khi, klo2, true, false, var, E, G.c4, p2);
+                cnt = lane == 0 ? p2.cnt : 0;
+            } else {                                       // per-lane counts; the convex lanes keep the count of their two ends
+                Pass2 p2;
+                p2.w = w_in; p2.D = D_in; p2.cnt = 0;
+                run_rows(tabv, t, G.T, Atop, C, need ? khi : -1, klo2, false, inner, var, E, G.c4, p2);
+                if (need) cnt = p2.cnt;
             }
         }
-        int total = block_sum_int(cnt + (bad << 24), sh, tid);
-        bad = (total >> 24) != 0;
-        total &= (1 << 24) - 1;
+        for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+        if (lane == 0) sh.red[par][wv] = cnt;
+        SCAN_TICK(7);
+        __syncthreads();
+        SCAN_TICK(8);
+        int total = 0;
+#pragma unroll
+        for (int q = 0; q < kW; ++q) total += sh.red[par][q];
         if (iexit <= 1 && s - 1 >= 2) total += ((u1 > 0.) != (u2 > 0.));       // step 2
         // the first comparison of the loop is against the sign of the start value u_{s-1} = us1 > 0 -- that of w_{s-1}, the incoming w
         // of the first lane.  Early return at count > limit: the value is limit + 1.
         if (total > limit) total = limit + 1;
         else if (iexit == 0) total += ((out.u0 > 0.) != (u1 > 0.));      // ran to the end: the extrapolated point (Numerov.h:343-347)
         out.count = total;
-    } else {
-        bad = __syncthreads_or(bad);
     }
-    out.bad = bad;
+    out.bad = anybad;
     return out;
 }
 
 // per slot and lane: {min, max} of veff over the lane's rows
-__global__ void __launch_bounds__(kT) k_scan_lane_minmax(const double2* __restrict__ tabs, int N, int logC, double2* __restrict__ mm)
+__global__ void __launch_bounds__(kT) k_scan_lane_minmax(const double* __restrict__ tabs, int N, int logC, double2* __restrict__ mm)
 {
-    const size_t rows = (size_t)N;
-    const double2* p = tabs + blockIdx.x * rows + threadIdx.x;
+    const double* p = tabs + (size_t)blockIdx.x * N + threadIdx.x;      // row k of lane t at (k << kLogT) + t
     const int C = 1 << logC;
     double lo = INFINITY, hi = -INFINITY;
     bool nan = false;
     for (int k = 0; k < C; ++k) {
-        const double v = p[(size_t)k << 10].x;
+        const double v = p[(size_t)k << kLogT];
         nan = nan || (v != v);
         lo = fmin(lo, v); hi = fmax(hi, v);
     }
@@ -384,18 +511,20 @@ __global__ void __launch_bounds__(kT) k_scan_lane_minmax(const double2* __restri
     mm[(size_t)blockIdx.x * kT + threadIdx.x] = o;
 }
 
-__global__ void __launch_bounds__(kT) k_scan_sweeps(ScanGrid G, int kind, const double2* __restrict__ tabs, const double2* __restrict__ mms, const int* __restrict__ trial_slot,
+__global__ void __launch_bounds__(kT) k_scan_sweeps(ScanGrid G0, const double* __restrict__ gr, const double* __restrict__ gAtop, const double* __restrict__ gT,
+                                                     int kind, const double* __restrict__ tabs, const double2* __restrict__ mms, const int* __restrict__ trial_slot,
                                                      const double* __restrict__ E, const int* __restrict__ limit, int* __restrict__ count,
                                                      double* __restrict__ u0, int* __restrict__ start, int* __restrict__ trip, int* __restrict__ bad)
 {
     __shared__ ScanShared sh;
+    ScanGrid G = G0;
+    G.r = gr; G.Atop = gAtop; G.T = gT;           // kernel-argument pointers: global address space, scalar loads where the index is uniform
     const int q = blockIdx.x;
-    const size_t rows = ((size_t)kT << G.logC) + 1;
-    const double2* tab = tabs + (size_t)trial_slot[q] * rows;
+    const double* tab = tabs + (size_t)trial_slot[q] * G.N;
     const double2* mm = mms + (size_t)trial_slot[q] * kT;
     SweepOut o;
-    if (kind == DFTA_SWEEP_COUNT) o = scan_sweep<DFTA_SWEEP_COUNT>(G, tab, mm, E[q], limit[q], sh);
-    else o = scan_sweep<DFTA_SWEEP_ZERO>(G, tab, mm, E[q], 0, sh);
+    if (kind == DFTA_SWEEP_COUNT) o = scan_sweep<DFTA_SWEEP_COUNT>(G, tab, mm, E[q], limit[q], sh, 0);
+    else o = scan_sweep<DFTA_SWEEP_ZERO>(G, tab, mm, E[q], 0, sh, 0);
     if (threadIdx.x == 0) {
         if (count) count[q] = o.count;
         if (u0) u0[q] = o.u0;
@@ -413,11 +542,14 @@ constexpr double kErr = 1e-12;        // energyErr, DFTAtom.cpp:349
 constexpr int kIter3 = 500;           // DFTAtom.cpp:517
 constexpr int kPhDone = 4;            // PH_DONE of levels.hip
 
-__global__ void __launch_bounds__(kT) k_scan_levels(ScanGrid G, dfta::Job* __restrict__ jobs, const int* __restrict__ chain_off, int chained,
-                                                     const double2* __restrict__ tabs, const double2* __restrict__ mms, int fixed_point,
+__global__ void __launch_bounds__(kT) k_scan_levels(ScanGrid G0, const double* __restrict__ gr, const double* __restrict__ gAtop, const double* __restrict__ gT,
+                                                     dfta::Job* __restrict__ jobs, const int* __restrict__ chain_off, int chained,
+                                                     const double* __restrict__ tabs, const double2* __restrict__ mms, int fixed_point,
                                                      unsigned long long* __restrict__ counters)
 {
     __shared__ ScanShared sh;
+    ScanGrid G = G0;
+    G.r = gr; G.Atop = gAtop; G.T = gT;
     const int c = blockIdx.x;
     const size_t rows = (size_t)G.N;
     double handed = 0;
@@ -426,8 +558,10 @@ __global__ void __launch_bounds__(kT) k_scan_levels(ScanGrid G, dfta::Job* __res
         dfta::Job* J = jobs + k;
         if (J->frozen) continue;
         const int nodes = J->nodes, slot = J->slot;
-        const double2* tab = tabs + (size_t)slot * rows;
+        const double* tab = tabs + (size_t)slot * rows;
         const double2* mm = mms + (size_t)slot * kT;
+        unsigned par = 0;
+        int hint = 0;
         const double bottom0 = (chained && have_handed) ? handed : J->bottom0;
         int n_count = 0, n_zero = 0, bad = 0, len2 = 0, n_fixed = 0;
         long long pts = 0;
@@ -435,7 +569,8 @@ __global__ void __launch_bounds__(kT) k_scan_levels(ScanGrid G, dfta::Job* __res
         double toe = 50., boe = bottom0;
         while (toe - boe > kErr) {
             const double E = (toe + boe) / 2;
-            const SweepOut o = scan_sweep<DFTA_SWEEP_COUNT>(G, tab, mm, E, nodes, sh);
+            const SweepOut o = scan_sweep<DFTA_SWEEP_COUNT>(G, tab, mm, E, nodes, sh, par++ & 1, hint);
+            hint = o.start;
             ++n_count; bad |= o.bad;
             pts += o.start - 1 - (o.iexit > 0 ? o.iexit : 1);
             if (o.count > nodes) toe = E; else boe = E;
@@ -448,7 +583,8 @@ __global__ void __launch_bounds__(kT) k_scan_levels(ScanGrid G, dfta::Job* __res
             const double E = (toe + boe) / 2;
             ++n_count; ++len2;
             if (nodes == 0) { toe = E; continue; }
-            const SweepOut o = scan_sweep<DFTA_SWEEP_COUNT>(G, tab, mm, E, nodes, sh);
+            const SweepOut o = scan_sweep<DFTA_SWEEP_COUNT>(G, tab, mm, E, nodes, sh, par++ & 1, hint);
+            hint = o.start;
             bad |= o.bad;
             pts += o.start - 1 - (o.iexit > 0 ? o.iexit : 1);
             if (o.count < nodes) boe = E; else toe = E;
@@ -458,12 +594,14 @@ __global__ void __launch_bounds__(kT) k_scan_levels(ScanGrid G, dfta::Job* __res
         double Top = top, Bot = bottom;
         int iter3 = 0, conv = 0;
         {
-            const SweepOut o = scan_sweep<DFTA_SWEEP_ZERO>(G, tab, mm, Bot, 0, sh);
+            const SweepOut o = scan_sweep<DFTA_SWEEP_ZERO>(G, tab, mm, Bot, 0, sh, par++ & 1, hint);
+            hint = o.start;
             ++n_zero; bad |= o.bad; pts += o.start - 2;
             const bool sgnBottom = o.u0 > 0;
             while (iter3 < kIter3) {
                 const double E = (Top + Bot) / 2;
-                const SweepOut z = scan_sweep<DFTA_SWEEP_ZERO>(G, tab, mm, E, 0, sh);
+                const SweepOut z = scan_sweep<DFTA_SWEEP_ZERO>(G, tab, mm, E, 0, sh, par++ & 1, hint);
+                hint = z.start;
                 ++n_zero; ++iter3; bad |= z.bad; pts += z.start - 2;
                 const double Top_was = Top, Bot_was = Bot;
                 if ((z.u0 > 0) == sgnBottom) Bot = E; else Top = E;
@@ -491,33 +629,31 @@ __global__ void __launch_bounds__(kT) k_scan_levels(ScanGrid G, dfta::Job* __res
     }
 }
 
-// interleaved tolerance-mode table of every slot: rows { V + c_l, 2 Rp^2 delta^2 e2 }
-__global__ void k_scan_build_tab(double2* __restrict__ tabs, const double* __restrict__ V, const double* __restrict__ cl,
-                                 const double* __restrict__ e2, const int* __restrict__ slot_v, const int* __restrict__ slot_l, int N,
-                                 int logC, double twoRp2d2)
+// interleaved tolerance-mode table of every slot: rows V + c_l
+__global__ void k_scan_build_tab(double* __restrict__ tabs, const double* __restrict__ V, const double* __restrict__ cl,
+                                 const int* __restrict__ slot_v, const int* __restrict__ slot_l, int N, int logC)
 {
     const int slot = blockIdx.y;
     const int v = slot_v[slot], l = slot_l[slot];
-    const size_t rows = (size_t)N;
     const int C = 1 << logC;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) {
-        double2 tt;
-        tt.x = V[(size_t)v * N + i] + cl[(size_t)l * N + i];
-        tt.y = twoRp2d2 * e2[i];
-        const size_t pos = (i == N - 1) ? (size_t)(N - 1) : (((size_t)(i & (C - 1)) << 10) + (i >> logC));
-        tabs[(size_t)slot * rows + pos] = tt;
+        const size_t pos = (i == N - 1) ? (size_t)(N - 1) : (((size_t)(i & (C - 1)) << kLogT) + (i >> logC));
+        tabs[(size_t)slot * N + pos] = V[(size_t)v * N + i] + cl[(size_t)l * N + i];
     }
 }
 
-ScanGrid scan_grid_of(const dfta_grid* g)
+ScanGrid scan_grid_of(const dfta_grid* g, const dfta_scan_tables& tb)
 {
     ScanGrid G;
     G.N = g->N;
-    G.logC = g->levels - 10;
+    G.logC = g->levels - kLogT;
     G.delta = g->delta;
     G.far_thr = g->far_arg_threshold;
     G.c4 = g->delta2p4;
+    G.Rp = g->Rp;
     G.r = g->d_r;
+    G.Atop = tb.Atop;
+    G.T = tb.T;
     return G;
 }
 
@@ -525,32 +661,73 @@ ScanGrid scan_grid_of(const dfta_grid* g)
 
 int dfta_scan_supported(const dfta_grid* g) { return g && !g->uniform && g->levels >= 12 && g->levels <= 24; }
 
-int dfta_launch_scan_build_tab(dfta_ctx* ctx, const dfta_grid* g, double2* tabs, double2* mm, const double* dV, const int* d_slot_v, const int* d_slot_l, int nslots)
+void dfta_scan_tables_destroy(dfta_scan_tables* tb)
 {
-    hipLaunchKernelGGL(k_scan_build_tab, dim3(std::min(256, (g->N + 255) / 256), nslots), dim3(256), 0, ctx->stream, tabs, dV, g->d_cl, g->d_e2,
-                       d_slot_v, d_slot_l, g->N, g->levels - 10, 2. * g->Rp2delta2);
+    if (!tb) return;
+    for (void* q : {(void*)tb->tabv, (void*)tb->mm, (void*)tb->Atop, (void*)tb->T}) if (q) (void)hipFree(q);
+    *tb = dfta_scan_tables();
+}
+
+int dfta_scan_tables_create(dfta_ctx* ctx, const dfta_grid* g, int nslots, dfta_scan_tables* tb)
+{
+    *tb = dfta_scan_tables();
+    tb->nslots = nslots;
+    const int N = g->N, logC = g->levels - kLogT, C = 1 << logC;
+    // A_i = 2 Rp^2 delta^2 exp(2 i delta) (Numerov.h:100) = Atop[t] T[k] for i = t C + k: the top row of every lane from the grid's own
+    // exp table (host libm), the C ratios exp(-2 delta (C-1-k)) likewise
+    std::vector<double> Atop(kT + 1), T(C);
+    for (int t = 0; t < kT; ++t) Atop[t] = 2. * g->Rp2delta2 * g->h_e2[(size_t)t * C + C - 1];
+    Atop[kT] = 2. * g->Rp2delta2 * g->h_e2[N - 1];
+    for (int k = 0; k < C; ++k) T[k] = exp(-g->twodelta * static_cast<double>(C - 1 - k));
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&tb->tabv), sizeof(double) * (size_t)nslots * N);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&tb->mm), sizeof(double2) * (size_t)nslots * kT);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&tb->Atop), sizeof(double) * (kT + 1));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&tb->T), sizeof(double) * C);
+    if (e == hipSuccess) e = hipMemcpy(tb->Atop, Atop.data(), sizeof(double) * (kT + 1), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(tb->T, T.data(), sizeof(double) * C, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        snprintf(ctx->err, sizeof(ctx->err), "scan tables: %s", hipGetErrorString(e));
+        dfta_scan_tables_destroy(tb);
+        return DFTA_ERR_HIP;
+    }
+    return DFTA_OK;
+}
+
+int dfta_launch_scan_build_tab(dfta_ctx* ctx, const dfta_grid* g, const dfta_scan_tables& tb, const double* dV, const int* d_slot_v, const int* d_slot_l)
+{
+    hipLaunchKernelGGL(k_scan_build_tab, dim3(std::min(256, (g->N + 255) / 256), tb.nslots), dim3(256), 0, ctx->stream, tb.tabv, dV, g->d_cl,
+                       d_slot_v, d_slot_l, g->N, g->levels - kLogT);
     DFTA_CHECK_LAUNCH(ctx);
-    hipLaunchKernelGGL(k_scan_lane_minmax, dim3(nslots), dim3(kT), 0, ctx->stream, tabs, g->N, g->levels - 10, mm);
+    hipLaunchKernelGGL(k_scan_lane_minmax, dim3(tb.nslots), dim3(kT), 0, ctx->stream, tb.tabv, g->N, g->levels - kLogT, tb.mm);
     DFTA_CHECK_LAUNCH(ctx);
     return DFTA_OK;
 }
 
-int dfta_launch_scan_sweeps(dfta_ctx* ctx, const dfta_grid* g, int kind, int ntrials, const double2* tabs, const double2* mm, const int* d_trial_slot,
+int dfta_launch_scan_sweeps(dfta_ctx* ctx, const dfta_grid* g, int kind, int ntrials, const dfta_scan_tables& tb, const int* d_trial_slot,
                             const double* dE, const int* dLimit, int* dCount, double* dU0, int* dStart, int* dTrip, int* dBad)
 {
-    hipLaunchKernelGGL(k_scan_sweeps, dim3(ntrials), dim3(kT), 0, ctx->stream, scan_grid_of(g), kind, tabs, mm, d_trial_slot, dE, dLimit, dCount, dU0,
+    hipLaunchKernelGGL(k_scan_sweeps, dim3(ntrials), dim3(kT), 0, ctx->stream, scan_grid_of(g, tb), g->d_r, tb.Atop, tb.T, kind, tb.tabv, tb.mm, d_trial_slot, dE, dLimit, dCount, dU0,
                        dStart, dTrip, dBad);
     DFTA_CHECK_LAUNCH(ctx);
     return DFTA_OK;
 }
 
 int dfta_launch_scan_levels(dfta_ctx* ctx, const dfta_grid* g, dfta::Job* d_jobs, const int* d_chain_off, int nchains, int chained,
-                            const double2* tabs, const double2* mm, int fixed_point, unsigned long long* d_counters)
+                            const dfta_scan_tables& tb, int fixed_point, unsigned long long* d_counters)
 {
-    hipLaunchKernelGGL(k_scan_levels, dim3(nchains), dim3(kT), 0, ctx->stream, scan_grid_of(g), d_jobs, d_chain_off, chained, tabs, mm, fixed_point, d_counters);
+    hipLaunchKernelGGL(k_scan_levels, dim3(nchains), dim3(kT), 0, ctx->stream, scan_grid_of(g, tb), g->d_r, tb.Atop, tb.T, d_jobs, d_chain_off, chained, tb.tabv, tb.mm, fixed_point, d_counters);
     DFTA_CHECK_LAUNCH(ctx);
     return DFTA_OK;
 }
+
+#ifdef DFTA_SCAN_PROF
+extern "C" int dfta_debug_scan_prof(unsigned long long* out16, int reset)
+{
+    if (out16 && hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_scan_prof), sizeof(unsigned long long) * 16) != hipSuccess) return DFTA_ERR_HIP;
+    if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_scan_prof), z, sizeof(z)) != hipSuccess) return DFTA_ERR_HIP; }
+    return DFTA_OK;
+}
+#endif
 
 // ---- C ABI: the tolerance-mode twin of dfta_numerov_sweeps -----------------------------------------------------------------
 extern "C" int dfta_numerov_sweeps_scan(dfta_ctx* ctx, const dfta_grid* g, int kind, int nV, const double* V, int ntrials, const int* vidx,
@@ -579,23 +756,23 @@ extern "C" int dfta_numerov_sweeps_scan(dfta_ctx* ctx, const dfta_grid* g, int k
     hipStream_t st = ctx->stream;
     DevBuf<double> dV, dE, dU0;
     DevBuf<int> dSv, dSl, dTs, dLim, dCount, dStart, dTrip, dBad;
-    DevBuf<double2> dTab, dMm;
     DFTA_HIP(ctx, dV.alloc((size_t)nV * N));
-    DFTA_HIP(ctx, dMm.alloc((size_t)nslots * kT));
+    struct Tables { dfta_scan_tables t; ~Tables() { dfta_scan_tables_destroy(&t); } } tb;
+    int rc = dfta_scan_tables_create(ctx, g, nslots, &tb.t);
+    if (rc) return rc;
     DFTA_HIP(ctx, hipMemcpyAsync(dV.p, V, (size_t)nV * N * sizeof(double), hipMemcpyHostToDevice, st));
     DFTA_HIP(ctx, dE.alloc(ntrials)); DFTA_HIP(ctx, dU0.alloc(ntrials));
     DFTA_HIP(ctx, dSv.alloc(nslots)); DFTA_HIP(ctx, dSl.alloc(nslots)); DFTA_HIP(ctx, dTs.alloc(ntrials)); DFTA_HIP(ctx, dLim.alloc(ntrials));
     DFTA_HIP(ctx, dCount.alloc(ntrials)); DFTA_HIP(ctx, dStart.alloc(ntrials)); DFTA_HIP(ctx, dTrip.alloc(ntrials)); DFTA_HIP(ctx, dBad.alloc(ntrials));
-    DFTA_HIP(ctx, dTab.alloc((size_t)nslots * N));
     DFTA_HIP(ctx, hipMemcpyAsync(dE.p, E, sizeof(double) * ntrials, hipMemcpyHostToDevice, st));
     DFTA_HIP(ctx, hipMemcpyAsync(dSv.p, slot_v.data(), sizeof(int) * nslots, hipMemcpyHostToDevice, st));
     DFTA_HIP(ctx, hipMemcpyAsync(dSl.p, slot_l.data(), sizeof(int) * nslots, hipMemcpyHostToDevice, st));
     DFTA_HIP(ctx, hipMemcpyAsync(dTs.p, tslot.data(), sizeof(int) * ntrials, hipMemcpyHostToDevice, st));
     DFTA_HIP(ctx, hipMemcpyAsync(dLim.p, lim.data(), sizeof(int) * ntrials, hipMemcpyHostToDevice, st));
-    int rc = dfta_launch_scan_build_tab(ctx, g, dTab.p, dMm.p, dV.p, dSv.p, dSl.p, nslots);
+    rc = dfta_launch_scan_build_tab(ctx, g, tb.t, dV.p, dSv.p, dSl.p);
     if (rc) return rc;
     DFTA_HIP(ctx, hipEventRecord(ctx->ev[0], st));
-    rc = dfta_launch_scan_sweeps(ctx, g, kind, ntrials, dTab.p, dMm.p, dTs.p, dE.p, dLim.p, dCount.p, dU0.p, dStart.p, dTrip.p, dBad.p);
+    rc = dfta_launch_scan_sweeps(ctx, g, kind, ntrials, tb.t, dTs.p, dE.p, dLim.p, dCount.p, dU0.p, dStart.p, dTrip.p, dBad.p);
     if (rc) return rc;
     DFTA_HIP(ctx, hipEventRecord(ctx->ev[1], st));
     ctx->have_kernel_time = true;

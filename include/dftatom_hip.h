@@ -118,7 +118,7 @@ int dfta_numerov_sweeps_dev(dfta_ctx* ctx, const dfta_grid* g, int kind,
                             int* dCount, double* dU0, int* dStartOut, int* dTrip);
 
 /* TOLERANCE MODE of the same two sweeps (opt-in; logarithmic grids of 12 .. 24 multigrid levels): the recurrence of Numerov.h:309-321
- * is linear in w, w_{i-1} = (2 + f_i/(1 - f_i/12)) w_i - w_{i+1}, so ONE trial is integrated by the 1024 lanes of a workgroup as a
+ * is linear in w, w_{i-1} = (2 + f_i/(1 - f_i/12)) w_i - w_{i+1}, so ONE trial is integrated by the 512 lanes of a workgroup as a
  * transfer-matrix scan (segment products, log-depth combine, a second pass for the sign changes) in ~25 us at 131 073 points instead
  * of 4 ms as a dependent chain.  Same cut-off index, start values (device exp) and exit rules as above; a different order of roundings:
  * node counts equal the exact kernels' except inside the round-off band of a count transition (a few 1e-12 |E| wide), u(0) agrees to
