@@ -140,4 +140,5 @@ struct LevelSolver {
 // scan.hip: LocateInterval + the u(0) bisection of every chain of jobs by one workgroup each; counters[0] += executed sweeps,
 // counters[1] += traversed points, counters[3] |= 1 when a sweep could not be decided by the scan
 int dfta_launch_scan_levels(dfta_ctx* ctx, const dfta_grid* g, dfta::Job* d_jobs, const int* d_chain_off, int nchains, int chained,
-                            const dfta_scan_tables& tb, int fixed_point, unsigned long long* d_counters);
+                            const dfta_scan_tables& tb, int fixed_point, unsigned long long* d_counters,
+                            int match_mode /* 0 none, 1 match, 2 match + Simpson-3/8 normalisation */, double* d_Psi, int* d_jstart_keep);

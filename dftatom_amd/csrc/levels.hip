@@ -1400,12 +1400,15 @@ int LevelSolver::run(const double* dV, const double* job_bottom, int run_mode, d
     // no rounds, no speculation.  A sweep the scan cannot decide (non-finite values, f >= 12 in a step row: never seen for the
     // potential of an SCF) sends the whole solve to the exact kernels below.
     bool scan = sweep_mode == DFTA_SWEEPS_TOLERANCE && scan_tb.tabv != nullptr;
+    // the match solve and the normalisation in the same kernel (SCAN_NOMATCH: the exact k_match / k_normalize follow, measurements)
+    const int scan_match_mode = dfta_knob("SCAN_NOMATCH") ? 0 : (integ_rule == DFTA_INT_SIMPSON38 ? 2 : 1);
     float ms_scan = 0;
     if (scan) {
         rc = dfta_launch_scan_build_tab(ctx, g, scan_tb, dV, d_slot_v, d_slot_l);
         if (rc) return rc;
         DFTA_HIP(ctx, hipEventRecord(ev[0], st));
-        rc = dfta_launch_scan_levels(ctx, g, d_jobs, d_chains, run_chains, chained ? 1 : 0, scan_tb, dfta_knob("LEVELS_NOFIXEDPOINT") ? 0 : 1, d_counters);
+        rc = dfta_launch_scan_levels(ctx, g, d_jobs, d_chains, run_chains, chained ? 1 : 0, scan_tb, dfta_knob("LEVELS_NOFIXEDPOINT") ? 0 : 1, d_counters,
+                                     scan_match_mode, d_Psi, d_jstart_keep);
         if (rc) return rc;
         DFTA_HIP(ctx, hipEventRecord(ev[1], st));
         unsigned long long flag = 0;
@@ -1526,22 +1529,30 @@ int LevelSolver::run(const double* dV, const double* job_bottom, int run_mode, d
     if (rounds >= max_rounds) { snprintf(ctx->err, sizeof(ctx->err), "level solver did not terminate"); return DFTA_ERR_NOT_CONVERGED; }
 
     // wavefunctions: match (the levels that were not matched while the others searched), normalise, accumulate
-    if (early_pending) DFTA_HIP(ctx, hipStreamWaitEvent(st, ev_early, 0));       // the early solves use the same per-job scratch arrays
-    hipLaunchKernelGGL(k_job_energies, dim3((njobs + 63) / 64), dim3(64), 0, st, d_jobs, njobs, d_jE, d_jslot, d_jl);
-    DFTA_CHECK_LAUNCH(ctx);
-    rc = dfta_launch_boundary(ctx, g, d_jE, njobs, d_jstart, d_jus, d_jus1, 1, d_jl, d_Q /* uniform: start value at the first node, one per job */);
-    if (rc) return rc;
-    // cut-off index -1 = skipped by k_match: frozen jobs (the result of their last solve stands) and jobs matched already;
-    // d_jstart_keep: the cut-off index of every job that was matched in this run (-1: frozen)
-    hipLaunchKernelGGL(k_mask_rest, dim3((njobs + 63) / 64), dim3(64), 0, st, d_jobs, njobs, d_jstart, d_jmatched, d_jstart_keep);
-    DFTA_CHECK_LAUNCH(ctx);
-    rc = dfta_launch_match(ctx, g, njobs, d_tab, d_jslot, d_jE, d_jstart, d_jus, d_jus1, d_jl, d_Psi, d_Q, d_jmp, g->uniform ? nullptr : d_bounds,
-                           d_Q);
-    if (rc) return rc;
-    hipLaunchKernelGGL(k_store_match, dim3((njobs + 63) / 64), dim3(64), 0, st, d_jobs, njobs, d_jmp, d_jstart_keep);
-    DFTA_CHECK_LAUNCH(ctx);
-    hipLaunchKernelGGL(k_normalize, dim3(njobs), dim3(kNormThreads), 0, st, d_Psi, d_Q, N, g->d_eh, g->d_cnst, nfrozen ? d_jstart_keep : nullptr, g->uniform ? g->h : 1.0, integ_rule);
-    DFTA_CHECK_LAUNCH(ctx);
+    if (scan && scan_match_mode) {
+        // k_scan_levels has matched (and, with Simpson 3/8, normalised) every live level
+        if (scan_match_mode == 1) {
+            hipLaunchKernelGGL(k_normalize, dim3(njobs), dim3(kNormThreads), 0, st, d_Psi, d_Q, N, g->d_eh, g->d_cnst, d_jstart_keep, g->uniform ? g->h : 1.0, integ_rule);
+            DFTA_CHECK_LAUNCH(ctx);
+        }
+    } else {
+        if (early_pending) DFTA_HIP(ctx, hipStreamWaitEvent(st, ev_early, 0));       // the early solves use the same per-job scratch arrays
+        hipLaunchKernelGGL(k_job_energies, dim3((njobs + 63) / 64), dim3(64), 0, st, d_jobs, njobs, d_jE, d_jslot, d_jl);
+        DFTA_CHECK_LAUNCH(ctx);
+        rc = dfta_launch_boundary(ctx, g, d_jE, njobs, d_jstart, d_jus, d_jus1, 1, d_jl, d_Q /* uniform: start value at the first node, one per job */);
+        if (rc) return rc;
+        // cut-off index -1 = skipped by k_match: frozen jobs (the result of their last solve stands) and jobs matched already;
+        // d_jstart_keep: the cut-off index of every job that was matched in this run (-1: frozen)
+        hipLaunchKernelGGL(k_mask_rest, dim3((njobs + 63) / 64), dim3(64), 0, st, d_jobs, njobs, d_jstart, d_jmatched, d_jstart_keep);
+        DFTA_CHECK_LAUNCH(ctx);
+        rc = dfta_launch_match(ctx, g, njobs, d_tab, d_jslot, d_jE, d_jstart, d_jus, d_jus1, d_jl, d_Psi, d_Q, d_jmp, g->uniform ? nullptr : d_bounds,
+                               d_Q);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_store_match, dim3((njobs + 63) / 64), dim3(64), 0, st, d_jobs, njobs, d_jmp, d_jstart_keep);
+        DFTA_CHECK_LAUNCH(ctx);
+        hipLaunchKernelGGL(k_normalize, dim3(njobs), dim3(kNormThreads), 0, st, d_Psi, d_Q, N, g->d_eh, g->d_cnst, nfrozen ? d_jstart_keep : nullptr, g->uniform ? g->h : 1.0, integ_rule);
+        DFTA_CHECK_LAUNCH(ctx);
+    }
     if (dNewDensity) {
         hipLaunchKernelGGL(k_accumulate_density, dim3(std::min(256, (N + 255) / 256), nV), dim3(256), 0, st, d_Psi, d_jobs, d_v_off,
                            N, dNewDensity);

@@ -64,6 +64,14 @@ struct ScanGrid {
     const double* T;              // C
 };
 
+struct ScanMatchArgs {            // the match solve at the end of k_scan_levels
+    int mode;                     // 0: none (the exact k_match follows), 1: Psi as Numerov.h:403-504 returns it, 2: normalised too (Simpson 3/8)
+    double* Psi;                  // njobs * N
+    const double *eh, *cnst;      // exp(i delta/2), Rp delta exp(delta i)   (DFTAtom.cpp:42,47)
+    double zero1[4];              // GetBoundaryValueZero(1, l)
+    int* jstart_keep;             // per job: cut-off index of the matched solve (-1: frozen)
+};
+
 struct Mat { double a, b, c, d; };   // [[a, b], [c, d]] acting on (w, D)
 
 __device__ __forceinline__ Mat mat_mul(const Mat& L, const Mat& E)    // L after E
@@ -110,6 +118,13 @@ struct ScanShared {
     int wave_bad[2][kW];
     Turn wave_turn[2][kW];
     int red[2][kW];
+};
+
+struct LaneState {     // what scan_sweep leaves in every lane (the match solve goes on from there)
+    double w_in, D_in;  // state (w_i, w_i - w_{i+1}) at the lane's top step row i = ibase + khi
+    int khi, klo;       // the lane's step rows [klo, khi] (empty: khi < klo)
+    int var;            // form of g for the wave's rows
+    double us, us1, w_fin, D_fin;
 };
 
 struct SweepOut {
@@ -303,7 +318,7 @@ __device__ __forceinline__ void run_rows(const double* __restrict__ tabv, int t,
 // mm: per lane {min, max} of veff over the lane's rows ({-inf, +inf} when a row is NaN).
 template <int KIND>
 __device__ SweepOut scan_sweep(const ScanGrid& G, const double* __restrict__ tabv, const double2* __restrict__ mm, double E, int limit, ScanShared& sh, unsigned par,
-                               int hint = 0)
+                               int hint = 0, LaneState* ls = nullptr)
 {
     const int tid = threadIdx.x;
     const int t = kT - 1 - tid;                 // segment of this lane: thread order = sweep order (descending index)
@@ -491,7 +506,235 @@ __device__ SweepOut scan_sweep(const ScanGrid& G, const double* __restrict__ tab
         out.count = total;
     }
     out.bad = anybad;
+    if (ls) { ls->w_in = w_in; ls->D_in = D_in; ls->khi = khi; ls->klo = klo; ls->var = var; ls->us = us; ls->us1 = us1; ls->w_fin = w_fin; ls->D_fin = D_fin; }
     return out;
+}
+
+// ---- SolveSchrodingerMatchSolutionCompletely (Numerov.h:403-504) + NormalizeNonUniform (DFTAtom.cpp:36-56) by the workgroup --------------
+// Inward from the cut-off to the first local maximum of u (the match point), outward from the origin up to it, the outer part rescaled so
+// that the two meet -- both integrations as scans.  Psi (N doubles, plain layout) receives the reference's Psi; with fused_norm the
+// wave function comes out normalised (Simpson 3/8 of Psi^2 Rp delta e^{delta i} as one parallel sum; the other rules stay with
+// k_normalize).  Returns the match point (< 2: the scan hands the level back to the exact kernels).
+struct MatchOut { int matchPoint, start, bad; };
+
+// u = w / (1 - x), x = f/12, by the series of the row's form of g
+template <int V>
+__device__ __forceinline__ double u_of(double w, double f)
+{
+    const double x = f * kInv12;
+    if (V == VDIV) return w / (1. - x);
+    const double x2 = x * x;
+    const double t1 = fma(w, x, w);
+    const double t2 = fma(t1, x2, t1);
+    if (V == V4) return t2;
+    return fma(t2, x2 * x2, t2);
+}
+
+template <int V>
+__device__ __forceinline__ void match_in_rows(const double* __restrict__ tabv, int t, const double* __restrict__ T, double Atop, int ibase, int khi, int klo,
+                                              double E, double c4, double w, double D, double uprev, int top_checked, double* __restrict__ Psi, int& cand)
+{
+    // rows khi .. klo, descending: at row i the state is (w_i, D_i): u_i = w_i / d_i is stored and compared with u_{i+1}
+    int k = khi;
+    while (k >= klo) {
+        double v[8], tk[8];
+        const int nb = min(8, k - klo + 1);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const int kk = j < nb ? k - j : klo; v[j] = tabv[((size_t)kk << kLogT) + t]; tk[j] = T[kk]; }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (j < nb) {
+                const int i = ibase + k - j;
+                const double f = fma(Atop * tk[j], v[j] - E, c4);
+                const double u = u_of<V>(w, f);
+                Psi[i] = u;
+                if (i <= top_checked && cand < 0 && (u < uprev || fabs(u) > 1E15)) cand = i;      // Numerov.h:455
+                uprev = u;
+                const double g = g_of<V>(f);
+                D = fma(g, w, D);
+                w = w + D;
+            }
+        }
+        k -= nb;
+    }
+}
+
+template <int V, bool WRITE>
+__device__ __forceinline__ void match_out_rows(const double* __restrict__ tabv, int t, const double* __restrict__ T, double Atop, int ibase, int klo, int khi,
+                                               double E, double c4, Mat& M, double& w, double& D, double* __restrict__ Psi)
+{
+    // rows klo .. khi, ASCENDING: step i maps (w_i, w_i - w_{i-1}) to (w_{i+1}, w_{i+1} - w_i); WRITE: u_i is stored (rows >= 2), else the matrix
+    int k = klo;
+    while (k <= khi) {
+        double v[8], tk[8];
+        const int nb = min(8, khi - k + 1);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const int kk = j < nb ? k + j : khi; v[j] = tabv[((size_t)kk << kLogT) + t]; tk[j] = T[kk]; }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (j < nb) {
+                const int i = ibase + k + j;
+                const double f = fma(Atop * tk[j], v[j] - E, c4);
+                const double g = g_of<V>(f);
+                if (WRITE) {
+                    if (i >= 2) Psi[i] = u_of<V>(w, f);
+                    D = fma(g, w, D);
+                    w = w + D;
+                } else {
+                    M.c = fma(g, M.a, M.c); M.a += M.c;
+                    M.d = fma(g, M.b, M.d); M.b += M.d;
+                }
+            }
+        }
+        k += nb;
+    }
+}
+
+__device__ MatchOut scan_match(const ScanGrid& G, const double* __restrict__ tabv, const double2* __restrict__ mm, double E, double zero1, ScanShared& sh,
+                               unsigned& par, int hint, double* __restrict__ Psi, const double* __restrict__ eh, const double* __restrict__ cnst, int fused_norm)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int C = 1 << G.logC, N = G.N;
+    MatchOut mo;
+    // ---- inward: the sweep of SolutionInZero leaves every lane's incoming state
+    LaneState ls;
+    const SweepOut so = scan_sweep<DFTA_SWEEP_ZERO>(G, tabv, mm, E, 0, sh, par++ & 1, hint, &ls);
+    const int s = so.start;
+    mo.start = s; mo.bad = so.bad;
+    auto f_of_row = [&](int ii) -> double {
+        const int i = __builtin_amdgcn_readfirstlane(ii);
+        const bool last = (i == (kT << G.logC));
+        const double v = last ? tabv[(size_t)kT << G.logC] : tabv[((size_t)(i & (C - 1)) << kLogT) + (i >> G.logC)];
+        const double A = last ? G.Atop[kT] : G.Atop[i >> G.logC] * G.T[i & (C - 1)];
+        return fma(A, v - E, G.c4);
+    };
+    {
+        const int t = kT - 1 - tid, ibase = t << G.logC;
+        int cand = -1;
+        if (ls.khi >= ls.klo) {
+            // u of the row above the lane's top row: from the incoming state, w_{i+1} = w_i - D_i
+            const int itop = ibase + ls.khi;
+            const double fa = (itop + 1 <= N - 1) ? fma((itop + 1 == N - 1 ? G.Atop[kT] : G.Atop[(itop + 1) >> G.logC] * G.T[(itop + 1) & (C - 1)]),
+                                                        (itop + 1 == N - 1 ? tabv[(size_t)kT << G.logC] : tabv[((size_t)((itop + 1) & (C - 1)) << kLogT) + ((itop + 1) >> G.logC)]) - E, G.c4) : 0.;
+            const double uabove = (ls.w_in - ls.D_in) / (1. - kInv12 * fa);
+            const bool innerl = (t == 0);
+            const int var = innerl ? VDIV : ls.var;
+            if (var == V4) match_in_rows<V4>(tabv, t, G.T, G.Atop[t], ibase, ls.khi, ls.klo, E, G.c4, ls.w_in, ls.D_in, uabove, s - 2, Psi, cand);
+            else if (var == V8) match_in_rows<V8>(tabv, t, G.T, G.Atop[t], ibase, ls.khi, ls.klo, E, G.c4, ls.w_in, ls.D_in, uabove, s - 2, Psi, cand);
+            else match_in_rows<VDIV>(tabv, t, G.T, G.Atop[t], ibase, ls.khi, ls.klo, E, G.c4, ls.w_in, ls.D_in, uabove, s - 2, Psi, cand);
+        }
+        for (int i = s + 1 + tid; i < N; i += kT) Psi[i] = 0.;                 // Numerov.h:427-428
+        for (int o = 32; o > 0; o >>= 1) cand = max(cand, __shfl_xor(cand, o, 64));
+        if (lane == 0) sh.red[par & 1][wv] = cand;
+        __syncthreads();
+        int mp = -1;
+#pragma unroll
+        for (int q = 0; q < kW; ++q) mp = max(mp, sh.red[par & 1][q]);
+        ++par;
+        // index 1 (after the last step): u_1 against u_2
+        const double f1 = f_of_row(1), f2 = f_of_row(2);
+        const double u1 = ls.w_fin / (1. - kInv12 * f1), u2 = (ls.w_fin - ls.D_fin) / (1. - kInv12 * f2);
+        if (mp < 0 && (u1 < u2 || fabs(u1) > 1E15)) mp = 1;
+        if (mp < 0) mp = 2;                                                    // Numerov.h:441: the loop never broke
+        mo.matchPoint = mp;
+        if (tid == 0) { Psi[s] = ls.us; Psi[s - 1] = ls.us1; }               // Numerov.h:435,441 (the two start values as they are)
+    }
+    const int mp = mo.matchPoint;
+    if (mp < 2 || mp > s - 2) { mo.bad = 1; return mo; }
+    __syncthreads();
+    const double u_in_mp = Psi[mp];                                            // the inward value at the match point
+    __syncthreads();
+    // ---- outward: Psi[0] = 0, Psi[1] = GetBoundaryValueZero (Numerov.h:462-468); steps 1 .. mp-1 in ascending thread order
+    double u_out_mp;
+    {
+        const int t = tid, ibase = t << G.logC;
+        const int klo = max(1 - ibase, 0), khi = min(mp - 1 - ibase, C - 1);
+        const bool has = khi >= klo;
+        const double2 m = mm[t];
+        const double Atop = G.Atop[t];
+        const double xb = (Atop * fmax(fabs(m.x - E), fabs(m.y - E)) + G.c4) * kInv12;
+        const int myvar = (t == 0) ? VDIV : (xb <= kX4 ? V4 : (xb <= kX8 ? V8 : VDIV));
+        int var = V4;
+        if (__any(has && myvar != V4)) var = __any(has && myvar == VDIV) ? VDIV : V8;
+        Mat M = {1., 0., 0., 1.};
+        double wd = 0, Dd = 0;
+        if (has) {
+            if (var == V4) match_out_rows<V4, false>(tabv, t, G.T, Atop, ibase, klo, khi, E, G.c4, M, wd, Dd, Psi);
+            else if (var == V8) match_out_rows<V8, false>(tabv, t, G.T, Atop, ibase, klo, khi, E, G.c4, M, wd, Dd, Psi);
+            else match_out_rows<VDIV, false>(tabv, t, G.T, Atop, ibase, klo, khi, E, G.c4, M, wd, Dd, Psi);
+        }
+        Mat P = M;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            Mat Ee;
+            Ee.a = shfl_up_d(P.a, off); Ee.b = shfl_up_d(P.b, off); Ee.c = shfl_up_d(P.c, off); Ee.d = shfl_up_d(P.d, off);
+            if (lane >= off) P = mat_mul(P, Ee);
+        }
+        const unsigned pp = par++ & 1;
+        if (lane == 63) sh.wave_tot[pp][wv] = P;
+        __syncthreads();
+        const double f1 = f_of_row(1);
+        const double w1 = (1. - kInv12 * f1) * zero1;                          // Numerov.h:467
+        double w_in = w1, D_in = w1, w_fin, D_fin;
+        {
+            double w = w1, D = w1;
+#pragma unroll
+            for (int q = 0; q < kW; ++q) {
+                if (q == wv) { w_in = w; D_in = D; }
+                const Mat Wq = sh.wave_tot[pp][q];
+                const double w2 = fma(Wq.a, w, Wq.b * D), D2 = fma(Wq.c, w, Wq.d * D);
+                w = w2; D = D2;
+            }
+            w_fin = w; D_fin = D;
+        }
+        {
+            Mat X;
+            X.a = shfl_up_d(P.a, 1); X.b = shfl_up_d(P.b, 1); X.c = shfl_up_d(P.c, 1); X.d = shfl_up_d(P.d, 1);
+            if (lane == 0) { X.a = 1; X.b = 0; X.c = 0; X.d = 1; }
+            const double w2 = fma(X.a, w_in, X.b * D_in), D2 = fma(X.c, w_in, X.d * D_in);
+            w_in = w2; D_in = D2;
+        }
+        if (has) {
+            double w = w_in, D = D_in;
+            if (var == V4) match_out_rows<V4, true>(tabv, t, G.T, Atop, ibase, klo, khi, E, G.c4, M, w, D, Psi);
+            else if (var == V8) match_out_rows<V8, true>(tabv, t, G.T, Atop, ibase, klo, khi, E, G.c4, M, w, D, Psi);
+            else match_out_rows<VDIV, true>(tabv, t, G.T, Atop, ibase, klo, khi, E, G.c4, M, w, D, Psi);
+        }
+        const double fmp = f_of_row(mp);
+        u_out_mp = w_fin / (1. - kInv12 * fmp);                                // Numerov.h:489-492: the outward value at the match point
+        mo.bad |= !(fabs(w_fin) < INFINITY) || !(fabs(D_fin) < INFINITY);
+        if (tid == 0) { Psi[0] = 0.; Psi[1] = zero1; Psi[mp] = u_out_mp; }
+    }
+    const double factor = u_out_mp / u_in_mp;                                  // Numerov.h:494-498
+    __syncthreads();
+    // ---- Psi[i > mp] *= factor, then NormalizeNonUniform: Psi *= e^{i delta/2}, 1 / sqrt(Simpson38(1, Psi^2 Rp delta e^{delta i}))
+    if (!fused_norm) {
+        for (int i = mp + 1 + tid; i <= s; i += kT) Psi[i] *= factor;
+        return mo;
+    }
+    double s1 = 0, s2 = 0, ends = 0;
+    for (int i = tid; i < N; i += kT) {
+        double p = Psi[i];
+        if (i > mp) p *= factor;
+        p *= eh[i];
+        Psi[i] = p;
+        const double r2 = p * p * cnst[i];
+        if (i == 0 || i == N - 1) ends += r2;
+        else if (i % 3 == 0) s2 += r2;
+        else s1 += r2;
+    }
+    double part = ends + 3. * s1 + 2. * s2;                                    // Integral.h:50-73, summed in parallel
+    for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+    const unsigned pp = par++ & 1;
+    if (lane == 0) sh.wave_tot[pp][wv].a = part;
+    __syncthreads();
+    double tot = 0;
+#pragma unroll
+    for (int q = 0; q < kW; ++q) tot += sh.wave_tot[pp][q].a;
+    const double unorm = 1. / sqrt(tot * (3. / 8.));
+    mo.bad |= !(unorm < INFINITY) || !(unorm > 0.);
+    for (int i = tid; i < N; i += kT) Psi[i] *= unorm;
+    return mo;
 }
 
 // per slot and lane: {min, max} of veff over the lane's rows
@@ -542,10 +785,11 @@ constexpr double kErr = 1e-12;        // energyErr, DFTAtom.cpp:349
 constexpr int kIter3 = 500;           // DFTAtom.cpp:517
 constexpr int kPhDone = 4;            // PH_DONE of levels.hip
 
+
 __global__ void __launch_bounds__(kT) k_scan_levels(ScanGrid G0, const double* __restrict__ gr, const double* __restrict__ gAtop, const double* __restrict__ gT,
                                                      dfta::Job* __restrict__ jobs, const int* __restrict__ chain_off, int chained,
                                                      const double* __restrict__ tabs, const double2* __restrict__ mms, int fixed_point,
-                                                     unsigned long long* __restrict__ counters)
+                                                     unsigned long long* __restrict__ counters, ScanMatchArgs ma)
 {
     __shared__ ScanShared sh;
     ScanGrid G = G0;
@@ -556,7 +800,7 @@ __global__ void __launch_bounds__(kT) k_scan_levels(ScanGrid G0, const double* _
     bool have_handed = false;
     for (int k = chain_off[c]; k < chain_off[c + 1]; ++k) {
         dfta::Job* J = jobs + k;
-        if (J->frozen) continue;
+        if (J->frozen) { if (ma.mode && threadIdx.x == 0) ma.jstart_keep[k] = -1; continue; }
         const int nodes = J->nodes, slot = J->slot;
         const double* tab = tabs + (size_t)slot * rows;
         const double2* mm = mms + (size_t)slot * kT;
@@ -616,7 +860,18 @@ __global__ void __launch_bounds__(kT) k_scan_levels(ScanGrid G0, const double* _
         }
         handed = Bot - 3;                                            // DFTAtom.cpp:541
         have_handed = true;
+        int matchPoint = 0;
+        if (ma.mode) {                                               // "now really solve it" (DFTAtom.cpp:543-546)
+            const int l = J->l;
+            const double z1 = l == 0 ? ma.zero1[0] : (l == 1 ? ma.zero1[1] : (l == 2 ? ma.zero1[2] : ma.zero1[3]));
+            const MatchOut mo = scan_match(G, tab, mm, Bot, z1, sh, par, hint, ma.Psi + (size_t)k * G.N, ma.eh, ma.cnst, ma.mode == 2);
+            bad |= mo.bad;
+            matchPoint = mo.matchPoint;
+            pts += mo.start;                                         // inward from the cut-off to the match point + outward up to it
+            if (threadIdx.x == 0) ma.jstart_keep[k] = mo.start;
+        }
         if (threadIdx.x == 0) {
+            if (ma.mode) J->matchPoint = matchPoint;
             J->top = top; J->bottom = bottom; J->toe = Top; J->boe = Bot; J->E = Bot;
             J->bottom0 = bottom0;
             J->converged = conv; J->n_count = n_count; J->n_zero = n_zero; J->iter3 = iter3; J->n_fixed = n_fixed;
@@ -713,9 +968,12 @@ int dfta_launch_scan_sweeps(dfta_ctx* ctx, const dfta_grid* g, int kind, int ntr
 }
 
 int dfta_launch_scan_levels(dfta_ctx* ctx, const dfta_grid* g, dfta::Job* d_jobs, const int* d_chain_off, int nchains, int chained,
-                            const dfta_scan_tables& tb, int fixed_point, unsigned long long* d_counters)
+                            const dfta_scan_tables& tb, int fixed_point, unsigned long long* d_counters, int match_mode, double* d_Psi, int* d_jstart_keep)
 {
-    hipLaunchKernelGGL(k_scan_levels, dim3(nchains), dim3(kT), 0, ctx->stream, scan_grid_of(g, tb), g->d_r, tb.Atop, tb.T, d_jobs, d_chain_off, chained, tb.tabv, tb.mm, fixed_point, d_counters);
+    ScanMatchArgs ma;
+    ma.mode = match_mode; ma.Psi = d_Psi; ma.eh = g->d_eh; ma.cnst = g->d_cnst; ma.jstart_keep = d_jstart_keep;
+    for (int q = 0; q < 4; ++q) ma.zero1[q] = g->zero1[q];
+    hipLaunchKernelGGL(k_scan_levels, dim3(nchains), dim3(kT), 0, ctx->stream, scan_grid_of(g, tb), g->d_r, tb.Atop, tb.T, d_jobs, d_chain_off, chained, tb.tabv, tb.mm, fixed_point, d_counters, ma);
     DFTA_CHECK_LAUNCH(ctx);
     return DFTA_OK;
 }
