@@ -216,9 +216,10 @@ def counter_rate(d, kernel, workload):
 # ---------------------------------------------------------------------------------------------------------------
 # one measured workload
 # ---------------------------------------------------------------------------------------------------------------
-def run_workload(D, ctx, grid, levels, atoms, lsda, steps, warmup, tree_depth, barrier, torch, after_steps=None, poisson_mode=None):
+def run_workload(D, ctx, grid, levels, atoms, lsda, steps, warmup, tree_depth, barrier, torch, after_steps=None, poisson_mode=None, sweep_mode=None):
     scf = D.Scf(ctx, grid, [86] * atoms, lsda=lsda, alpha=0.5, levels_mode=D.LEVELS_BATCHED, tree_depth=tree_depth,
-                poisson_mode=D.POISSON_EXACT if poisson_mode is None else poisson_mode)
+                poisson_mode=D.POISSON_EXACT if poisson_mode is None else poisson_mode,
+                sweep_mode=D.SWEEPS_EXACT if sweep_mode is None else sweep_mode)
     for _ in range(warmup):
         scf.step()
     barrier()
@@ -242,7 +243,9 @@ def run_workload(D, ctx, grid, levels, atoms, lsda, steps, warmup, tree_depth, b
     tot["trials_per_round"] = scf.trials_per_round
     tot["tree_depth"] = scf.tree_depth
     tot["levels_layout"] = {0: "one block of 2^depth trials per job", 1: "latency mode (slots re-allotted every round)",
-                            2: "packed rounds (depth chosen per round, floor = tree depth)", 3: "latency mode over the live jobs"}.get(int(st.levels_layout), "?")
+                            2: "packed rounds (depth chosen per round, floor = tree depth)", 3: "latency mode over the live jobs",
+                            4: "scan sweeps (tolerance mode: one workgroup per level, no rounds)"}.get(int(st.levels_layout), "?")
+    tot["scan"] = int(st.levels_layout) == 4
     tot["poisson_G"] = scf.poisson_info()[0]
     tot["energies"] = scf.energies()[0][0].as_list()
     return scf, tot
@@ -254,7 +257,7 @@ def kernel_figures(tot, levels, N, atoms, workload=None):
     make it exceed what HBM moves); `hbm_GBps_counters` = rocprofv3 FETCH/WRITE bytes of the committed profile of `workload` / time."""
     forced = os.environ.get("DFTA_SWEEP_KERNEL", "")
     piped = forced == "pipe" or (forced != "fused" and tot["trials_per_round"] // 64 <= 768)
-    sname = "k_sweep_pipe" if piped else "k_sweep"
+    sname = "k_scan_levels" if tot.get("scan") else ("k_sweep_pipe" if piped else "k_sweep")
     t_sw = tot["ms_sweep_kernels"] * 1e-3
     launches = max(tot["rounds"], 1)
     b_issued = NUMEROV_BYTES_PER_POINT * tot["points_traversed"]
@@ -266,7 +269,8 @@ def kernel_figures(tot, levels, N, atoms, workload=None):
              "algorithmic_GBps": b_ref / t_sw / 1e9 if t_sw else None,
              "frac": b_ref / t_sw / 1e9 / HBM_PEAK_GBS if t_sw else None,
              "bytes_per_launch_issued": b_issued / launches, "bytes_per_launch": b_ref / launches,
-             "binding_resource": "fp64 VALU issue of the integrator wave (one block of 64 trials per CU; sequential three-term recurrence)",
+             "binding_resource": ("fp64 VALU issue of one compute unit per level (transfer-matrix scan of one trial by 512 lanes, ~150 sweeps back to back)"
+                                  if tot.get("scan") else "fp64 VALU issue of the integrator wave (one block of 64 trials per CU; sequential three-term recurrence)"),
              "valu_issue": {"wave_instr_per_block_point": SWEEP_VALU_PER_BLOCK_POINT, "block_points_per_s": block_points / t_sw if t_sw else None,
                             "ceiling_wave_instr_per_s": VALU_WAVE_INSTR_PER_S,
                             "frac": SWEEP_VALU_PER_BLOCK_POINT * block_points / t_sw / VALU_WAVE_INSTR_PER_S if t_sw else None,
@@ -368,14 +372,12 @@ def compact_line(full):
                 ex[name] = {k: _r(v) for k, v in e.items() if not isinstance(v, (dict, list))} or {"see": "side file"}
                 continue
             k2 = e.get("kernels", {})
-            ex[name] = {"ms_per_step": _r(e["ms_per_step"]), "ms_per_atom_step": _r(e.get("ms_per_atom_step")),
-                        "sweeps_executed_per_s": _r(e.get("sweeps_executed_per_s")), "vcycles_per_s": _r(e.get("vcycles_per_s")),
-                        "issued_per_useful": _r(e.get("issued_per_useful"), 4), "rounds_per_step": _r(e.get("rounds_per_step"), 4),
-                        "sweep_frac": _r(k2.get("sweep", {}).get("frac")), "sweep_frac_issued": _r(k2.get("sweep", {}).get("frac_issued")),
-                        "sweep_frac_counters": _r(k2.get("sweep", {}).get("frac_counters")),
-                        "poisson_ms": _r(k2.get("poisson", {}).get("avg_launch_ms")), "poisson_frac": _r(k2.get("poisson", {}).get("frac")),
-                        "poisson_frac_counters": _r(k2.get("poisson", {}).get("frac_counters")),
-                        "steps": e.get("steps"), "warmup": e.get("warmup")}
+            ph = e.get("phase_ms_per_step", {})
+            ex[name] = {"ms_per_step": _r(e["ms_per_step"], 5), "sweeps_per_s": _r(e.get("sweeps_executed_per_s"), 5), "vcycles_per_s": _r(e.get("vcycles_per_s"), 5),
+                        "levels_ms": _r(ph.get("levels"), 4), "poisson_ms": _r(ph.get("poisson"), 4),
+                        "issued_per_useful": _r(e.get("issued_per_useful"), 3),
+                        "sweep_frac": _r(k2.get("sweep", {}).get("frac"), 3), "poisson_frac": _r(k2.get("poisson", {}).get("frac"), 3),
+                        "poisson_frac_counters": _r(k2.get("poisson", {}).get("frac_counters"), 3)}
         out["extra"] = ex
     if full.get("full_result"):
         out["full_result"] = full["full_result"]
@@ -416,6 +418,7 @@ def main():
     ap.add_argument("--levels", type=int, default=17)
     ap.add_argument("--lsda", action="store_true")
     ap.add_argument("--tolerance", action="store_true", help="the multigrid smoother's opt-in tolerance mode (DFTA_POISSON_TOLERANCE) for the headline workload")
+    ap.add_argument("--scan-sweeps", action="store_true", help="the sweeps' opt-in tolerance mode (DFTA_SWEEPS_TOLERANCE: transfer-matrix scans) for the headline workload")
     ap.add_argument("--tree-depth", type=int, default=0)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra workloads (256-atom batch, LSDA, 1 048 577 nodes)")
@@ -491,7 +494,8 @@ def main():
             dist.all_gather(gathered, mine)
 
     scf, tot = run_workload(D, ctx, grid, args.levels, args.atoms, args.lsda, args.steps, args.warmup, args.tree_depth, barrier, torch, gather,
-                            poisson_mode=D.POISSON_TOLERANCE if args.tolerance else D.POISSON_EXACT)
+                            poisson_mode=D.POISSON_TOLERANCE if args.tolerance else D.POISSON_EXACT,
+                            sweep_mode=D.SWEEPS_TOLERANCE if args.scan_sweeps else D.SWEEPS_EXACT)
     elapsed = tot["elapsed"]
     # max over ranks of the elapsed time, sums of the work
     if world > 1:
@@ -508,7 +512,9 @@ def main():
     if rank == 0:
         ncu, devname = ctx.device_info()
         wl = None
-        if args.atoms == 1 and args.levels == 17:
+        if args.scan_sweeps:
+            wl = ("scan_tol" if args.tolerance else "scan") if (args.atoms == 1 and args.levels == 17 and not args.lsda) else None
+        elif args.atoms == 1 and args.levels == 17:
             wl = "tolerance" if args.tolerance and not args.lsda else "rn_lsda" if args.lsda and not args.tolerance else "default" if not args.lsda else None
         elif args.atoms == 256 and args.levels == 17 and not args.lsda:
             wl = "batch256"
@@ -547,7 +553,7 @@ def main():
             "config": {"workload": "Rn Z=86 %s, %d levels (%d pts), delta=%g, Rmax=%g, mixing 0.5, %d atom(s)/GPU, %s"
                                    % ("LSDA" if args.lsda else "LDA", args.levels, grid.N, delta, rmax, args.atoms, tot["levels_layout"]),
                        "atoms_per_gpu": args.atoms, "parallelism": "replicas x%d" % world,
-                       "poisson_mode": "tolerance" if args.tolerance else "exact"},
+                       "poisson_mode": "tolerance" if args.tolerance else "exact", "sweep_mode": "tolerance (scan)" if args.scan_sweeps else "exact"},
             "scf_step_ms": 1e3 * elapsed / args.steps,
             "value_definition": "value = sweeps on the reference's bisection path that are actually integrated here (CountNodes + SolutionInZero + "
                                 "Match) / whole-step wall time; value_reference_equivalent also counts the ~52 CountNodes calls per node-less level's "
@@ -575,23 +581,31 @@ def main():
             # on one level ends its third bisection at the reference's 500-iteration cap in most steps); a few seconds each.
             # --all-extras adds LSDA in tolerance mode, the 1024-atom batch and the dense-K sweep benchmark of SURVEY 8d.
             extra = {}
-            sel = [("rn_lda_tolerance_mode", args.levels, 1, False, 10, 5, D.POISSON_TOLERANCE, "tolerance"),
-                   ("rn_lsda", args.levels, 1, True, 10, 5, None, "rn_lsda"),
-                   ("batch256_lda", args.levels, 256, False, 6, 5, None, "batch256"),
-                   ("rn_lsda_l20", 20, 1, True, 6, 6, None, None), ("rn_lsda_l20_batch16", 20, 16, True, 4, 6, None, "l20_batch16")]
+            TOL, SCAN = D.POISSON_TOLERANCE, D.SWEEPS_TOLERANCE
+            sel = [("rn_lda_scan_sweeps", args.levels, 1, False, 10, 5, None, SCAN, "scan"),
+                   ("rn_lda_both_tolerance_modes", args.levels, 1, False, 10, 5, TOL, SCAN, "scan_tol"),
+                   ("rn_lda_poisson_tolerance", args.levels, 1, False, 10, 5, TOL, None, "tolerance"),
+                   ("rn_lsda", args.levels, 1, True, 10, 5, None, None, "rn_lsda"),
+                   ("rn_lsda_both_tolerance_modes", args.levels, 1, True, 10, 5, TOL, SCAN, None),
+                   ("batch256_lda", args.levels, 256, False, 6, 5, None, None, "batch256"),
+                   ("batch256_lda_scan_sweeps", args.levels, 256, False, 6, 5, None, SCAN, None),
+                   ("rn_lsda_l20", 20, 1, True, 6, 6, None, None, None), ("rn_lsda_l20_scan_sweeps", 20, 1, True, 6, 6, None, SCAN, None),
+                   ("rn_lsda_l20_batch16", 20, 16, True, 4, 6, None, None, "l20_batch16")]
             if args.all_extras:
-                sel += [("rn_lsda_tolerance_mode", args.levels, 1, True, 10, 5, D.POISSON_TOLERANCE, None),
-                        ("batch1024_lda", args.levels, 1024, False, 4, 2, None, None)]
-            for name, lv, atoms, lsda, st, wu, pm, wl2 in sel:
+                sel += [("rn_lsda_poisson_tolerance", args.levels, 1, True, 10, 5, TOL, None, None),
+                        ("batch1024_lda", args.levels, 1024, False, 4, 2, None, None, None),
+                        ("batch1024_lda_scan_sweeps", args.levels, 1024, False, 4, 2, None, SCAN, None)]
+            for name, lv, atoms, lsda, st, wu, pm, sm, wl2 in sel:
                 if lv == args.levels:
                     g2, d2, r2 = grid, delta, rmax
                 else:
                     d2, r2 = GRIDS[lv]
                     g2 = D.Grid(ctx, lv, d2, r2)
-                s2, t2 = run_workload(D, ctx, g2, lv, atoms, lsda, st, wu, 0, barrier, torch, poisson_mode=pm)
+                s2, t2 = run_workload(D, ctx, g2, lv, atoms, lsda, st, wu, 0, barrier, torch, poisson_mode=pm, sweep_mode=sm)
                 s2.close()
                 extra[name] = summarize(t2, lv, g2.N, atoms, lsda, world, d2, r2, wl2 if args.levels == 17 else None)
                 extra[name]["poisson_mode"] = "tolerance" if pm == D.POISSON_TOLERANCE else "exact"
+                extra[name]["sweep_mode"] = "tolerance (scan)" if sm == D.SWEEPS_TOLERANCE else "exact"
                 extra[name]["warmup"] = wu
                 if g2 is not grid:
                     g2.close()

@@ -41,8 +41,9 @@ def full_result(bench):
                              "level_parallel": {"value": 2075.0, "cores": 15, "note": "n" * 300},
                              "all_cores": {"value": 6417.0, "cores": 128, "note": "n" * 500}},
             "extra": {}}
-    for name, atoms in (("rn_lda_tolerance_mode", 1), ("rn_lsda", 1), ("rn_lsda_tolerance_mode", 1), ("batch256_lda", 256), ("batch1024_lda", 1024),
-                        ("rn_lsda_l20", 1), ("rn_lsda_l20_batch16", 16)):
+    for name, atoms in (("rn_lda_scan_sweeps", 1), ("rn_lda_both_tolerance_modes", 1), ("rn_lda_poisson_tolerance", 1), ("rn_lsda", 1),
+                        ("rn_lsda_both_tolerance_modes", 1), ("batch256_lda", 256), ("batch256_lda_scan_sweeps", 256), ("batch1024_lda", 1024),
+                        ("batch1024_lda_scan_sweeps", 1024), ("rn_lsda_l20", 1), ("rn_lsda_l20_scan_sweeps", 1), ("rn_lsda_l20_batch16", 16)):
         full["extra"][name] = bench.summarize(canned_tot(atoms, 10), 17, 131073, atoms, False, 1, 1e-4, 50.0, None)
         full["extra"][name]["warmup"] = 5
     full["extra"]["dense_k_sweeps"] = {"K512_count_nodes": {"sweeps": 7680, "note": "q" * 2000}, "error": None}
@@ -67,7 +68,7 @@ def test_line_is_compact_and_complete():
     c = d["cpu_baseline"]
     assert c["value"] == 573.6 and c["cores"] == 1 and c["kind"] == "port" and c["unit"] == "sweeps/s" and len(c["sample"]) <= 200
     assert c["level_parallel_value"] == 2075.0 and c["all_cores_cores"] == 128
-    assert set(d["extra"]) >= {"rn_lsda", "batch256_lda", "rn_lsda_l20_batch16"}
+    assert set(d["extra"]) >= {"rn_lsda", "batch256_lda", "rn_lsda_l20_batch16", "rn_lda_scan_sweeps", "rn_lda_both_tolerance_modes"}
     for e in d["extra"].values():
         assert all(not isinstance(v, (dict, list)) for v in e.values())       # flat
     assert d["extra"]["rn_lsda"]["ms_per_step"] > 0 and d["extra"]["rn_lsda"]["poisson_frac"] > 0
