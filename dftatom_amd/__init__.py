@@ -22,7 +22,8 @@ BOUNDARY_DEVICE, BOUNDARY_HOST = 0, 1
 LEVELS_CHAINED, LEVELS_BATCHED = 0, 1
 LEVELS_SCAN_SWEEPS = 0x10          # OR-ed into the mode of solve_levels: tolerance mode of the sweeps (transfer-matrix scan)
 SWEEPS_EXACT, SWEEPS_TOLERANCE = 0, 1
-ABI_VERSION = 4
+ABI_VERSION = 5
+LEVEL_CONVERGED, LEVEL_ITERATION_CAP, LEVEL_FIXED_POINT, LEVEL_U0_NONFINITE = 1, 2, 4, 8
 POISSON_DEFAULT, POISSON_EXACT, POISSON_TOLERANCE = -1, 0, 1    # dfta_poisson_create_ex / dfta_scf_options::poisson_mode
 INT_TRAPEZOID, INT_SIMPSON13, INT_SIMPSON38, INT_BOOLE, INT_ROMBERG = range(5)
 XC_VWN, XC_CHACHIYO, XC_CHACHIYO_IMPROVED = range(3)
@@ -41,7 +42,7 @@ class DftaError(RuntimeError):
 
 class LevelResult(C.Structure):
     _fields_ = [("E", C.c_double), ("top", C.c_double), ("bottom", C.c_double), ("n_count", C.c_int),
-                ("n_zero", C.c_int), ("converged", C.c_int), ("matchPoint", C.c_int)]
+                ("n_zero", C.c_int), ("converged", C.c_int), ("matchPoint", C.c_int), ("status", C.c_int)]
 
 
 class Energies(C.Structure):
@@ -118,6 +119,7 @@ SIGNATURES = {
     "dfta_scf_info": (C.c_int, [vp, c_ip, c_ip, c_lp]),
     "dfta_scf_num_levels": (C.c_int, [vp, C.c_int, C.c_int]),
     "dfta_scf_get_levels": (C.c_int, [vp, C.c_int, C.c_int, c_ip, c_ip, c_ip, c_dp, c_ip]),
+    "dfta_scf_get_level_status": (C.c_int, [vp, C.c_int, C.c_int, c_ip, c_ip, c_ip]),
     "dfta_scf_get_array": (C.c_int, [vp, C.c_int, C.c_int, c_dp]),
     "dfta_scf_get_records_dev": (C.c_int, [vp, vp]),
     "dfta_get_subshells": (C.c_int, [C.c_int, c_ip, c_ip, c_ip, C.c_int]),
@@ -317,7 +319,7 @@ def solve_levels(ctx, grid, V, levels, bottom0, vidx=None, mode=LEVELS_BATCHED, 
                                         nl, _ip(vi), _ip(n), _ip(l),
                                         _ip(occ), res, _dp(nd), _dp(eel), _dp(psi) if want_psi else None, C.byref(issued)))
     out = {k: np.array([getattr(res[i], k) for i in range(nl)]) for k in
-           ("E", "top", "bottom", "n_count", "n_zero", "converged", "matchPoint")}
+           ("E", "top", "bottom", "n_count", "n_zero", "converged", "matchPoint", "status")}
     out.update(newDensity=nd, Eelectronic=eel, psi=psi, issued=issued.value)
     return out
 
@@ -462,7 +464,11 @@ class Scf:
         E = np.zeros(max(cnt, 1))
         if cnt > 0:
             self.ctx.check(self.ctx.lib.dfta_scf_get_levels(self.h, atom, spin, _ip(n), _ip(l), _ip(occ), _dp(E), _ip(conv)))
-        return {"n": n[:cnt], "l": l[:cnt], "occ": occ[:cnt], "E": E[:cnt], "converged": conv[:cnt]}
+        status, nc, nz = (np.zeros(max(cnt, 1), np.int32) for _ in range(3))
+        if cnt > 0:
+            self.ctx.check(self.ctx.lib.dfta_scf_get_level_status(self.h, atom, spin, _ip(status), _ip(nc), _ip(nz)))
+        return {"n": n[:cnt], "l": l[:cnt], "occ": occ[:cnt], "E": E[:cnt], "converged": conv[:cnt], "status": status[:cnt],
+                "n_count": nc[:cnt], "n_zero": nz[:cnt]}
 
     def array(self, which, atom=0):
         out = np.zeros(self.grid.N)

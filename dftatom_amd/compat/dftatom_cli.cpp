@@ -10,6 +10,9 @@
 // options dialog does (OptionsFrame.cpp:46,152-175: Z 1..118, levels 10..20, MaxR 1..90, deltaGrid in (0, 1], alpha in [0, 1]);
 // any other method value is refused (exit code 2).
 // --integrator: trapezoid | simpson13 | simpson38 (default, what the reference calls) | boole | romberg (README.md:81).
+// --json[=FILE]: one JSON line per SCF step (17-digit energies and eigenvalues, per-level status bits and sweep counts, rounds, V-cycles,
+//                phase times) to FILE, or to stderr -- the console protocol on stdout stays the reference's.
+// --sweeps=exact|tolerance, --poisson=exact|tolerance: the opt-in tolerance modes of the device path (include/dftatom_hip.h).
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
@@ -71,6 +74,17 @@ int main(int argc, char** argv)
         else if (a == "--ini" && i + 1 < argc) {
             if (!load_ini(argv[++i], o)) { std::cerr << "cannot read " << argv[i] << std::endl; return 2; }
             have = true;
+        } else if (a == "--json") {
+            DFT::DFTAtom::jsonOut = &std::cerr;
+        } else if (a.rfind("--json=", 0) == 0) {
+            static std::ofstream jf;
+            jf.open(a.substr(7));
+            if (!jf) { std::cerr << "cannot write " << a.substr(7) << std::endl; return 2; }
+            DFT::DFTAtom::jsonOut = &jf;
+        } else if (a == "--sweeps=tolerance" || a == "--sweeps=exact") {
+            DFT::DFTAtom::sweepMode = a == "--sweeps=tolerance" ? DFTA_SWEEPS_TOLERANCE : DFTA_SWEEPS_EXACT;
+        } else if (a == "--poisson=tolerance" || a == "--poisson=exact") {
+            DFT::DFTAtom::poissonMode = a == "--poisson=tolerance" ? DFTA_POISSON_TOLERANCE : DFTA_POISSON_EXACT;
         } else if (a.rfind("--integrator=", 0) == 0) {
             const std::string n = a.substr(13);
             const char* names[] = {"trapezoid", "simpson13", "simpson38", "boole", "romberg"};

@@ -9,8 +9,9 @@ int dfta_launch_build_tab(dfta_ctx* ctx, const dfta_grid* g, double2* tab, const
                           const int* d_slot_l, int nslots, double2* bounds /* nslots, may be null */);
 // for_match / dL / dUz: uniform grid only -- the match solve re-derives its step from the truncated step count, so its
 // second start value differs from a sweep's, and it needs GetBoundaryValueZero(h', l) per trial (Numerov.h:430,475)
+// stream: nullptr = the context's stream (the early match solves of levels.hip run on a second one)
 int dfta_launch_boundary(dfta_ctx* ctx, const dfta_grid* g, const double* dE, int ntrials, int* dStart, double* dUs,
-                         double* dUs1, int for_match = 0, const int* dL = nullptr, double* dUz = nullptr);
+                         double* dUs1, int for_match = 0, const int* dL = nullptr, double* dUz = nullptr, hipStream_t stream = nullptr);
 // flag in SweepArgs::istop (numerov.hip): the sweep left CountNodes because the count exceeded the limit
 constexpr int kStopOver = 0x40000000;
 
@@ -23,7 +24,7 @@ int dfta_launch_sweep(dfta_ctx* ctx, const dfta_grid* g, int kind, const int* bl
 int dfta_launch_match(dfta_ctx* ctx, const dfta_grid* g, int ntrials, const double2* tab, const int* d_trial_slot,
                       const double* dE, const int* dStart, const double* dUs, const double* dUs1, const int* dL,
                       double* dPsi, double* dQ, int* dMatch, const double2* bounds /* per slot (dfta_bounds_stride), may be null */,
-                      const double* dUz = nullptr /* uniform grid: start value at the first node per trial */);
+                      const double* dUz = nullptr /* uniform grid: start value at the first node per trial */, hipStream_t stream = nullptr);
 
 // scan.hip: the tolerance mode of the sweeps (transfer-matrix scan: one workgroup per trial)
 struct dfta_scan_tables {

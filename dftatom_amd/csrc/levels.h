@@ -67,6 +67,7 @@ struct Job {
     // machine; re-allotted every round by k_allot when a handful of jobs leave compute units idle (levels.hip).
     int tbase, tcap;
     int n_fixed;                     // iterations of the third bisection counted in n_zero but not integrated: the bisection stood on a fixed point (walk_job)
+    int status;                      // DFTA_LEVEL_* bits: how the third bisection ended (DFTAtom.cpp:517-539)
     long long n_points;              // grid points traversed by the sweeps ON the bisection path (n_count + n_zero executed ones) + the match solve
 };
 
@@ -115,8 +116,10 @@ struct LevelSolver {
     // Early match solves (latency mode): a level whose search has ended is matched on a second stream while the remaining levels'
     // last rounds run -- the outer levels, whose outward streams are the long ones, end a round or two before the core levels.
     hipStream_t st2 = nullptr;
-    hipEvent_t ev_walk = nullptr, ev_early = nullptr;
+    hipEvent_t ev_walk = nullptr, ev_early = nullptr, ev_taken = nullptr;
     int *d_jmatched = nullptr, *d_jstart_keep = nullptr;
+    double* d_snapE = nullptr;          // snapshot of the jobs' eigenvalues / "search ended" flags, taken on the first stream after every walk
+    int *d_snapReady = nullptr, *d_jtake = nullptr;
     bool early_match = false;
     // Tolerance mode of the sweeps (scan.hip; DFTA_SWEEPS_TOLERANCE, set before setup()): interleaved tables per slot, per-lane {min, max}
     int sweep_mode = DFTA_SWEEPS_EXACT;

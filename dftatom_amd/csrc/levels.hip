@@ -476,7 +476,8 @@ __device__ void walk_job(dfta::Job& j, const int* __restrict__ count, const doub
             j.haveSgn = 1;
         }
         double hi = j.toe, lo = j.boe;
-        bool conv = false;
+        bool conv = false, fixed = false;
+        double last_ad = 0;
         while (j.iter3 < kMaxIter3) {
             const int h = c.node();
             if (h < 0) { if (c.off) j.miss = 1; j.toe = hi; j.boe = lo; return; }
@@ -491,6 +492,7 @@ __device__ void walk_job(dfta::Job& j, const int* __restrict__ count, const doub
             c.advance(bit, pred_bit(j, 2, j.phase_done));
             record_bit(j, 2, bit);
             const double ad = fabs(d);
+            last_ad = ad;
             if (hi - lo < kEnergyErr && !isnan(ad) && ad < 1E15) { conv = true; break; }
             if (g_fixed_point && hi == hi_was && lo == lo_was) {
                 // A level whose u(0) never gets below 1e15 (or is NaN) keeps the reference bisecting until its 500-iteration cap
@@ -502,6 +504,7 @@ __device__ void walk_job(dfta::Job& j, const int* __restrict__ count, const doub
                 j.n_zero += rest;
                 j.n_fixed += rest;
                 j.iter3 = kMaxIter3;
+                fixed = true;
                 break;
             }
         }
@@ -510,6 +513,9 @@ __device__ void walk_job(dfta::Job& j, const int* __restrict__ count, const doub
         j.boe = lo;
         j.E = lo;                                                    // level.E = BottomEnergy
         j.converged = conv ? 1 : 0;
+        // how it ended (include/dftatom_hip.h): the reference folds all of it into didNotConverge (DFTAtom.cpp:517-539)
+        j.status = conv ? DFTA_LEVEL_CONVERGED
+                        : (DFTA_LEVEL_ITERATION_CAP | (fixed ? DFTA_LEVEL_FIXED_POINT : 0) | (!(last_ad < INFINITY) ? DFTA_LEVEL_U0_NONFINITE : 0));
         j.phase = PH_DONE;
         j.spine = 0;
         j.capz = 0;
@@ -1038,16 +1044,46 @@ __global__ void k_store_match(dfta::Job* __restrict__ jobs, int njobs, const int
     }
 }
 
-// early match solves: of the jobs whose cut-off indices were just computed, keep those whose search has ended and that have not been
-// matched yet (the others get -1: skipped by k_match); remember the kept ones' cut-off index for the statistics and the final passes
-__global__ void k_mask_ready(const dfta::Job* __restrict__ jobs, int njobs, int* __restrict__ jstart, int* __restrict__ matched,
+// Early match solves run on a SECOND stream while the next round runs on the first, whose k_walk rewrites the job records.  What the
+// second stream needs of them is therefore SNAPSHOT on the first stream, in order with the round -- right after k_walk, before the
+// event the second stream waits for: the eigenvalue of every job and whether its search has ended.  (Before round 4 the second stream
+// read jobs[k].E and, two kernels later, jobs[k].phase: a level that finished in the NEXT round between those two reads would have
+// been matched with a stale energy.  Unlikely -- a sweep outlasts three small kernels -- but not ordered.)
+__global__ void k_snapshot_done(const dfta::Job* __restrict__ jobs, int njobs, double* __restrict__ snapE, int* __restrict__ snapReady)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= njobs) return;
+    snapE[k] = jobs[k].E;
+    snapReady[k] = jobs[k].phase == PH_DONE && !jobs[k].frozen;
+}
+// second stream: the snapshot's finished jobs that have not been matched yet take their energy; the others keep what they had
+__global__ void k_take_ready(const double* __restrict__ snapE, const int* __restrict__ snapReady, const int* __restrict__ matched, int njobs,
+                             double* __restrict__ jE, int* __restrict__ take)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= njobs) return;
+    const int t = snapReady[k] && !matched[k];
+    take[k] = t;
+    if (t) jE[k] = snapE[k];
+    else if (!(jE[k] == jE[k])) jE[k] = -1.;         // never written yet: any finite energy (its cut-off index is masked out below)
+}
+// of the jobs whose cut-off indices were just computed, keep the taken ones (the others get -1: skipped by k_match); remember the kept
+// ones' cut-off index for the statistics and the final passes
+__global__ void k_mask_ready(const int* __restrict__ take, int njobs, int* __restrict__ jstart, int* __restrict__ matched,
                              int* __restrict__ jstart_keep)
 {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= njobs) return;
-    const bool ready = jobs[k].phase == PH_DONE && !jobs[k].frozen && !matched[k];
-    if (ready) { matched[k] = 1; jstart_keep[k] = jstart[k]; }
+    if (take[k]) { matched[k] = 1; jstart_keep[k] = jstart[k]; }
     else jstart[k] = -1;
+}
+// slot and l of every job (they never change during a run)
+__global__ void k_job_slots(const dfta::Job* __restrict__ jobs, int njobs, int* __restrict__ slot, int* __restrict__ l)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= njobs) return;
+    slot[k] = jobs[k].slot;
+    l[k] = jobs[k].l;
 }
 // the final pass: every job that is neither frozen nor matched already
 __global__ void k_mask_rest(const dfta::Job* __restrict__ jobs, int njobs, int* __restrict__ jstart, const int* __restrict__ matched,
@@ -1087,6 +1123,9 @@ void LevelSolver::release()
     if (st2) { (void)hipStreamDestroy(st2); st2 = nullptr; }
     if (ev_walk) { (void)hipEventDestroy(ev_walk); ev_walk = nullptr; }
     if (ev_early) { (void)hipEventDestroy(ev_early); ev_early = nullptr; }
+    if (ev_taken) { (void)hipEventDestroy(ev_taken); ev_taken = nullptr; }
+    for (void* q : {(void*)d_snapE, (void*)d_snapReady, (void*)d_jtake}) if (q) (void)hipFree(q);
+    d_snapE = nullptr; d_snapReady = nullptr; d_jtake = nullptr;
     for (hipEvent_t& e : ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
     d_jobs = nullptr; d_chain_off = nullptr; d_chain_off_b = nullptr; d_v_off = nullptr; d_slot_v = nullptr; d_slot_l = nullptr; d_tab = nullptr;
     d_E = nullptr; d_limit = nullptr; d_start = nullptr; d_us = nullptr; d_us1 = nullptr; d_count = nullptr; d_u0 = nullptr; d_phi = nullptr; d_istop = nullptr; d_trip = nullptr;
@@ -1256,10 +1295,12 @@ int LevelSolver::setup(dfta_ctx* c, const dfta_grid* grid, int mode_, int tree_d
     ALLOC(d_Q, double, (size_t)njobs * N);
     ALLOC(d_jE, double, njobs); ALLOC(d_jslot, int, njobs); ALLOC(d_jl, int, njobs); ALLOC(d_jstart, int, njobs);
     ALLOC(d_jmatched, int, njobs); ALLOC(d_jstart_keep, int, njobs);
+    ALLOC(d_snapE, double, njobs); ALLOC(d_snapReady, int, njobs); ALLOC(d_jtake, int, njobs);
     if (early_match) {
         DFTA_HIP(ctx, hipStreamCreateWithFlags(&st2, hipStreamNonBlocking));
         DFTA_HIP(ctx, hipEventCreateWithFlags(&ev_walk, hipEventDisableTiming));
         DFTA_HIP(ctx, hipEventCreateWithFlags(&ev_early, hipEventDisableTiming));
+        DFTA_HIP(ctx, hipEventCreateWithFlags(&ev_taken, hipEventDisableTiming));
     }
     ALLOC(d_jus, double, njobs); ALLOC(d_jus1, double, njobs); ALLOC(d_jmp, int, njobs);
     ALLOC(d_slot_min, double, nslots);
@@ -1438,6 +1479,11 @@ int LevelSolver::run(const double* dV, const double* job_bottom, int run_mode, d
         DFTA_HIP(ctx, hipStreamSynchronize(st));
         round_trials = pack_out[0];
     }
+    if (early && !scan) {
+        hipLaunchKernelGGL(k_job_slots, dim3((njobs + 63) / 64), dim3(64), 0, st, d_jobs, njobs, d_jslot, d_jl);
+        DFTA_CHECK_LAUNCH(ctx);
+        DFTA_HIP(ctx, hipMemsetAsync(d_jE, 0xff, sizeof(double) * njobs, st));      // NaN: "no energy yet" (k_take_ready)
+    }
     int* d_ndone = reinterpret_cast<int*>(d_counters + 2);
     int rounds = scan ? 1 : 0;
     float ms_sweep = ms_scan;
@@ -1465,7 +1511,12 @@ int LevelSolver::run(const double* dV, const double* job_bottom, int run_mode, d
         DFTA_HIP(ctx, hipMemsetAsync(d_ndone, 0, sizeof(int), st));
         hipLaunchKernelGGL(k_walk, dim3((run_chains + 63) / 64), dim3(64), 0, st, d_jobs, d_chains, run_chains, d_count, d_u0, d_phi, d_istop, stats ? d_trip : nullptr, d_tab, N, d_ndone);
         DFTA_CHECK_LAUNCH(ctx);
-        if (early) DFTA_HIP(ctx, hipEventRecord(ev_walk, st));
+        if (early) {
+            DFTA_HIP(ctx, hipStreamWaitEvent(st, ev_taken, 0));      // the second stream has consumed the previous snapshot (no-op if none was taken)
+            hipLaunchKernelGGL(k_snapshot_done, dim3((njobs + 63) / 64), dim3(64), 0, st, d_jobs, njobs, d_snapE, d_snapReady);
+            DFTA_CHECK_LAUNCH(ctx);
+            DFTA_HIP(ctx, hipEventRecord(ev_walk, st));
+        }
         rc = plan();
         if (rc) return rc;
         int ndone = 0;
@@ -1479,15 +1530,15 @@ int LevelSolver::run(const double* dV, const double* job_bottom, int run_mode, d
             // under the next round's sweeps (two waves and 8 KB of LDS per level fit next to a sweep block)
             done_seen = ndone;
             DFTA_HIP(ctx, hipStreamWaitEvent(st2, ev_walk, 0));
-            ctx->stream = st2;                       // the launch helpers below use the context's stream
-            int erc = DFTA_OK;
-            hipLaunchKernelGGL(k_job_energies, dim3((njobs + 63) / 64), dim3(64), 0, st2, d_jobs, njobs, d_jE, d_jslot, d_jl);
-            erc = dfta_launch_boundary(ctx, g, d_jE, njobs, d_jstart, d_jus, d_jus1, 1, d_jl, d_Q);
+            hipLaunchKernelGGL(k_take_ready, dim3((njobs + 63) / 64), dim3(64), 0, st2, d_snapE, d_snapReady, d_jmatched, njobs, d_jE, d_jtake);
+            DFTA_CHECK_LAUNCH(ctx);
+            DFTA_HIP(ctx, hipEventRecord(ev_taken, st2));
+            int erc = dfta_launch_boundary(ctx, g, d_jE, njobs, d_jstart, d_jus, d_jus1, 1, d_jl, d_Q, st2);
             if (!erc) {
-                hipLaunchKernelGGL(k_mask_ready, dim3((njobs + 63) / 64), dim3(64), 0, st2, d_jobs, njobs, d_jstart, d_jmatched, d_jstart_keep);
-                erc = dfta_launch_match(ctx, g, njobs, d_tab, d_jslot, d_jE, d_jstart, d_jus, d_jus1, d_jl, d_Psi, d_Q, d_jmp, d_bounds, d_Q);
+                hipLaunchKernelGGL(k_mask_ready, dim3((njobs + 63) / 64), dim3(64), 0, st2, d_jtake, njobs, d_jstart, d_jmatched, d_jstart_keep);
+                DFTA_CHECK_LAUNCH(ctx);
+                erc = dfta_launch_match(ctx, g, njobs, d_tab, d_jslot, d_jE, d_jstart, d_jus, d_jus1, d_jl, d_Psi, d_Q, d_jmp, d_bounds, d_Q, st2);
             }
-            ctx->stream = st;
             if (erc) return erc;
             DFTA_HIP(ctx, hipEventRecord(ev_early, st2));
             early_pending = true;
@@ -1626,6 +1677,7 @@ extern "C" int dfta_solve_levels(dfta_ctx* ctx, const dfta_grid* g, int mode, in
         const dfta::Job& j = jobs[k];
         results[k].E = j.E; results[k].top = j.top; results[k].bottom = j.bottom; results[k].n_count = j.n_count;
         results[k].n_zero = j.n_zero; results[k].converged = j.converged; results[k].matchPoint = j.matchPoint;
+        results[k].status = j.status;
         if (Eelectronic) Eelectronic[j.v] += j.occ * j.E;            // DFTAtom.cpp:561
         allconv = allconv && j.converged;
     }

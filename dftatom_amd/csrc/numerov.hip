@@ -1606,15 +1606,16 @@ int dfta_launch_build_tab(dfta_ctx* ctx, const dfta_grid* g, double2* tab, const
 }
 
 int dfta_launch_boundary(dfta_ctx* ctx, const dfta_grid* g, const double* dE, int ntrials, int* dStart, double* dUs, double* dUs1,
-                         int for_match, const int* dL, double* dUz)
+                         int for_match, const int* dL, double* dUz, hipStream_t stream)
 {
+    hipStream_t st = stream ? stream : ctx->stream;
     if (g->uniform) {
-        hipLaunchKernelGGL(k_boundary_uniform, dim3((ntrials + 255) / 256), dim3(256), 0, ctx->stream, dE, ntrials, scalars_of(g), dStart,
+        hipLaunchKernelGGL(k_boundary_uniform, dim3((ntrials + 255) / 256), dim3(256), 0, st, dE, ntrials, scalars_of(g), dStart,
                            dUs, dUs1, for_match, dL, dL ? dUz : nullptr);
         DFTA_CHECK_LAUNCH(ctx);
         return DFTA_OK;
     }
-    hipLaunchKernelGGL(k_boundary, dim3((ntrials + 255) / 256), dim3(256), 0, ctx->stream, g->d_r, dE, ntrials,
+    hipLaunchKernelGGL(k_boundary, dim3((ntrials + 255) / 256), dim3(256), 0, st, g->d_r, dE, ntrials,
                        scalars_of(g), dStart, dUs, dUs1);
     DFTA_CHECK_LAUNCH(ctx);
     return DFTA_OK;
@@ -1647,16 +1648,17 @@ int dfta_launch_sweep(dfta_ctx* ctx, const dfta_grid* g, int kind, const int* bl
 
 int dfta_launch_match(dfta_ctx* ctx, const dfta_grid* g, int ntrials, const double2* tab, const int* d_trial_slot,
                       const double* dE, const int* dStart, const double* dUs, const double* dUs1, const int* dL,
-                      double* dPsi, double* dQ, int* dMatch, const double2* bounds, const double* dUz)
+                      double* dPsi, double* dQ, int* dMatch, const double2* bounds, const double* dUz, hipStream_t stream)
 {
+    hipStream_t st = stream ? stream : ctx->stream;
     if (g->uniform) {
         if (!dUz) { snprintf(ctx->err, sizeof(ctx->err), "uniform match needs the start values at the origin"); return DFTA_ERR_INVALID; }
-        hipLaunchKernelGGL(k_umatch, dim3(ntrials), dim3(64), 0, ctx->stream, tab, d_trial_slot, dE, dStart, dUs, dUs1, dUz, dL, scalars_of(g),
+        hipLaunchKernelGGL(k_umatch, dim3(ntrials), dim3(64), 0, st, tab, d_trial_slot, dE, dStart, dUs, dUs1, dUz, dL, scalars_of(g),
                            dPsi, dMatch);
         DFTA_CHECK_LAUNCH(ctx);
         return DFTA_OK;
     }
-    hipLaunchKernelGGL(k_match, dim3(ntrials), dim3(128), 0, ctx->stream, tab, d_trial_slot, dE, dStart, dUs, dUs1, dL,
+    hipLaunchKernelGGL(k_match, dim3(ntrials), dim3(128), 0, st, tab, d_trial_slot, dE, dStart, dUs, dUs1, dL,
                        g->zero1[0], g->zero1[1], g->zero1[2], g->zero1[3], scalars_of(g), bounds, dfta_bounds_stride(g), dPsi, dQ,
                        dMatch);
     DFTA_CHECK_LAUNCH(ctx);

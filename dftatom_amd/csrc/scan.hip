@@ -836,7 +836,8 @@ __global__ void __launch_bounds__(kT) k_scan_levels(ScanGrid G0, const double* _
         const double bottom = toe;
         // third bisection: the sign change of u(0) inside [bottom, top] (DFTAtom.cpp:513-534)
         double Top = top, Bot = bottom;
-        int iter3 = 0, conv = 0;
+        int iter3 = 0, conv = 0, fixed = 0;
+        double last_ad = 0;
         {
             const SweepOut o = scan_sweep<DFTA_SWEEP_ZERO>(G, tab, mm, Bot, 0, sh, par++ & 1, hint);
             hint = o.start;
@@ -850,10 +851,11 @@ __global__ void __launch_bounds__(kT) k_scan_levels(ScanGrid G0, const double* _
                 const double Top_was = Top, Bot_was = Bot;
                 if ((z.u0 > 0) == sgnBottom) Bot = E; else Top = E;
                 const double ad = fabs(z.u0);
+                last_ad = ad;
                 if (Top - Bot < kErr && !(ad != ad) && ad < 1E15) { conv = 1; break; }
                 if (fixed_point && Top == Top_was && Bot == Bot_was) {      // the same midpoint, sweep and decision to the cap (levels.hip)
                     const int rest = kIter3 - iter3;
-                    n_zero += rest; n_fixed += rest; iter3 = kIter3;
+                    n_zero += rest; n_fixed += rest; iter3 = kIter3; fixed = 1;
                     break;
                 }
             }
@@ -874,6 +876,8 @@ __global__ void __launch_bounds__(kT) k_scan_levels(ScanGrid G0, const double* _
             if (ma.mode) J->matchPoint = matchPoint;
             J->top = top; J->bottom = bottom; J->toe = Top; J->boe = Bot; J->E = Bot;
             J->bottom0 = bottom0;
+            J->status = conv ? DFTA_LEVEL_CONVERGED
+                             : (DFTA_LEVEL_ITERATION_CAP | (fixed ? DFTA_LEVEL_FIXED_POINT : 0) | (!(last_ad < INFINITY) ? DFTA_LEVEL_U0_NONFINITE : 0));
             J->converged = conv; J->n_count = n_count; J->n_zero = n_zero; J->iter3 = iter3; J->n_fixed = n_fixed;
             J->cur_len[1] = len2; J->n_points = pts; J->phase = kPhDone; J->haveSgn = 1;
             const int skipped = (nodes == 0 ? len2 : 0) + n_fixed;          // counted, not integrated

@@ -620,6 +620,23 @@ int dfta_scf_get_levels(dfta_scf* s, int atom, int spin, int* n, int* l, int* oc
     return DFTA_OK;
 }
 
+int dfta_scf_get_level_status(dfta_scf* s, int atom, int spin, int* status, int* n_count, int* n_zero)
+{
+    if (!s) return DFTA_ERR_INVALID;
+    dfta_ctx* ctx = s->ctx;
+    DFTA_ENTER(ctx);
+    DFTA_REQUIRE(ctx, atom >= 0 && atom < s->natoms && spin >= 0 && spin < s->nspin, "atom/spin");
+    const std::vector<dfta::Job>& jobs = s->h_jobs;
+    DFTA_REQUIRE(ctx, !jobs.empty(), "no SCF step has run yet");
+    const int k0 = s->h_atoms[atom].job_off + (spin ? s->spin_nlev[0][atom] : 0);
+    for (int k = 0; k < s->spin_nlev[spin][atom]; ++k) {
+        if (status) status[k] = jobs[k0 + k].status;
+        if (n_count) n_count[k] = jobs[k0 + k].n_count;
+        if (n_zero) n_zero[k] = jobs[k0 + k].n_zero;
+    }
+    return DFTA_OK;
+}
+
 int dfta_scf_get_array(dfta_scf* s, int atom, int which, double* out)
 {
     if (!s) return DFTA_ERR_INVALID;

@@ -165,7 +165,20 @@ typedef struct dfta_level_result {
     int    n_zero;       /* reference-equivalent SolutionInZero sweeps                   */
     int    converged;    /* !didNotConverge                                              */
     int    matchPoint;
+    int    status;       /* DFTA_LEVEL_* bits: HOW the u(0) bisection ended (below)      */
 } dfta_level_result;
+/* The reference folds every way its u(0) bisection (DFTAtom.cpp:517-539) can fail to meet `Top - Bottom < 1e-12 && |u(0)| < 1e15` into
+ * one flag, didNotConverge.  status tells them apart:
+ *   CONVERGED       the stop test was met (converged != 0, no other bit);
+ *   ITERATION_CAP   the 500-iteration cap ended the loop;
+ *   FIXED_POINT     ... and the interval had collapsed long before: a step left (Top, Bottom) as they were, i.e. the same midpoint, sweep and
+ *                   decision repeated to the cap -- |u(0)| never came below 1e15 (the case at 1 048 577 nodes from the seventh SCF step on;
+ *                   those repeats are counted in n_zero but not integrated);
+ *   U0_NONFINITE    u(0) of the last trial was NaN or infinite (overflow of the inward solution). */
+#define DFTA_LEVEL_CONVERGED     1
+#define DFTA_LEVEL_ITERATION_CAP 2
+#define DFTA_LEVEL_FIXED_POINT   4
+#define DFTA_LEVEL_U0_NONFINITE  8
 
 int dfta_solve_levels(dfta_ctx* ctx, const dfta_grid* g, int mode, int tree_depth,
                       int nV, const double* V, const double* bottom0 /* nV */,
@@ -286,7 +299,7 @@ typedef struct dfta_scf_options {
 /* The option and statistics structs grow at the END between versions of this header and carry no size field: zero-initialise them
  * (every member's 0 is the reference's behaviour) and build against the header of the library you load -- dfta_abi_version()
  * returns the DFTA_ABI_VERSION the library was built with, for a run-time check. */
-#define DFTA_ABI_VERSION 4
+#define DFTA_ABI_VERSION 5
 int  dfta_abi_version(void);
 int  dfta_scf_create_ex(dfta_ctx* ctx, const dfta_grid* g, int lsda, int natoms, const int* Z, double alpha, int levels_mode,
                         int tree_depth, const dfta_scf_options* options, dfta_scf** out);
@@ -306,6 +319,8 @@ int  dfta_scf_poisson_info(const dfta_scf* s, int* G, int* degraded, int* aborts
 int  dfta_scf_set_integrator(dfta_scf* s, int rule);   /* dfta_poisson_group_info of the SCF's solver */
 int  dfta_scf_num_levels(const dfta_scf* s, int atom, int spin);
 int  dfta_scf_get_levels(dfta_scf* s, int atom, int spin, int* n, int* l, int* occ, double* E, int* converged);
+/* DFTA_LEVEL_* bits of every level of (atom, spin) after the last step, and the reference-equivalent sweep counts (any pointer may be NULL) */
+int  dfta_scf_get_level_status(dfta_scf* s, int atom, int spin, int* status, int* n_count, int* n_zero);
 int  dfta_scf_get_array(dfta_scf* s, int atom, int which, double* out /* N */);  /* 0 density,1 densityA,2 densityB,3 potA,4 potB,5 U */
 /* fixed-size per-atom record for the periodic-table gather: 64 doubles */
 #define DFTA_RECORD_DOUBLES 64

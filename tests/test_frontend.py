@@ -160,3 +160,35 @@ def test_cli_integrator_switch():
     for a, b in zip(e0, eb):
         assert abs(a - b) <= 2e-5 * max(1.0, abs(a)), (e0, eb)
     assert "Finished!" in rom.stdout and rom.stdout.strip().splitlines()[-1].strip() == "1s2 2s2 2p6"
+
+
+@pytest.mark.gpu
+def test_cli_json_lines(tmp_path):
+    """--json=FILE: one JSON line per SCF step with full-precision values (metrics): the eigenvalues and energies
+    round to the six decimals of the console protocol, every converged level carries status == DFTA_LEVEL_CONVERGED, the sweep counts and
+    phase times are there; stdout is untouched by the flag.  Also through the tolerance modes' switches."""
+    ref = _golden("N_LSDA_L12")
+    js = tmp_path / "steps.jsonl"
+    plain = _run(*ref["args"], "chained")
+    r = _run(*ref["args"], "chained", "--json=%s" % js)
+    assert r.returncode == 0 and r.stdout == plain.stdout
+    rows = [json.loads(ln) for ln in open(js).read().splitlines()]
+    _, steps, _ = _steps(r.stdout)
+    assert len(rows) == len(steps) and rows[-1]["finished"] is True and [q["step"] for q in rows] == list(range(len(rows)))
+    last = rows[-1]
+    assert ("Etotal = %.6f" % last["Etotal"]) in steps[-1][-1] or ("Etotal = %.6f" % last["Etotal"]) in "\n".join(steps[-1])
+    assert all(lv["status"] == 1 and lv["count_sweeps"] > 0 and lv["zero_sweeps"] > 0 for lv in last["levels"])
+    assert last["vcycles"] > 0 and last["sweeps_reference"] > 0 and last["ms_levels"] > 0 and last["ms_poisson"] > 0
+    energy_lines = [ln for ln in steps[-1] if ln.startswith("Energy ")]
+    assert len(energy_lines) == len(last["levels"])
+    for ln, lv in zip(energy_lines, last["levels"]):
+        assert ("%.6f" % lv["E"]) in ln
+    # the tolerance modes through the front end: same protocol shape, energies to 1e-8 relative
+    t = _run(18, 14, 0.5, 25, 0.0005, 0, "--sweeps=tolerance", "--poisson=tolerance", "--json=%s" % (tmp_path / "tol.jsonl"))
+    e = _run(18, 14, 0.5, 25, 0.0005, 0, "--json=%s" % (tmp_path / "ex.jsonl"))
+    assert t.returncode == 0 and e.returncode == 0
+    jt = [json.loads(ln) for ln in open(tmp_path / "tol.jsonl").read().splitlines()]
+    je = [json.loads(ln) for ln in open(tmp_path / "ex.jsonl").read().splitlines()]
+    assert jt[0]["levels_layout"] == 4 and je[0]["levels_layout"] != 4
+    for a, b in zip(jt[:20], je[:20]):
+        assert abs(a["Etotal"] - b["Etotal"]) <= 1e-8 * abs(b["Etotal"])

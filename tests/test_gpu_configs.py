@@ -354,7 +354,7 @@ def test_l20_third_bisection_on_its_fixed_point(ctx, grid20):
             st = scf.step()
             rows.append((scf.energies()[0][0].as_list(), [scf.levels(0, sp)["E"].copy() for sp in range(2)],
                          [scf.levels(0, sp)["converged"].copy() for sp in range(2)], int(st.sweeps_reference), int(st.sweeps_reference_executed),
-                         int(st.rounds)))
+                         int(st.rounds), [scf.levels(0, sp)["status"].copy() for sp in range(2)]))
         scf.close()
         return rows
     got, full = run(""), run("LEVELS_NOFIXEDPOINT")
@@ -367,6 +367,13 @@ def test_l20_third_bisection_on_its_fixed_point(ctx, grid20):
         if y[5] >= 50:                                   # a step in which a level runs to the iteration cap
             hit = True
             assert x[4] <= y[4] - 300 and not (x[2][0].all() and x[2][1].all()), (k, x[4], y[4])
+            # dfta_level_result.status tells the ways of not converging apart (the reference has one flag): the capped level stood on a
+            # fixed point of its bisection; with every iteration integrated it is "iteration cap" alone -- the same level either way
+            for sp in range(2):
+                capped = ~x[2][sp].astype(bool)
+                assert np.all(x[6][sp][capped] & D.LEVEL_ITERATION_CAP) and np.all(x[6][sp][capped] & D.LEVEL_FIXED_POINT)
+                assert np.all(x[6][sp][~capped] == D.LEVEL_CONVERGED)
+                assert np.all((y[6][sp][capped] & (D.LEVEL_ITERATION_CAP | D.LEVEL_FIXED_POINT)) == D.LEVEL_ITERATION_CAP)
     assert hit, [r[5] for r in full]
 
 

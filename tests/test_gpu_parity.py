@@ -697,3 +697,40 @@ def test_open_shell_lsda_vs_oracle(ctx):
     assert a[0] < b[0] and a[1] < b[1]                              # majority-spin levels lie deeper
     scf.close()
     grid.close()
+
+
+def test_early_match_solves_equal_late_ones(ctx):
+    """the early match solves (levels.hip: a level whose search has ended is matched on a second stream under the
+    next round's sweeps) must be a pure re-ordering.  Rn LSDA at 131 073 nodes, four SCF steps, with and without LEVELS_NOEARLYMATCH:
+    energies, eigenvalues, match statistics and the density itself bit for bit.  (Since round 4 the second stream works on a snapshot
+    of the job records taken on the first stream in order with the round -- k_snapshot_done -- instead of re-reading records that the
+    next round's walk rewrites.)"""
+    L, d, R = GRIDS["L17"]
+    grid = D.Grid(ctx, L, d, R)
+
+    def run(knob):
+        old = os.environ.get("DFTA_DEBUG")
+        try:
+            if knob:
+                os.environ["DFTA_DEBUG"] = knob
+            else:
+                os.environ.pop("DFTA_DEBUG", None)
+            scf = D.Scf(ctx, grid, [86], lsda=True)
+            out = []
+            for _ in range(4):
+                st = scf.step()
+                en, _ = scf.energies()
+                out.append((en[0].as_list(), scf.levels(0, 0)["E"].copy(), scf.levels(0, 1)["E"].copy(), int(st.sweeps_reference), int(st.points_reference),
+                            scf.array(1).copy(), scf.array(2).copy()))
+            scf.close()
+            return out
+        finally:
+            if old is None:
+                os.environ.pop("DFTA_DEBUG", None)
+            else:
+                os.environ["DFTA_DEBUG"] = old
+    a, b = run(None), run("LEVELS_NOEARLYMATCH")
+    for x, y in zip(a, b):
+        assert x[0] == y[0] and np.array_equal(x[1], y[1]) and np.array_equal(x[2], y[2]) and x[3:5] == y[3:5]
+        assert np.array_equal(x[5], y[5]) and np.array_equal(x[6], y[6])
+    grid.close()
