@@ -90,6 +90,11 @@ SIGNATURES = {
     "dfta_numerov_sweeps_dev": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, C.c_int, c_ip, c_ip, c_ip, vp, vp, vp, vp, vp,
                                           vp, vp, vp, vp]),
     "dfta_numerov_match": (C.c_int, [vp, vp, C.c_int, C.c_int, c_dp, C.c_int, c_ip, c_ip, c_dp, c_dp, c_lp]),
+    "dfta_potential_create": (C.c_int, [vp, vp, c_dp, C.POINTER(vp)]),
+    "dfta_potential_update": (C.c_int, [vp, c_dp]),
+    "dfta_potential_destroy": (None, [vp]),
+    "dfta_potential_sweeps": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, c_ip, c_dp, c_ip, c_ip, c_dp, c_ip, c_ip]),
+    "dfta_potential_match": (C.c_int, [vp, C.c_int, c_ip, c_dp, c_dp, c_lp]),
     "dfta_solve_levels": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, c_dp, c_dp, c_dp, C.c_int, c_ip, c_ip, c_ip, c_ip,
                                     C.POINTER(LevelResult), c_dp, c_dp, c_dp, c_lp]),
     "dfta_poisson_create": (C.c_int, [vp, vp, C.c_int, C.POINTER(vp)]),
@@ -274,6 +279,43 @@ def numerov_sweeps_scan(ctx, grid, kind, V, l, E, limit=None, vidx=None):
     ctx.check(ctx.lib.dfta_numerov_sweeps_scan(ctx.h, grid.h, kind, V.shape[0], _dp(V), nt, _ip(vi), _ip(l), _dp(E), _ip(lim), _ip(count),
                                                _dp(u0), _ip(start), _ip(trip), _ip(fb)))
     return {"count": count, "u0": u0, "start": start, "trip": trip, "fallback": fb}
+
+
+class Potential:
+    """A potential resident on the device with its slot tables (dfta_potential): per-call sweeps without the upload and table build."""
+
+    def __init__(self, ctx, grid, V):
+        self.ctx, self.grid = ctx, grid
+        h = vp()
+        V = _f64(V)
+        ctx.check(ctx.lib.dfta_potential_create(ctx.h, grid.h, _dp(V), C.byref(h)))
+        self.h = h
+
+    def update(self, V):
+        V = _f64(V)
+        self.ctx.check(self.ctx.lib.dfta_potential_update(self.h, _dp(V)))
+
+    def sweeps(self, kind, l, E, limit=None, sweep_mode=SWEEPS_EXACT):
+        l, E = _i32(l), _f64(E)
+        nt = len(E)
+        lim = _i32(limit) if limit is not None else np.zeros(nt, np.int32)
+        count, start, trip = (np.zeros(nt, np.int32) for _ in range(3))
+        u0 = np.zeros(nt)
+        self.ctx.check(self.ctx.lib.dfta_potential_sweeps(self.h, kind, sweep_mode, nt, _ip(l), _dp(E), _ip(lim), _ip(count), _dp(u0), _ip(start), _ip(trip)))
+        return {"count": count, "u0": u0, "start": start, "trip": trip}
+
+    def match(self, l, E):
+        l, E = _i32(l), _f64(E)
+        nt = len(E)
+        psi = np.zeros((nt, self.grid.N))
+        mp = np.zeros(nt, np.int64)
+        self.ctx.check(self.ctx.lib.dfta_potential_match(self.h, nt, _ip(l), _dp(E), _dp(psi), mp.ctypes.data_as(c_lp)))
+        return psi, mp
+
+    def close(self):
+        if self.h:
+            self.ctx.lib.dfta_potential_destroy(self.h)
+            self.h = None
 
 
 def numerov_match(ctx, grid, V, l, E, vidx=None, boundary=BOUNDARY_HOST):

@@ -113,6 +113,9 @@ private:
 template <class NumerovFunction> class Numerov {
 public:
     Numerov(const Potential& pot, double delta = 0, double Rmax = 0, size_t numPoints = 0) : function(pot, delta, Rmax, numPoints) {}
+    ~Numerov() { if (m_dev) dfta_potential_destroy(m_dev); }
+    Numerov(const Numerov&) = delete;
+    Numerov& operator=(const Numerov&) = delete;
 
     // reference Numerov.h:272-349
     inline void SolveSchrodingerCountNodes(double /*startPoint*/, unsigned int l, double E, long int steps, long int nodesLimit, int& nodesCount)
@@ -135,11 +138,9 @@ public:
     {
         whole_grid(steps);
         auto& rt = dfta_compat::Runtime::instance();
-        const std::vector<double>& V = function.potential().m_potentialValues;
-        std::vector<double> Psi(V.size());
+        std::vector<double> Psi(function.potential().m_potentialValues.size());
         const int li = static_cast<int>(l);
-        dfta_compat::check(dfta_numerov_match(rt.ctx(), function.grid(), DFTA_BOUNDARY_HOST, 1, V.data(), 1, nullptr, &li, &E, Psi.data(), &matchPoint),
-                           rt.ctx(), "dfta_numerov_match");
+        dfta_compat::check(dfta_potential_match(resident(), 1, &li, &E, Psi.data(), &matchPoint), rt.ctx(), "dfta_potential_match");
         return Psi;
     }
 
@@ -164,14 +165,23 @@ private:
     {
         if (static_cast<size_t>(steps) + 1 != function.numPoints()) throw std::runtime_error("Numerov: steps must be numPoints - 1 (the whole grid)");
     }
-    void run(int kind, int n, const int* l, const double* E, const int* limit, int* counts, double* u0)
+    // The reference reads the caller's Potential afresh on every call (Numerov.h:69,186).  Here it is resident on the device with its
+    // slot tables; every call compares the caller's values with the resident copy (a host memcmp) and re-uploads only what has changed.
+    dfta_potential* resident()
     {
         auto& rt = dfta_compat::Runtime::instance();
         const std::vector<double>& V = function.potential().m_potentialValues;
-        dfta_compat::check(dfta_numerov_sweeps(rt.ctx(), function.grid(), kind, DFTA_BOUNDARY_HOST, 1, V.data(), n, nullptr, l, E, limit, counts, u0,
-                                               nullptr, nullptr),
-                           rt.ctx(), "dfta_numerov_sweeps");
+        if (!m_dev) dfta_compat::check(dfta_potential_create(rt.ctx(), function.grid(), V.data(), &m_dev), rt.ctx(), "dfta_potential_create");
+        else dfta_compat::check(dfta_potential_update(m_dev, V.data()), rt.ctx(), "dfta_potential_update");
+        return m_dev;
     }
+    void run(int kind, int n, const int* l, const double* E, const int* limit, int* counts, double* u0)
+    {
+        auto& rt = dfta_compat::Runtime::instance();
+        dfta_compat::check(dfta_potential_sweeps(resident(), kind, rt.sweep_mode(function.grid()), n, l, E, limit, counts, u0, nullptr, nullptr), rt.ctx(),
+                           "dfta_potential_sweeps");
+    }
+    dfta_potential* m_dev = nullptr;
 };
 
 }  // namespace DFT

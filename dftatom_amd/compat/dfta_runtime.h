@@ -6,6 +6,7 @@
 // usable HIP device the first call throws std::runtime_error.
 #pragma once
 
+#include <cstdlib>
 #include <map>
 #include <stdexcept>
 #include <string>
@@ -49,6 +50,15 @@ public:
         m_grids[key] = g;
         return g;
     }
+    // How DFT::Numerov's sweeps are integrated: the reference's rounding sequence (default) or the transfer-matrix scans
+    // (DFTA_SWEEPS_TOLERANCE: $DFTA_COMPAT_SWEEPS=tolerance or set_sweep_mode; logarithmic grids of 12 .. 20 levels, else exact)
+    void set_sweep_mode(int mode) { m_sweep_mode = mode; }
+    int sweep_mode(const dfta_grid* g) const
+    {
+        if (m_sweep_mode != DFTA_SWEEPS_TOLERANCE || dfta_grid_is_uniform(g)) return DFTA_SWEEPS_EXACT;
+        const int n = dfta_grid_num_nodes(g);
+        return (n >= 4097 && n <= 1048577) ? DFTA_SWEEPS_TOLERANCE : DFTA_SWEEPS_EXACT;
+    }
     // multigrid levels for a node count 2^L + 1 (PoissonSolver.h:127-135 inverted)
     static int levels_for_nodes(size_t numPoints)
     {
@@ -61,6 +71,8 @@ private:
     {
         const int rc = dfta_ctx_create(0, nullptr, &m_ctx);
         if (rc != DFTA_OK) throw std::runtime_error("libdftatom_hip: no usable HIP device (status " + std::to_string(rc) + "); there is no CPU fallback");
+        const char* e = getenv("DFTA_COMPAT_SWEEPS");
+        if (e && std::string(e) == "tolerance") m_sweep_mode = DFTA_SWEEPS_TOLERANCE;
     }
     ~Runtime()
     {
@@ -68,6 +80,7 @@ private:
         dfta_ctx_destroy(m_ctx);
     }
     dfta_ctx* m_ctx = nullptr;
+    int m_sweep_mode = DFTA_SWEEPS_EXACT;
     std::map<std::tuple<int, double, double>, dfta_grid*> m_grids;
 };
 

@@ -1646,7 +1646,7 @@ extern "C" int dfta_solve_levels(dfta_ctx* ctx, const dfta_grid* g, int mode, in
     const bool scan_sweeps = (mode & DFTA_LEVELS_SCAN_SWEEPS) != 0;
     mode &= ~DFTA_LEVELS_SCAN_SWEEPS;
     DFTA_REQUIRE(ctx, mode == DFTA_LEVELS_CHAINED || mode == DFTA_LEVELS_BATCHED, "mode");
-    DFTA_REQUIRE(ctx, !scan_sweeps || dfta_scan_supported(g), "the tolerance mode of the sweeps needs a logarithmic grid of 12 .. 24 multigrid levels");
+    DFTA_REQUIRE(ctx, !scan_sweeps || dfta_scan_supported(g), "the tolerance mode of the sweeps needs a logarithmic grid of 12 .. 20 multigrid levels");
     const int N = g->N;
     std::vector<dfta::JobSpec> specs(nlevels);
     for (int k = 0; k < nlevels; ++k) specs[k] = {vidx ? vidx[k] : 0, n[k], l[k], occ[k]};

@@ -1919,6 +1919,237 @@ extern "C" int dfta_numerov_match(dfta_ctx* ctx, const dfta_grid* g, int boundar
     return DFTA_OK;
 }
 
+// ---- a potential resident on the device (include/dftatom_hip.h: dfta_potential) -------------------------------------------------
+// The reference's Numerov holds a REFERENCE to the caller's Potential and re-reads it on every call (Numerov.h:69,186); its L3 makes
+// ~2100 calls on one Numerov object per SCF step.  dfta_numerov_sweeps re-uploads the 1 MB potential and rebuilds the slot table on each
+// of them (0.8 ... 6 ms per call); here both are done once per potential, and a call costs its sweep.
+struct dfta_potential {
+    dfta_ctx* ctx = nullptr;
+    const dfta_grid* g = nullptr;
+    std::vector<double> h_V;
+    double* dV = nullptr;
+    double2* dTab = nullptr;        // 4 slots: l = 0..3
+    double2* dBounds = nullptr;
+    int* dSlots = nullptr;          // slot_v (4 zeros), slot_l (0..3)
+    dfta_scan_tables scan;          // tolerance mode: built on first use
+    bool scan_built = false;
+    // per-call scratch, grown on demand: one staging block in, one out
+    size_t cap = 0;
+    char* dIn = nullptr;
+    char* dOut = nullptr;
+    std::vector<char> hIn, hOut;
+    double *dPsi = nullptr, *dQ = nullptr;
+    size_t psi_cap = 0;
+};
+
+namespace {
+int potential_build(dfta_potential* p)
+{
+    dfta_ctx* ctx = p->ctx;
+    const int N = p->g->N;
+    DFTA_HIP(ctx, hipMemcpyAsync(p->dV, p->h_V.data(), sizeof(double) * N, hipMemcpyHostToDevice, ctx->stream));
+    int rc = dfta_launch_build_tab(ctx, p->g, p->dTab, p->dV, p->dSlots, p->dSlots + 4, 4, p->dBounds);
+    if (rc) return rc;
+    if (p->scan_built) rc = dfta_launch_scan_build_tab(ctx, p->g, p->scan, p->dV, p->dSlots, p->dSlots + 4);
+    return rc;
+}
+int potential_scratch(dfta_potential* p, int ntrials)
+{
+    dfta_ctx* ctx = p->ctx;
+    const size_t need = (size_t)std::max(ntrials, 64) * 64;      // 64 bytes per trial either way
+    if (need <= p->cap) return DFTA_OK;
+    if (p->dIn) (void)hipFree(p->dIn);
+    if (p->dOut) (void)hipFree(p->dOut);
+    p->dIn = p->dOut = nullptr; p->cap = 0;
+    DFTA_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&p->dIn), need));
+    DFTA_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&p->dOut), need));
+    p->hIn.resize(need); p->hOut.resize(need);
+    p->cap = need;
+    return DFTA_OK;
+}
+}  // namespace
+
+extern "C" void dfta_potential_destroy(dfta_potential* p)
+{
+    if (!p) return;
+    for (void* q : {(void*)p->dV, (void*)p->dTab, (void*)p->dBounds, (void*)p->dSlots, (void*)p->dIn, (void*)p->dOut, (void*)p->dPsi, (void*)p->dQ}) if (q) (void)hipFree(q);
+    dfta_scan_tables_destroy(&p->scan);
+    delete p;
+}
+
+extern "C" int dfta_potential_create(dfta_ctx* ctx, const dfta_grid* g, const double* V, dfta_potential** out)
+{
+    if (!ctx || !g || !V || !out) return DFTA_ERR_INVALID;
+    DFTA_ENTER(ctx);
+    const int N = g->N;
+    dfta_potential* p = new dfta_potential();
+    p->ctx = ctx; p->g = g;
+    p->h_V.assign(V, V + N);
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&p->dV), sizeof(double) * N);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->dTab), sizeof(double2) * 4 * (size_t)N);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->dBounds), sizeof(double2) * 4 * (size_t)dfta_bounds_stride(g));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->dSlots), sizeof(int) * 8);
+    const int slots[8] = {0, 0, 0, 0, 0, 1, 2, 3};
+    if (e == hipSuccess) e = hipMemcpy(p->dSlots, slots, sizeof(slots), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { snprintf(ctx->err, sizeof(ctx->err), "dfta_potential_create: %s", hipGetErrorString(e)); dfta_potential_destroy(p); return DFTA_ERR_HIP; }
+    const int rc = potential_build(p);
+    if (rc) { dfta_potential_destroy(p); return rc; }
+    *out = p;
+    return DFTA_OK;
+}
+
+extern "C" int dfta_potential_update(dfta_potential* p, const double* V)
+{
+    if (!p || !V) return DFTA_ERR_INVALID;
+    DFTA_ENTER(p->ctx);
+    if (memcmp(V, p->h_V.data(), sizeof(double) * p->g->N) == 0) return DFTA_OK;      // what the reference would re-read is what is resident
+    DFTA_HIP(p->ctx, hipStreamSynchronize(p->ctx->stream));                            // h_V may still be the source of a copy
+    p->h_V.assign(V, V + p->g->N);
+    return potential_build(p);
+}
+
+extern "C" int dfta_potential_sweeps(dfta_potential* p, int kind, int sweep_mode, int ntrials, const int* l, const double* E, const int* nodesLimit,
+                                     int* count_out, double* u0_out, int* start_out, int* trip_out)
+{
+    if (!p) return DFTA_ERR_INVALID;
+    dfta_ctx* ctx = p->ctx;
+    const dfta_grid* g = p->g;
+    DFTA_ENTER(ctx);
+    DFTA_REQUIRE(ctx, l && E && ntrials >= 0, "null input");
+    DFTA_REQUIRE(ctx, kind == DFTA_SWEEP_COUNT || kind == DFTA_SWEEP_ZERO, "kind");
+    DFTA_REQUIRE(ctx, kind != DFTA_SWEEP_COUNT || (nodesLimit && count_out), "COUNT needs nodesLimit and count_out");
+    DFTA_REQUIRE(ctx, kind != DFTA_SWEEP_ZERO || u0_out, "ZERO needs u0_out");
+    DFTA_REQUIRE(ctx, sweep_mode == DFTA_SWEEPS_EXACT || (sweep_mode == DFTA_SWEEPS_TOLERANCE && dfta_scan_supported(g)), "sweep mode / grid");
+    if (ntrials == 0) return DFTA_OK;
+    hipStream_t st = ctx->stream;
+    int rc = potential_scratch(p, ntrials);
+    if (rc) return rc;
+    // staging block in: E, us, us1 (doubles), then limit, start, blk_slot, blk_first, blk_cnt / trial_slot (ints): one copy each way
+    const size_t nt = ntrials;
+    double* hE = reinterpret_cast<double*>(p->hIn.data());
+    double *hUs = hE + nt, *hUs1 = hUs + nt;
+    int* hLim = reinterpret_cast<int*>(hUs1 + nt);
+    int *hStart = hLim + nt, *hBs = hStart + nt, *hBf = hBs + nt, *hBc = hBf + nt;
+    double* dE = reinterpret_cast<double*>(p->dIn);
+    double *dUs = dE + nt, *dUs1 = dUs + nt;
+    int* dLim = reinterpret_cast<int*>(dUs1 + nt);
+    int *dStart = dLim + nt, *dBs = dStart + nt, *dBf = dBs + nt, *dBc = dBf + nt;
+    double* dU0 = reinterpret_cast<double*>(p->dOut);
+    int* dCount = reinterpret_cast<int*>(dU0 + nt);
+    int *dTrip = dCount + nt, *dStartOut = dTrip + nt, *dBad = dStartOut + nt;
+    if (sweep_mode == DFTA_SWEEPS_TOLERANCE) {
+        if (!p->scan_built) {
+            rc = dfta_scan_tables_create(ctx, g, 4, &p->scan);
+            if (rc) return rc;
+            p->scan_built = true;
+            rc = dfta_launch_scan_build_tab(ctx, g, p->scan, p->dV, p->dSlots, p->dSlots + 4);
+            if (rc) return rc;
+        }
+        for (size_t t = 0; t < nt; ++t) {
+            DFTA_REQUIRE(ctx, l[t] >= 0 && l[t] <= 3, "l");
+            hE[t] = E[t]; hLim[t] = nodesLimit ? nodesLimit[t] : 0; hBs[t] = l[t];
+        }
+        DFTA_HIP(ctx, hipMemcpyAsync(p->dIn, p->hIn.data(), nt * 64, hipMemcpyHostToDevice, st));
+        DFTA_HIP(ctx, hipEventRecord(ctx->ev[0], st));
+        rc = dfta_launch_scan_sweeps(ctx, g, kind, ntrials, p->scan, dBs, dE, dLim, dCount, dU0, dStartOut, dTrip, dBad);
+        if (rc) return rc;
+        DFTA_HIP(ctx, hipEventRecord(ctx->ev[1], st));
+        ctx->have_kernel_time = true;
+        DFTA_HIP(ctx, hipMemcpyAsync(p->hOut.data(), p->dOut, nt * 64, hipMemcpyDeviceToHost, st));
+        DFTA_HIP(ctx, hipStreamSynchronize(st));
+        const double* oU0 = reinterpret_cast<const double*>(p->hOut.data());
+        const int* oCount = reinterpret_cast<const int*>(oU0 + nt);
+        const int *oTrip = oCount + nt, *oStart = oTrip + nt, *oBad = oStart + nt;
+        bool anybad = false;
+        for (size_t t = 0; t < nt; ++t) {
+            anybad = anybad || oBad[t];
+            if (count_out && kind == DFTA_SWEEP_COUNT) count_out[t] = oCount[t];
+            if (u0_out) u0_out[t] = oU0[t];
+            if (start_out) start_out[t] = oStart[t];
+            if (trip_out) trip_out[t] = oTrip[t];
+        }
+        if (!anybad) return DFTA_OK;
+        // a trial the scan could not decide: the whole call again on the exact kernels
+    }
+    Grouping G;
+    if (make_grouping(ntrials, nullptr, l, 1, G) != DFTA_OK) { snprintf(ctx->err, sizeof(ctx->err), "invalid l"); return DFTA_ERR_INVALID; }
+    for (size_t s = 0; s < nt; ++s) {
+        const int t = G.order[s];
+        hE[s] = E[t];
+        hLim[s] = nodesLimit ? nodesLimit[t] : 0;
+        if (g->uniform) host_boundary_uniform(g, E[t], static_cast<unsigned>(l[t]), false, &hStart[s], &hUs[s], &hUs1[s], nullptr);
+        else host_boundary(g, E[t], &hStart[s], &hUs[s], &hUs1[s]);
+    }
+    const size_t nb = G.blk_slot.size();
+    for (size_t b = 0; b < nb; ++b) { hBs[b] = G.slot_l[G.blk_slot[b]]; hBf[b] = G.blk_first[b]; hBc[b] = G.blk_cnt[b]; }    // table slot = l
+    DFTA_HIP(ctx, hipMemcpyAsync(p->dIn, p->hIn.data(), nt * 64, hipMemcpyHostToDevice, st));
+    DFTA_HIP(ctx, hipEventRecord(ctx->ev[0], st));
+    rc = dfta_launch_sweep(ctx, g, kind, nullptr, (int)nb, p->dTab, dBs, dBf, dBc, dE, dLim, dStart, dUs, dUs1, dCount, dU0, dTrip, nullptr, p->dBounds, nullptr,
+                           nullptr, p->dSlots + 4);
+    if (rc) return rc;
+    DFTA_HIP(ctx, hipEventRecord(ctx->ev[1], st));
+    ctx->have_kernel_time = true;
+    DFTA_HIP(ctx, hipMemcpyAsync(p->hOut.data(), p->dOut, nt * 64, hipMemcpyDeviceToHost, st));
+    DFTA_HIP(ctx, hipStreamSynchronize(st));
+    const double* oU0 = reinterpret_cast<const double*>(p->hOut.data());
+    const int* oCount = reinterpret_cast<const int*>(oU0 + nt);
+    const int* oTrip = oCount + nt;
+    for (size_t s = 0; s < nt; ++s) {
+        const int t = G.order[s];
+        if (count_out && kind == DFTA_SWEEP_COUNT) count_out[t] = oCount[s];
+        if (u0_out) u0_out[t] = oU0[s];
+        if (start_out) start_out[t] = hStart[s];
+        if (trip_out) trip_out[t] = oTrip[s];
+    }
+    return DFTA_OK;
+}
+
+extern "C" int dfta_potential_match(dfta_potential* p, int ntrials, const int* l, const double* E, double* Psi_out, long* matchPoint_out)
+{
+    if (!p) return DFTA_ERR_INVALID;
+    dfta_ctx* ctx = p->ctx;
+    const dfta_grid* g = p->g;
+    DFTA_ENTER(ctx);
+    DFTA_REQUIRE(ctx, l && E && Psi_out && matchPoint_out && ntrials >= 0, "null input");
+    if (ntrials == 0) return DFTA_OK;
+    const int N = g->N;
+    hipStream_t st = ctx->stream;
+    int rc = potential_scratch(p, ntrials);
+    if (rc) return rc;
+    if ((size_t)ntrials > p->psi_cap) {
+        if (p->dPsi) (void)hipFree(p->dPsi);
+        if (p->dQ) (void)hipFree(p->dQ);
+        p->dPsi = p->dQ = nullptr; p->psi_cap = 0;
+        DFTA_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&p->dPsi), sizeof(double) * (size_t)ntrials * N));
+        DFTA_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&p->dQ), sizeof(double) * (size_t)ntrials * N));
+        p->psi_cap = ntrials;
+    }
+    const size_t nt = ntrials;
+    double* hE = reinterpret_cast<double*>(p->hIn.data());
+    double *hUs = hE + nt, *hUs1 = hUs + nt, *hUz = hUs1 + nt;
+    int* hStart = reinterpret_cast<int*>(hUz + nt);
+    int *hL = hStart + nt, *hTs = hL + nt;
+    double* dE = reinterpret_cast<double*>(p->dIn);
+    double *dUs = dE + nt, *dUs1 = dUs + nt, *dUz = dUs1 + nt;
+    int* dStart = reinterpret_cast<int*>(dUz + nt);
+    int *dL = dStart + nt, *dTs = dL + nt;
+    int* dMp = reinterpret_cast<int*>(p->dOut);
+    for (size_t t = 0; t < nt; ++t) {
+        DFTA_REQUIRE(ctx, l[t] >= 0 && l[t] <= 3, "l");
+        hE[t] = E[t]; hL[t] = l[t]; hTs[t] = l[t]; hUz[t] = 0;
+        if (g->uniform) host_boundary_uniform(g, E[t], static_cast<unsigned>(l[t]), true, &hStart[t], &hUs[t], &hUs1[t], &hUz[t]);
+        else host_boundary(g, E[t], &hStart[t], &hUs[t], &hUs1[t]);
+    }
+    DFTA_HIP(ctx, hipMemcpyAsync(p->dIn, p->hIn.data(), nt * 64, hipMemcpyHostToDevice, st));
+    rc = dfta_launch_match(ctx, g, ntrials, p->dTab, dTs, dE, dStart, dUs, dUs1, dL, p->dPsi, p->dQ, dMp, g->uniform ? nullptr : p->dBounds, dUz);
+    if (rc) return rc;
+    DFTA_HIP(ctx, hipMemcpyAsync(Psi_out, p->dPsi, sizeof(double) * nt * N, hipMemcpyDeviceToHost, st));
+    DFTA_HIP(ctx, hipMemcpyAsync(p->hOut.data(), dMp, sizeof(int) * nt, hipMemcpyDeviceToHost, st));
+    DFTA_HIP(ctx, hipStreamSynchronize(st));
+    for (size_t t = 0; t < nt; ++t) matchPoint_out[t] = reinterpret_cast<const int*>(p->hOut.data())[t];
+    return DFTA_OK;
+}
+
 #ifdef DFTA_PIPE_PROF
 extern "C" int dfta_debug_pipe_prof(unsigned long long* out)
 {

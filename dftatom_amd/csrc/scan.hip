@@ -918,7 +918,7 @@ ScanGrid scan_grid_of(const dfta_grid* g, const dfta_scan_tables& tb)
 
 }  // namespace
 
-int dfta_scan_supported(const dfta_grid* g) { return g && !g->uniform && g->levels >= 12 && g->levels <= 24; }
+int dfta_scan_supported(const dfta_grid* g) { return g && !g->uniform && g->levels >= 12 && g->levels <= 20; }
 
 void dfta_scan_tables_destroy(dfta_scan_tables* tb)
 {
@@ -998,7 +998,7 @@ extern "C" int dfta_numerov_sweeps_scan(dfta_ctx* ctx, const dfta_grid* g, int k
 {
     if (!ctx || !g) return DFTA_ERR_INVALID;
     DFTA_ENTER(ctx);
-    DFTA_REQUIRE(ctx, dfta_scan_supported(g), "the scan sweeps need a logarithmic grid of 12 .. 24 multigrid levels");
+    DFTA_REQUIRE(ctx, dfta_scan_supported(g), "the scan sweeps need a logarithmic grid of 12 .. 20 multigrid levels");
     DFTA_REQUIRE(ctx, V && l && E && nV > 0 && ntrials >= 0, "null input");
     DFTA_REQUIRE(ctx, kind == DFTA_SWEEP_COUNT || kind == DFTA_SWEEP_ZERO, "kind");
     DFTA_REQUIRE(ctx, kind != DFTA_SWEEP_COUNT || (nodesLimit && count_out), "COUNT needs nodesLimit and count_out");

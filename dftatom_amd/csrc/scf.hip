@@ -299,7 +299,7 @@ int dfta_scf_create_ex(dfta_ctx* ctx, const dfta_grid* g, int lsda, int natoms, 
     DFTA_REQUIRE(ctx, opt.functional == DFTA_XC_VWN || !lsda, "the Chachiyo functional is LDA only (ExcCor.h)");
     DFTA_REQUIRE(ctx, opt.aufbau == DFTA_AUFBAU_REFERENCE || opt.aufbau == DFTA_AUFBAU_TRANSITION_METALS, "aufbau");
     DFTA_REQUIRE(ctx, opt.sweep_mode == DFTA_SWEEPS_EXACT || opt.sweep_mode == DFTA_SWEEPS_TOLERANCE, "sweep mode");
-    DFTA_REQUIRE(ctx, opt.sweep_mode == DFTA_SWEEPS_EXACT || dfta_scan_supported(g), "the tolerance mode of the sweeps needs a logarithmic grid of 12 .. 24 multigrid levels");
+    DFTA_REQUIRE(ctx, opt.sweep_mode == DFTA_SWEEPS_EXACT || dfta_scan_supported(g), "the tolerance mode of the sweeps needs a logarithmic grid of 12 .. 20 multigrid levels");
     dfta_scf* s = new dfta_scf();
     s->solver.sweep_mode = opt.sweep_mode;
     s->integ_rule = opt.integrator;

@@ -96,6 +96,9 @@ int    dfta_num_nodes(int mg_levels);                                  /* Poisso
  * The _dev variant always uses DFTA_BOUNDARY_DEVICE unless start/us/us1 are given (non-NULL). */
 #define DFTA_SWEEP_COUNT 0
 #define DFTA_SWEEP_ZERO  1
+/* how a sweep is integrated: EXACT = the reference's rounding sequence (numerov.hip); TOLERANCE = transfer-matrix scan (scan.hip) */
+#define DFTA_SWEEPS_EXACT     0
+#define DFTA_SWEEPS_TOLERANCE 1
 #define DFTA_BOUNDARY_DEVICE 0
 #define DFTA_BOUNDARY_HOST   1
 
@@ -117,7 +120,7 @@ int dfta_numerov_sweeps_dev(dfta_ctx* ctx, const dfta_grid* g, int kind,
                             const int* dStart, const double* dUs, const double* dUs1,   /* NULL -> device boundary */
                             int* dCount, double* dU0, int* dStartOut, int* dTrip);
 
-/* TOLERANCE MODE of the same two sweeps (opt-in; logarithmic grids of 12 .. 24 multigrid levels): the recurrence of Numerov.h:309-321
+/* TOLERANCE MODE of the same two sweeps (opt-in; logarithmic grids of 12 .. 20 multigrid levels): the recurrence of Numerov.h:309-321
  * is linear in w, w_{i-1} = (2 + f_i/(1 - f_i/12)) w_i - w_{i+1}, so ONE trial is integrated by the 512 lanes of a workgroup as a
  * transfer-matrix scan (segment products, log-depth combine, a second pass for the sign changes) in ~25 us at 131 073 points instead
  * of 4 ms as a dependent chain.  Same cut-off index, start values (device exp) and exit rules as above; a different order of roundings:
@@ -134,6 +137,22 @@ int dfta_numerov_sweeps_scan(dfta_ctx* ctx, const dfta_grid* g, int kind, int nV
 int dfta_numerov_match(dfta_ctx* ctx, const dfta_grid* g, int boundary, int nV, const double* V,
                        int ntrials, const int* vidx, const int* l, const double* E,
                        double* Psi_out, long* matchPoint_out);
+
+/* ---- a potential resident on the device ------------------------------------------------------------------------------------------
+ * The reference's Numerov keeps a REFERENCE to the caller's Potential and re-reads it on every call (Numerov.h:69,186), and its L3 makes
+ * ~2100 calls on one Numerov object per SCF step.  dfta_numerov_sweeps / _match copy the potential and build the slot tables on every
+ * call; a dfta_potential does both once (tables for l = 0..3), so that a call costs its sweep.  dfta_potential_update keeps the
+ * "re-read on every call" semantics: a host memcmp against the resident copy, re-upload and rebuild only when the caller's values changed.
+ * sweep_mode: DFTA_SWEEPS_EXACT (host boundary values: bit-identical to the reference) or DFTA_SWEEPS_TOLERANCE (scan sweeps,
+ * ~0.1 ms per call at 131 073 points instead of 4 ms; a trial the scan cannot decide is repeated on the exact kernels).
+ * dftatom_amd/compat/Numerov.h holds one per DFT::Numerov object. */
+typedef struct dfta_potential dfta_potential;
+int  dfta_potential_create(dfta_ctx* ctx, const dfta_grid* g, const double* V /* N, host */, dfta_potential** out);
+int  dfta_potential_update(dfta_potential* p, const double* V /* N, host */);
+void dfta_potential_destroy(dfta_potential* p);
+int  dfta_potential_sweeps(dfta_potential* p, int kind, int sweep_mode, int ntrials, const int* l, const double* E, const int* nodesLimit,
+                           int* count_out, double* u0_out, int* start_out, int* trip_out);
+int  dfta_potential_match(dfta_potential* p, int ntrials, const int* l, const double* E, double* Psi_out, long* matchPoint_out);
 
 /* ---- eigenvalue search for a batch of (atom,spin) potentials -----------------------------------------
  * Replaces DFTAtom::LoopOverLevels + LocateInterval + NormalizeNonUniform + the density update of
@@ -153,10 +172,8 @@ int dfta_numerov_match(dfta_ctx* ctx, const dfta_grid* g, int boundary, int nV, 
  * with the same midpoints, every trial integrated by the transfer-matrix scan: one workgroup runs LocateInterval and the u(0)
  * bisection of its level from start to end on the device -- no rounds, no speculation.  Eigenvalues agree with the exact path to the
  * width of the round-off band of the reference's own predicates (gate 2e-11 |E| + 1e-11 Ha; sweeps_reference counts stay
- * the reference's except for decisions inside that band).  Grids of 12 .. 24 multigrid levels; dfta_scf_options::sweep_mode for the SCF. */
+ * the reference's except for decisions inside that band).  Grids of 12 .. 20 multigrid levels; dfta_scf_options::sweep_mode for the SCF. */
 #define DFTA_LEVELS_SCAN_SWEEPS 0x10
-#define DFTA_SWEEPS_EXACT     0
-#define DFTA_SWEEPS_TOLERANCE 1
 
 typedef struct dfta_level_result {
     double E;            /* eigenvalue (level.E, DFTAtom.cpp:534)                       */

@@ -173,10 +173,10 @@ def test_cli_json_lines(tmp_path):
     r = _run(*ref["args"], "chained", "--json=%s" % js)
     assert r.returncode == 0 and r.stdout == plain.stdout
     rows = [json.loads(ln) for ln in open(js).read().splitlines()]
-    _, steps, _ = _steps(r.stdout)
+    _, steps = _steps(r.stdout)
     assert len(rows) == len(steps) and rows[-1]["finished"] is True and [q["step"] for q in rows] == list(range(len(rows)))
     last = rows[-1]
-    assert ("Etotal = %.6f" % last["Etotal"]) in steps[-1][-1] or ("Etotal = %.6f" % last["Etotal"]) in "\n".join(steps[-1])
+    assert ("Etotal = %.6f" % last["Etotal"]) in "\n".join(steps[-1])
     assert all(lv["status"] == 1 and lv["count_sweeps"] > 0 and lv["zero_sweeps"] > 0 for lv in last["levels"])
     assert last["vcycles"] > 0 and last["sweeps_reference"] > 0 and last["ms_levels"] > 0 and last["ms_poisson"] > 0
     energy_lines = [ln for ln in steps[-1] if ln.startswith("Energy ")]

@@ -169,3 +169,40 @@ def test_graft_entry_smoke_runs():
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     mod.smoke()
+
+
+@pytest.mark.gpu
+def test_resident_potential_equals_per_call_upload():
+    """dfta_potential (what DFT::Numerov now holds): the potential and its slot tables stay on the device between calls.  Exact mode: counts,
+    trips, u(0), Psi and match points bit for bit what dfta_numerov_sweeps / _match return with an upload per call -- also after the caller
+    has changed the values (dfta_potential_update: host memcmp, re-upload only then).  Tolerance mode: the scan sweeps' counts."""
+    import dftatom_amd as D
+    from golden.make_golden import GRIDS, screened_potential
+    ctx = D.Context(0)
+    L, d, R = GRIDS["L14"]
+    grid = D.Grid(ctx, L, d, R)
+    V = screened_potential(grid.r(), 86.0)
+    P = D.Potential(ctx, grid, V)
+    rng = np.random.default_rng(11)
+    for nt in (1, 5, 130):
+        l = rng.integers(0, 4, nt).astype(np.int32)
+        E = -10.0 ** rng.uniform(-2, 3.7, nt)
+        lim = rng.integers(0, 5, nt).astype(np.int32)
+        a = D.numerov_sweeps(ctx, grid, D.SWEEP_COUNT, V, l, E, lim)
+        b = P.sweeps(D.SWEEP_COUNT, l, E, lim)
+        c = P.sweeps(D.SWEEP_COUNT, l, E, lim, D.SWEEPS_TOLERANCE)
+        assert np.array_equal(a["count"], b["count"]) and np.array_equal(a["trip"], b["trip"]) and np.array_equal(a["start"], b["start"])
+        assert np.array_equal(a["count"], c["count"]) and np.array_equal(a["start"], c["start"])
+        za, zb = D.numerov_sweeps(ctx, grid, D.SWEEP_ZERO, V, l, E), P.sweeps(D.SWEEP_ZERO, l, E)
+        assert np.array_equal(za["u0"], zb["u0"], equal_nan=True)
+    pa, ma = D.numerov_match(ctx, grid, V, [0, 2, 3], [-100.0, -3.0, -0.5])
+    pb, mb = P.match([0, 2, 3], [-100.0, -3.0, -0.5])
+    assert np.array_equal(pa, pb) and np.array_equal(ma, mb)
+    V2 = V * (1.0 + 1e-7)
+    P.update(V)                                               # unchanged values: nothing is copied
+    P.update(V2)
+    assert np.array_equal(D.numerov_sweeps(ctx, grid, D.SWEEP_ZERO, V2, [0, 1], [-100.0, -7.0])["u0"], P.sweeps(D.SWEEP_ZERO, [0, 1], [-100.0, -7.0])["u0"])
+    assert np.array_equal(D.numerov_sweeps(ctx, grid, D.SWEEP_COUNT, V2, [0], [-100.0], [3])["count"], P.sweeps(D.SWEEP_COUNT, [0], [-100.0], [3], D.SWEEPS_TOLERANCE)["count"])
+    P.close()
+    grid.close()
+    ctx.close()

@@ -293,16 +293,23 @@ def test_l20_radon_lsda_steps_vs_reference(ctx, grid20):
     ps.close()
     kabs = float(np.max(np.abs(Ua - Ub)))
     krel = float(np.max(np.abs(Ua[0, 1:] - Ub[0, 1:]) / np.abs(Ua[0, 1:])))
-    print("  conditioning of the solve: density perturbed by 1e-12 relative -> max |dU| %.2e (%.2e relative)" % (kabs, krel))
-    assert kabs > 1e-8                                   # twelve digits in, fewer than nine out
+    # the gate of step 1 is the conditioning measured ON THE REFERENCE (tests/golden/make_golden_table.py l20cond: the compiled reference's
+    # own solve moves by max |dU| = 5.4e-7 under the same 1e-12 perturbation of a Z = 86 density) -- VERDICT r3: not the product's own
+    # number, which is only required to be of that size
+    cond = meta["poisson_conditioning"]
+    ref_abs, ref_rel = cond["max_abs_dU"], cond["max_rel_dU"]
+    print("  conditioning of the solve: density perturbed by 1e-12 relative -> max |dU| %.2e (%.2e relative); the reference: %.2e (%.2e)"
+          % (kabs, krel, ref_abs, ref_rel))
+    assert ref_abs > 1e-8                                # twelve digits in, fewer than nine out
+    assert ref_abs / 8 <= kabs <= 8 * ref_abs            # the product's solver is conditioned like the reference's
     st = scf.step()
     en, _ = scf.energies()
     want_lv = np.array([x[1] for x in steps[1]["levels"]])
     dlv = np.abs(_levels_of(scf, 0, True) - want_lv)
     den = np.array([abs(a - b) / abs(b) for a, b in zip(en[0].as_list(), steps[1]["energies"])])
     print("  step 1: max eigenvalue difference %.2e Ha, energies %.2e rel (gates: %.1e Ha, %.1e rel)"
-          % (dlv.max(), den.max(), 4 * kabs + 1e-8, 4 * krel + 1e-9))
-    assert dlv.max() <= 4 * kabs + 1e-8 and den.max() <= 4 * krel + 1e-9
+          % (dlv.max(), den.max(), 4 * ref_abs + 1e-8, 4 * ref_rel + 1e-9))
+    assert dlv.max() <= 4 * ref_abs + 1e-8 and den.max() <= 4 * ref_rel + 1e-9
     assert st.vcycles == 100
     scf.close()
 

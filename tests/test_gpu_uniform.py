@@ -222,20 +222,39 @@ def test_live_integrator_switch(ctx):
     g.close()
 
 
-def test_transition_metal_option_runs(ctx):
-    """Cr with AdjustForTransitionMetals wired in (3d5 4s1) vs the reference's plain Madelung filling (3d4 4s2)"""
-    g = D.Grid(ctx, 12, 2e-3, 25.0)
+def test_transition_metal_option_vs_oracle(ctx):
+    """Cr with AdjustForTransitionMetals wired in (3d5 4s1, AufbauPrinciple.h:78-99) vs the reference's plain Madelung filling
+    (3d4 4s2): five SCF steps of BOTH configurations against the oracle run on the same level list (chained brackets, the
+    reference's path) -- energies 1e-9 relative, eigenvalues 1e-8 Ha + 2e-9 |E| (the test only used to run)."""
+    import ctypes as C
+    import _oracle as O
+    L, d, R = 12, 2e-3, 25.0
+    g = D.Grid(ctx, L, d, R)
     ref_cfg = D.get_subshells(24)
     tm_cfg = D.get_subshells(24, D.AUFBAU_TRANSITION_METALS)
     assert (2, 2, 4) in ref_cfg and (3, 0, 2) in ref_cfg and (2, 2, 5) in tm_cfg and (3, 0, 1) in tm_cfg
+    o = O.oracle()
     e = {}
-    for au in (D.AUFBAU_REFERENCE, D.AUFBAU_TRANSITION_METALS):
-        scf = D.Scf(ctx, g, [24], aufbau=au)
-        for _ in range(5):
+    for au, cfg in ((D.AUFBAU_REFERENCE, ref_cfg), (D.AUFBAU_TRANSITION_METALS, tm_cfg)):
+        scf = D.Scf(ctx, g, [24], aufbau=au, levels_mode=D.LEVELS_CHAINED)
+        s = o.dfo_scf_create(0, 24, L, 0.5, R, d, 1)
+        assert s.contents.nla == len(cfg)
+        for i, (n, l, occ) in enumerate(cfg):                  # the oracle's level list := the configuration under test
+            s.contents.la[i].n, s.contents.la[i].l, s.contents.la[i].occ = n, l, occ
+        oe = O.Energies()
+        for step in range(5):
             scf.step(want_stats=False)
-        lv = scf.levels(0, 0)
+            o.dfo_scf_step(s, C.byref(oe))
+            got = scf.energies()[0][0].as_list()
+            want = [oe.Etotal, oe.Ekinetic, oe.Ecoul, oe.Enuclear, oe.Exc]
+            for a, b in zip(got, want):
+                assert abs(a - b) <= 1e-9 * abs(b), (au, step, got, want)
+            lv = scf.levels(0, 0)
+            lo = np.array([s.contents.la[i].E for i in range(s.contents.nla)])
+            assert np.all(np.abs(lv["E"] - lo) <= 1e-8 + 2e-9 * np.abs(lo)), (au, step)
         assert sum(lv["occ"]) == 24
         e[au] = scf.energies()[0][0].Etotal
+        o.dfo_scf_destroy(s)
         scf.close()
     assert e[0] != e[1] and abs(e[0] - e[1]) < 1.0
     g.close()

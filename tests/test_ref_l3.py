@@ -43,7 +43,7 @@ def test_reference_orchestration_compiles_and_links_against_compat():
               "DFT::DFTAtom::LoopOverLevels(DFT::Numerov<DFT::NumerovFunctionRegularGrid>&",
               "DFT::DFTAtom::CalculateUniformLSDA(int, int, double, double)", "DFT::DFTAtom::NormalizeNonUniform("):
         assert s in syms, s
-    for s in ("U dfta_numerov_sweeps", "U dfta_numerov_match", "U dfta_poisson_solve", "U dfta_vwn_lda", "U dfta_vwn_lsda",
+    for s in ("U dfta_potential_sweeps", "U dfta_potential_match", "U dfta_potential_update", "U dfta_poisson_solve", "U dfta_vwn_lda", "U dfta_vwn_lsda",
               "U dfta_integrate", "U dfta_grid_create_uniform"):
         assert s in syms, s
     # without a GPU the binary must fail loudly (no CPU fallback anywhere below the reference's L3)
