@@ -124,6 +124,9 @@ struct LevelSolver {
     // Tolerance mode of the sweeps (scan.hip; DFTA_SWEEPS_TOLERANCE, set before setup()): interleaved tables per slot, per-lane {min, max}
     int sweep_mode = DFTA_SWEEPS_EXACT;
     dfta_scan_tables scan_tb;
+    int* d_scan_live = nullptr;                   // live jobs of a grouped scan search
+    unsigned long long* d_scan_xch = nullptr;     // 32 words per job: the members' results of a round, two parities
+    int scan_group = 1;             // workgroups per level of the last scan search (1, 3, 7 or 15)
     int scan_fallbacks = 0;         // solves the scan handed back to the exact kernels (a trial it could not decide)
 
     LevelSolver() = default;
@@ -145,3 +148,6 @@ struct LevelSolver {
 int dfta_launch_scan_levels(dfta_ctx* ctx, const dfta_grid* g, dfta::Job* d_jobs, const int* d_chain_off, int nchains, int chained,
                             const dfta_scan_tables& tb, int fixed_point, unsigned long long* d_counters,
                             int match_mode /* 0 none, 1 match, 2 match + Simpson-3/8 normalisation */, double* d_Psi, int* d_jstart_keep);
+// K = 3, 7 or 15 workgroups per live job (un-chained brackets); DFTA_ERR_NOT_CONVERGED: the grid cannot be co-resident (use the one above)
+int dfta_launch_scan_levels_group(dfta_ctx* ctx, const dfta_grid* g, dfta::Job* d_jobs, const int* d_live, int nlive, int K, const dfta_scan_tables& tb,
+                                  int fixed_point, unsigned long long* d_counters, unsigned long long* d_xch, int match_mode, double* d_Psi, int* d_jstart_keep);

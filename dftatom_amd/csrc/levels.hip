@@ -1116,6 +1116,9 @@ void LevelSolver::release()
                     d_jstart, d_jus, d_jus1, d_jmp, d_slot_min, d_bounds};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     dfta_scan_tables_destroy(&scan_tb);
+    if (d_scan_live) (void)hipFree(d_scan_live);
+    if (d_scan_xch) (void)hipFree(d_scan_xch);
+    d_scan_live = nullptr; d_scan_xch = nullptr;
     if (d_jmatched) (void)hipFree(d_jmatched);
     if (d_jstart_keep) (void)hipFree(d_jstart_keep);
     d_jmatched = nullptr; d_jstart_keep = nullptr;
@@ -1308,6 +1311,8 @@ int LevelSolver::setup(dfta_ctx* c, const dfta_grid* grid, int mode_, int tree_d
     if (sweep_mode == DFTA_SWEEPS_TOLERANCE && dfta_scan_supported(g)) {      // scan.hip: interleaved tables + per-lane {min, max}
         const int trc = dfta_scan_tables_create(ctx, g, nslots, &scan_tb);
         if (trc) return trc;
+        ALLOC(d_scan_live, int, njobs);
+        ALLOC(d_scan_xch, unsigned long long, 32 * (size_t)njobs);
     }
 #undef ALLOC
 #undef UPLOAD
@@ -1447,16 +1452,36 @@ int LevelSolver::run(const double* dV, const double* job_bottom, int run_mode, d
     if (scan) {
         rc = dfta_launch_scan_build_tab(ctx, g, scan_tb, dV, d_slot_v, d_slot_l);
         if (rc) return rc;
+        // a handful of levels leave compute units idle: K = 15, 7 or 3 workgroups per level take a depth-4, 3 or 2 bisection tree per round
+        std::vector<int> live_jobs;
+        for (int k = 0; k < njobs; ++k) if (!jobs[k].frozen) live_jobs.push_back(k);
+        int K = 1;
+        if (!chained && !live_jobs.empty()) {
+            for (int cand : {15, 7, 3}) if ((long)live_jobs.size() * cand <= ctx->num_cu) { K = cand; break; }
+            if (const char* e = dfta_knob("SCAN_GROUP")) { const int f = atoi(e); K = (f == 15 || f == 7 || f == 3) && (long)live_jobs.size() * f <= ctx->num_cu ? f : 1; }
+        }
         DFTA_HIP(ctx, hipEventRecord(ev[0], st));
-        rc = dfta_launch_scan_levels(ctx, g, d_jobs, d_chains, run_chains, chained ? 1 : 0, scan_tb, dfta_knob("LEVELS_NOFIXEDPOINT") ? 0 : 1, d_counters,
-                                     scan_match_mode, d_Psi, d_jstart_keep);
+        rc = DFTA_ERR_NOT_CONVERGED;
+        if (K > 1) {
+            DFTA_HIP(ctx, hipMemcpyAsync(d_scan_live, live_jobs.data(), sizeof(int) * live_jobs.size(), hipMemcpyHostToDevice, st));
+            DFTA_HIP(ctx, hipMemsetAsync(d_jstart_keep, 0xff, sizeof(int) * njobs, st));      // -1: frozen (the live jobs write their cut-off index)
+            rc = dfta_launch_scan_levels_group(ctx, g, d_jobs, d_scan_live, (int)live_jobs.size(), K, scan_tb, dfta_knob("LEVELS_NOFIXEDPOINT") ? 0 : 1, d_counters,
+                                               d_scan_xch, scan_match_mode, d_Psi, d_jstart_keep);
+            if (rc && rc != DFTA_ERR_NOT_CONVERGED) return rc;
+        }
+        if (rc == DFTA_ERR_NOT_CONVERGED) {
+            K = 1;
+            rc = dfta_launch_scan_levels(ctx, g, d_jobs, d_chains, run_chains, chained ? 1 : 0, scan_tb, dfta_knob("LEVELS_NOFIXEDPOINT") ? 0 : 1, d_counters,
+                                         scan_match_mode, d_Psi, d_jstart_keep);
+        }
         if (rc) return rc;
+        scan_group = K;
         DFTA_HIP(ctx, hipEventRecord(ev[1], st));
         unsigned long long flag = 0;
         DFTA_HIP(ctx, hipMemcpyAsync(&flag, d_counters + 3, sizeof(flag), hipMemcpyDeviceToHost, st));
         DFTA_HIP(ctx, hipStreamSynchronize(st));
         if (stats) DFTA_HIP(ctx, hipEventElapsedTime(&ms_scan, ev[0], ev[1]));
-        if (flag) {                  // back to the exact kernels with the job records as they were uploaded
+        if (flag) {                  // back to the exact kernels with the job records as they were uploaded (a trial the scan could not decide, or a lost group member)
             scan = false;
             ++scan_fallbacks;
             DFTA_HIP(ctx, hipMemcpyAsync(d_jobs, jobs.data(), sizeof(Job) * njobs, hipMemcpyHostToDevice, st));

@@ -118,6 +118,7 @@ struct ScanShared {
     int wave_bad[2][kW];
     Turn wave_turn[2][kW];
     int red[2][kW];
+    unsigned long long xres[16];  // k_scan_levels_group: the round's results of the job's members
 };
 
 struct LaneState {     // what scan_sweep leaves in every lane (the match solve goes on from there)
@@ -888,6 +889,181 @@ __global__ void __launch_bounds__(kT) k_scan_levels(ScanGrid G0, const double* _
     }
 }
 
+// ---- the same search by a GROUP of K = 2^d - 1 workgroups per level: one round = the K midpoints of a depth-d bisection tree ----------
+// One compute unit integrates a trial in 40 ... 80 us, and a single atom leaves 240 of 256 idle: the K members of a job each integrate one
+// node of the tree that hangs at the running interval (member m: heap node m + 1, its midpoint found by following the node's path with
+// the reference's (toe + boe) / 2), publish the outcome in ONE 64-bit word -- [round:16][trips:24][count:12][flags:12], an agent-scope
+// atomic store; the word validates itself, no fence -- read the other members' words (agent-scope atomic loads, bounded spin) and all walk
+// the tree with the reference's predicates: d decisions per round, ~150 / d rounds per level, the same decisions as one workgroup alone
+// takes (tests: bit-identical job records).  A phase that ends inside a tree ends the round; the sweep at BottomEnergy that fixes the
+// sign convention of the third bisection (DFTAtom.cpp:513) is a round of its own.  Member 0 then matches and normalises.
+// The members wait for each other: the launch is cooperative (or plain under a profiler with the grid within the compute units), spins
+// are bounded, a time-out sets counters[3] and the host repeats the solve on the exact kernels.
+constexpr unsigned kNone = 1u << 4, kPos = 1u, kSmall = 2u, kNonFinite = 4u, kBad = 8u;
+
+__device__ __forceinline__ unsigned long long xch_pack(unsigned round, int trips, int count, unsigned flags)
+{
+    return (static_cast<unsigned long long>(round & 0xffffu) << 48) | (static_cast<unsigned long long>(trips & 0xffffff) << 24) |
+           (static_cast<unsigned long long>(count & 0xfff) << 12) | (flags & 0xfffu);
+}
+
+__global__ void __launch_bounds__(kT) k_scan_levels_group(ScanGrid G0, const double* __restrict__ gr, const double* __restrict__ gAtop, const double* __restrict__ gT,
+                                                           dfta::Job* __restrict__ jobs, const int* __restrict__ live, int K, int depth,
+                                                           const double* __restrict__ tabs, const double2* __restrict__ mms, int fixed_point,
+                                                           unsigned long long* __restrict__ counters, unsigned long long* __restrict__ xch, ScanMatchArgs ma)
+{
+    __shared__ ScanShared sh;
+    ScanGrid G = G0;
+    G.r = gr; G.Atop = gAtop; G.T = gT;
+    const int k = live[blockIdx.x / K], m = blockIdx.x % K;
+    dfta::Job* J = jobs + k;
+    const int nodes = J->nodes, slot = J->slot;
+    const double* tab = tabs + (size_t)slot * G.N;
+    const double2* mm = mms + (size_t)slot * kT;
+    unsigned long long* X = xch + (size_t)(blockIdx.x / K) * 32;          // [parity][16]
+    unsigned par = 0;
+    int hint = 0;
+    const double bottom0 = J->bottom0;
+    int n_count = 0, n_zero = 0, bad = 0, len2 = 0, n_fixed = 0, iter3 = 0, conv = 0, fixed = 0, nonfinite = 0;
+    long long pts = 0;
+    // ph 1, 2: the two count bisections; 4: the sweep at BottomEnergy; 3: the u(0) bisection; 0: done
+    int ph = 1;
+    double lo = bottom0, hi = 50., top = 0, bottom = 0;
+    bool sgnBottom = false;
+    unsigned rnd = 0;
+    while (ph) {
+        ++rnd;
+        // ---- this member's trial: heap node h = m + 1 of the tree at (lo, hi)
+        unsigned long long mine = xch_pack(rnd, 0, 0, kNone);
+        {
+            double E = 0;
+            bool have = false;
+            if (ph == 4) { have = (m == 0); E = lo; }
+            else {
+                const int h = m + 1, q = 31 - __clz(h);                // depth of the node
+                double a = lo, b = hi;
+                int it = iter3;
+                have = true;
+                for (int j = q - 1; j >= 0 && have; --j) {
+                    if (ph == 3 ? it >= kIter3 : !(b - a > kErr)) { have = false; break; }
+                    const double mid = (b + a) / 2;
+                    if ((h >> j) & 1) a = mid; else b = mid;             // bit 1: "BottomEnergy = E"
+                    ++it;
+                }
+                if (have && (ph == 3 ? it >= kIter3 : !(b - a > kErr))) have = false;
+                E = (b + a) / 2;
+            }
+            if (have) {
+                if (ph == 1 || ph == 2) {
+                    const SweepOut o = scan_sweep<DFTA_SWEEP_COUNT>(G, tab, mm, E, nodes, sh, par++ & 1, hint);
+                    hint = o.start;
+                    mine = xch_pack(rnd, o.start - 1 - (o.iexit > 0 ? o.iexit : 1), o.count, o.bad ? kBad : 0u);
+                } else {
+                    const SweepOut z = scan_sweep<DFTA_SWEEP_ZERO>(G, tab, mm, E, 0, sh, par++ & 1, hint);
+                    hint = z.start;
+                    const double ad = fabs(z.u0);
+                    mine = xch_pack(rnd, z.start - 2, 0, (z.u0 > 0 ? kPos : 0u) | ((!(ad != ad) && ad < 1E15) ? kSmall : 0u) | (!(ad < INFINITY) ? kNonFinite : 0u) | (z.bad ? kBad : 0u));
+                }
+            }
+        }
+        // ---- publish, gather
+        if (threadIdx.x == 0) {
+            unsigned long long* slotp = X + (rnd & 1) * 16;
+            __hip_atomic_store(slotp + m, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            bool timeout = false;
+            for (int q = 0; q < K; ++q) {
+                unsigned long long v = q == m ? mine : 0ull;
+                long spins = 0;
+                while (q != m) {
+                    v = __hip_atomic_load(slotp + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if ((v >> 48) == (rnd & 0xffffu)) break;
+                    if (++spins > (1L << 24) || (__hip_atomic_load(counters + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 2ull)) { timeout = true; break; }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                sh.xres[q] = v;
+            }
+            if (timeout) { atomicOr(counters + 3, 3ull); sh.xres[0] = ~0ull; }
+        }
+        __syncthreads();
+        if (sh.xres[0] == ~0ull) return;                                 // a member is missing: the host repeats the solve on the exact kernels
+        // ---- walk the tree with the reference's predicates (every member alike)
+        if (ph == 4) {
+            const unsigned long long v = sh.xres[0];
+            ++n_zero; pts += (v >> 24) & 0xffffff; bad |= (v & kBad) != 0;
+            sgnBottom = (v & kPos) != 0;
+            ph = 3;
+        } else {
+            int h = 1;
+            bool stop = false;
+            while (h <= K && !stop) {
+                if (ph == 3 ? iter3 >= kIter3 : !(hi - lo > kErr)) { stop = true; continue; }
+                const unsigned long long v = sh.xres[h - 1];
+                const unsigned fl = static_cast<unsigned>(v & 0xfff);
+                if (fl & kNone) { bad = 1; stop = true; continue; }      // cannot happen: an active node without a result
+                const int cnt = static_cast<int>((v >> 12) & 0xfff);
+                const double E = (hi + lo) / 2;
+                pts += (v >> 24) & 0xffffff; bad |= (fl & kBad) != 0;
+                bool bit;
+                if (ph == 1) { ++n_count; bit = !(cnt > nodes); }         // DFTAtom.cpp:579-582
+                else if (ph == 2) { ++n_count; ++len2; bit = cnt < nodes; }   // DFTAtom.cpp:597-600
+                else {
+                    ++n_zero; ++iter3;
+                    bit = ((fl & kPos) != 0) == sgnBottom;                // DFTAtom.cpp:522-525
+                    nonfinite = (fl & kNonFinite) != 0;
+                }
+                const double hi_was = hi, lo_was = lo;
+                if (bit) lo = E; else hi = E;
+                if (ph == 3) {
+                    const double width = hi - lo;
+                    if (width < kErr && (fl & kSmall) != 0u) { conv = 1; stop = true; }
+                    else if (fixed_point && hi == hi_was && lo == lo_was) {
+                        const int rest = kIter3 - iter3;
+                        n_zero += rest; n_fixed += rest; iter3 = kIter3; fixed = 1;
+                        stop = true;
+                    }
+                }
+                h = 2 * h + (bit ? 1 : 0);
+            }
+            // end of a phase?
+            if (ph == 1 && !(hi - lo > kErr)) {
+                top = hi; lo = bottom0; ph = 2;
+                if (nodes == 0) {                                          // "count < 0" never holds: arithmetic (levels.hip)
+                    while (hi - lo > kErr) { hi = (hi + lo) / 2; ++n_count; ++len2; }
+                }
+            }
+            if (ph == 2 && !(hi - lo > kErr)) { bottom = hi; lo = bottom; hi = top; ph = 4; }
+            else if (ph == 3 && (conv || fixed || iter3 >= kIter3)) ph = 0;
+        }
+#ifdef DFTA_SCAN_DEBUG
+        if (threadIdx.x == 0 && blockIdx.x == 0) printf("rnd %u ph %d lo %.6f hi %.6f iter3 %d conv %d fixed %d nz %d nc %d bad %d x0 %llx\n", rnd, ph, lo, hi, iter3, conv, fixed, n_zero, n_count, bad, sh.xres[0]);
+#endif
+        __syncthreads();                                                   // xres is rewritten in the next round
+    }
+    if (m != 0) return;
+    const double Bot = lo, Top = hi;
+    int matchPoint = 0;
+    if (ma.mode) {
+        const int l = J->l;
+        const double z1 = l == 0 ? ma.zero1[0] : (l == 1 ? ma.zero1[1] : (l == 2 ? ma.zero1[2] : ma.zero1[3]));
+        const MatchOut mo = scan_match(G, tab, mm, Bot, z1, sh, par, hint, ma.Psi + (size_t)k * G.N, ma.eh, ma.cnst, ma.mode == 2);
+        bad |= mo.bad;
+        matchPoint = mo.matchPoint;
+        pts += mo.start;
+        if (threadIdx.x == 0) ma.jstart_keep[k] = mo.start;
+    }
+    if (threadIdx.x == 0) {
+        if (ma.mode) J->matchPoint = matchPoint;
+        J->top = top; J->bottom = bottom; J->toe = Top; J->boe = Bot; J->E = Bot;
+        J->status = conv ? DFTA_LEVEL_CONVERGED : (DFTA_LEVEL_ITERATION_CAP | (fixed ? DFTA_LEVEL_FIXED_POINT : 0) | (nonfinite ? DFTA_LEVEL_U0_NONFINITE : 0));
+        J->converged = conv; J->n_count = n_count; J->n_zero = n_zero; J->iter3 = iter3; J->n_fixed = n_fixed;
+        J->cur_len[1] = len2; J->n_points = pts; J->phase = kPhDone; J->haveSgn = 1;
+        const int skipped = (nodes == 0 ? len2 : 0) + n_fixed;
+        atomicAdd(counters, (unsigned long long)(n_count + n_zero - skipped));
+        atomicAdd(counters + 1, (unsigned long long)pts);
+        if (bad) atomicOr(counters + 3, 1ull);
+    }
+}
+
 // interleaved tolerance-mode table of every slot: rows V + c_l
 __global__ void k_scan_build_tab(double* __restrict__ tabs, const double* __restrict__ V, const double* __restrict__ cl,
                                  const int* __restrict__ slot_v, const int* __restrict__ slot_l, int N, int logC)
@@ -990,6 +1166,33 @@ extern "C" int dfta_debug_scan_prof(unsigned long long* out16, int reset)
     return DFTA_OK;
 }
 #endif
+
+int dfta_launch_scan_levels_group(dfta_ctx* ctx, const dfta_grid* g, dfta::Job* d_jobs, const int* d_live, int nlive, int K, const dfta_scan_tables& tb,
+                                  int fixed_point, unsigned long long* d_counters, unsigned long long* d_xch, int match_mode, double* d_Psi, int* d_jstart_keep)
+{
+    ScanMatchArgs ma;
+    ma.mode = match_mode; ma.Psi = d_Psi; ma.eh = g->d_eh; ma.cnst = g->d_cnst; ma.jstart_keep = d_jstart_keep;
+    for (int q = 0; q < 4; ++q) ma.zero1[q] = g->zero1[q];
+    int depth = 0;
+    while ((1 << (depth + 1)) - 1 <= K) ++depth;
+    DFTA_HIP(ctx, hipMemsetAsync(d_xch, 0, sizeof(unsigned long long) * 32 * (size_t)nlive, ctx->stream));
+    ScanGrid G = scan_grid_of(g, tb);
+    const double *pr = g->d_r, *pA = tb.Atop, *pT = tb.T, *ptab = tb.tabv;
+    const double2* pmm = tb.mm;
+    // the members of a job wait for each other: co-residency is the launch's business.  Under a profiler (rocprofiler-sdk 7.2 crashes in an
+    // exit handler after a cooperative launch, see poisson.hip) the launch is an ordinary one: the grid is within the compute units, one
+    // workgroup of 8 waves x 248 VGPRs fills a compute unit, and the bounded spins catch what is left.
+    const bool plain = getenv("ROCP_TOOL_LIBRARIES") != nullptr || dfta_knob("SCAN_PLAIN_LAUNCH") != nullptr;
+    if (plain) {
+        hipLaunchKernelGGL(k_scan_levels_group, dim3(nlive * K), dim3(kT), 0, ctx->stream, G, pr, pA, pT, d_jobs, d_live, K, depth, ptab, pmm, fixed_point, d_counters, d_xch, ma);
+        DFTA_CHECK_LAUNCH(ctx);
+        return DFTA_OK;
+    }
+    void* args[] = {&G, &pr, &pA, &pT, &d_jobs, &d_live, &K, &depth, &ptab, &pmm, &fixed_point, &d_counters, &d_xch, &ma};
+    const hipError_t e = hipLaunchCooperativeKernel(reinterpret_cast<const void*>(k_scan_levels_group), dim3(nlive * K), dim3(kT), args, 0, ctx->stream);
+    if (e != hipSuccess) { (void)hipGetLastError(); return DFTA_ERR_NOT_CONVERGED; }      // not co-resident: the caller falls back to one workgroup per level
+    return DFTA_OK;
+}
 
 // ---- C ABI: the tolerance-mode twin of dfta_numerov_sweeps -----------------------------------------------------------------
 extern "C" int dfta_numerov_sweeps_scan(dfta_ctx* ctx, const dfta_grid* g, int kind, int nV, const double* V, int ntrials, const int* vidx,

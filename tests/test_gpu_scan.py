@@ -240,3 +240,39 @@ def test_scan_mode_small_grid_and_batch(ctx):
     a.close()
     b.close()
     grid.close()
+
+
+def test_scan_groups_take_the_same_decisions(ctx, grid17):
+    """k_scan_levels_group (15 / 7 / 3 workgroups per level, a depth-4 / 3 / 2 bisection tree per round) against one workgroup per level
+    (SCAN_GROUP=1): the same reference decisions, so eigenvalues, intervals, sweep counts, status bits and the density bit for bit -- Rn
+    LDA (15 levels x 15 members) and LSDA (30 levels x 7), four SCF steps each"""
+    def run(knob, lsda):
+        old = os.environ.get("DFTA_DEBUG")
+        try:
+            if knob:
+                os.environ["DFTA_DEBUG"] = knob
+            else:
+                os.environ.pop("DFTA_DEBUG", None)
+            scf = D.Scf(ctx, grid17, [86], lsda=lsda, sweep_mode=D.SWEEPS_TOLERANCE)
+            out = []
+            for _ in range(4):
+                st = scf.step()
+                lv = [scf.levels(0, sp) for sp in range(2 if lsda else 1)]
+                out.append((scf.energies()[0][0].as_list(), [x["E"].copy() for x in lv], [x["status"].copy() for x in lv], [x["n_count"].copy() for x in lv],
+                            [x["n_zero"].copy() for x in lv], int(st.sweeps_reference), int(st.points_reference), scf.array(0).copy(), float(st.ms_levels)))
+            scf.close()
+            return out
+        finally:
+            if old is None:
+                os.environ.pop("DFTA_DEBUG", None)
+            else:
+                os.environ["DFTA_DEBUG"] = old
+    for lsda in (False, True):
+        a = run(None, lsda)
+        for knob in ("SCAN_GROUP=1", "SCAN_GROUP=3"):
+            b = run(knob, lsda)
+            for x, y in zip(a, b):
+                assert x[0] == y[0] and x[5:7] == y[5:7] and np.array_equal(x[7], y[7]), knob
+                for q in range(1, 5):
+                    assert all(np.array_equal(u, v) for u, v in zip(x[q], y[q])), (knob, q)
+        print("scan level search Rn %s: %.2f ms per step grouped, %.2f ms with one workgroup per level" % ("LSDA" if lsda else "LDA", a[-1][8], run("SCAN_GROUP=1", lsda)[-1][8]))
