@@ -386,7 +386,7 @@ def test_reference_late_step_jitter():
     BASELINE.md's 1e-8: the COMPILED REFERENCE's own eigenvalues still move by that much from one SCF step to the next when it stops (or hits
     its 100-step cap) -- the multigrid's 100-V-cycle end state is a round-off floor that the 1/r-weighted potential amplifies.  Fixture:
     tests/golden/late_step_jitter.json (make_golden_table.py jitter: the last four steps of Rn and of a sample of the loosest atoms, L = 17).
-    Asserted: the jitter is there (>= 5e-8 Ha for every atom of the sample), and every gate is within 4x (atoms that finish) / 12x (atoms that
+    Asserted: the jitter is there (>= 3e-8 Ha for every atom of the sample: 3.6e-8 for Ni ... 1.3e-6 for Gd), and every gate is within 4x (atoms that finish) / 12x (atoms that
     run to the cap, whose trajectories keep wandering) of the largest step-to-step movement observed in its group -- while Etotal, which is
     variational, is steady to 1e-9 relative."""
     import json
@@ -398,7 +398,7 @@ def test_reference_late_step_jitter():
         lv = [np.array([x[1] for x in s["levels"]]) for s in rec["last_steps"]]
         en = [s["energies"][0] for s in rec["last_steps"]]
         jit[int(Z)] = max(float(np.max(np.abs(lv[i + 1] - lv[i]))) for i in range(len(lv) - 1))
-        assert jit[int(Z)] >= 5e-8, (Z, jit[int(Z)])
+        assert jit[int(Z)] >= 3e-8, (Z, jit[int(Z)])
         assert max(abs((en[i + 1] - en[i]) / en[i]) for i in range(len(en) - 1)) <= 1e-9
     groups = {"Rn": ([86], 2e-7, 4.0), "Z <= 86": ([z for z in jit if z < 86], 1e-6, 4.0), "Z > 86": ([z for z in jit if z > 86], 8e-6, 12.0)}
     for name, (zs, gate, factor) in groups.items():
