@@ -13,7 +13,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdftatom_hip.so")
+LIB_PATH = os.environ.get("DFTA_LIB_PATH") or os.path.join(_HERE, "libdftatom_hip.so")      # DFTA_LIB_PATH: measurement builds
 
 OK = 0
 SWEEP_COUNT, SWEEP_ZERO = 0, 1

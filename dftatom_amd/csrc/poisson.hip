@@ -137,6 +137,9 @@ namespace mg_exact {
 namespace mg_tol {
 #define DFTA_MG_KWARM 32
 #define DFTA_MG_KWARM3 32
+#ifndef DFTA_MG_NO_SCAN_COARSE
+#define DFTA_MG_SCAN_COARSE 1      // the coarse section's sweeps as affine scans (poisson_kernels.inc: cs_sweep_scan)
+#endif
 #include "poisson_kernels.inc"
 #undef DFTA_MG_KWARM
 #undef DFTA_MG_KWARM3
@@ -521,7 +524,7 @@ void dfta_poisson_destroy(dfta_poisson* p)
 #ifdef DFTA_POISSON_RPROF
     {
         unsigned long long hr[2 * 8 * 8];
-        if (p->resident && hipMemcpyFromSymbol(hr, HIP_SYMBOL(mg_exact::g_rprof), sizeof(hr)) == hipSuccess) {
+        if (p->resident && (p->tol ? hipMemcpyFromSymbol(hr, HIP_SYMBOL(mg_tol::g_rprof), sizeof(hr)) : hipMemcpyFromSymbol(hr, HIP_SYMBOL(mg_exact::g_rprof), sizeof(hr))) == hipSuccess) {
             const char* mn[8] = {"pass    ", "publish ", "exchange", "commit  ", "restrict", "prolong ", "handover", "redo    "};
             const char* cn[8] = {"passive ", "-       ", "iterate ", "coarsesc", "restrict", "prolong ", "handover", "-       "};
             for (int role = 0; role < 2; ++role)
@@ -532,7 +535,8 @@ void dfta_poisson_destroy(dfta_poisson* p)
                     fprintf(stderr, "  = %llu\n", t);
                 }
             unsigned long long zz[2 * 8 * 8] = {0};
-            (void)hipMemcpyToSymbol(HIP_SYMBOL(mg_exact::g_rprof), zz, sizeof(zz));
+            if (p->tol) (void)hipMemcpyToSymbol(HIP_SYMBOL(mg_tol::g_rprof), zz, sizeof(zz));
+            else (void)hipMemcpyToSymbol(HIP_SYMBOL(mg_exact::g_rprof), zz, sizeof(zz));
         }
     }
 #endif
