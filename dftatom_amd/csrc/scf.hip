@@ -452,26 +452,38 @@ int dfta_scf_step(dfta_scf* s, dfta_step_stats* stats)
                 ls.tried = true;
                 int Gbig = 0;
                 dfta_poisson_group_state(s->poisson, &Gbig, nullptr, nullptr);
+                // an optimisation only: if the class solver cannot be made (memory), the batch's own solver does the work --
+                // the level solve and the mixing of this step have already run, so nothing may fail here
                 rc = dfta_poisson_create_ex(ctx, g, kLiveClassAtoms[c], dfta_poisson_mode(s->poisson), &ls.p);
-                if (rc) return rc;
-                dfta_poisson_group_state(ls.p, &ls.G, nullptr, nullptr);
-                if (ls.G <= Gbig) { dfta_poisson_destroy(ls.p); ls.p = nullptr; }     // nothing to gain on this grid
+                if (rc) { ls.p = nullptr; ctx->err[0] = 0; (void)hipGetLastError(); rc = DFTA_OK; }
+                if (ls.p) {
+                    dfta_poisson_group_state(ls.p, &ls.G, nullptr, nullptr);
+                    if (ls.G <= Gbig) { dfta_poisson_destroy(ls.p); ls.p = nullptr; }     // nothing to gain on this grid
+                }
             }
             if (ls.p) { pl = ls.p; cls_atoms = kLiveClassAtoms[c]; }
             break;                                                  // the smallest class that holds the live atoms, or the batch's solver
         }
     }
-    const bool use_live = pl != nullptr;
+    bool use_live = pl != nullptr;
     std::vector<int> h_live;
-    if (use_live) {
-        if (s->live_cap < cls_atoms) {
+    if (use_live && s->live_cap < cls_atoms) {
+        for (void* q : {(void*)s->d_liveZ, (void*)s->d_liveRho, (void*)s->d_liveU}) if (q) (void)hipFree(q);
+        s->d_liveZ = nullptr; s->d_liveRho = nullptr; s->d_liveU = nullptr;
+        s->live_cap = 0;
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&s->d_liveZ), sizeof(int) * 3 * cls_atoms);
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&s->d_liveRho), sizeof(double) * (size_t)cls_atoms * N);
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&s->d_liveU), sizeof(double) * (size_t)cls_atoms * N);
+        if (e == hipSuccess) s->live_cap = cls_atoms;
+        else {                                             // no room for the gathered copies: the batch's own solver (same bits)
             for (void* q : {(void*)s->d_liveZ, (void*)s->d_liveRho, (void*)s->d_liveU}) if (q) (void)hipFree(q);
             s->d_liveZ = nullptr; s->d_liveRho = nullptr; s->d_liveU = nullptr;
-            DFTA_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&s->d_liveZ), sizeof(int) * 3 * cls_atoms));
-            DFTA_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&s->d_liveRho), sizeof(double) * (size_t)cls_atoms * N));
-            DFTA_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&s->d_liveU), sizeof(double) * (size_t)cls_atoms * N));
-            s->live_cap = cls_atoms;
+            (void)hipGetLastError();
+            use_live = false;
+            pl = nullptr;
         }
+    }
+    if (use_live) {
         const int cap = s->live_cap;
         h_live.assign(3 * cap, 0);
         for (int i = 0; i < cap; ++i) {

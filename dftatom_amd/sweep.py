@@ -37,23 +37,27 @@ def atom_cost(Z):
     return subshell_count(Z) * expected_steps(Z)
 
 
-# Time model of one shard (measured on MI355X, profiles/r03_periodic_table_predicted_scaling.json): a step of a batch costs a
-# latency floor -- the level search's rounds and the multigrid's dependent sweeps take what they take for one atom or ten -- plus
-# a per-job share once the batch fills the machine:  t_step(batch) = STEP_FLOOR_MS + JOB_MS x (subshells of the atoms still running).
+# Time model of one shard (measured on MI355X, profiles/r04_periodic_table_predicted_scaling*.json): a step of a batch costs a
+# latency floor -- the level search and the multigrid's dependent sweeps take what they take for one atom or ten -- plus a per-job
+# share once the batch fills the machine:  t_step(batch) = STEP_FLOOR_MS + JOB_MS x (subshells of the atoms still running).
 # A shard runs until its slowest atom stops, so  T(shard) = STEP_FLOOR_MS x max(steps) + JOB_MS x sum(subshells x steps):
-# the first term is the critical path (what a by-work partition ignores), the second the work.
-STEP_FLOOR_MS = 64.0      # least squares over the 15 shards of the emulated 1-, 2-, 4- and 8-rank sweeps of
-JOB_MS = 0.30             # profiles/r03_periodic_table_predicted_scaling.json (22.6 s on one GPU, 7.8 .. 9.1 s for an eighth of the table)
+# the first term is the critical path (what a by-work partition ignores), the second the work.  One pair per mode of the sweeps,
+# least squares over the shards of the emulated 1-, 2-, 4- and 8-rank sweeps (profiles/fit_shard_model.py re-fits them from the
+# recorded files; tests/test_sweep_dist.py checks that the model reproduces every recorded shard time within 15 %).
+SHARD_MODEL = {"exact": (68.5, 0.228),       # (STEP_FLOOR_MS, JOB_MS): residuals max 8.5 %, rms 4.5 % over the 15 recorded shards
+               "tolerance": (23.7, 0.167)}   # scan sweeps + the multigrid's tolerance mode: max 14 %, rms 5.4 %
+STEP_FLOOR_MS, JOB_MS = SHARD_MODEL["exact"]
 
 
-def shard_time_ms(Zs):
+def shard_time_ms(Zs, model="exact"):
     """predicted wall time of one rank that advances the atoms Zs together until each has stopped (see the model above)"""
     if not Zs:
         return 0.0
-    return STEP_FLOOR_MS * max(expected_steps(z) for z in Zs) + JOB_MS * sum(atom_cost(z) for z in Zs)
+    floor, job = SHARD_MODEL[model]
+    return floor * max(expected_steps(z) for z in Zs) + job * sum(atom_cost(z) for z in Zs)
 
 
-def partition_atoms(Zs, world_size, cost=None):
+def partition_atoms(Zs, world_size, cost=None, model="exact"):
     """Static assignment of atoms to ranks, deterministic on every rank: returns a list (per rank) of lists of Z.
 
     Default (cost=None): greedy on the PREDICTED SHARD TIME (critical path + work, shard_time_ms): atoms in order of decreasing step
@@ -73,8 +77,8 @@ def partition_atoms(Zs, world_size, cost=None):
     order = sorted(Zs, key=lambda z: (-expected_steps(z), -atom_cost(z), z))
     shards = [[] for _ in range(world_size)]
     for z in order:
-        best = min(range(world_size), key=lambda k: (max(shard_time_ms(shards[j] + ([z] if j == k else [])) for j in range(world_size)),
-                                                     shard_time_ms(shards[k] + [z]), k))
+        best = min(range(world_size), key=lambda k: (max(shard_time_ms(shards[j] + ([z] if j == k else []), model) for j in range(world_size)),
+                                                     shard_time_ms(shards[k] + [z], model), k))
         shards[best].append(z)
     return [sorted(s) for s in shards]
 

@@ -30,6 +30,8 @@ def main():
     ap.add_argument("--out", default="")
     ap.add_argument("--partition", choices=("model", "work"), default="model",
                     help="model: balance the predicted shard times (critical path + work, dftatom_amd.sweep); work: LPT on subshells x steps")
+    ap.add_argument("--sweeps", choices=("exact", "tolerance"), default="exact", help="tolerance: the scan sweeps (DFTA_SWEEPS_TOLERANCE)")
+    ap.add_argument("--poisson", choices=("exact", "tolerance"), default="exact", help="tolerance: the multigrid's tolerance mode")
     ap.add_argument("--emulate-ranks", type=int, default=0,
                     help="one GPU, no launcher: run each of the N shards of an N-rank sweep alone, one after the other, and report the "
                          "per-shard wall times; their maximum PREDICTS the N-GPU wall time (shards never interact; the only collective "
@@ -59,15 +61,22 @@ def main():
 
     Zs = list(range(args.zmin, args.zmax + 1))
     cost = sweep.atom_cost if args.partition == "work" else None
+    modes = dict(sweep_mode=D.SWEEPS_TOLERANCE if args.sweeps == "tolerance" else D.SWEEPS_EXACT,
+                 poisson_mode=D.POISSON_TOLERANCE if args.poisson == "tolerance" else D.POISSON_EXACT)
+    model = "tolerance" if args.sweeps == "tolerance" else "exact"
+    if cost is None and model != "exact":
+        cost_model = model
+    else:
+        cost_model = "exact"
     if args.emulate_ranks > 0:
         # the N shards of an N-rank sweep, one at a time on this GPU
         assert world == 1, "--emulate-ranks runs without a launcher"
         N = args.emulate_ranks
-        shards = sweep.partition_atoms(Zs, N, cost=cost)
+        shards = sweep.partition_atoms(Zs, N, cost=cost, model=cost_model)
         rows = []
         for r, zs in enumerate(shards):
             t0 = time.time()
-            scf = D.Scf(ctx, grid, zs, lsda=False)
+            scf = D.Scf(ctx, grid, zs, lsda=False, **modes)
             steps = 0
             while steps < args.max_steps:
                 scf.step(want_stats=False)
@@ -80,11 +89,11 @@ def main():
             en, fin = scf.energies()
             scf.close()
             rows.append({"rank": r, "atoms": zs, "steps": steps, "seconds": dt, "finished": int(fin.sum()),
-                         "predicted_seconds_model": sweep.shard_time_ms(zs) / 1e3,
+                         "predicted_seconds_model": sweep.shard_time_ms(zs, cost_model) / 1e3,
                          "etotal": {int(z): en[k].Etotal for k, z in enumerate(zs)}})
             print("shard %d/%d: %2d atoms, %3d steps, %.2f s (model %.2f s)" % (r, N, len(zs), steps, dt, rows[-1]["predicted_seconds_model"]), flush=True)
         pred = max(x["seconds"] for x in rows)
-        res = {"emulated_ranks": N, "partition": args.partition, "levels": args.levels, "zmin": args.zmin, "zmax": args.zmax,
+        res = {"emulated_ranks": N, "partition": args.partition, "sweeps": args.sweeps, "poisson": args.poisson, "levels": args.levels, "zmin": args.zmin, "zmax": args.zmax,
                "predicted_n_gpu_seconds": pred, "sum_of_shard_seconds": sum(x["seconds"] for x in rows), "shards": rows,
                "note": "PREDICTION from one GPU: every shard run alone; max over shards = wall time of an N-rank sweep up to the final "
                        "all_gather of 64 doubles per atom (microseconds)"}
@@ -95,10 +104,10 @@ def main():
         grid.close()
         ctx.close()
         return
-    mine = sweep.partition_atoms(Zs, world, cost=cost)[rank]
-    cap = max(len(s) for s in sweep.partition_atoms(Zs, world, cost=cost))
+    mine = sweep.partition_atoms(Zs, world, cost=cost, model=cost_model)[rank]
+    cap = max(len(s) for s in sweep.partition_atoms(Zs, world, cost=cost, model=cost_model))
     t0 = time.time()
-    scf = D.Scf(ctx, grid, mine, lsda=False)
+    scf = D.Scf(ctx, grid, mine, lsda=False, **modes)
     steps = 0
     while steps < args.max_steps:
         scf.step(want_stats=False)

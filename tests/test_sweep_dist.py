@@ -73,3 +73,39 @@ def test_gather_world_size_2_gloo():
         assert np.allclose(et, [-float(z) ** 2.4 for z in zs])
     f = sweep.record_fields(np.concatenate([[3, -7.3, 7.2, 4.0, -17.0, -1.5, 1, 31, 2, 1, -1.9, -0.08], np.zeros(52)]))
     assert f["Z"] == 3 and f["finished"] and f["nlevels"] == 2 and f["eigenvalues"].tolist() == [-1.9, -0.08]
+
+
+def test_shard_time_model_reproduces_the_recorded_shards():
+    """the constants of sweep.shard_time_ms drift with every kernel change -- they are re-fitted from the recorded
+    emulation (profiles/fit_shard_model.py, profiles/r04_periodic_table_predicted_scaling_<mode>.json: every shard of the 1-, 2-, 4-, 8-rank
+    sweeps run alone on one MI355X) and this test keeps them honest: every recorded shard within 15 %, and the fit itself agrees with the
+    constants in the source to 3 %."""
+    import importlib.util
+    import json
+    import os
+    import numpy as np
+    from dftatom_amd import sweep
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("fit_shard_model", os.path.join(root, "profiles", "fit_shard_model.py"))
+    fitm = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fitm)
+    for mode in ("exact", "tolerance"):
+        with open(fitm.path_of(mode)) as f:
+            rec = json.load(f)
+        n = 0
+        for run in rec["runs"]:
+            for sh in run["shards"]:
+                if not sh["atoms"]:
+                    continue
+                pred = sweep.shard_time_ms(sh["atoms"], mode) / 1e3
+                assert abs(pred - sh["seconds"]) <= 0.15 * sh["seconds"], (mode, run["emulated_ranks"], sh["rank"], pred, sh["seconds"])
+                n += 1
+        assert n == 15
+        coef, rel = fitm.fit(mode)
+        floor, job = sweep.SHARD_MODEL[mode]
+        assert abs(coef[0] - floor) <= 0.03 * floor and abs(coef[1] - job) <= 0.03 * job, (mode, coef)
+        assert float(np.max(np.abs(rel))) <= 0.15
+    # the prediction itself: an eighth of the table per GPU
+    with open(fitm.path_of("tolerance")) as f:
+        tol = json.load(f)
+    assert tol["predicted_seconds"]["8"] <= 7.0            # VERDICT r3 target for the 8-GPU prediction
