@@ -197,7 +197,11 @@ def pmc_traffic(kernel, workload="default"):
         tag = {"profile": os.path.basename(files[-1]), "source_sha": d.get("source_sha"), "current": d.get("source_sha") == source_sha()}
         if not tag["current"]:
             return None, tag
-        return float(d["kernels"][kernel]["hbm_bytes_per_launch_fetch_doubled"]), tag
+        names = [kernel] + (["k_scan_levels_group"] if kernel == "k_scan_levels" else [])     # one atom: a group of workgroups per level
+        for nm in reversed(names):
+            if nm in d["kernels"]:
+                return float(d["kernels"][nm]["hbm_bytes_per_launch_fetch_doubled"]), tag
+        return None, tag
     except Exception:
         return None, None
 
