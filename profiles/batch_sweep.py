@@ -21,6 +21,8 @@ def main():
     ap.add_argument("--sizes", default="64,128,256,512,1024,2048")
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--scan-sweeps", action="store_true", help="the sweeps' tolerance mode (scan.hip)")
+    ap.add_argument("--tolerance", action="store_true", help="the multigrid's tolerance mode")
     args = ap.parse_args()
     import torch
     import bench
@@ -28,7 +30,8 @@ def main():
     ctx = D.Context(0, torch.cuda.current_stream().cuda_stream)
     grid = D.Grid(ctx, 17, 1e-4, 50.0)
     bench.HBM_MEASURED["copy"], bench.HBM_MEASURED["triad"] = ctx.measure_hbm(1 << 27, 5)
-    out = {"workload": "B Rn atoms, LDA, 131073 nodes, %d steps after %d warm-up steps" % (args.steps, args.warmup),
+    out = {"workload": "B Rn atoms, LDA, 131073 nodes, %d steps after %d warm-up steps; sweeps %s, multigrid %s"
+                       % (args.steps, args.warmup, "tolerance (scan)" if args.scan_sweeps else "exact", "tolerance" if args.tolerance else "exact"),
            "hbm_copy_GBps": bench.HBM_MEASURED["copy"], "sizes": {}}
 
     def barrier():
@@ -36,7 +39,8 @@ def main():
 
     for B in [int(x) for x in args.sizes.split(",")]:
         t0 = time.time()
-        scf, tot = bench.run_workload(D, ctx, grid, 17, B, False, args.steps, args.warmup, 0, barrier, torch)
+        scf, tot = bench.run_workload(D, ctx, grid, 17, B, False, args.steps, args.warmup, 0, barrier, torch,
+                                      poisson_mode=D.POISSON_TOLERANCE if args.tolerance else None, sweep_mode=D.SWEEPS_TOLERANCE if args.scan_sweeps else None)
         scf.close()
         s = bench.summarize(tot, 17, grid.N, B, False, 1, 1e-4, 50.0)
         out["sizes"][str(B)] = {"ms_per_step": s["ms_per_step"], "ms_per_atom_step": s["ms_per_atom_step"],
@@ -45,7 +49,8 @@ def main():
                                 "vcycles_per_s": s["vcycles_per_s"], "issued_per_useful": s["issued_per_useful"],
                                 "rounds_per_step": s["rounds_per_step"], "phase_ms_per_step": s["phase_ms_per_step"],
                                 "tree_depth": tot["tree_depth"], "poisson_workgroups_per_atom": tot["poisson_G"],
-                                "sweep_kernel": s["kernels"]["sweep"]["kernel"].split(" ")[0],
+                                "sweep_kernel": s["kernels"]["sweep"]["kernel"].split(" ")[0], "levels_ms": s["phase_ms_per_step"]["levels"],
+                                "poisson_ms": s["phase_ms_per_step"]["poisson"],
                                 "sweep_frac_issued": s["kernels"]["sweep"]["frac_issued"],
                                 "sweep_frac_executed_path": s["kernels"]["sweep"]["frac"],
                                 "poisson_frac_algorithmic": s["kernels"]["poisson"]["frac"],

@@ -21,7 +21,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def run(D, ctx, grid, peak_gbs=8000.0, measured_gbs=None, Z=86, reps=3):
+def run(D, ctx, grid, peak_gbs=8000.0, measured_gbs=None, Z=86, reps=3, scan=False):
     scf = D.Scf(ctx, grid, [Z], lsda=False)
     V = scf.array(3, 0).copy()                    # potential of spin 0 at step 0
     scf.close()
@@ -34,7 +34,10 @@ def run(D, ctx, grid, peak_gbs=8000.0, measured_gbs=None, Z=86, reps=3):
         for kind, name in ((D.SWEEP_COUNT, "count_nodes"), (D.SWEEP_ZERO, "solution_in_zero")):
             best, pts = None, 0
             for _ in range(reps + 1):
-                r = D.numerov_sweeps(ctx, grid, kind, V, l, E, lim if kind == D.SWEEP_COUNT else None)
+                if scan:          # tolerance mode: one workgroup per trial (dfta_numerov_sweeps_scan); trips = the turning-point exits
+                    r = D.numerov_sweeps_scan(ctx, grid, kind, V, l, E, lim if kind == D.SWEEP_COUNT else None)
+                else:
+                    r = D.numerov_sweeps(ctx, grid, kind, V, l, E, lim if kind == D.SWEEP_COUNT else None)
                 ms = ctx.last_kernel_ms()
                 pts = int(r["trip"].astype(np.int64).sum())
                 best = ms if best is None else min(best, ms)
@@ -55,6 +58,7 @@ if __name__ == "__main__":
     grid = D.Grid(ctx, 17, 1e-4, 50.0)
     copy, triad = ctx.measure_hbm(1 << 27, 5)
     res = run(D, ctx, grid, 8000.0, copy)
+    res["scan_sweeps"] = run(D, ctx, grid, 8000.0, copy, scan=True)["sets"]      # the same trial sets through the tolerance-mode kernel
     res["hbm_copy_GBps"], res["hbm_triad_GBps"] = copy, triad
     print(json.dumps(res, indent=1))
     grid.close()
