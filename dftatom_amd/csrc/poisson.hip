@@ -77,6 +77,8 @@ struct MgDesc {
     // workgroup 0 alone, entirely in LDS.  -1: off.  cs_phi / cs_src: offsets of a level's arrays inside the staging memory
     // (doubles), cs_lc: log2(nodes per lane) of its 64-lane interleaved layout, or -1 for natural order.
     int cs_top;
+    int rc_src[6];   // ... offsets (doubles, inside the staging memory) of the sources of levels rc_top .. rc_top + 5 (256 C entries each)
+    int rc_top;      // tolerance mode, resident groups: the coarse workgroup runs levels rc_top .. levels-1 of a V-cycle with their nodes in registers (coarse_resident_cycle); -1: off
     int cs_phi[kMaxLevels], cs_src[kMaxLevels], cs_lc[kMaxLevels];
     Lvl lv[kMaxLevels];
 };
@@ -462,7 +464,33 @@ static int poisson_create_impl(dfta_ctx* ctx, const dfta_grid* g, int batch, int
                 D.cs_src[l] = at; at += L.n + 1;
             } else ok = false;
         }
-        if (ok && at <= 2 * kStageArr) D.cs_top = top;
+        if (ok && at <= 2 * kStageArr - 64) D.cs_top = top;
+    }
+    // tolerance mode, resident groups: the coarse workgroup's sub-cycle in registers (poisson_kernels.inc: coarse_resident_cycle) -- its
+    // first level has 8193 nodes (32 per thread), the levels down to 257 nodes halve the chunk, the 129-node level and below are the
+    // one-wave coarse section's
+    D.rc_top = -1;
+    if (p->tol && res_kres > 0 && D.cs_top > 0 && !dfta_knob("POISSON_NORC")) {
+        const Lvl& Lk = D.lv[res_kres];
+        bool ok = Lk.n == 8193 && Lk.logT == 8 && Lk.logC == 5 && res_kres + 6 < D.levels && D.lv[res_kres + 5].n == 257 &&
+                  D.lv[res_kres + 6].n == 129 && res_kres + 6 >= D.cs_top && D.cs_lc[res_kres + 6] == 1;
+        if (ok) {
+            // the sources of the six register levels live in the staging memory around the coarse section's arrays of the levels it
+            // still runs (129 nodes and below): 8192 + 4096 behind them, 2048 + 1024 + 512 + 256 in front (where the section's own
+            // copies of the 1025 .. 257-node levels would be)
+            int first10 = 1 << 30, end_cs = 0;
+            for (int l = res_kres + 6; l < D.levels; ++l) {
+                first10 = std::min(first10, std::min(D.cs_phi[l], D.cs_src[l]) - (D.cs_lc[l] >= 0 ? kStagePad : 0));
+                end_cs = std::max(end_cs, std::max(D.cs_phi[l], D.cs_src[l]) + D.lv[l].n + 8);
+            }
+            const int cap = 2 * kStageArr - 64;
+            ok = first10 >= 3840 && end_cs + 12288 <= cap;
+            if (ok) {
+                D.rc_src[0] = end_cs; D.rc_src[1] = end_cs + 8192;
+                D.rc_src[2] = 0; D.rc_src[3] = 2048; D.rc_src[4] = 3072; D.rc_src[5] = 3584;
+                D.rc_top = res_kres;
+            }
+        }
     }
     if (soff > kSeqCap) { delete p; snprintf(ctx->err, sizeof(ctx->err), "sequential levels exceed LDS budget"); return DFTA_ERR_INVALID; }
     const size_t tot = (size_t)off * batch;
