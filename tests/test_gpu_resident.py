@@ -25,7 +25,7 @@ import dftatom_amd as D                 # noqa: E402
 from golden.make_golden import GRIDS    # noqa: E402
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-KNOBS = ("DFTA_POISSON_GROUP", "DFTA_POISSON_RES", "DFTA_POISSON_MODE", "DFTA_POISSON_NOFUSE3")
+KNOBS = ("DFTA_POISSON_NORC", "DFTA_POISSON_GROUP", "DFTA_POISSON_RES", "DFTA_POISSON_MODE", "DFTA_POISSON_NOFUSE3")
 
 
 @pytest.fixture(scope="module")
@@ -145,10 +145,11 @@ def test_resident_lost_member_is_detected(ctx):
     grid.close()
 
 
-@pytest.mark.parametrize("kv", [{}, {"DFTA_POISSON_RES": "0"}, {"DFTA_POISSON_GROUP": "0"}, {"DFTA_POISSON_GROUP": "1"}, {"DFTA_POISSON_GROUP": "2"},
-                                {"DFTA_POISSON_GROUP": "3"}])
+@pytest.mark.parametrize("kv", [{}, {"DFTA_POISSON_NORC": "1"}, {"DFTA_POISSON_RES": "0"}, {"DFTA_POISSON_GROUP": "0"}, {"DFTA_POISSON_GROUP": "1"},
+                                {"DFTA_POISSON_GROUP": "2"}, {"DFTA_POISSON_GROUP": "3"}])
 def test_tolerance_mode_poisson(ctx, kv):
-    """opt-in 32-node warm-ups, every flavour of the solver: U within 2e-9 Z of the exact mode's (= the reference's) solution"""
+    """opt-in 32-node warm-ups, every flavour of the solver (the default: resident groups with the coarse workgroup's V-cycle in registers;
+    POISSON_NORC: its level-by-level code): U within 2e-9 Z of the exact mode's (= the reference's) solution"""
     L, d, R = GRIDS["L17"]
     grid = D.Grid(ctx, L, d, R)
     rr = grid.r()
@@ -164,6 +165,25 @@ def test_tolerance_mode_poisson(ctx, kv):
         assert 1 <= int(vct[0]) <= 100
         assert np.max(np.abs(Ut[0] - Z * (1 - (1 + rr) * np.exp(-2 * rr)))) < 3e-7 * Z     # analytic Hartree potential of 1s
     print("tolerance mode %s: max |dU| / Z = %.2e" % (kv, worst))
+    grid.close()
+
+
+@pytest.mark.parametrize("grid_key", ["L14", "L17"])
+def test_tolerance_mode_register_cycle_in_a_batch(ctx, grid_key):
+    """the register cycle of the coarse workgroup with three atoms side by side (3 x 33 workgroups) on the 16385- and the
+    131073-node grid: every atom within 2e-9 Z of the exact solve, and the same bits as the atom solved alone (groups are independent)"""
+    L, d, R = GRIDS[grid_key]
+    grid = D.Grid(ctx, L, d, R)
+    rr = grid.r()
+    Zs = [1, 18, 86]
+    rho = np.stack([Z * np.exp(-2 * rr) / np.pi for Z in Zs])
+    Ue, _, _, info_e = _solve(ctx, grid, Zs, rho, D.POISSON_EXACT)
+    Ut, vct, _, info_t = _solve(ctx, grid, Zs, rho, D.POISSON_TOLERANCE)
+    assert info_t[0] == 33 and info_e[0] == 33, (info_e, info_t)          # resident groups
+    for k, Z in enumerate(Zs):
+        assert float(np.max(np.abs(Ue[k] - Ut[k]))) <= 2e-9 * Z, (Z, float(np.max(np.abs(Ue[k] - Ut[k]))) / Z)
+        U1, vc1, _, _ = _solve(ctx, grid, [Z], rho[k:k + 1], D.POISSON_TOLERANCE)
+        assert np.array_equal(U1[0].view(np.int64), Ut[k].view(np.int64)) and int(vc1[0]) == int(vct[k])
     grid.close()
 
 
