@@ -15,7 +15,7 @@ makes, including the ~52 CountNodes calls per node-less level whose outcome -- "
 integrating; `sweeps_reference_executed` leaves those out) divided by the elapsed time including Poisson / XC / integrals:
 the same quantity the CPU baseline reports.
 
-The ONE line on stdout is compact (< 6 KB: the driver keeps the last 8 KB of stdout; compact_line()); the complete result with every
+The ONE line on stdout is compact (< 7 KB: the driver keeps the last 8 KB of stdout; compact_line()); the complete result with every
 kernel object and its notes goes to profiles/bench_full_last.json (and gpurun_out/bench_full_last.json).  On the line:
   roofline       the DOMINANT kernel of the timed region (by HIP-event time): the persistent multigrid kernel or the sweep
                  kernel; achieved = algorithmic bytes / its HIP-event time, against 8 TB/s; traffic,
@@ -325,7 +325,7 @@ def summarize(tot, levels, N, atoms, lsda, world, delta, rmax, workload=None):
 # ---------------------------------------------------------------------------------------------------------------
 # the ONE line on stdout: compact (the driver keeps the last 8 KB of stdout); everything else goes to a side file
 # ---------------------------------------------------------------------------------------------------------------
-LINE_LIMIT = 6000
+LINE_LIMIT = 7000
 
 
 def _r(x, sig=6):
@@ -593,8 +593,11 @@ def main():
                    ("rn_lsda_both_tolerance_modes", args.levels, 1, True, 10, 5, TOL, SCAN, None),
                    ("batch256_lda", args.levels, 256, False, 6, 5, None, None, "batch256"),
                    ("batch256_lda_scan_sweeps", args.levels, 256, False, 6, 5, None, SCAN, None),
+                   ("batch256_lda_both_tolerance_modes", args.levels, 256, False, 6, 5, TOL, SCAN, None),
                    ("rn_lsda_l20", 20, 1, True, 6, 6, None, None, None), ("rn_lsda_l20_scan_sweeps", 20, 1, True, 6, 6, None, SCAN, None),
-                   ("rn_lsda_l20_batch16", 20, 16, True, 4, 6, None, None, "l20_batch16")]
+                   ("rn_lsda_l20_both_tolerance_modes", 20, 1, True, 6, 6, TOL, SCAN, None),
+                   ("rn_lsda_l20_batch16", 20, 16, True, 4, 6, None, None, "l20_batch16"),
+                   ("rn_lsda_l20_batch16_both_tolerance_modes", 20, 16, True, 4, 6, TOL, SCAN, None)]
             if args.all_extras:
                 sel += [("rn_lsda_poisson_tolerance", args.levels, 1, True, 10, 5, TOL, None, None),
                         ("batch1024_lda", args.levels, 1024, False, 4, 2, None, None, None),

@@ -358,9 +358,12 @@ static int poisson_create_impl(dfta_ctx* ctx, const dfta_grid* g, int batch, int
     // End of round 3, with fused visits on the global levels too (gs_fused3, also on shared levels): 16 atoms 45.1 (16) / 50.1 (8);
     // 32: 53.6 (8) / 64.7 (4); 64: 77.3 (4) / 99.5 (2) / 137 (1); 96: 113 (2) / 145 (1); 112: 118 / 154; 128: 129 (2) / 153 (1)
     int logG = batch <= 16 ? 4 : (batch <= 32 ? 3 : (batch <= 64 ? 2 : ((batch <= 128 && 2 * batch <= std::max(ctx->num_cu, 1)) ? 1 : 0)));
+    // 1 048 577 nodes, up to four atoms: 32 workgroups per atom (measured: 95.3 -> 84.0 ms for one atom, 99.5 -> 92.0 for four; 64 workgroups
+    // 88.5; at eight atoms, and at 131 073 nodes, 16 remain faster: the barrier of a larger group costs more than the shorter chunks save)
+    if (batch <= 4 && g->N - 1 >= (1 << 20)) logG = 5;
     if (const char* e = dfta_knob("POISSON_GROUP")) {      // measurements: force log2 of the group size
         const int v = atoi(e);
-        if (v >= 0 && v <= 4 && (batch << v) <= 256) logG = v;
+        if (v >= 0 && v <= 6 && (batch << v) <= 256) logG = v;
     }
     if (force_logG >= 0) logG = force_logG;
     if (const char* e = dfta_knob("FAULT_POISSON_MEMBER")) p->fault = atoi(e) != 0;
