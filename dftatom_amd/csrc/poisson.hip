@@ -469,20 +469,24 @@ static int poisson_create_impl(dfta_ctx* ctx, const dfta_grid* g, int batch, int
         }
         if (ok && at <= 2 * kStageArr - 64) D.cs_top = top;
     }
-    // tolerance mode, resident groups: the coarse workgroup's sub-cycle in registers (poisson_kernels.inc: coarse_resident_cycle) -- its
-    // first level has 8193 nodes (32 per thread), the levels down to 257 nodes halve the chunk, the 129-node level and below are the
-    // one-wave coarse section's
+    // tolerance mode: the sub-cycle from the 8193-node level down in registers (poisson_kernels.inc: coarse_resident_cycle) -- 32 nodes per
+    // thread on its first level, the levels down to 257 nodes halve the chunk, the 129-node level and below run in one wave.  Resident
+    // groups: the coarse workgroup's levels; staged groups of 16 and one workgroup per atom: workgroup 0's, where that level is the first
+    // one it does not share (groups of 2 .. 8 share it: level by level there)
     D.rc_top = -1;
-    if (p->tol && res_kres > 0 && D.cs_top > 0 && !dfta_knob("POISSON_NORC")) {
-        const Lvl& Lk = D.lv[res_kres];
-        bool ok = Lk.n == 8193 && Lk.logT == 8 && Lk.logC == 5 && res_kres + 6 < D.levels && D.lv[res_kres + 5].n == 257 &&
-                  D.lv[res_kres + 6].n == 129 && res_kres + 6 >= D.cs_top && D.cs_lc[res_kres + 6] == 1;
+    int k8193 = -1;
+    for (int l = 0; l < D.levels; ++l) if (D.lv[l].n == 8193) k8193 = l;
+    if (p->tol && k8193 > 0 && D.cs_top > 0 && (res_kres > 0 ? k8193 == res_kres : k8193 >= D.kcoop) && !dfta_knob("POISSON_NORC")) {
+        const int kt = k8193;
+        const Lvl& Lk = D.lv[kt];
+        bool ok = !Lk.seq && Lk.logT == 8 && Lk.logC == 5 && kt + 6 < D.levels && D.lv[kt + 5].n == 257 &&
+                  D.lv[kt + 6].n == 129 && kt + 6 >= D.cs_top && D.cs_lc[kt + 6] == 1;
         if (ok) {
             // the sources of the six register levels live in the staging memory around the coarse section's arrays of the levels it
             // still runs (129 nodes and below): 8192 + 4096 behind them, 2048 + 1024 + 512 + 256 in front (where the section's own
             // copies of the 1025 .. 257-node levels would be)
             int first10 = 1 << 30, end_cs = 0;
-            for (int l = res_kres + 6; l < D.levels; ++l) {
+            for (int l = kt + 6; l < D.levels; ++l) {
                 first10 = std::min(first10, std::min(D.cs_phi[l], D.cs_src[l]) - (D.cs_lc[l] >= 0 ? kStagePad : 0));
                 end_cs = std::max(end_cs, std::max(D.cs_phi[l], D.cs_src[l]) + D.lv[l].n + 8);
             }
@@ -491,7 +495,7 @@ static int poisson_create_impl(dfta_ctx* ctx, const dfta_grid* g, int batch, int
             if (ok) {
                 D.rc_src[0] = end_cs; D.rc_src[1] = end_cs + 8192;
                 D.rc_src[2] = 0; D.rc_src[3] = 2048; D.rc_src[4] = 3072; D.rc_src[5] = 3584;
-                D.rc_top = res_kres;
+                D.rc_top = kt;
             }
         }
     }

@@ -39,22 +39,34 @@ def atom_cost(Z):
 
 # Time model of one shard (measured on MI355X, profiles/r04_periodic_table_predicted_scaling*.json): a step of a batch costs a
 # latency floor -- the level search and the multigrid's dependent sweeps take what they take for one atom or ten -- plus a per-job
-# share once the batch fills the machine:  t_step(batch) = STEP_FLOOR_MS + JOB_MS x (subshells of the atoms still running).
-# A shard runs until its slowest atom stops, so  T(shard) = STEP_FLOOR_MS x max(steps) + JOB_MS x sum(subshells x steps):
-# the first term is the critical path (what a by-work partition ignores), the second the work.  One pair per mode of the sweeps,
-# least squares over the shards of the emulated 1-, 2-, 4- and 8-rank sweeps (profiles/fit_shard_model.py re-fits them from the
-# recorded files; tests/test_sweep_dist.py checks that the model reproduces every recorded shard time within 15 %).
-SHARD_MODEL = {"exact": (68.5, 0.228),       # (STEP_FLOOR_MS, JOB_MS): residuals max 8.5 %, rms 4.5 % over the 15 recorded shards
-               "tolerance": (23.7, 0.167)}   # scan sweeps + the multigrid's tolerance mode: max 14 %, rms 5.4 %
-STEP_FLOOR_MS, JOB_MS = SHARD_MODEL["exact"]
+# share once the batch fills the machine:  t_step = FLOOR(live atoms) + JOB_MS x (subshells of the atoms still running).  The floor
+# has two values: with up to RESIDENT_MAX_ATOMS live atoms the multigrid runs in resident groups (and, in tolerance mode, the coarse
+# workgroup's V-cycle in registers and the level search in groups of workgroups per level), above that in staged groups.  A shard runs
+# until its slowest atom stops, so  T(shard) = FLOOR_SMALL_MS x (steps with <= 7 live atoms) + FLOOR_BIG_MS x (steps with more) +
+# JOB_MS x sum(subshells x steps): the first two terms are the critical path (what a by-work partition ignores), the third the work.
+# One triple per mode of the sweeps, least squares over the shards of the emulated 1-, 2-, 4- and 8-rank sweeps (profiles/fit_shard_model.py
+# re-fits them from the recorded files; tests/test_sweep_dist.py checks that the model reproduces every recorded shard time within 15 %).
+RESIDENT_MAX_ATOMS = 7
+SHARD_MODEL = {"exact": (62.9, 70.8, 0.223),        # residuals of the 15 recorded shards: max 13.0 %, rms 4.4 %
+               "tolerance": (19.4, 15.8, 0.182)}    # scan sweeps + the multigrid's tolerance mode: max 8.7 %, rms 4.9 %
+STEP_FLOOR_MS, JOB_MS = SHARD_MODEL["exact"][1], SHARD_MODEL["exact"][2]
+
+
+def shard_features(Zs):
+    """(steps with <= RESIDENT_MAX_ATOMS live atoms, steps with more, sum of subshells x steps) of a shard, from the expected step counts"""
+    steps = [expected_steps(z) for z in Zs]
+    smax = max(steps)
+    small = sum(1 for k in range(1, smax + 1) if sum(1 for t in steps if t >= k) <= RESIDENT_MAX_ATOMS)
+    return small, smax - small, sum(atom_cost(z) for z in Zs)
 
 
 def shard_time_ms(Zs, model="exact"):
     """predicted wall time of one rank that advances the atoms Zs together until each has stopped (see the model above)"""
     if not Zs:
         return 0.0
-    floor, job = SHARD_MODEL[model]
-    return floor * max(expected_steps(z) for z in Zs) + job * sum(atom_cost(z) for z in Zs)
+    f_small, f_big, job = SHARD_MODEL[model]
+    small, big, work = shard_features(Zs)
+    return f_small * small + f_big * big + job * work
 
 
 def partition_atoms(Zs, world_size, cost=None, model="exact"):

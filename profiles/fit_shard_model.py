@@ -1,5 +1,5 @@
-"""Re-fit the shard time model of dftatom_amd/sweep.py -- T(shard) = STEP_FLOOR_MS x max(expected steps) + JOB_MS x sum(subshells x expected steps)
--- to the recorded shards of the emulated 1-, 2-, 4- and 8-rank periodic-table sweeps (examples/periodic_table.py --emulate-ranks N,
+"""Re-fit the shard time model of dftatom_amd/sweep.py -- T(shard) = FLOOR_SMALL_MS x (steps with <= 7 live atoms) + FLOOR_BIG_MS x (steps with
+more) + JOB_MS x sum(subshells x expected steps) -- to the recorded shards of the emulated 1-, 2-, 4- and 8-rank periodic-table sweeps (examples/periodic_table.py --emulate-ranks N,
 one GPU; profiles/r04_periodic_table_predicted_scaling_<mode>.json), by least squares, per mode of the sweeps.
 
     python profiles/fit_shard_model.py            # prints the pairs to paste into sweep.SHARD_MODEL and the residuals
@@ -44,7 +44,7 @@ def shards_of(mode):
 def fit(mode):
     from dftatom_amd import sweep
     sh = shards_of(mode)
-    A = np.array([[max(sweep.expected_steps(z) for z in s["atoms"]), sum(sweep.atom_cost(z) for z in s["atoms"])] for s in sh], dtype=float)
+    A = np.array([sweep.shard_features(s["atoms"]) for s in sh], dtype=float)
     y = np.array([s["seconds"] * 1e3 for s in sh])
     # relative least squares: every shard counts alike
     w = 1.0 / y
@@ -64,5 +64,5 @@ if __name__ == "__main__":
     for mode in ("exact", "tolerance"):
         if os.path.exists(path_of(mode)):
             coef, rel = fit(mode)
-            print('%-9s (STEP_FLOOR_MS, JOB_MS) = (%.1f, %.3f)   residuals: max %.1f %%, rms %.1f %% over %d shards'
-                  % (mode, coef[0], coef[1], 100 * np.max(np.abs(rel)), 100 * np.sqrt(np.mean(rel ** 2)), len(rel)))
+            print('%-9s (FLOOR_SMALL_MS, FLOOR_BIG_MS, JOB_MS) = (%.1f, %.1f, %.3f)   residuals: max %.1f %%, rms %.1f %% over %d shards'
+                  % (mode, coef[0], coef[1], coef[2], 100 * np.max(np.abs(rel)), 100 * np.sqrt(np.mean(rel ** 2)), len(rel)))

@@ -102,8 +102,8 @@ def test_shard_time_model_reproduces_the_recorded_shards():
                 n += 1
         assert n == 15
         coef, rel = fitm.fit(mode)
-        floor, job = sweep.SHARD_MODEL[mode]
-        assert abs(coef[0] - floor) <= 0.03 * floor and abs(coef[1] - job) <= 0.03 * job, (mode, coef)
+        # the constants in the source are this fit (floor of a step with <= 7 live atoms, with more, per-job share)
+        assert all(abs(c - m) <= 0.03 * m for c, m in zip(coef, sweep.SHARD_MODEL[mode])), (mode, coef)
         assert float(np.max(np.abs(rel))) <= 0.15
     # the prediction itself: an eighth of the table per GPU
     with open(fitm.path_of("tolerance")) as f:
