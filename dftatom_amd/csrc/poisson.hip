@@ -481,6 +481,9 @@ static int poisson_create_impl(dfta_ctx* ctx, const dfta_grid* g, int batch, int
         const Lvl& Lk = D.lv[kt];
         bool ok = !Lk.seq && Lk.logT == 8 && Lk.logC == 5 && kt + 6 < D.levels && D.lv[kt + 5].n == 257 &&
                   D.lv[kt + 6].n == 129 && kt + 6 >= D.cs_top && D.cs_lc[kt + 6] == 1;
+        // a wave's scan end value goes to the next wave without what entered the wave itself: a^(64 C) of it, largest on the 257-node level
+        // (C = 1, a = (1 + delta_l / 2) / 2) -- 3e-19 on the grids of BASELINE.md; a grid coarse enough to make it matter stays level by level
+        if (ok) ok = std::pow(0.5 * (1.0 + 0.5 * D.lv[kt + 5].d), 64.0) < 1e-16;
         if (ok) {
             // the sources of the six register levels live in the staging memory around the coarse section's arrays of the levels it
             // still runs (129 nodes and below): 8192 + 4096 behind them, 2048 + 1024 + 512 + 256 in front (where the section's own
