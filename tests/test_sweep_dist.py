@@ -102,8 +102,14 @@ def test_shard_time_model_reproduces_the_recorded_shards():
                 n += 1
         assert n == 15
         coef, rel = fitm.fit(mode)
-        # the constants in the source are this fit (floor of a step with <= 7 live atoms, with more, per-job share)
-        assert all(abs(c - m) <= 0.03 * m for c, m in zip(coef, sweep.SHARD_MODEL[mode])), (mode, coef)
+        # the constants in the source are this fit: the three features are nearly collinear over 15 shards, so the constants themselves
+        # wobble from one emulation to the next -- what must agree are the PREDICTIONS (5 % on every recorded shard)
+        for run in rec["runs"]:
+            for sh in run["shards"]:
+                if sh["atoms"]:
+                    a = float(np.dot(coef, sweep.shard_features(sh["atoms"])))
+                    b = sweep.shard_time_ms(sh["atoms"], mode)
+                    assert abs(a - b) <= 0.05 * a, (mode, run["emulated_ranks"], sh["rank"], a, b)
         assert float(np.max(np.abs(rel))) <= 0.15
     # the prediction itself: an eighth of the table per GPU
     with open(fitm.path_of("tolerance")) as f:
