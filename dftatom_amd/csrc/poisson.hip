@@ -471,33 +471,35 @@ static int poisson_create_impl(dfta_ctx* ctx, const dfta_grid* g, int batch, int
     }
     // tolerance mode: the sub-cycle from the 8193-node level down in registers (poisson_kernels.inc: coarse_resident_cycle) -- 32 nodes per
     // thread on its first level, the levels down to 257 nodes halve the chunk, the 129-node level and below run in one wave.  Resident
-    // groups: the coarse workgroup's levels; staged groups of 16 and one workgroup per atom: workgroup 0's, where that level is the first
-    // one it does not share (groups of 2 .. 8 share it: level by level there)
+    // groups: the coarse workgroup's levels; staged groups and one workgroup per atom: workgroup 0's, from the first level it does not share
+    // (8193 nodes for groups of 8 and 16 and for a lone workgroup, 4097 / 2049 nodes -- 16 / 8 per thread -- for groups of 4 / 2)
     D.rc_top = -1;
     int k8193 = -1;
     for (int l = 0; l < D.levels; ++l) if (D.lv[l].n == 8193) k8193 = l;
-    if (p->tol && k8193 > 0 && D.cs_top > 0 && (res_kres > 0 ? k8193 == res_kres : k8193 >= D.kcoop) && !dfta_knob("POISSON_NORC")) {
-        const int kt = k8193;
+    int sft = 0;                                    // the cycle starts `sft` levels below the 8193-node level
+    if (k8193 > 0 && res_kres == 0) while (sft < 2 && k8193 + sft < D.kcoop) ++sft;
+    if (p->tol && k8193 > 0 && D.cs_top > 0 && (res_kres > 0 ? k8193 == res_kres : k8193 + sft >= D.kcoop) && !dfta_knob("POISSON_NORC")) {
+        const int kt = k8193 + sft;
         const Lvl& Lk = D.lv[kt];
-        bool ok = !Lk.seq && Lk.logT == 8 && Lk.logC == 5 && kt + 6 < D.levels && D.lv[kt + 5].n == 257 &&
-                  D.lv[kt + 6].n == 129 && kt + 6 >= D.cs_top && D.cs_lc[kt + 6] == 1;
+        bool ok = !Lk.seq && Lk.logT == 8 && Lk.logC == 5 - sft && k8193 + 6 < D.levels && D.lv[k8193 + 5].n == 257 &&
+                  D.lv[k8193 + 6].n == 129 && k8193 + 6 >= D.cs_top && D.cs_lc[k8193 + 6] == 1;
         // a wave's scan end value goes to the next wave without what entered the wave itself: a^(64 C) of it, largest on the 257-node level
         // (C = 1, a = (1 + delta_l / 2) / 2) -- 3e-19 on the grids of BASELINE.md; a grid coarse enough to make it matter stays level by level
-        if (ok) ok = std::pow(0.5 * (1.0 + 0.5 * D.lv[kt + 5].d), 64.0) < 1e-16;
+        if (ok) ok = std::pow(0.5 * (1.0 + 0.5 * D.lv[k8193 + 5].d), 64.0) < 1e-16;
         if (ok) {
             // the sources of the six register levels live in the staging memory around the coarse section's arrays of the levels it
             // still runs (129 nodes and below): 8192 + 4096 behind them, 2048 + 1024 + 512 + 256 in front (where the section's own
             // copies of the 1025 .. 257-node levels would be)
             int first10 = 1 << 30, end_cs = 0;
-            for (int l = kt + 6; l < D.levels; ++l) {
+            for (int l = k8193 + 6; l < D.levels; ++l) {
                 first10 = std::min(first10, std::min(D.cs_phi[l], D.cs_src[l]) - (D.cs_lc[l] >= 0 ? kStagePad : 0));
                 end_cs = std::max(end_cs, std::max(D.cs_phi[l], D.cs_src[l]) + D.lv[l].n + 8);
             }
             const int cap = 2 * kStageArr - 64;
             ok = first10 >= 3840 && end_cs + 12288 <= cap;
             if (ok) {
-                D.rc_src[0] = end_cs; D.rc_src[1] = end_cs + 8192;
-                D.rc_src[2] = 0; D.rc_src[3] = 2048; D.rc_src[4] = 3072; D.rc_src[5] = 3584;
+                const int slot[6] = {end_cs, end_cs + 8192, 0, 2048, 3072, 3584};      // by level: 8193, 4097, 2049, 1025, 513, 257 nodes
+                for (int j = 0; j < 6; ++j) D.rc_src[j] = j + sft < 6 ? slot[j + sft] : 0;          // index: level - rc_top
                 D.rc_top = kt;
             }
         }
