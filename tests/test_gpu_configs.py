@@ -58,8 +58,11 @@ def _levels_of(scf, atom, lsda):
     return np.concatenate([scf.levels(atom, 0)["E"]] + ([scf.levels(atom, 1)["E"]] if lsda else []))
 
 
-def _check_step(scf, atom, lsda, want, tag, stats, lv_rel=1e-10):
-    """one SCF step's printed values: energies 1e-9 relative, eigenvalues 1e-8 Ha + lv_rel |E|"""
+def _check_step(scf, atom, lsda, want, tag, stats, lv_rel=1e-10, en_abs_rel_etot=0.0):
+    """one SCF step's printed values: energies 1e-9 relative, eigenvalues 1e-8 Ha + lv_rel |E|.  en_abs_rel_etot (tolerance modes): an
+    energy COMPONENT may also differ by that fraction of |Etotal| -- the scan sweeps' eigenvalues are within 6e-11 |E| + 6e-10 Ha of the
+    exact search (tests/test_gpu_scan.py), and a component that is a small difference of large terms (hydrogen's kinetic term in the
+    first step: -0.0097 Ha of -0.545) turns 1e-11 Ha into 3e-9 of itself."""
     en, _ = scf.energies()
     want_lv = np.array([x[1] for x in want["levels"]])
     got_lv = _levels_of(scf, atom, lsda)
@@ -72,7 +75,8 @@ def _check_step(scf, atom, lsda, want, tag, stats, lv_rel=1e-10):
     if os.environ.get("DFTA_TEST_VERBOSE"):
         print(tag, "dE levels", np.array2string(dlv, precision=2), "energies rel", np.array2string(den, precision=2))
     assert np.all(dlv <= 1e-8 + lv_rel * np.abs(want_lv)), (tag, dlv.max())
-    assert np.all(den <= 1e-9), (tag, den)
+    slack = en_abs_rel_etot * abs(want["energies"][0])
+    assert all(abs(a - b) <= 1e-9 * abs(b) + slack for a, b in zip(en[atom].as_list(), want["energies"])), (tag, den)
 
 
 def _check_converged(en, lv, want, tag, stats, lv_abs=2e-7, comp_rel=2e-9):
@@ -124,8 +128,11 @@ def test_radon_lsda_vs_reference(ctx, grid17):
 # ---------------------------------------------------------------------------------------------------------------
 # configs[3]: the periodic table as one batch
 # ---------------------------------------------------------------------------------------------------------------
-def test_periodic_table_batch_vs_reference(ctx, grid17):
-    """Z = 1..86 as ONE batch on one GPU (the unit that examples/periodic_table.py shards over ranks), default product path,
+@pytest.mark.parametrize("modes", ["exact", "tolerance"])
+def test_periodic_table_batch_vs_reference(ctx, grid17, modes):
+    """(modes = "tolerance": the same run with the scan sweeps and the multigrid's tolerance mode -- the opt-in fast path has to hold the
+    same gates against the compiled reference for every atom of the table, not only for Rn.)
+    Z = 1..86 as ONE batch on one GPU (the unit that examples/periodic_table.py shards over ranks), default product path,
     every atom advanced until it meets the reference's stop test or the reference's cap of 100 steps (DFTAtom.cpp:396):
       * steps 0 and 1 of every atom against the compiled reference's first two steps.  Step 0 (identical start potential):
         eigenvalues 1e-8 Ha + 1e-10 |E|.  Step 1 sees the potential that step 0's Poisson solve left, and the 100-V-cycle end
@@ -147,21 +154,34 @@ def test_periodic_table_batch_vs_reference(ctx, grid17):
     assert len(Zs) >= 86, "tests/golden/periodic_table_L17.json must hold at least Z = 1..86"
     per_step, conv = {}, {}
     # steps 0 and 1 on the reference's own bisection path (bracket hand-over from level to level, DFTAtom.cpp:541)
-    scf = D.Scf(ctx, grid17, Zs, lsda=False, levels_mode=D.LEVELS_CHAINED)
+    kw = dict(sweep_mode=D.SWEEPS_TOLERANCE, poisson_mode=D.POISSON_TOLERANCE) if modes == "tolerance" else {}
+    scf = D.Scf(ctx, grid17, Zs, lsda=False, levels_mode=D.LEVELS_CHAINED, **kw)
     for it in range(2):
         scf.step(want_stats=False)
         for k, z in enumerate(Zs):
             _check_step(scf, k, False, table[str(z)]["first" if it == 0 else "second"], "Z=%d step %d" % (z, it), per_step,
-                        lv_rel=1e-10 if it == 0 else 2e-9)
+                        lv_rel=1e-10 if it == 0 else 2e-9, en_abs_rel_etot=2e-10 if modes == "tolerance" else 0.0)
     scf.close()
     # the product's default path to the end
-    scf = D.Scf(ctx, grid17, Zs, lsda=False)
+    scf = D.Scf(ctx, grid17, Zs, lsda=False, **kw)
     cap = 100
     nsteps = 0
+    # (tolerance run) every atom's own movement in its last step: eigenvalues (Ha) and energy components (relative)
+    track = modes == "tolerance"
+    last_lv, last_en, move_lv, move_en = {}, {}, {}, {}
+    live = np.ones(len(Zs), bool)
     for it in range(cap):
         scf.step(want_stats=False)
         nsteps += 1
-        _, fin = scf.energies()
+        en_now, fin = scf.energies()
+        if track:
+            for k in np.nonzero(live)[0]:
+                lv_k, en_k = np.array(scf.levels(int(k), 0)["E"]), np.array(en_now[k].as_list())
+                if k in last_lv:
+                    move_lv[k] = float(np.max(np.abs(lv_k - last_lv[k])))
+                    move_en[k] = float(np.max(np.abs(en_k[1:] - last_en[k][1:]) / np.abs(en_k[1:])))
+                last_lv[k], last_en[k] = lv_k, en_k
+            live = ~fin.astype(bool)
         if fin.all():
             break
     en, fin = scf.energies()
@@ -170,7 +190,9 @@ def test_periodic_table_batch_vs_reference(ctx, grid17):
         ref = table[str(z)]
         c = {}
         _check_converged(en[k].as_list(), scf.levels(k, 0)["E"], ref["last"], "Z=%d" % z, c, lv_abs=None)
-        worst.append((c["etot"], c["comp"], c["lv"], z, bool(ref["finished"] and fin[k])))
+        # tolerance run: what exceeds four of the atom's own last steps is what counts (see the gates below)
+        worst.append((c["etot"], max(0.0, c["comp"] - 4 * move_en.get(k, 0.0)), max(0.0, c["lv"] - 4 * move_lv.get(k, 0.0)), z,
+                      bool(ref["finished"] and fin[k])))
     # Final-state gates.  Both runs end where Etotal has stopped moving (or at the cap); Etotal is variational (second order in
     # what is left of the density error), its components and the eigenvalues are first order, and the two runs end at different
     # steps of the same jitter.  Gates = about twice the observed maxima (asserted below, printed with the summary):
@@ -178,7 +200,16 @@ def test_periodic_table_batch_vs_reference(ctx, grid17):
     #               components 2e-8 (1.1e-8), eigenvalues 1e-6 Ha + 1e-10 |E| (4.9e-7)
     #   Z = 87..118 (round 3; ten of these atoms never meet the reference's stop test within its 100 steps and still move by
     #               ~1e-6 Ha per step at the cap): Etotal 3e-9, components 3e-8 (1.2e-8), eigenvalues 8e-6 Ha (3.7e-6, Z = 111)
-    for lo, hi, g_et, g_etf, g_comp, g_lv in ((1, 86, 3e-9, 1e-9, 2e-8, 1e-6), (87, 118, 3e-9, 1e-9, 3e-8, 8e-6)):
+    # Tolerance modes: the stop test |dE/E| < 1e-11 is decided by round-off (late-step jitter 5e-10), so a different order of roundings
+    # stops an atom at a different coincidence, and an atom that runs to the cap is caught at a different phase of its wandering --
+    # observed: Ce (Z = 58) meets the test around step 22 in this batch (step 42 when run alone, 60 in exact mode, 65 in the reference; the
+    # single-atom trajectories agree step by step to 1.6e-7 Ha) where its eigenvalues still move by 2e-6 Ha per step, and ends 3.7e-6 Ha /
+    # 3.6e-8 from the reference's end state; Z > 86: 1.1e-5 Ha.  The tolerance run is therefore gated on what EXCEEDS four of the atom's
+    # own last step (eigenvalues in Ha, components relative); Etotal, which is variational, with the exact mode's bounds.
+    rows = ((1, 86, 3e-9, 1e-9, 2e-8, 1e-6), (87, 118, 3e-9, 1e-9, 3e-8, 8e-6))
+    if modes == "tolerance":
+        rows = ((1, 86, 3e-9, 1e-9, 1e-8, 1e-7), (87, 118, 3e-9, 1e-9, 1e-8, 1e-7))       # observed: Etotal 8.8e-10 / 4.1e-10, excess 2.2e-9, 2.2e-8 Ha
+    for lo, hi, g_et, g_etf, g_comp, g_lv in rows:
         grp = [w for w in worst if lo <= w[3] <= hi]
         if not grp:
             continue
