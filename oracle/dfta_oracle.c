@@ -1418,3 +1418,48 @@ double dfo_solve_poisson_uniform(dfo_poisson* p, int Z, double maxRadius, const 
     memcpy(U, p->Phi[0], sizeof(double) * size);
     return err;
 }
+
+/* ---- precision yardstick (tests/test_scan_precision.py) --------------------------------------------------------------------------- */
+#include <math.h>
+double dfo_u0_yardstick(const dfo_grid* g, const double* V, unsigned l, double E, long s, int variant)
+{
+    const double d = g->delta, Rp = g->Rp;
+    if (variant == 1) {
+        typedef long double T;
+        const T dl = (T)d, Rpl = (T)Rp, c2 = (T)(Rp * Rp * d * d), c4 = (T)(d * d * 0.25), El = (T)E, ll = (T)(l * (l + 1)) * (T)0.5;
+        const T sq = sqrtl((T)2 * fabsl(El));
+#define DFO_F(i) ({ const T r_ = Rpl * (expl(dl * (T)(i)) - 1); T v_ = (T)V[i]; if (l > 0 && (i) > 0) v_ += ll / (r_ * r_); \
+                    (T)2 * (v_ - El) * c2 * expl((T)2 * dl * (T)(i)) + c4; })
+        const T rs = Rpl * (expl(dl * (T)s) - 1), rs1 = Rpl * (expl(dl * (T)(s - 1)) - 1);
+        const T us = expl(-rs * sq - (T)s * dl * (T)0.5), us1 = expl(-rs1 * sq - (T)(s - 1) * dl * (T)0.5);
+        T wp = (1 - DFO_F(s) / 12) * us, w = (1 - DFO_F(s - 1) / 12) * us1, u = us1, uprev = us1;
+        for (long k = s - 2; k > 0; --k) {
+            const T wn = 2 * w - wp + u * DFO_F(k + 1);
+            wp = w; w = wn;
+            uprev = u; u = w / (1 - DFO_F(k) / 12);
+        }
+        return (double)(u * (2 + DFO_F(1)) - uprev);
+#undef DFO_F
+    }
+    /* double: f exactly as the sweeps of this file see it */
+    const double sq = sqrt(2 * fabs(E));
+    const double us = exp(-dfo_position(g, s) * sq - s * d * 0.5), us1 = exp(-dfo_position(g, s - 1) * sq - (s - 1) * d * 0.5);
+    double wp = (1 - dfo_f(g, V, l, E, s) / 12) * us, w = (1 - dfo_f(g, V, l, E, s - 1) / 12) * us1;
+    if (variant == 0) {
+        double u = us1, uprev = us1;
+        for (long k = s - 2; k > 0; --k) {
+            const double wn = 2 * w - wp + u * dfo_f(g, V, l, E, k + 1);
+            wp = w; w = wn;
+            uprev = u; u = w / (1 - dfo_f(g, V, l, E, k) / 12);
+        }
+        return u * (2 + dfo_f(g, V, l, E, 1)) - uprev;
+    }
+    double D = w - wp;
+    for (long k = s - 1; k > 1; --k) {
+        const double f = dfo_f(g, V, l, E, k);
+        D = D + f / (1 - f / 12) * w;
+        w = w + D;
+    }
+    const double f1 = dfo_f(g, V, l, E, 1), f2 = dfo_f(g, V, l, E, 2);
+    return (w / (1 - f1 / 12)) * (2 + f1) - (w - D) / (1 - f2 / 12);
+}

@@ -54,6 +54,11 @@ int    dfo_count_nodes(const dfo_grid* g, const double* V, unsigned l, double E,
                        long* start, long* trip);                     /* Numerov.h:272-349 */
 double dfo_solution_in_zero(const dfo_grid* g, const double* V, unsigned l, double E,
                             long* start);                            /* Numerov.h:351-401 */
+/* Precision yardstick of tests/test_scan_precision.py (no reference counterpart): u(0) of the inward sweep from cut-off index s in
+ * three arithmetics -- variant 0: the reference's recurrence w_{i-1} = 2 w_i - w_{i+1} + u_i f_i in double (Numerov.h:309-321, 398),
+ * 1: the same recurrence, its tables and start values in long double (80-bit on x86-64), 2: the summed form that
+ * dftatom_amd/csrc/scan.hip integrates (D_{i-1} = D_i + g_i w_i, w_{i-1} = w_i + D_{i-1}, g = f / (1 - f/12)) in double. */
+double dfo_u0_yardstick(const dfo_grid* g, const double* V, unsigned l, double E, long s, int variant);
 /* Psi must hold N doubles; returns matchPoint */
 long   dfo_match(const dfo_grid* g, const double* V, unsigned l, double E, double* Psi,
                  long* start);                                       /* Numerov.h:403-504 */

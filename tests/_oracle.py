@@ -101,6 +101,7 @@ def oracle():
         "dfo_max_radius_index": (C.c_long, [G, C.c_double, C.c_long]),
         "dfo_count_nodes": (C.c_int, [G, c_dp, C.c_uint, C.c_double, C.c_long, c_lp, c_lp]),
         "dfo_solution_in_zero": (C.c_double, [G, c_dp, C.c_uint, C.c_double, c_lp]),
+        "dfo_u0_yardstick": (C.c_double, [G, c_dp, C.c_uint, C.c_double, C.c_long, C.c_int]),
         "dfo_match": (C.c_long, [G, c_dp, C.c_uint, C.c_double, c_dp, c_lp]),
         "dfo_locate_interval": (None, [G, c_dp, c_dp, c_dp, C.c_int, C.c_int, C.c_double, c_ip]),
         "dfo_normalize_nonuniform": (None, [G, c_dp]),

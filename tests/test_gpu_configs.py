@@ -299,8 +299,10 @@ def test_l20_poisson_vs_reference(ctx, grid20):
         assert np.array_equal(U2[0].view(np.int64), ref), var
 
 
-def test_l20_radon_lsda_steps_vs_reference(ctx, grid20):
-    """First two SCF steps of Rn LSDA at 1 048 577 nodes against the compiled reference.
+@pytest.mark.parametrize("modes", ["exact", "tolerance"])
+def test_l20_radon_lsda_steps_vs_reference(ctx, grid20, modes):
+    """First two SCF steps of Rn LSDA at 1 048 577 nodes against the compiled reference (modes = "tolerance": with the scan sweeps -- 2048
+    rows per lane -- and the multigrid's tolerance mode; same gates, a component may also differ by 2e-10 |Etotal|).
 
     Step 0 (identical start potential): the usual per-step gates.  From step 1 on the comparison is limited by the
     CONDITIONING of the reference's own Poisson solve at this size, not by this implementation: the solver here returns
@@ -310,11 +312,17 @@ def test_l20_radon_lsda_steps_vs_reference(ctx, grid20):
     nodes cancel ten digits).  The test measures that amplification on the step-0 density and gates step 1 with it."""
     meta = json.load(open(os.path.join(HERE, "golden", "l20_meta.json")))
     steps = meta["Rn_LSDA_L20"]["steps"]
-    scf = D.Scf(ctx, grid20, [86], lsda=True, levels_mode=D.LEVELS_CHAINED)
+    kw = dict(sweep_mode=D.SWEEPS_TOLERANCE, poisson_mode=D.POISSON_TOLERANCE) if modes == "tolerance" else {}
+    scf = D.Scf(ctx, grid20, [86], lsda=True, levels_mode=D.LEVELS_CHAINED, **kw)
     stats = {}
     st = scf.step()
-    _check_step(scf, 0, True, steps[0], "L20 step 0", stats)
+    # tolerance: at this size the REFERENCE's double recurrence is up to 1.3e-9 |E| away from the 80-bit eigenvalue (7.8e-11 ... 1.3e-9 from
+    # level to level; the scan's summed form 7e-13: tests/test_scan_precision.py, CPU), so the scan sweeps are gated at 1e-9 |E| here
+    _check_step(scf, 0, True, steps[0], "L20 step 0", stats, lv_rel=1e-9 if modes == "tolerance" else 1e-10,
+                en_abs_rel_etot=2e-10 if modes == "tolerance" else 0.0)
     assert st.vcycles == 100
+    if modes == "tolerance":
+        assert st.levels_layout == 4                     # the scan search ran (no hand-back to the exact kernels)
     print("Rn LSDA @ 1048577, step 0: eigenvalue excess over 1e-10|E| %.2e Ha, energies %.2e rel" % (stats["lv"], stats["en"]))
     rho = scf.array(0)
     ps = D.Poisson(ctx, grid20, 1)
@@ -340,7 +348,8 @@ def test_l20_radon_lsda_steps_vs_reference(ctx, grid20):
     den = np.array([abs(a - b) / abs(b) for a, b in zip(en[0].as_list(), steps[1]["energies"])])
     print("  step 1: max eigenvalue difference %.2e Ha, energies %.2e rel (gates: %.1e Ha, %.1e rel)"
           % (dlv.max(), den.max(), 4 * ref_abs + 1e-8, 4 * ref_rel + 1e-9))
-    assert dlv.max() <= 4 * ref_abs + 1e-8 and den.max() <= 4 * ref_rel + 1e-9
+    tol_rel = 1e-9 if modes == "tolerance" else 0.0          # the reference's rounding bias at this size (see step 0)
+    assert np.all(dlv <= 4 * ref_abs + 1e-8 + tol_rel * np.abs(want_lv)) and den.max() <= 4 * ref_rel + 1e-9 + 2e-10 * (modes == "tolerance")
     assert st.vcycles == 100
     scf.close()
 

@@ -84,3 +84,49 @@ def test_summed_form_is_closer_to_the_exact_arithmetic_eigenvalue_than_the_refer
         assert dsum <= 2e-14                       # the summed form reproduces the 80-bit eigenvalue to a few ulp
         assert dsum * 20 <= dref                   # ... and is at least 20x closer than the reference's own double arithmetic (observed 700x ... 6000x)
     assert worst_ref >= 1e-13                      # the bias the GPU gate of tests/test_gpu_scan.py has to allow for (grows with the grid: 3e-11 |E| at 131 073 nodes)
+
+
+def _u0_c(g, V, E, l, variant):
+    """the same three arithmetics in C (oracle/dfta_oracle.c: dfo_u0_yardstick -- 0: reference double, 1: long double, 2: summed form)"""
+    st = C.c_long()
+    O.oracle().dfo_count_nodes(C.byref(g), O.dp(V), l, float(E), 1000, C.byref(st), None)
+    return O.oracle().dfo_u0_yardstick(C.byref(g), O.dp(V), l, float(E), st.value, variant)
+
+
+def test_c_yardstick_equals_the_numpy_loops():
+    g, r, d, V = _setup()
+    for l, E in ((0, -3350.0), (0, -600.0), (2, -20.0)):
+        for variant, mode in ((0, "ref"), (2, "sum")):
+            a, b = _u0_c(g, V, E, l, variant), _u0(g, r, d, V, E, l, mode)
+            assert abs(a - b) <= 1e-9 * abs(b), (l, E, mode, a, b)       # (f from the oracle's dfo_f here, from numpy tables there: last bits)
+        a, b = _u0_c(g, V, E, l, 1), _u0(g, r, d, V, E, l, "ld")
+        assert abs(a - b) <= 1e-9 * abs(b), (l, E, a, b)
+
+
+def test_rounding_bias_of_the_reference_grows_with_the_grid():
+    """The gates of the GPU suite for the scan sweeps against the exact kernels / the compiled reference: 6e-11 |E| + 6e-10 Ha at 131 073 nodes
+    (tests/test_gpu_scan.py), 1e-9 |E| at 1 048 577 nodes (tests/test_gpu_configs.py::test_l20_radon_lsda_steps_vs_reference[tolerance],
+    observed 5.3e-10).  Measured here on the three grids of BASELINE.md, same screened Z = 86 potential, deep and shallow levels: the
+    reference's double recurrence ends |E_ref - E_80bit| away from the 80-bit eigenvalue, growing with the number of steps, while the
+    summed form stays within 1e-12 |E| of it on every grid (observed: reference 4.3e-12 / 3.8e-11 / 1.3e-9 |E| at 16 385 / 131 073 /
+    1 048 577 nodes, summed form 7e-16 / 4e-14 / 7e-13; at 1 048 577 nodes 7.8e-11 for 1s, 2.0e-10 for 2s, 1.3e-9 for the l = 2 level at -21.7 Ha)."""
+    out = {}
+    for key in ("L14", "L17", "L20"):
+        L, d, R = GRIDS[key]
+        g = O.make_grid(L, d, R)
+        V = screened_potential(O.grid_r(g), 86.0)
+        worst_ref, worst_sum = 0.0, 0.0
+        # (the 80-bit sweep costs ~0.15 s at 1 048 577 nodes: the deepest and the shallowest level only there)
+        for l, lo, hi in ((0, -3400.0, -3300.0), (0, -700.0, -550.0), (2, -30.0, -15.0))[::2 if key == "L20" else 1]:
+            xs = np.linspace(lo, hi, 21)
+            vals = [_u0_c(g, V, x, l, 0) for x in xs]
+            k = [i for i in range(20) if (vals[i] > 0) != (vals[i + 1] > 0)][-1]
+            e = [_root(lambda E, v=v: _u0_c(g, V, E, l, v), xs[k], xs[k + 1]) for v in (0, 1, 2)]
+            worst_ref = max(worst_ref, abs(e[0] - e[1]) / abs(e[1]))
+            worst_sum = max(worst_sum, abs(e[2] - e[1]) / abs(e[1]))
+        out[key] = (worst_ref, worst_sum)
+        print("%s (%d nodes): reference arithmetic up to %.2e |E| from the 80-bit eigenvalue, summed form %.2e |E|" % (key, g.N, worst_ref, worst_sum))
+        assert worst_sum <= 2e-12                 # observed 7e-16, 4e-14, 7e-13
+    assert out["L14"][0] < out["L17"][0] < out["L20"][0]              # the bias grows with the number of steps
+    # observed 4.3e-12, 3.8e-11, 1.3e-9: what the GPU gates allow for
+    assert out["L17"][0] <= 6e-11 and 1e-10 <= out["L20"][0] <= 3e-9
