@@ -908,7 +908,7 @@ __device__ __forceinline__ unsigned long long xch_pack(unsigned round, int trips
 }
 
 __global__ void __launch_bounds__(kT) k_scan_levels_group(ScanGrid G0, const double* __restrict__ gr, const double* __restrict__ gAtop, const double* __restrict__ gT,
-                                                           dfta::Job* __restrict__ jobs, const int* __restrict__ live, int K, int depth,
+                                                           dfta::Job* __restrict__ jobs, const int* __restrict__ live, int K, int spine,
                                                            const double* __restrict__ tabs, const double2* __restrict__ mms, int fixed_point,
                                                            unsigned long long* __restrict__ counters, unsigned long long* __restrict__ xch, ScanMatchArgs ma)
 {
@@ -924,6 +924,12 @@ __global__ void __launch_bounds__(kT) k_scan_levels_group(ScanGrid G0, const dou
     unsigned par = 0;
     int hint = 0;
     const double bottom0 = J->bottom0;
+    // history bracket of the three bisections (set by the host from the previous two solves; hm < 0: none)
+    const bool hok = J->hist_ok == 2;
+    const double hT0 = J->hist_T[0], hT1 = J->hist_T[1], hT2 = J->hist_T[2];
+    const double hm0 = hok && J->hist_d[0] >= 0 ? 2.0 * J->hist_d[0] + 1e-10 * fabs(hT0) + 64 * kErr : -1.0;
+    const double hm1 = hok && J->hist_d[1] >= 0 ? 2.0 * J->hist_d[1] + 1e-10 * fabs(hT1) + 64 * kErr : -1.0;
+    const double hm2 = hok && J->hist_d[2] >= 0 ? 2.0 * J->hist_d[2] + 1e-10 * fabs(hT2) + 64 * kErr : -1.0;
     int n_count = 0, n_zero = 0, bad = 0, len2 = 0, n_fixed = 0, iter3 = 0, conv = 0, fixed = 0, nonfinite = 0;
     long long pts = 0;
     // ph 1, 2: the two count bisections; 4: the sweep at BottomEnergy; 3: the u(0) bisection; 0: done
@@ -933,25 +939,62 @@ __global__ void __launch_bounds__(kT) k_scan_levels_group(ScanGrid G0, const dou
     unsigned rnd = 0;
     while (ph) {
         ++rnd;
-        // ---- this member's trial: heap node h = m + 1 of the tree at (lo, hi)
+        // ---- the round's layout: a SPINE of s1 predicted decisions, one member each, and the full tree of depth d at its end.  The
+        // prediction is the history bracket of the exact path (levels.h): this step's end point of the running bisection lies within
+        // hm = 2 x the last movement of the previous step's; while a midpoint is outside [hT - hm, hT + hm] its decision is known
+        // beforehand -- integrated at the reference's midpoint all the same, and checked: a miss ends the round after that decision.
+        // Every member builds the same layout (no `break` in these loops: see the compiler note in DESIGN.md 4.2b).
+        int s1 = 0, d = 0;
+        unsigned spbits = 0;
+        double sa = lo, sb = hi;
+        int sit = iter3;
+        if (ph != 4) {
+            const double hT = ph == 1 ? hT0 : (ph == 2 ? hT1 : hT2), hm = ph == 1 ? hm0 : (ph == 2 ? hm1 : hm2);
+            bool more = spine != 0 && hm >= 0;
+            for (int j = 0; j < K; ++j) {
+                if (more) {
+                    if (ph == 3 ? sit >= kIter3 : !(sb - sa > kErr)) more = false;
+                    else {
+                        const double mid = (sb + sa) / 2;
+                        const int pb = mid < hT - hm ? 1 : (mid > hT + hm ? 0 : -1);
+                        if (pb < 0) more = false;
+                        else {
+                            spbits |= static_cast<unsigned>(pb) << s1;
+                            ++s1; ++sit;
+                            if (pb) sa = mid; else sb = mid;
+                        }
+                    }
+                }
+            }
+            while ((2 << d) - 1 <= K - s1) ++d;                             // the largest tree that fits behind the spine: 2^d - 1 <= K - s1
+        }
+        // ---- this member's trial: spine node m, or heap node h = m - s1 + 1 of the tree at the spine's end
         unsigned long long mine = xch_pack(rnd, 0, 0, kNone);
         {
             double E = 0;
             bool have = false;
             if (ph == 4) { have = (m == 0); E = lo; }
-            else {
-                const int h = m + 1, q = 31 - __clz(h);                // depth of the node
+            else if (m < s1) {
                 double a = lo, b = hi;
-                int it = iter3;
-                have = true;
-                for (int j = q - 1; j >= 0 && have; --j) {
-                    if (ph == 3 ? it >= kIter3 : !(b - a > kErr)) { have = false; break; }
-                    const double mid = (b + a) / 2;
-                    if ((h >> j) & 1) a = mid; else b = mid;             // bit 1: "BottomEnergy = E"
-                    ++it;
-                }
-                if (have && (ph == 3 ? it >= kIter3 : !(b - a > kErr))) have = false;
+                for (int j = 0; j < m; ++j) { const double mid = (b + a) / 2; if ((spbits >> j) & 1u) a = mid; else b = mid; }
                 E = (b + a) / 2;
+                have = true;
+            } else {
+                const int h = m - s1 + 1;
+                if (h < (1 << d)) {
+                    const int q = 31 - __clz(h);                           // depth of the node
+                    double a = sa, b = sb;
+                    int it = sit;
+                    have = true;
+                    for (int j = q - 1; j >= 0 && have; --j) {
+                        if (ph == 3 ? it >= kIter3 : !(b - a > kErr)) { have = false; break; }
+                        const double mid = (b + a) / 2;
+                        if ((h >> j) & 1) a = mid; else b = mid;             // bit 1: "BottomEnergy = E"
+                        ++it;
+                    }
+                    if (have && (ph == 3 ? it >= kIter3 : !(b - a > kErr))) have = false;
+                    E = (b + a) / 2;
+                }
             }
             if (have) {
                 if (ph == 1 || ph == 2) {
@@ -993,13 +1036,11 @@ __global__ void __launch_bounds__(kT) k_scan_levels_group(ScanGrid G0, const dou
             sgnBottom = (v & kPos) != 0;
             ph = 3;
         } else {
-            int h = 1;
             bool stop = false;
-            while (h <= K && !stop) {
-                if (ph == 3 ? iter3 >= kIter3 : !(hi - lo > kErr)) { stop = true; continue; }
-                const unsigned long long v = sh.xres[h - 1];
+            // one decision from the result word of the member that integrated the midpoint of (lo, hi); returns the bit taken
+            auto take = [&](const unsigned long long v) -> int {
                 const unsigned fl = static_cast<unsigned>(v & 0xfff);
-                if (fl & kNone) { bad = 1; stop = true; continue; }      // cannot happen: an active node without a result
+                if (fl & kNone) { bad = 1; stop = true; return 0; }        // cannot happen: an active node without a result
                 const int cnt = static_cast<int>((v >> 12) & 0xfff);
                 const double E = (hi + lo) / 2;
                 pts += (v >> 24) & 0xffffff; bad |= (fl & kBad) != 0;
@@ -1022,7 +1063,22 @@ __global__ void __launch_bounds__(kT) k_scan_levels_group(ScanGrid G0, const dou
                         stop = true;
                     }
                 }
-                h = 2 * h + (bit ? 1 : 0);
+                return bit ? 1 : 0;
+            };
+            for (int j = 0; j < s1; ++j) {                                 // the spine: a miss ends the round (the decision itself stands)
+                if (!stop) {
+                    if (ph == 3 ? iter3 >= kIter3 : !(hi - lo > kErr)) stop = true;
+                    else {
+                        const int bit = take(sh.xres[j]);
+                        if (bit != static_cast<int>((spbits >> j) & 1u)) stop = true;
+                    }
+                }
+            }
+            int h = 1;
+            while (h < (1 << d) && !stop) {
+                if (ph == 3 ? iter3 >= kIter3 : !(hi - lo > kErr)) { stop = true; continue; }
+                const int bit = take(sh.xres[s1 + h - 1]);
+                h = 2 * h + bit;
             }
             // end of a phase?
             if (ph == 1 && !(hi - lo > kErr)) {
@@ -1173,8 +1229,7 @@ int dfta_launch_scan_levels_group(dfta_ctx* ctx, const dfta_grid* g, dfta::Job* 
     ScanMatchArgs ma;
     ma.mode = match_mode; ma.Psi = d_Psi; ma.eh = g->d_eh; ma.cnst = g->d_cnst; ma.jstart_keep = d_jstart_keep;
     for (int q = 0; q < 4; ++q) ma.zero1[q] = g->zero1[q];
-    int depth = 0;
-    while ((1 << (depth + 1)) - 1 <= K) ++depth;
+    int depth = dfta_knob("SCAN_NOSPINE") ? 0 : 1;         // (kernel argument `spine`) rounds start with a spine of predicted decisions
     DFTA_HIP(ctx, hipMemsetAsync(d_xch, 0, sizeof(unsigned long long) * 32 * (size_t)nlive, ctx->stream));
     ScanGrid G = scan_grid_of(g, tb);
     const double *pr = g->d_r, *pA = tb.Atop, *pT = tb.T, *ptab = tb.tabv;

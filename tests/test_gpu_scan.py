@@ -245,7 +245,9 @@ def test_scan_mode_small_grid_and_batch(ctx):
 def test_scan_groups_take_the_same_decisions(ctx, grid17):
     """k_scan_levels_group (15 / 7 / 3 workgroups per level, a depth-4 / 3 / 2 bisection tree per round) against one workgroup per level
     (SCAN_GROUP=1): the same reference decisions, so eigenvalues, intervals, sweep counts, status bits and the density bit for bit -- Rn
-    LDA (15 levels x 15 members) and LSDA (30 levels x 7), four SCF steps each"""
+    LDA (15 levels x 15 members) and LSDA (30 levels x 7), six SCF steps each.  From the third step on a round starts with a spine of
+    decisions predicted from the history bracket (SCAN_NOSPINE switches it off): a prediction only selects which midpoints are integrated
+    together, so the run without spines is the same bit for bit as well"""
     def run(knob, lsda):
         old = os.environ.get("DFTA_DEBUG")
         try:
@@ -255,7 +257,7 @@ def test_scan_groups_take_the_same_decisions(ctx, grid17):
                 os.environ.pop("DFTA_DEBUG", None)
             scf = D.Scf(ctx, grid17, [86], lsda=lsda, sweep_mode=D.SWEEPS_TOLERANCE)
             out = []
-            for _ in range(4):
+            for _ in range(6):
                 st = scf.step()
                 lv = [scf.levels(0, sp) for sp in range(2 if lsda else 1)]
                 out.append((scf.energies()[0][0].as_list(), [x["E"].copy() for x in lv], [x["status"].copy() for x in lv], [x["n_count"].copy() for x in lv],
@@ -269,7 +271,7 @@ def test_scan_groups_take_the_same_decisions(ctx, grid17):
                 os.environ["DFTA_DEBUG"] = old
     for lsda in (False, True):
         a = run(None, lsda)
-        for knob in ("SCAN_GROUP=1", "SCAN_GROUP=3"):
+        for knob in ("SCAN_GROUP=1", "SCAN_GROUP=3", "SCAN_NOSPINE", "SCAN_GROUP=7,SCAN_NOSPINE"):
             b = run(knob, lsda)
             for x, y in zip(a, b):
                 assert x[0] == y[0] and x[5:7] == y[5:7] and np.array_equal(x[7], y[7]), knob
