@@ -45,4 +45,7 @@ int dfta_launch_scan_sweeps(dfta_ctx* ctx, const dfta_grid* g, int kind, int ntr
 // sequential summation order, one wave per vector: out[k] = rule(delta, vals + k*stride) for k < nvec
 int dfta_launch_integrate_ordered(dfta_ctx* ctx, int rule /* DFTA_INT_* */, double delta, const double* dVals, int n, int nvec,
                                   size_t stride, double* dOut);
+// Simpson 3/8 (Integral.h:50-73) with its two sums taken in parallel (tolerance mode of the sweeps: the normalisation integral of
+// scan_match is summed that way too); same weights, a different order of additions
+int dfta_launch_integrate_simpson38_parallel(dfta_ctx* ctx, double delta, const double* dVals, int n, int nvec, size_t stride, double* dOut);
 int dfta_integral_shape_ok(int rule, int sz);

@@ -22,6 +22,28 @@ __global__ __launch_bounds__(128) void k_integrate(const double* __restrict__ va
     if (threadIdx.x == 0) out[blockIdx.x] = r;
 }
 
+// Simpson 3/8 with parallel sums: one block per vector, thread t adds the nodes t + 1, t + 257, ... to sum1 (i % 3 != 0) or sum2 (i % 3 == 0)
+__global__ __launch_bounds__(256) void k_integrate_simpson38_par(const double* __restrict__ vals, int n, size_t stride, double delta, double* __restrict__ out)
+{
+    __shared__ double red[8];
+    const double* v = vals + (size_t)blockIdx.x * stride;
+    double s1 = 0, s2 = 0;
+    for (int i = 1 + threadIdx.x; i < n - 1; i += 256) {
+        const double x = v[i];
+        if (i % 3 == 0) s2 += x; else s1 += x;
+    }
+    for (int off = 32; off > 0; off >>= 1) { s1 += __shfl_xor(s1, off); s2 += __shfl_xor(s2, off); }
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = s1; red[4 + (threadIdx.x >> 6)] = s2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double sum1 = (red[0] + red[1]) + (red[2] + red[3]), sum2 = (red[4] + red[5]) + (red[6] + red[7]);
+        double sum = v[0] + v[n - 1];
+        sum += 3. * sum1 + 2. * sum2;
+        constexpr double coef = 3. / 8.;
+        out[blockIdx.x] = sum * delta * coef;
+    }
+}
+
 // Attainable HBM bandwidth of this device: the second denominator of every roofline figure (SURVEY.md 8d asks for the spec
 // figure AND a stream measurement on the box).  Plain grid-stride kernels, 16 bytes per lane and access, buffers far larger
 // than the 256 MB Infinity Cache; launch shape from profiles/microbench/hbm_stream.hip (results_r03.txt).
@@ -79,6 +101,13 @@ extern "C" int dfta_ctx_measure_hbm(dfta_ctx* ctx, size_t doubles_per_array, int
 int dfta_launch_integrate_ordered(dfta_ctx* ctx, int rule, double delta, const double* dVals, int n, int nvec, size_t stride, double* dOut)
 {
     hipLaunchKernelGGL(k_integrate, dim3(nvec), dim3(128), 0, ctx->stream, dVals, n, stride, rule, delta, dOut);
+    DFTA_CHECK_LAUNCH(ctx);
+    return DFTA_OK;
+}
+
+int dfta_launch_integrate_simpson38_parallel(dfta_ctx* ctx, double delta, const double* dVals, int n, int nvec, size_t stride, double* dOut)
+{
+    hipLaunchKernelGGL(k_integrate_simpson38_par, dim3(nvec), dim3(256), 0, ctx->stream, dVals, n, stride, delta, dOut);
     DFTA_CHECK_LAUNCH(ctx);
     return DFTA_OK;
 }
