@@ -585,15 +585,18 @@ def main():
             # on one level ends its third bisection at the reference's 500-iteration cap in most steps); a few seconds each.
             # --all-extras adds LSDA in tolerance mode, the 1024-atom batch and the dense-K sweep benchmark of SURVEY 8d.
             extra = {}
-            TOL, SCAN = D.POISSON_TOLERANCE, D.SWEEPS_TOLERANCE
+            TOL, SCAN, ADAPT = D.POISSON_TOLERANCE, D.SWEEPS_TOLERANCE, D.POISSON_ADAPTIVE
             sel = [("rn_lda_scan_sweeps", args.levels, 1, False, 10, 5, None, SCAN, "scan"),
                    ("rn_lda_both_tolerance_modes", args.levels, 1, False, 10, 5, TOL, SCAN, "scan_tol"),
                    ("rn_lda_poisson_tolerance", args.levels, 1, False, 10, 5, TOL, None, "tolerance"),
+                   # DFTA_POISSON_ADAPTIVE: the V-cycles stop on the round-off floor (6 .. 8 per solve) instead of at the reference's cap of 100
+                   ("rn_lda_scan_sweeps_adaptive_vcycles", args.levels, 1, False, 10, 5, ADAPT, SCAN, None),
                    ("rn_lsda", args.levels, 1, True, 10, 5, None, None, "rn_lsda"),
                    ("rn_lsda_both_tolerance_modes", args.levels, 1, True, 10, 5, TOL, SCAN, None),
                    ("batch256_lda", args.levels, 256, False, 6, 5, None, None, "batch256"),
                    ("batch256_lda_scan_sweeps", args.levels, 256, False, 6, 5, None, SCAN, None),
                    ("batch256_lda_both_tolerance_modes", args.levels, 256, False, 6, 5, TOL, SCAN, None),
+                   ("batch256_lda_scan_sweeps_adaptive_vcycles", args.levels, 256, False, 6, 5, ADAPT, SCAN, None),
                    ("rn_lsda_l20", 20, 1, True, 6, 6, None, None, None), ("rn_lsda_l20_scan_sweeps", 20, 1, True, 6, 6, None, SCAN, None),
                    ("rn_lsda_l20_both_tolerance_modes", 20, 1, True, 6, 6, TOL, SCAN, None),
                    ("rn_lsda_l20_batch16", 20, 16, True, 4, 6, None, None, "l20_batch16"),
@@ -611,7 +614,7 @@ def main():
                 s2, t2 = run_workload(D, ctx, g2, lv, atoms, lsda, st, wu, 0, barrier, torch, poisson_mode=pm, sweep_mode=sm)
                 s2.close()
                 extra[name] = summarize(t2, lv, g2.N, atoms, lsda, world, d2, r2, wl2 if args.levels == 17 else None)
-                extra[name]["poisson_mode"] = "tolerance" if pm == D.POISSON_TOLERANCE else "exact"
+                extra[name]["poisson_mode"] = {D.POISSON_TOLERANCE: "tolerance", D.POISSON_ADAPTIVE: "adaptive (tolerance kernels, V-cycles stop on the round-off floor)"}.get(pm, "exact")
                 extra[name]["sweep_mode"] = "tolerance (scan)" if sm == D.SWEEPS_TOLERANCE else "exact"
                 extra[name]["warmup"] = wu
                 if g2 is not grid:

@@ -24,7 +24,7 @@ LEVELS_SCAN_SWEEPS = 0x10          # OR-ed into the mode of solve_levels: tolera
 SWEEPS_EXACT, SWEEPS_TOLERANCE = 0, 1
 ABI_VERSION = 5
 LEVEL_CONVERGED, LEVEL_ITERATION_CAP, LEVEL_FIXED_POINT, LEVEL_U0_NONFINITE = 1, 2, 4, 8
-POISSON_DEFAULT, POISSON_EXACT, POISSON_TOLERANCE = -1, 0, 1    # dfta_poisson_create_ex / dfta_scf_options::poisson_mode
+POISSON_DEFAULT, POISSON_EXACT, POISSON_TOLERANCE, POISSON_ADAPTIVE = -1, 0, 1, 2    # dfta_poisson_create_ex / dfta_scf_options::poisson_mode
 INT_TRAPEZOID, INT_SIMPSON13, INT_SIMPSON38, INT_BOOLE, INT_ROMBERG = range(5)
 XC_VWN, XC_CHACHIYO, XC_CHACHIYO_IMPROVED = range(3)
 AUFBAU_REFERENCE, AUFBAU_TRANSITION_METALS = range(2)

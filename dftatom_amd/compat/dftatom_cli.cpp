@@ -12,7 +12,7 @@
 // --integrator: trapezoid | simpson13 | simpson38 (default, what the reference calls) | boole | romberg (README.md:81).
 // --json[=FILE]: one JSON line per SCF step (17-digit energies and eigenvalues, per-level status bits and sweep counts, rounds, V-cycles,
 //                phase times) to FILE, or to stderr -- the console protocol on stdout stays the reference's.
-// --sweeps=exact|tolerance, --poisson=exact|tolerance: the opt-in tolerance modes of the device path (include/dftatom_hip.h).
+// --sweeps=exact|tolerance, --poisson=exact|tolerance|adaptive: the opt-in tolerance modes of the device path (include/dftatom_hip.h).
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
@@ -83,8 +83,8 @@ int main(int argc, char** argv)
             DFT::DFTAtom::jsonOut = &jf;
         } else if (a == "--sweeps=tolerance" || a == "--sweeps=exact") {
             DFT::DFTAtom::sweepMode = a == "--sweeps=tolerance" ? DFTA_SWEEPS_TOLERANCE : DFTA_SWEEPS_EXACT;
-        } else if (a == "--poisson=tolerance" || a == "--poisson=exact") {
-            DFT::DFTAtom::poissonMode = a == "--poisson=tolerance" ? DFTA_POISSON_TOLERANCE : DFTA_POISSON_EXACT;
+        } else if (a == "--poisson=tolerance" || a == "--poisson=adaptive" || a == "--poisson=exact") {
+            DFT::DFTAtom::poissonMode = a == "--poisson=tolerance" ? DFTA_POISSON_TOLERANCE : (a == "--poisson=adaptive" ? DFTA_POISSON_ADAPTIVE : DFTA_POISSON_EXACT);
         } else if (a.rfind("--integrator=", 0) == 0) {
             const std::string n = a.substr(13);
             const char* names[] = {"trapezoid", "simpson13", "simpson38", "boole", "romberg"};

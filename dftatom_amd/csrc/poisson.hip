@@ -78,6 +78,7 @@ struct MgDesc {
     // (doubles), cs_lc: log2(nodes per lane) of its 64-lane interleaved layout, or -1 for natural order.
     int cs_top;
     int rc_src[6];   // ... offsets (doubles, inside the staging memory) of the sources of levels rc_top .. rc_top + 5 (256 C entries each)
+    int adaptive;    // DFTA_POISSON_ADAPTIVE: stop the V-cycles at the round-off floor (run_cycles / res_cycles)
     int rc_top;      // tolerance mode, resident groups: the coarse workgroup runs levels rc_top .. levels-1 of a V-cycle with their nodes in registers (coarse_resident_cycle); -1: off
     int cs_phi[kMaxLevels], cs_src[kMaxLevels], cs_lc[kMaxLevels];
     Lvl lv[kMaxLevels];
@@ -171,6 +172,7 @@ struct dfta_poisson {
     int fault = 0;                  // $DFTA_FAULT_POISSON_MEMBER (tests): the last member of every group never arrives
     bool plain_launch = false;      // groups started with an ordinary launch instead of a cooperative one (profilers, see poisson_create_impl)
     bool tol = false;               // tolerance mode: the kernels of namespace mg_tol (32-node warm-ups) instead of mg_exact
+    bool adaptive = false;          // DFTA_POISSON_ADAPTIVE: tolerance mode + the V-cycles stop at the round-off floor
     bool resident = false;          // k_poisson_solve_res: kResWG workgroups per atom, the shared levels live in the members' LDS
     double* d_res_slots = nullptr;  // per atom: res_slot_doubles() exchange slots (sentinel-filled before every launch)
     bool grouped() const { return D.G > 1 || resident; }
@@ -190,7 +192,7 @@ static long host_addr(const Lvl& L, int i)
 static int degrade(dfta_poisson* p)
 {
     if (!p->fallback) {
-        int rc = poisson_create_impl(p->ctx, p->g, p->batch, 0, p->tol ? DFTA_POISSON_TOLERANCE : DFTA_POISSON_EXACT, &p->fallback);
+        int rc = poisson_create_impl(p->ctx, p->g, p->batch, 0, dfta_poisson_mode(p), &p->fallback);
         if (rc) return rc;
     }
     p->degraded = true;
@@ -325,7 +327,7 @@ int dfta_poisson_create_ex(dfta_ctx* ctx, const dfta_grid* g, int batch, int mod
 {
     if (!ctx || !g || !out) return DFTA_ERR_INVALID;
     DFTA_ENTER(ctx);
-    DFTA_REQUIRE(ctx, mode == DFTA_POISSON_EXACT || mode == DFTA_POISSON_TOLERANCE, "poisson mode");
+    DFTA_REQUIRE(ctx, mode == DFTA_POISSON_EXACT || mode == DFTA_POISSON_TOLERANCE || mode == DFTA_POISSON_ADAPTIVE, "poisson mode");
     return poisson_create_impl(ctx, g, batch, -1, mode, out);
 }
 
@@ -333,10 +335,10 @@ int dfta_poisson_create(dfta_ctx* ctx, const dfta_grid* g, int batch, dfta_poiss
 {
     // $DFTA_POISSON_MODE = tolerance: measurements and tests of the opt-in mode through callers that do not pass a mode
     const char* e = dfta_knob("POISSON_MODE");
-    return dfta_poisson_create_ex(ctx, g, batch, (e && e[0] == 't') ? DFTA_POISSON_TOLERANCE : DFTA_POISSON_EXACT, out);
+    return dfta_poisson_create_ex(ctx, g, batch, (e && e[0] == 't') ? DFTA_POISSON_TOLERANCE : ((e && e[0] == 'a') ? DFTA_POISSON_ADAPTIVE : DFTA_POISSON_EXACT), out);
 }
 
-int dfta_poisson_mode(const dfta_poisson* p) { return p ? (p->tol ? DFTA_POISSON_TOLERANCE : DFTA_POISSON_EXACT) : -1; }
+int dfta_poisson_mode(const dfta_poisson* p) { return p ? (p->adaptive ? DFTA_POISSON_ADAPTIVE : (p->tol ? DFTA_POISSON_TOLERANCE : DFTA_POISSON_EXACT)) : -1; }
 
 }  // extern "C"
 
@@ -346,7 +348,8 @@ static int poisson_create_impl(dfta_ctx* ctx, const dfta_grid* g, int batch, int
     DFTA_REQUIRE(ctx, batch >= 1 && g->levels <= kMaxLevels, "poisson batch/levels");
     dfta_poisson* p = new dfta_poisson();
     p->ctx = ctx; p->g = g; p->batch = batch;
-    p->tol = mode == DFTA_POISSON_TOLERANCE;
+    p->tol = mode == DFTA_POISSON_TOLERANCE || mode == DFTA_POISSON_ADAPTIVE;
+    p->adaptive = mode == DFTA_POISSON_ADAPTIVE;
     MgDesc& D = p->D;
     D.levels = g->levels;
     // Workgroups per atom: a solve is bound by ONE compute unit's vector-memory path, so while the batch leaves compute
@@ -473,6 +476,7 @@ static int poisson_create_impl(dfta_ctx* ctx, const dfta_grid* g, int batch, int
     // thread on its first level, the levels down to 257 nodes halve the chunk, the 129-node level and below run in one wave.  Resident
     // groups: the coarse workgroup's levels; staged groups and one workgroup per atom: workgroup 0's, from the first level it does not share
     // (8193 nodes for groups of 8 and 16 and for a lone workgroup, 4097 / 2049 nodes -- 16 / 8 per thread -- for groups of 4 / 2)
+    D.adaptive = p->adaptive ? 1 : 0;
     D.rc_top = -1;
     int k8193 = -1;
     for (int l = 0; l < D.levels; ++l) if (D.lv[l].n == 8193) k8193 = l;

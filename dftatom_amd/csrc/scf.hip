@@ -293,7 +293,7 @@ int dfta_scf_create_ex(dfta_ctx* ctx, const dfta_grid* g, int lsda, int natoms, 
     DFTA_REQUIRE(ctx, natoms >= 1 && Z && alpha >= 0 && alpha <= 1, "scf arguments");
     dfta_scf_options opt = {DFTA_INT_SIMPSON38, DFTA_XC_VWN, DFTA_AUFBAU_REFERENCE, -1, DFTA_SWEEPS_EXACT};
     if (options) opt = *options;
-    DFTA_REQUIRE(ctx, opt.poisson_mode >= -1 && opt.poisson_mode <= DFTA_POISSON_TOLERANCE, "poisson mode");
+    DFTA_REQUIRE(ctx, opt.poisson_mode >= -1 && opt.poisson_mode <= DFTA_POISSON_ADAPTIVE, "poisson mode");
     DFTA_REQUIRE(ctx, dfta_integral_shape_ok(opt.integrator, g->N), "integration rule / grid size");
     DFTA_REQUIRE(ctx, opt.functional >= DFTA_XC_VWN && opt.functional <= DFTA_XC_CHACHIYO_IMPROVED, "functional");
     DFTA_REQUIRE(ctx, opt.functional == DFTA_XC_VWN || !lsda, "the Chachiyo functional is LDA only (ExcCor.h)");

@@ -31,7 +31,8 @@ def main():
     ap.add_argument("--partition", choices=("model", "work"), default="model",
                     help="model: balance the predicted shard times (critical path + work, dftatom_amd.sweep); work: LPT on subshells x steps")
     ap.add_argument("--sweeps", choices=("exact", "tolerance"), default="exact", help="tolerance: the scan sweeps (DFTA_SWEEPS_TOLERANCE)")
-    ap.add_argument("--poisson", choices=("exact", "tolerance"), default="exact", help="tolerance: the multigrid's tolerance mode")
+    ap.add_argument("--poisson", choices=("exact", "tolerance", "adaptive"), default="exact",
+                    help="tolerance: the multigrid's tolerance mode; adaptive: that, and the V-cycles stop at the round-off floor")
     ap.add_argument("--emulate-ranks", type=int, default=0,
                     help="one GPU, no launcher: run each of the N shards of an N-rank sweep alone, one after the other, and report the "
                          "per-shard wall times; their maximum PREDICTS the N-GPU wall time (shards never interact; the only collective "
@@ -62,7 +63,7 @@ def main():
     Zs = list(range(args.zmin, args.zmax + 1))
     cost = sweep.atom_cost if args.partition == "work" else None
     modes = dict(sweep_mode=D.SWEEPS_TOLERANCE if args.sweeps == "tolerance" else D.SWEEPS_EXACT,
-                 poisson_mode=D.POISSON_TOLERANCE if args.poisson == "tolerance" else D.POISSON_EXACT)
+                 poisson_mode={"tolerance": D.POISSON_TOLERANCE, "adaptive": D.POISSON_ADAPTIVE}.get(args.poisson, D.POISSON_EXACT))
     model = "tolerance" if args.sweeps == "tolerance" else "exact"
     if cost is None and model != "exact":
         cost_model = model

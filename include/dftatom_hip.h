@@ -219,6 +219,11 @@ int  dfta_poisson_create(dfta_ctx* ctx, const dfta_grid* g, int batch, dfta_pois
  * dfta_poisson_create takes the mode from $DFTA_POISSON_MODE (= tolerance), default EXACT. */
 #define DFTA_POISSON_EXACT     0
 #define DFTA_POISSON_TOLERANCE 1
+/* DFTA_POISSON_ADAPTIVE: the tolerance mode's kernels, and the V-cycles stop where the cycle has reached its round-off floor -- the norm of
+ * the last level-0 sweep has not fallen below 0.7 x the previous cycle's twice in a row (and is below 1e-3 of the first cycle's) -- instead
+ * of at the reference's cap of 100 (PoissonSolver.cpp:185-197: its test ||dPhi|| < 1e-14 lies below that floor, so the reference always
+ * runs to the cap; the floor is reached after 6 .. 8 cycles).  Same gates as the tolerance mode; opt-in, never the default. */
+#define DFTA_POISSON_ADAPTIVE 2
 int  dfta_poisson_create_ex(dfta_ctx* ctx, const dfta_grid* g, int batch, int mode, dfta_poisson** out);
 int  dfta_poisson_mode(const dfta_poisson* p);
 void dfta_poisson_destroy(dfta_poisson* p);
@@ -310,7 +315,7 @@ typedef struct dfta_scf_options {
     int integrator;   /* DFTA_INT_*: quadrature of the energy integrals and of the normalisation (default SIMPSON38) */
     int functional;   /* DFTA_XC_*                                                                                */
     int aufbau;       /* DFTA_AUFBAU_*                                                                            */
-    int poisson_mode; /* DFTA_POISSON_EXACT (0, default) / DFTA_POISSON_TOLERANCE; -1: as dfta_poisson_create ($DFTA_POISSON_MODE) */
+    int poisson_mode; /* DFTA_POISSON_EXACT (0, default) / DFTA_POISSON_TOLERANCE / DFTA_POISSON_ADAPTIVE; -1: as dfta_poisson_create ($DFTA_POISSON_MODE) */
     int sweep_mode;   /* DFTA_SWEEPS_EXACT (0, default) / DFTA_SWEEPS_TOLERANCE (scan sweeps, see DFTA_LEVELS_SCAN_SWEEPS)                */
 } dfta_scf_options;
 /* The option and statistics structs grow at the END between versions of this header and carry no size field: zero-initialise them

@@ -208,16 +208,20 @@ def test_scan_mode_radon_steps_vs_reference(ctx, grid17, lsda):
         assert np.all(dl <= 1e-8 + 2e-9 * np.abs(wl)), (key, dl.max())
     scf.close()
     traj = np.array(gold["etotal_all"])
-    for pm in (D.POISSON_EXACT, D.POISSON_TOLERANCE):
+    for pm in (D.POISSON_EXACT, D.POISSON_TOLERANCE, D.POISSON_ADAPTIVE):
         scf2 = D.Scf(ctx, grid17, [86], lsda=lsda, sweep_mode=D.SWEEPS_TOLERANCE, poisson_mode=pm)
-        got = []
+        got, vcs = [], []
         for _ in range(len(traj)):
-            scf2.step(want_stats=False)
+            st = scf2.step()
+            if st.vcycles > 0:                      # (a step after the atom has met the stop test integrates nothing)
+                vcs.append(int(st.vcycles))
             got.append(scf2.energies()[0][0].Etotal)
         rel = np.abs(np.array(got) - traj) / np.abs(traj)
-        print("scan sweeps, Rn %s, multigrid %s: steps 0/1 energies %.2e rel, eigenvalues %.2e |E|; trajectory (%d steps) %.2e"
-              % ("LSDA" if lsda else "LDA", "tolerance" if pm else "exact", worst_e, worst_l, len(traj), rel.max()))
+        print("scan sweeps, Rn %s, multigrid %s: steps 0/1 energies %.2e rel, eigenvalues %.2e |E|; trajectory (%d steps) %.2e; V-cycles per solve %d .. %d"
+              % ("LSDA" if lsda else "LDA", ("exact", "tolerance", "adaptive")[pm], worst_e, worst_l, len(traj), rel.max(), min(vcs), max(vcs)))
         assert rel.max() <= 2e-9
+        # the reference's stop test lies below the cycle's round-off floor: it always runs to its cap; the adaptive mode stops on the floor
+        assert (max(vcs) <= 12) if pm == D.POISSON_ADAPTIVE else (min(vcs) == 100)
         scf2.close()
 
 
