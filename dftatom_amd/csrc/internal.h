@@ -26,6 +26,25 @@ int dfta_launch_match(dfta_ctx* ctx, const dfta_grid* g, int ntrials, const doub
                       double* dPsi, double* dQ, int* dMatch, const double2* bounds /* per slot (dfta_bounds_stride), may be null */,
                       const double* dUz = nullptr /* uniform grid: start value at the first node per trial */, hipStream_t stream = nullptr);
 
+// persist.inc (compiled with numerov.hip): the exact level search of up to 64 levels on the device, every level at its own pace
+namespace dfta { struct Job; }
+struct dfta_persist_buffers {
+    void* d_ctl = nullptr;         // control block, mailboxes, per-level workgroup lists, trace
+    size_t ctl_bytes = 0;
+    double *E = nullptr, *us = nullptr, *us1 = nullptr, *u0 = nullptr, *phi = nullptr;      // trial arrays: nlive_cap x tmax
+    int *limit = nullptr, *start = nullptr, *count = nullptr, *istop = nullptr, *trip = nullptr;
+    double *candP = nullptr, *candQ = nullptr;     // per workgroup: wavefunction + scratch of a speculative match (null: none)
+    int* blk = nullptr;            // per workgroup: table slot, first trial, trial count of its running block
+    int nblocks = 0, tmax = 0, nlive_cap = 0, trace_cap = 0;
+    std::vector<unsigned char> h_stage;
+};
+int dfta_persist_create(dfta_ctx* ctx, const dfta_grid* g, int nlive_cap, dfta_persist_buffers* pb);
+void dfta_persist_destroy(dfta_persist_buffers* pb);
+int dfta_launch_levels_persist(dfta_ctx* ctx, const dfta_grid* g, dfta_persist_buffers* pb, dfta::Job* d_jobs, const int* live, int nlive,
+                               const double2* d_tab, const double2* d_bounds, double* d_Psi, double* d_Q, int* d_jstart_keep,
+                               unsigned long long* d_counters, bool stats, int nopredict, int integ_rule, const double* tuning, int fixed_point,
+                               int* rounds, int* aborted, std::vector<unsigned long long>* trace_out, const int* share = nullptr /* host, nlive: workgroups per level */);
+
 // scan.hip: the tolerance mode of the sweeps (transfer-matrix scan: one workgroup per trial)
 struct dfta_scan_tables {
     double* tabv = nullptr;    // nslots * N: veff = V + c_l per slot, lane-interleaved (row i = t C + k at k 512 + t, row N-1 at N-1)

@@ -68,6 +68,10 @@ struct Job {
     int tbase, tcap;
     int n_fixed;                     // iterations of the third bisection counted in n_zero but not integrated: the bisection stood on a fixed point (walk_job)
     int status;                      // DFTA_LEVEL_* bits: how the third bisection ended (DFTAtom.cpp:517-539)
+    // device-side search (persist.inc): the certain part of the band (count == nodes) as the planner of the round saw it -- the scouts'
+    // grid; the workers of a round must not read a sibling's record while it moves -- and the rounds this job has taken
+    double sb_lo, sb_hi;
+    int rounds, pad_;
     long long n_points;              // grid points traversed by the sweeps ON the bisection path (n_count + n_zero executed ones) + the match solve
 };
 
@@ -128,6 +132,15 @@ struct LevelSolver {
     unsigned long long* d_scan_xch = nullptr;     // 32 words per job: the members' results of a round, two parities
     int scan_group = 1;             // workgroups per level of the last scan search (1, 3, 7 or 15)
     int scan_fallbacks = 0;         // solves the scan handed back to the exact kernels (a trial it could not decide)
+    // Device-side exact search (persist.inc): up to 64 live levels of an un-chained solve on the logarithmic grid run their three bisections in ONE
+    // persistent kernel, every level at its own pace; the host rounds of run() remain for everything else and as the fallback
+    bool persist_ok = false;        // the solver's shape allows it (decided in setup(); $DFTA_DEBUG LEVELS_NOPERSIST switches it off)
+    dfta_persist_buffers pb;
+    int persist_fallbacks = 0;      // solves repeated with host rounds after a lost worker
+    int persist_runs = 0;
+    double tuning[4] = {1e-11, 16e-12, 1.5e-11, 0.25};     // noise band (rel, abs, secant) and the secant's kappa, as set in setup()
+    int fixed_point = 1;
+    std::vector<unsigned long long> persist_trace;          // $DFTA_DEBUG LEVELS_PERSIST_TRACE: 4 words per closed round of the last run
 
     LevelSolver() = default;
     LevelSolver(const LevelSolver&) = delete;

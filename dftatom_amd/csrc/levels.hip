@@ -28,47 +28,7 @@
 
 namespace {
 
-constexpr double kEnergyErr = 1E-12;   // DFTAtom.cpp:348
-constexpr int kMaxIter3 = 500;         // DFTAtom.cpp:517
-
-enum Phase { PH_WAIT = 0, PH_TOP = 1, PH_BOTTOM = 2, PH_ZERO = 3, PH_DONE = 4 };
-
-// ---- trial layout of a round -------------------------------------------------------------------------------------
-// Trial 0 of a job is the Bottom probe of the sign bisection (DFTAtom.cpp:513).  Trials 1..S are the SPINE: the
-// bisection nodes along the predicted decision string (previous SCF step).  Trials S+g, g = 1..2^d'-1, form a full
-// binary tree (heap order) rooted at the end of the spine.  Every node's energy is produced by the reference's own
-// expression (toe + boe) / 2 applied along its path, so whichever nodes the walk visits carry exactly the energies
-// the sequential bisection would have used; the prediction only selects WHICH nodes are integrated speculatively.
-__device__ __forceinline__ int phase_index(int phase) { return phase - 1; }   // PH_TOP, PH_BOTTOM, PH_ZERO -> 0, 1, 2
-
-__device__ __forceinline__ int tree_depth_for(int tpj, int spine)
-{
-    const int room = tpj - spine;            // heap indices 1 .. room-1 are available
-    return room >= 2 ? 31 - __clz(room) : 0; // full levels: nodes 1 .. 2^d' - 1
-}
-
-__device__ __forceinline__ int capz_of(const dfta::Job& j, int tpj) { return j.capz > 0 ? j.capz : tpj; }
-
-// the part of the band (count == nodes) that is certain so far, from the running first bisections of the job and its sibling
-__device__ __forceinline__ void band_of(const dfta::Job& j, const dfta::Job* __restrict__ jobs, double& blo, double& bhi)
-{
-    blo = j.bottom0;
-    if (j.nodes > 0) {
-        blo = 1e300;                                                   // unknown: no band
-        if (j.sib >= 0) {
-            const dfta::Job sb = jobs[j.sib];
-            if (sb.phase == PH_TOP) blo = sb.toe;                      // count > nodes-1 there
-            else if (sb.phase == PH_BOTTOM || sb.phase == PH_ZERO || sb.phase == PH_DONE) blo = sb.top;
-        }
-    }
-    bhi = j.phase == PH_TOP ? j.boe : j.top - kEnergyErr;             // count <= nodes there
-}
-
-__device__ __forceinline__ bool pred_bit(const dfta::Job& j, int ph, int k)
-{
-    if (j.use_sp) return (j.sp_bits >> (k & 63)) & 1ull;
-    return (j.pred_bits[ph] >> (k & 63)) & 1ull;
-}
+#include "levels_device.inc"
 
 // ---- expand: trial energies of the current round of every job, plus their far boundary values ----------------------
 __global__ __launch_bounds__(256) void k_expand(const dfta::Job* __restrict__ jobs, const int* __restrict__ wave_job, int wshift, int ntrials, const double* __restrict__ r,
@@ -86,74 +46,9 @@ __global__ __launch_bounds__(256) void k_expand(const dfta::Job* __restrict__ jo
         return;
     }
     const dfta::Job j = jobs[job];
-    const int tpj = j.tcap;
-    const int h = gt - j.tbase;
-    bool active = false;
-    double e = 0;
-    const int capz = capz_of(j, tpj);
-    if (h >= capz) {
-        // eigenvalue scouts: u(0) on a grid inside the band, later inside the bracket of its sign change
-        if (j.phase == PH_TOP || j.phase == PH_BOTTOM) {
-            const int n = tpj - capz, i = h - capz;
-            if (j.se_state == 1) {
-                e = j.se_lo + (i + 1) * ((j.se_hi - j.se_lo) / (n + 1));
-                active = e > j.se_lo && e < j.se_hi;
-            } else {
-                // scan of the band: uniform in the middle, geometric towards both edges (1.5 bits per sample)
-                double blo, bhi;
-                band_of(j, jobs, blo, bhi);
-                const int q = n / 4 < 32 ? n / 4 : 32;           // 48 bits towards each edge
-                double u;
-                if (i < q) u = exp2(-1.5 * (q - i) - 1.);
-                else if (i >= n - q) u = 1. - exp2(-1.5 * (i - (n - q) + 1) - 1.);
-                else u = 0.25 + (i - q + 1) * (0.5 / (n - 2 * q + 1));
-                e = blo + u * (bhi - blo);
-                active = bhi > blo && e > blo && e < bhi;
-            }
-        }
-    } else if (j.phase == PH_TOP || j.phase == PH_BOTTOM || j.phase == PH_ZERO) {
-        if (h == 0) {
-            if (j.phase == PH_ZERO && !j.haveSgn) { active = true; e = j.boe; }   // DFTAtom.cpp:513
-        } else {
-            const int ph = phase_index(j.phase);
-            const int S = j.spine;
-            double hi = j.toe, lo = j.boe;
-            int depth;                                        // decisions taken before this node in this round
-            bool exists = true;
-            if (h <= S) {
-                depth = h - 1;
-                for (int k = 0; k < depth; ++k) {
-                    const double m = (hi + lo) / 2;
-                    if (pred_bit(j, ph, j.phase_done + k)) lo = m; else hi = m;
-                }
-            } else {
-                // the tree's trials are laid out in ENERGY order (in-order rank of the heap node): the 64 trials of a
-                // sweep block then have neighbouring energies -- similar cut-off radii, and whole blocks above the count
-                // threshold leave CountNodes early and free their compute unit
-                const int rank = h - S;
-                const int dsub = tree_depth_for(capz, S);
-                int g = 1, gdepth = 0;
-                exists = dsub > 0 && rank < (1 << dsub);
-                if (exists) {
-                    const int tz = __ffs(rank) - 1;
-                    gdepth = dsub - 1 - tz;
-                    g = (1 << gdepth) + (rank >> (tz + 1));
-                }
-                for (int k = 0; k < S; ++k) {
-                    const double m = (hi + lo) / 2;
-                    if (pred_bit(j, ph, j.phase_done + k)) lo = m; else hi = m;
-                }
-                for (int b = gdepth - 1; b >= 0; --b) {
-                    const double m = (hi + lo) / 2;
-                    if ((g >> b) & 1) lo = m; else hi = m;       // child 2g: toe = E ; child 2g+1: boe = E
-                }
-                depth = S + gdepth;
-            }
-            e = (hi + lo) / 2;
-            if (j.phase == PH_ZERO) active = exists && (depth < kMaxIter3 - j.iter3);
-            else active = exists && (hi - lo > kEnergyErr);       // loop condition of DFTAtom.cpp:571,589
-        }
-    }
+    const TrialSpec ts = trial_spec<false>(j, jobs, gt - j.tbase);
+    const double e = ts.e;
+    const bool active = ts.active;
     E[gt] = e;
     limit[gt] = j.nodes;
     int st = 0;
@@ -166,437 +61,23 @@ __global__ __launch_bounds__(256) void k_expand(const dfta::Job* __restrict__ jo
         us[gt] = exp(-sp * s);
         us1[gt] = exp(-(sp - hstep) * s);
     } else if (active) {
-        // GetMaxRadiusIndex (Numerov.h:119-136); exp(arg) < 1e-200 <=> arg < far_thr
-        const double s = sqrt(2. * fabs(e));
-        int maxIndex = N - 1, minIndex = 1;
-        while (maxIndex - minIndex > 1) {
-            const int mid = (maxIndex + minIndex) / 2;
-            const double arg = -r[mid] * s - static_cast<double>(mid) * delta * 0.5;
-            if (arg < far_thr) maxIndex = mid; else minIndex = mid;
-        }
-        st = maxIndex;
-        us[gt] = exp(-r[st] * s - static_cast<double>(st) * delta * 0.5);              // Numerov.h:107
-        us1[gt] = exp(-r[st - 1] * s - static_cast<double>(st - 1) * delta * 0.5);
+        double a, b;
+        st = trial_boundary(e, r, N, delta, far_thr, a, b);
+        us[gt] = a;
+        us1[gt] = b;
     }
     start[gt] = st;
-    if ((gt & 63) == 0) wave_kind[gt >> 6] = (j.phase == PH_ZERO || h >= capz) ? DFTA_SWEEP_ZERO : DFTA_SWEEP_COUNT;
+    if ((gt & 63) == 0) wave_kind[gt >> 6] = ts.zero_kind ? DFTA_SWEEP_ZERO : DFTA_SWEEP_COUNT;
     if (issued) {
         const unsigned long long m = __ballot(active);
         if ((threadIdx.x & 63) == 0 && m) atomicAdd(issued, (unsigned long long)__popcll(m));
     }
 }
 
-// ---- walk: follow each job's spine + tree with the reference's predicates ---------------------------------------------
-// Cursor over the trial layout of a round: returns the trial index of the node reached after the decisions taken so
-// far, or -1 when that node was not part of this round (prediction missed or tree exhausted).
-struct Cursor {
-    int S, dsub, k, g;     // spine length, subtree depth, decisions taken this round, heap index inside the subtree
-    bool off;
-    __device__ void init(int spine, int tpj) { S = spine; dsub = tree_depth_for(tpj, spine); k = 0; g = 1; off = false; }
-    __device__ int node() const
-    {
-        if (off) return -1;
-        if (k < S) return k + 1;
-        const int gdepth = 31 - __clz(g);
-        if (gdepth >= dsub) return -1;
-        const int p = g - (1 << gdepth);
-        return S + ((2 * p + 1) << (dsub - 1 - gdepth));      // in-order rank of heap node g (see k_expand)
-    }
-    __device__ void advance(bool bit, bool predicted)
-    {
-        if (k < S) { if (bit != predicted) off = true; }
-        else g = 2 * g + (bit ? 1 : 0);
-        ++k;
-    }
-};
-
-__device__ __forceinline__ void record_bit(dfta::Job& j, int ph, bool bit)
-{
-    if (j.phase_done < 64) {
-        if (bit) j.cur_bits[ph] |= (1ull << j.phase_done);
-        j.cur_len[ph] = j.phase_done + 1;
-    }
-    ++j.phase_done;
-}
-
-// at the end of a phase: how long did the prediction hold?  Plan the first spine of the next phase.
-__device__ __forceinline__ void finish_phase(dfta::Job& j, int ph)
-{
-    int common = 0;
-    const int m = j.cur_len[ph] < j.pred_len[ph] ? j.cur_len[ph] : j.pred_len[ph];
-    while (common < m && (((j.cur_bits[ph] ^ j.pred_bits[ph]) >> common) & 1ull) == 0ull) ++common;
-    j.trust[ph] = common;       // read by the NEXT solve (after pred := cur)
-    j.phase_done = 0;
-    j.miss = 0;
-}
-
-// Simulate the running bisection from its current interval against a bracket [blo, bhi] of the energy at which its
-// predicate flips: a midpoint at or below blo takes the "boe = E" branch (bit 1), one at or above bhi the other one.
-__device__ __forceinline__ void predict_from_bracket(dfta::Job& j, double lo, double hi, double blo, double bhi, bool strict_end)
-{
-    unsigned long long bits = 0;
-    int k = j.phase_done;
-    while (k < 64 && (strict_end ? !(hi - lo < kEnergyErr) : (hi - lo > kEnergyErr))) {
-        const double m = (hi + lo) / 2;
-        bool bit;
-        if (m <= blo) bit = true;
-        else if (m >= bhi) bit = false;
-        else break;
-        if (bit) { bits |= 1ull << k; lo = m; } else hi = m;
-        ++k;
-    }
-    j.sp_bits = bits;
-    j.sp_len = k;
-}
-
-// The band of energies around a transition inside which CountNodes' count and the sign of u(0) are round-off (not monotonic in
-// E).  Spines stop there -- a predicted decision inside it is a coin toss, and a miss forfeits the round's tree.  Measured on
-// Rn's fifteen levels (16384-point scans of the count and of sign u(0) around every transition, end of round 2): the band is
-// 1.2e-12 .. 7.4e-12 |E| wide (6p: 1.4e-11 |E| = 2.5e-12 absolute), the same for both predicates.  Guards: rel |E| + abs on either
-// side of a predicted transition (sibling's end point, own top for l = 0), g_secant_noise |E| added to the secant's error bound.
-// Round 1 used 2e-11 / 64e-12 / 3e-11; DFTA_LEVELS_NOISE="rel,abs,secant" overrides (read when a solver is created).
-__device__ double g_noise_rel = 1e-11, g_noise_abs = 16e-12, g_secant_noise = 1.5e-11;
-__device__ int g_fixed_point = 1;      // 0 ($DFTA_DEBUG LEVELS_NOFIXEDPOINT): a third bisection on its fixed point is integrated to the iteration cap (tests)
-// Spine of the job's next round.  `jobs` is read for the sibling only (k_plan runs after every walk of the round).
-__device__ __forceinline__ void plan_round(dfta::Job& j, const dfta::Job* __restrict__ jobs, int tpj)
-{
-    const int ph = phase_index(j.phase);
-    // A miss ON the spine forfeits the tree of that round, so a spine from the previous SCF step stops one bit short of
-    // what held last time (eigenvalues move by roughly half as much every SCF step: the prediction gains about one bit
-    // per step anyway).
-    int S = j.trust[ph] - 1 - j.phase_done;
-    const int avail = j.pred_len[ph] - j.phase_done;
-    if (S > avail) S = avail;
-    if (j.hist_ok == 2) S = 0;                 // two steps of history: the bracket below replaces the bit-prefix rule
-    j.use_sp = 0;
-    j.sp_len = 0;
-    // history bracket (levels.h): this step's end point within kHistSafety x the last movement of the previous one
-    constexpr double kHistSafety = 2.0;
-    unsigned long long hbits = 0;
-    int hlen = 0;
-    if (j.hist_ok == 2 && !j.miss && j.hist_d[ph] >= 0) {
-        const double T = j.hist_T[ph];
-        const double m = kHistSafety * j.hist_d[ph] + 1e-10 * fabs(T) + 64 * kEnergyErr;
-        predict_from_bracket(j, j.boe, j.toe, T - m, T + m, j.phase == PH_ZERO);
-        hbits = j.sp_bits;
-        hlen = j.sp_len;
-        j.sp_len = 0;
-    }
-    // the last decisions before the predicted flip are left to the tree: at that scale (a few 1e-11) the counted nodes
-    // and the sign of u(0) are not monotonic in the energy, and a miss on the spine costs the whole round
-    const double kGuard = g_noise_abs;
-    const double kNoise = g_noise_rel;
-    bool secant = false;
-    if (j.phase == PH_TOP) {
-        if (j.sc_ok && j.miss < 2) {
-            predict_from_bracket(j, j.boe, j.toe, j.sc_lo - kGuard, j.sc_hi + kGuard, false);
-            secant = true;
-        }
-    } else if (j.phase == PH_BOTTOM) {
-        if (j.nodes == 0) predict_from_bracket(j, j.boe, j.toe, -1e300, -1e300, false);   // "count < 0" never holds
-        else if (j.sib >= 0) {
-            const dfta::Job sb = jobs[j.sib];
-            if (sb.phase == PH_BOTTOM || sb.phase == PH_ZERO || sb.phase == PH_DONE) {
-                // the spine stops where the count stops being a monotonic function of the energy (round-off of the sweep,
-                // about 1e-11 |E|): a spine that runs into that band misses and forfeits the round's tree
-                const double gd = kGuard + kNoise * fabs(sb.top);
-                predict_from_bracket(j, j.boe, j.toe, sb.top - gd, sb.top + gd, false);
-            }
-            else if (sb.phase == PH_TOP)
-                predict_from_bracket(j, j.boe, j.toe, sb.boe - kGuard, sb.toe + kGuard, false);
-        }
-    } else if (j.phase == PH_ZERO) {
-        // l == 0: no inner turning point, the count changes exactly where u(0) changes sign -- at the upper end
-        // (inside ~2e-11 |E| of it the sign of u(0), like the count, is round-off: a spine that runs into that band misses and
-        // forfeits the round's tree)
-        if (j.l == 0) { const double gd = kGuard + kNoise * fabs(j.top); predict_from_bracket(j, j.boe, j.toe, j.top - gd, j.top + gd, true); }
-        else if (j.se_state == 1 && j.se_tok && !j.miss) predict_from_bracket(j, j.boe, j.toe, j.se_tlo - kGuard, j.se_thi + kGuard, true);
-        else if (j.se_state == 1) predict_from_bracket(j, j.boe, j.toe, j.se_lo - kGuard, j.se_hi + kGuard, true);
-    }
-    // scouts for the third bisection of l > 0 (whole blocks of their own kind: tpj >= 128)
-    j.capz = tpj;
-    if (j.l > 0 && tpj >= 128 && (j.phase == PH_TOP || j.phase == PH_BOTTOM) && !j.se_stop &&
-        !(j.phase == PH_TOP && j.phase_done == 0) &&
-        !(j.se_state == 1 && j.se_hi - j.se_lo <= kEnergyErr)) {
-        double blo, bhi;
-        band_of(j, jobs, blo, bhi);
-        if (j.se_state == 1 || bhi > blo) j.capz = tpj / 2;
-    }
-    // a long predicted spine needs the whole tree behind it to finish the bisection in this round: the scouts pause
-    if (j.sp_len - j.phase_done >= 40) j.capz = tpj;
-    // the history bracket where nothing better (sibling, top rule, scouts, secant) reaches further
-    if (hlen > j.sp_len) { j.sp_bits = hbits; j.sp_len = hlen; secant = false; }
-    // once a prediction has missed in this phase the predicted path and the real one have parted: plain trees from there,
-    // except for spines from the secant estimate, which is made afresh from this round's samples (until one of those misses)
-    if (j.miss && !secant) { S = 0; j.sp_len = 0; }
-    if (j.miss && secant) S = 0;
-    if (j.sp_len - j.phase_done > S) { S = j.sp_len - j.phase_done; j.use_sp = secant ? 2 : 1; }
-    if (S > j.capz / 2 - 1) S = j.capz / 2 - 1;  // keep at least half of the trials for the tree
-    j.spine = S > 0 ? S : 0;
-}
-
-// Secant estimate of the end point of the first bisection from the samples kept in the job (see levels.h).  With
-// F(E) = (stop index of the sample - stop index of the boe-side sample) + phi -- the distance of the nearest zero of u from
-// the point where CountNodes stops, in grid cells -- the count changes where F crosses 0.  The error bound is the
-// interpolation error of the secant with the second divided difference taken from the third sample (times 4).
-__device__ double g_secant_kappa = 0.25;     // 0: secant only (DFTA_LEVELS_SECANT_KAPPA overrides, read when a solver is created)
-__device__ __forceinline__ void secant_predict(dfta::Job& j, const double2* __restrict__ veff /* table rows of the job's slot */)
-{
-    j.sc_ok = 0;
-    const int ia = j.sc_is[0], ib = j.sc_is[1], ic = j.sc_is[2];
-    if (ia < 0 || ib < 0 || ic < 0 || (ia & kStopOver)) return;
-    // x0(E) = stop index + phi = position of the zero of u next to the stop point, in grid cells (absolute): smooth in E
-    // whatever made the sweep stop.  The count changes where x0(E) reaches the point at which CountNodes stops for THAT
-    // energy: s(E) = 0 for l == 0, the inner turning point -- the largest i below the well with veff_i > E -- otherwise,
-    // a step function that comes down as E goes up (by about a cell while the zero moves a few dozen).
-    auto X = [&](int k) { return static_cast<double>(j.sc_is[k] & ~kStopOver) + j.sc_phi[k]; };
-    const double a = j.sc_e[0], b = j.sc_e[1], c = j.sc_e[2];
-    const double xa = X(0), xb = X(1), xc = X(2);
-    if (!(b > a) || c == a || c == b || !(xb > xa) || !(fabs(xc) < 1e300) || !(xa < ia)) return;
-    const double w = b - a;
-    const double f1 = (xb - xa) / w;
-    const double f2 = ((xc - xb) / (c - b) - f1) / (c - a);
-    double t = 0;
-    bool found = false, at_step = false;
-    int s = ia;                                       // stop index at E = a (the boe-side sample ran to its turning point)
-    for (int it = 0; it < 16 && !found; ++it) {
-        // the stop index stays s while E < veff_s (l == 0: for ever)
-        const double Ej = (ia != 0 && s >= 1) ? veff[s].x : 1e300;
-        const double tl = a + (static_cast<double>(s) - xa) / f1;        // the zero reaches s here
-        if (tl < Ej) { t = tl; found = true; }
-        else if (xa + (Ej - a) * f1 >= static_cast<double>(s - 1)) { t = Ej; found = true; at_step = true; }   // the stop point
-        else --s;                                                                 // steps over the zero at E = veff_s
-        if (s < 1 && ia != 0) break;
-    }
-    if (!found || !(t > a && t < b)) return;
-    // 4 x |f2 / f1| (b - a)^2 / 4 for the secant, plus the scale below which the count is no longer a monotonic function of
-    // the energy (round-off of the sweep: about 1e-11 of |E|)
-    double e = (at_step ? 0.0 : fabs(f2 / f1) * w * w) + g_secant_noise * fabs(t);
-    // The third sample gives more than a bound: the parabola through the three samples (Newton form
-    // xa + f1 (E - a) + f2 (E - a)(E - b)) meets the stop point at t - f2 (t - a)(t - b) / f1 to first order -- measured, the
-    // end point of the bisection sits at -0.20 .. -0.25 of the secant's error bound, i.e. ON that correction, time after
-    // time.  The corrected estimate is trusted to a fraction g_secant_kappa of the correction itself (plus the noise floor);
-    // it is dropped where it would cross the turning-point step that the secant's solution lies under.
-    if (!at_step && g_secant_kappa > 0) {
-        double tq = t;
-        for (int it = 0; it < 2; ++it) tq = a + (static_cast<double>(s) - xa - f2 * (tq - a) * (tq - b)) / f1;
-        const double Ej = (ia != 0 && s >= 1) ? veff[s].x : 1e300;
-        if (tq > a && tq < b && tq < Ej) {
-            const double e2 = g_secant_kappa * fabs(tq - t) + g_secant_noise * fabs(tq);
-            if (e2 < e) { e = e2; t = tq; }
-        }
-    }
-    if (!(e < w * 0.125)) return;
-    j.sc_lo = t - e;
-    j.sc_hi = t + e;
-    j.sc_ok = 1;
-}
-
-__device__ void walk_job(dfta::Job& j, const int* __restrict__ count, const double* __restrict__ u0, const double* __restrict__ phi,
-                         const int* __restrict__ istop, const int* __restrict__ trip, const double2* __restrict__ veff)
-{
-    const int tpj = j.tcap, base = j.tbase;
-    Cursor c;
-    c.init(j.spine, capz_of(j, tpj));
-    if (j.phase == PH_TOP) {                                        // DFTAtom.cpp:568-585
-        double hi = j.toe, lo = j.boe;
-        while (hi - lo > kEnergyErr) {
-            const int h = c.node();
-            if (h < 0) { if (c.off) j.miss = (j.use_sp == 2) ? 2 : (j.miss > 1 ? j.miss : 1); j.toe = hi; j.boe = lo; secant_predict(j, veff); return; }
-            const double e = (hi + lo) / 2;
-            const int cn = count[base + h];
-            ++j.n_count;
-            if (trip) j.n_points += trip[base + h];
-            const bool bit = !(cn > j.nodes);                        // 1: boe = E
-            if (bit) lo = e; else hi = e;
-            {
-                const int side = bit ? 0 : 1;
-                j.sc_e[2] = j.sc_e[side]; j.sc_phi[2] = j.sc_phi[side]; j.sc_is[2] = j.sc_is[side];
-                j.sc_e[side] = e; j.sc_phi[side] = phi[base + h]; j.sc_is[side] = istop[base + h];
-            }
-            c.advance(bit, pred_bit(j, 0, j.phase_done));
-            record_bit(j, 0, bit);
-        }
-        finish_phase(j, 0);
-        j.sc_ok = 0;
-        j.top = hi;
-        j.toe = hi;
-        j.boe = j.bottom0;                                          // DFTAtom.cpp:587
-        j.phase = PH_BOTTOM;
-        if (j.nodes == 0) {
-            // A level without nodes: the second bisection asks "count < 0", which CountNodes can never answer with yes
-            // (Numerov.h:272-349 counts up from 0).  Its whole path -- toe = E at every step (DFTAtom.cpp:589-601) -- is
-            // therefore known without a single sweep: it is taken here, in the round that ended the first bisection, and
-            // only counted in n_count (the reference does integrate those ~52 trials).
-            double hi2 = j.toe, lo2 = j.boe;
-            while (hi2 - lo2 > kEnergyErr) {
-                hi2 = (hi2 + lo2) / 2;
-                ++j.n_count;
-                record_bit(j, 1, false);
-            }
-            finish_phase(j, 1);
-            j.bottom = hi2;                                         // BottomEnergy = toe
-            j.toe = j.top;
-            j.boe = hi2;
-            j.haveSgn = 0;
-            j.iter3 = 0;
-            j.phase = PH_ZERO;
-        }
-        return;
-    }
-    if (j.phase == PH_BOTTOM) {                                     // DFTAtom.cpp:587-603
-        double hi = j.toe, lo = j.boe;
-        while (hi - lo > kEnergyErr) {
-            const int h = c.node();
-            if (h < 0) { if (c.off) j.miss = 1; j.toe = hi; j.boe = lo; return; }
-            const double e = (hi + lo) / 2;
-            const int cn = count[base + h];
-            ++j.n_count;
-            if (trip) j.n_points += trip[base + h];
-            const bool bit = (cn < j.nodes);                         // 1: boe = E
-            if (bit) lo = e; else hi = e;
-            c.advance(bit, pred_bit(j, 1, j.phase_done));
-            record_bit(j, 1, bit);
-        }
-        finish_phase(j, 1);
-        j.bottom = hi;                                              // BottomEnergy = toe
-        j.toe = j.top;
-        j.boe = hi;
-        j.haveSgn = 0;
-        j.iter3 = 0;
-        j.phase = PH_ZERO;
-        return;
-    }
-    if (j.phase == PH_ZERO) {                                       // DFTAtom.cpp:513-534
-        if (!j.haveSgn) {
-            const double d0 = u0[base];
-            ++j.n_zero;
-            if (trip) j.n_points += trip[base];
-            j.sgnBottom = d0 > 0;
-            j.haveSgn = 1;
-        }
-        double hi = j.toe, lo = j.boe;
-        bool conv = false, fixed = false;
-        double last_ad = 0;
-        while (j.iter3 < kMaxIter3) {
-            const int h = c.node();
-            if (h < 0) { if (c.off) j.miss = 1; j.toe = hi; j.boe = lo; return; }
-            const double e = (hi + lo) / 2;
-            const double d = u0[base + h];
-            ++j.n_zero;
-            if (trip) j.n_points += trip[base + h];
-            ++j.iter3;
-            const bool bit = ((d > 0) == (j.sgnBottom != 0));        // 1: BottomEnergy = E
-            const double hi_was = hi, lo_was = lo;
-            if (bit) lo = e; else hi = e;
-            c.advance(bit, pred_bit(j, 2, j.phase_done));
-            record_bit(j, 2, bit);
-            const double ad = fabs(d);
-            last_ad = ad;
-            if (hi - lo < kEnergyErr && !isnan(ad) && ad < 1E15) { conv = true; break; }
-            if (g_fixed_point && hi == hi_was && lo == lo_was) {
-                // A level whose u(0) never gets below 1e15 (or is NaN) keeps the reference bisecting until its 500-iteration cap
-                // (DFTAtom.cpp:517-534) although the interval has long collapsed: once a step leaves (toe, boe) as they were, the
-                // midpoint, its sweep, its sign and the decision repeat unchanged to the end -- a fixed point.  The remaining
-                // iterations are taken here without their sweeps (counted: the reference integrates every one of them); they used to
-                // cost a round per ~7 of them -- 70 rounds, 2.1 s per SCF step at 1 048 577 nodes whenever a level ended that way.
-                const int rest = kMaxIter3 - j.iter3;
-                j.n_zero += rest;
-                j.n_fixed += rest;
-                j.iter3 = kMaxIter3;
-                fixed = true;
-                break;
-            }
-        }
-        finish_phase(j, 2);
-        j.toe = hi;
-        j.boe = lo;
-        j.E = lo;                                                    // level.E = BottomEnergy
-        j.converged = conv ? 1 : 0;
-        // how it ended (include/dftatom_hip.h): the reference folds all of it into didNotConverge (DFTAtom.cpp:517-539)
-        j.status = conv ? DFTA_LEVEL_CONVERGED
-                        : (DFTA_LEVEL_ITERATION_CAP | (fixed ? DFTA_LEVEL_FIXED_POINT : 0) | (!(last_ad < INFINITY) ? DFTA_LEVEL_U0_NONFINITE : 0));
-        j.phase = PH_DONE;
-        j.spine = 0;
-        j.capz = 0;
-    }
-}
-
-// ---- scouts: bracket of the sign change of u(0) inside the band, one wave per job, before the walk of the round ------
 __global__ __launch_bounds__(64) void k_scout(dfta::Job* __restrict__ jobs, const double* __restrict__ E,
                                               const int* __restrict__ start, const double* __restrict__ u0)
 {
-    const int job = blockIdx.x, lane = threadIdx.x;
-    const dfta::Job j = jobs[job];
-    const int tpj = j.tcap;
-    const int capz = capz_of(j, tpj);
-    if (!(j.phase == PH_TOP || j.phase == PH_BOTTOM) || capz >= tpj) return;
-    const int base = j.tbase;
-    // samples [capz, tpj) in ascending energy, m consecutive ones per lane
-    const int n = tpj - capz, m = n / 64;
-    const bool bracketed = j.se_state == 1;
-    bool all_active = true;
-    int first = 0x7fffffff;                  // first sample whose sign differs from its left neighbour / from se_sl
-    int prev;                                // sign of the sample to the left of this lane's first one (-1: none)
-    {
-        const int last = base + capz + lane * m + m - 1;
-        const int mine = start[last] >= 2 ? (u0[last] > 0 ? 1 : 0) : -1;
-        prev = __shfl_up(mine, 1);
-        if (lane == 0) prev = bracketed ? j.se_sl : -1;
-    }
-    for (int q = 0; q < m; ++q) {
-        const int i = lane * m + q, idx = base + capz + i;
-        if (start[idx] < 2) { all_active = false; prev = -1; continue; }
-        const int sg = u0[idx] > 0 ? 1 : 0;
-        const bool flip = bracketed ? (sg != j.se_sl) : (prev >= 0 && sg != prev);
-        if (flip && i < first) first = i;
-        prev = sg;
-    }
-    for (int off = 32; off > 0; off >>= 1) first = min(first, __shfl_xor(first, off));
-    all_active = __ballot(all_active) == ~0ull;
-    if (lane != 0 || !all_active) return;
-    const double* Es = E + base + capz;
-    // u(0) itself is the smooth function here: every sweep starts from the analytic decaying solution, so its scale does
-    // not depend on where the sweep starts
-    const double* Ps = u0 + base + capz;
-    double nlo, nhi, plo, phi_hi;
-    if (!bracketed) {
-        if (first >= n) return;              // first >= 1 here
-        nlo = Es[first - 1]; plo = Ps[first - 1];
-        nhi = Es[first]; phi_hi = Ps[first];
-        jobs[job].se_sl = u0[base + capz + first - 1] > 0 ? 1 : 0;
-        jobs[job].se_state = 1;
-    } else {
-        nlo = first < n ? (first > 0 ? Es[first - 1] : j.se_lo) : Es[n - 1];
-        plo = first < n ? (first > 0 ? Ps[first - 1] : j.se_plo) : Ps[n - 1];
-        nhi = first < n ? Es[first] : j.se_hi;
-        phi_hi = first < n ? Ps[first] : j.se_phi;
-        if (!((nhi - nlo) * 2 < j.se_hi - j.se_lo)) jobs[job].se_stop = 1;
-    }
-    jobs[job].se_lo = nlo;
-    jobs[job].se_hi = nhi;
-    jobs[job].se_plo = plo;
-    jobs[job].se_phi = phi_hi;
-    // secant estimate of the sign change from phi at the two ends, error bound from a third sample (the next one outside
-    // the bracket on either side); speculation only: it predicts the third bisection (plan_round)
-    int tok = 0;
-    double tlo = 0, thi = 0;
-    {
-        double c = 0, pc = NAN;
-        if (first < n && first + 1 < n) { c = Es[first + 1]; pc = Ps[first + 1]; }
-        else if (first < n && first >= 2) { c = Es[first - 2]; pc = Ps[first - 2]; }
-        const double w = nhi - nlo;
-        if (w > 0 && plo * phi_hi < 0 && fabs(pc) < 1e300 && c != nlo && c != nhi) {
-            const double f1 = (phi_hi - plo) / w;
-            const double f2 = ((pc - phi_hi) / (c - nhi) - f1) / (c - nlo);
-            const double t = nlo + w * (plo / (plo - phi_hi));
-            const double e = fabs(f2 / f1) * w * w + g_secant_noise * fabs(t);
-            if (e < w * 0.125) { tok = 1; tlo = t - e; thi = t + e; }
-        }
-    }
-    jobs[job].se_tok = tok;
-    jobs[job].se_tlo = tlo;
-    jobs[job].se_thi = thi;
+    scout_job(jobs + blockIdx.x, threadIdx.x, E, start, u0);
 }
 
 __global__ void k_walk(dfta::Job* __restrict__ jobs, const int* __restrict__ chain_off, int nchains,
@@ -667,7 +148,6 @@ __global__ void k_plan(dfta::Job* __restrict__ jobs, int njobs, int nopredict, i
 constexpr int kPackThreads = 1024;
 constexpr int kPackSpineCap = 40;      // decisions of one round's spine (the tree behind it adds d more)
 
-__device__ __forceinline__ bool job_searching(int phase) { return phase == PH_TOP || phase == PH_BOTTOM || phase == PH_ZERO; }
 
 __global__ __launch_bounds__(kPackThreads) void k_pack(dfta::Job* __restrict__ jobs, int njobs, int nslots, const int* __restrict__ slot_off,
                                                        const int* __restrict__ slot_jobs, int lanes_small, int dsmall, int lanes_large, int dmin, int dmax,
@@ -804,16 +284,6 @@ __global__ __launch_bounds__(256) void k_pack_lanes(const dfta::Job* __restrict_
 // use -- probe + spine + a tree as deep as the decisions that remain after the spine (6 .. kMaxTreeDepth), twice that when
 // it also scouts -- and the requests are cut back, deepest tree first, until they fit.  Which midpoints are integrated
 // changes, the decisions taken do not (the walk follows the reference's predicates on whatever nodes it finds).
-constexpr int kMaxTreeDepth = 14;
-__device__ __forceinline__ int decisions_left(const dfta::Job& j)
-{
-    double w = j.toe - j.boe;
-    int n = 0;
-    if (j.phase == PH_ZERO) { while (!(w < kEnergyErr) && n < 64) { w *= 0.5; ++n; } }
-    else                    { while (w > kEnergyErr && n < 64) { w *= 0.5; ++n; } }
-    return n;
-}
-
 __global__ __launch_bounds__(64) void k_allot(dfta::Job* __restrict__ jobs, int njobs, int budget, int nopredict, int* __restrict__ wave_job,
                                               int* __restrict__ wave_slot, const int* __restrict__ live)
 {
@@ -1116,6 +586,8 @@ void LevelSolver::release()
                     d_jstart, d_jus, d_jus1, d_jmp, d_slot_min, d_bounds};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     dfta_scan_tables_destroy(&scan_tb);
+    dfta_persist_destroy(&pb);
+    persist_ok = false;
     if (d_scan_live) (void)hipFree(d_scan_live);
     if (d_scan_xch) (void)hipFree(d_scan_xch);
     d_scan_live = nullptr; d_scan_xch = nullptr;
@@ -1153,6 +625,8 @@ int LevelSolver::setup(dfta_ctx* c, const dfta_grid* grid, int mode_, int tree_d
         (void)hipMemcpyToSymbol(HIP_SYMBOL(g_secant_kappa), &k, sizeof(double));
         const int fp = dfta_knob("LEVELS_NOFIXEDPOINT") ? 0 : 1;
         (void)hipMemcpyToSymbol(HIP_SYMBOL(g_fixed_point), &fp, sizeof(int));
+        tuning[0] = v[0]; tuning[1] = v[1]; tuning[2] = v[2]; tuning[3] = k;
+        fixed_point = fp;
     }
     debug_rounds = dfta_knob("DEBUG_ROUNDS") ? atoi(dfta_knob("DEBUG_ROUNDS")) : 0;
     njobs = static_cast<int>(specs.size());
@@ -1250,6 +724,8 @@ int LevelSolver::setup(dfta_ctx* c, const dfta_grid* grid, int mode_, int tree_d
     }
     nwaves = static_cast<int>(ntrials / 64);
     early_match = (dynamic || can_switch) && !g->uniform && dfta_knob("LEVELS_NOEARLYMATCH") == nullptr;
+    // the device-side search serves the latency regime (one atom, or the last live atoms of a batch) on the logarithmic grid
+    persist_ok = (dynamic || can_switch) && !g->uniform && ctx->sweep_kernel != DFTA_SWEEP_FUSED && dfta_knob("LEVELS_NOPERSIST") == nullptr;
 
     std::vector<int> wave_slot(nwaves), wave_first(nwaves), wave_cnt(nwaves, 64), wave_job(nwaves);
     for (int w = 0; w < nwaves; ++w) {
@@ -1293,6 +769,7 @@ int LevelSolver::setup(dfta_ctx* c, const dfta_grid* grid, int mode_, int tree_d
         DFTA_HIP(ctx, hipStreamSynchronize(st));     // the vectors above are the sources of the copies
     }
     ALLOC(d_counters, unsigned long long, 4);
+    if (persist_ok) { const int prc = dfta_persist_create(ctx, g, std::min(njobs, 64), &pb); if (prc) return prc; }
     if (can_switch) ALLOC(d_live, int, 64);
     ALLOC(d_Psi, double, (size_t)njobs * N);
     ALLOC(d_Q, double, (size_t)njobs * N);
@@ -1348,6 +825,15 @@ int LevelSolver::run(const double* dV, const double* job_bottom, int run_mode, d
     const bool dyn = dynamic || sw;
     const bool pk = packed && !sw;
     const bool early = early_match && dyn;
+    // the live levels of a latency-mode run search on the device, each at its own pace (persist.inc), when every one of them can have two
+    // 64-trial blocks of its own; the host rounds below are the fallback
+    std::vector<int> plive;
+    if (sw) plive = live;
+    else for (int k = 0; k < njobs; ++k) if (!(frozen && frozen[k] && h_last.size() == jobs.size())) plive.push_back(k);
+    const bool use_persist = persist_ok && dyn && !chained && sweep_mode != DFTA_SWEEPS_TOLERANCE && !plive.empty() && (int)plive.size() <= pb.nlive_cap &&
+                             pb.nblocks / (int)plive.size() >= 2 && debug_rounds == 0;
+    std::vector<int> plevel(njobs, -1);
+    if (use_persist) for (size_t q = 0; q < plive.size(); ++q) plevel[plive[q]] = (int)q;
     if (sw) {
         DFTA_HIP(ctx, hipMemcpyAsync(d_live, live.data(), sizeof(int) * live.size(), hipMemcpyHostToDevice, st));
         tables_dirty = true;
@@ -1370,6 +856,8 @@ int LevelSolver::run(const double* dV, const double* job_bottom, int run_mode, d
         j.frozen = 0;
         j.tbase = (pk || sw) ? 0 : k * tpj;      // packed rounds: k_pack lays the trials out (latency mode: k_allot)
         j.tcap = (pk || sw) ? 0 : tpj;
+        if (use_persist) { j.tbase = plevel[k] * pb.tmax; j.tcap = 0; }      // its own region of the device-side search's trial arrays
+        j.rounds = 0;
         j.bottom0 = job_bottom[k];
         const bool first = (k == 0 || jobs[k].v != jobs[k - 1].v);
         if (!chained || first) { j.phase = PH_TOP; j.toe = 50; j.boe = j.bottom0; }   // DFTAtom.cpp:499
@@ -1492,30 +980,82 @@ int LevelSolver::run(const double* dV, const double* job_bottom, int run_mode, d
             }
         }
     }
-    if (!scan) {
+    bool persisted = false;
+    int persist_rounds = 0;
+    float ms_persist = 0;
+    if (!scan && use_persist) {
+        dfta_range r_p("dfta: level search on the device (persistent kernel: sweeps, walk, match, normalisation)");
+        DFTA_HIP(ctx, hipMemsetAsync(d_jstart_keep, 0xff, sizeof(int) * njobs, st));      // -1: frozen (the live levels write their cut-off index)
+        if (stats) DFTA_HIP(ctx, hipEventRecord(ev[0], st));
+        int aborted = 0;
+        const bool want_trace = dfta_knob("LEVELS_PERSIST_TRACE") != nullptr;
+        // A level without nodes has no second bisection (walk_job takes it without a sweep): a third of the search less, so half of its equal
+        // share goes to the pool, from which the levels whose phases need one decision more than their trees hold take deeper ones
+        std::vector<int> share(plive.size());
+        const int equal = pb.nblocks / (int)plive.size();
+        const bool float_shares = dfta_knob("LEVELS_PERSIST_EQUAL") == nullptr && equal >= 8;
+        for (size_t q = 0; q < plive.size(); ++q) share[q] = (float_shares && jobs[plive[q]].nodes == 0) ? equal - equal / 2 : equal;
+        rc = dfta_launch_levels_persist(ctx, g, &pb, d_jobs, plive.data(), (int)plive.size(), d_tab, d_bounds, d_Psi, d_Q, d_jstart_keep, d_counters, stats != nullptr,
+                                        use_prediction ? 0 : 1, integ_rule, tuning, fixed_point, &persist_rounds, &aborted, want_trace ? &persist_trace : nullptr, share.data());
+        if (rc) return rc;
+        if (stats) { DFTA_HIP(ctx, hipEventRecord(ev[1], st)); DFTA_HIP(ctx, hipEventSynchronize(ev[1])); DFTA_HIP(ctx, hipEventElapsedTime(&ms_persist, ev[0], ev[1])); }
+        ++persist_runs;
+        if (want_trace && !aborted) {
+            // one line per closed round, in the order of the closings: time since the first record [us], level, rounds taken, then what was planned
+            const size_t n = persist_trace.size() / 4;
+            std::vector<size_t> order(n);
+            for (size_t q = 0; q < n; ++q) order[q] = q;
+            std::sort(order.begin(), order.end(), [&](size_t x, size_t y) { return persist_trace[4 * x] < persist_trace[4 * y]; });
+            const unsigned long long t0 = n ? persist_trace[4 * order[0]] : 0;
+            fprintf(stderr, "persist trace: %zu records, kernel %.3f ms\n", n, ms_persist);
+            for (size_t q : order) {
+                const unsigned long long *w = &persist_trace[4 * q];
+                const int ph = (int)(w[2] >> 56);
+                if (ph == PH_DONE + 1) fprintf(stderr, "  %9.1f us  job %2d round %2d  search ended\n", (w[0] - t0) * 0.01, (int)(w[1] >> 32), (int)(w[1] & 0xffffffff));
+                else if (ph == PH_DONE) fprintf(stderr, "  %9.1f us  job %2d round %2d  DONE (matched, start %llu, candidate %d)\n", (w[0] - t0) * 0.01, (int)(w[1] >> 32), (int)(w[1] & 0xffffffff), w[3] & 0xffffffffull, (int)(signed char)((w[3] >> 32) & 0xff));
+                else fprintf(stderr, "  %9.1f us  job %2d round %2d  next: phase %d done %2d blocks %3d spine %2d capz %5d tcap %5d cand %d/%d\n", (w[0] - t0) * 0.01, (int)(w[1] >> 32),
+                             (int)(w[1] & 0xffffffff), ph, (int)((w[2] >> 32) & 0xff), (int)((w[2] >> 16) & 0xffff), (int)(w[2] & 0xffff), (int)((w[3] >> 32) & 0xffff), (int)(w[3] & 0xffffffff),
+                             (int)((w[3] >> 56) & 0xff), (int)(signed char)((w[3] >> 48) & 0xff));
+            }
+        }
+        if (!aborted) persisted = true;
+        else {
+            // a worker was lost (or the grid cannot be co-resident): the whole solve again with host rounds, from the records as they were
+            ++persist_fallbacks;
+            for (int k = 0; k < njobs; ++k)
+                if (!jobs[k].frozen) { jobs[k].tbase = (pk || sw) ? 0 : k * tpj; jobs[k].tcap = (pk || sw) ? 0 : tpj; }
+            DFTA_HIP(ctx, hipMemcpyAsync(d_jobs, jobs.data(), sizeof(Job) * njobs, hipMemcpyHostToDevice, st));
+            DFTA_HIP(ctx, hipMemsetAsync(d_counters, 0, sizeof(unsigned long long) * 4, st));
+            if (!chained && clamp_bottoms) {
+                hipLaunchKernelGGL(k_clamp_bottoms, dim3((njobs + 63) / 64), dim3(64), 0, st, d_jobs, njobs, d_slot_min);
+                DFTA_CHECK_LAUNCH(ctx);
+            }
+        }
+    }
+    if (!scan && !persisted) {
         rc = plan();
         if (rc) return rc;
     }
     // trials of the coming round: the whole static / latency-mode layout, or what k_pack has just laid out
     long round_trials = dyn ? budget_trials : static_trials;
     int pack_out[4] = {0, 0, 0, 0};
-    if (pk && !scan) {
+    if (pk && !scan && !persisted) {
         DFTA_HIP(ctx, hipMemcpyAsync(pack_out, d_pack_out, sizeof(pack_out), hipMemcpyDeviceToHost, st));
         DFTA_HIP(ctx, hipStreamSynchronize(st));
         round_trials = pack_out[0];
     }
-    if (early && !scan) {
+    if (early && !scan && !persisted) {
         hipLaunchKernelGGL(k_job_slots, dim3((njobs + 63) / 64), dim3(64), 0, st, d_jobs, njobs, d_jslot, d_jl);
         DFTA_CHECK_LAUNCH(ctx);
         DFTA_HIP(ctx, hipMemsetAsync(d_jE, 0xff, sizeof(double) * njobs, st));      // NaN: "no energy yet" (k_take_ready)
     }
     int* d_ndone = reinterpret_cast<int*>(d_counters + 2);
-    int rounds = scan ? 1 : 0;
-    float ms_sweep = ms_scan;
+    int rounds = scan ? 1 : (persisted ? persist_rounds : 0);
+    float ms_sweep = persisted ? ms_persist : ms_scan;
     const int max_rounds = 4096;
     int done_seen = nfrozen;
     bool early_pending = false;
-    while (!scan && rounds < max_rounds) {
+    while (!scan && !persisted && rounds < max_rounds) {
         dfta_range r_round("dfta: level-search round (expand, sweeps, scout, walk, plan)");
         if (round_trials <= 0 || round_trials > ntrials) { snprintf(ctx->err, sizeof(ctx->err), "level solver: packed round of %ld trials (room for %ld)", round_trials, ntrials); return DFTA_ERR_HIP; }
         const int round_waves = static_cast<int>(round_trials / 64);
@@ -1605,7 +1145,9 @@ int LevelSolver::run(const double* dV, const double* job_bottom, int run_mode, d
     if (rounds >= max_rounds) { snprintf(ctx->err, sizeof(ctx->err), "level solver did not terminate"); return DFTA_ERR_NOT_CONVERGED; }
 
     // wavefunctions: match (the levels that were not matched while the others searched), normalise, accumulate
-    if (scan && scan_match_mode) {
+    if (persisted) {
+        // every live level was matched and normalised by the workgroup that closed its search
+    } else if (scan && scan_match_mode) {
         // k_scan_levels has matched (and, with Simpson 3/8, normalised) every live level
         if (scan_match_mode == 1) {
             hipLaunchKernelGGL(k_normalize, dim3(njobs), dim3(kNormThreads), 0, st, d_Psi, d_Q, N, g->d_eh, g->d_cnst, d_jstart_keep, g->uniform ? g->h : 1.0, integ_rule);
@@ -1642,7 +1184,7 @@ int LevelSolver::run(const double* dV, const double* job_bottom, int run_mode, d
         stats->sweeps_issued = static_cast<long>(cnt[0]) + 2L * (njobs - nfrozen);    // + inward/outward halves of the match solve
         stats->points_traversed = static_cast<long>(cnt[1]);
         stats->ms_sweep = ms_sweep;
-        stats->layout = scan ? 4 : (sw ? 3 : (dynamic ? 1 : (pk ? 2 : 0)));
+        stats->layout = persisted ? 5 : (scan ? 4 : (sw ? 3 : (dynamic ? 1 : (pk ? 2 : 0))));
     }
     return DFTA_OK;
 }

@@ -25,6 +25,8 @@
 #include <vector>
 
 #include "internal.h"
+#include "levels.h"
+#include "ordered_sum.h"
 
 namespace {
 
@@ -42,6 +44,15 @@ __device__ __forceinline__ double f_of(double veff, double e2, double E, const G
     // Numerov.h:100: 2. * (effectivePotential - E) * Rp2delta2 * exp(posIndex * twodelta) + delta2p4
     return 2. * (veff - E) * gs.Rp2delta2 * e2 + gs.delta2p4;
 }
+
+// A pointer that reaches device code through a struct or a call (not as a kernel argument) is a generic one to the compiler: flat
+// loads and stores, which count against the LDS counter as well -- `s_waitcnt lgkmcnt(0)` before an LDS-only barrier then waits for
+// global memory.  The assumption below (never LDS, never scratch) lets the address-space inference use global instructions.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define DFTA_ASSUME_GLOBAL(p) __builtin_assume(!__builtin_amdgcn_is_shared(p) && !__builtin_amdgcn_is_private(p))
+#else
+#define DFTA_ASSUME_GLOBAL(p) ((void)0)
+#endif
 
 // ---- table of wave-uniform per-point inputs -----------------------------------------------------------
 // tab[(slot)*N + i] = { V[v][i] + cl[l][i], e2[i] }   (Numerov.h:93: V + l(l+1)/(r r) * 0.5)
@@ -1102,38 +1113,31 @@ struct MatchShared {
     int done0[2], done1[2], quit[2], mp;   // control, double-buffered by batch parity (written by the helper in iteration b, read after its barrier)
 };
 
-__global__ __launch_bounds__(128) void k_match(const double2* __restrict__ tab, const int* __restrict__ trial_slot,
-                                               const double* __restrict__ Earr, const int* __restrict__ startArr,
-                                               const double* __restrict__ usArr, const double* __restrict__ us1Arr,
-                                               const int* __restrict__ larr, double zero_l0, double zero_l1, double zero_l2,
-                                               double zero_l3, GridScalars gs, const double2* __restrict__ bounds, int bstride,
-                                               double* __restrict__ Psi, double* __restrict__ Q, int* __restrict__ matchPoint)
+// The solve for ONE trial by a workgroup of NT threads: wave 0 integrates, wave 1 helps, further waves (the device-side level search of
+// persist.inc runs this with the 320 threads of a sweep workgroup) only keep the barriers company.  Returns the match point to every thread.
+template <int NT>
+__device__ __forceinline__ int match_solve(MatchShared& sh, const double2* __restrict__ T, const double E, const int steps, const double us0, const double us10,
+                                           const double zero1, const GridScalars& gs, const double2* __restrict__ bounds_slot /* the slot's bounds, or null */,
+                                           double* __restrict__ P, double* __restrict__ Qt)
 {
-    __shared__ MatchShared sh;
-    const int t = blockIdx.x;
+    DFTA_ASSUME_GLOBAL(T);
+    DFTA_ASSUME_GLOBAL(P);
+    DFTA_ASSUME_GLOBAL(Qt);
+    if (bounds_slot) DFTA_ASSUME_GLOBAL(bounds_slot);
     const int lane = threadIdx.x & 63;
-    const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // 0: integrator, 1: helper
+    const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // 0: integrator, 1: helper, 2..: idle
     const int N = gs.N;
-    const int slot = trial_slot[t];
-    const double2* __restrict__ T = tab + (size_t)slot * N;
-    double* __restrict__ P = Psi + (size_t)t * N;
-    double* __restrict__ Qt = Q + (size_t)t * N;
-    const double E = Earr[t];
-    const int steps = startArr[t];
-    if (steps < 0) return;               // frozen job (levels.hip): Psi of its last solve stands
-    const int l = larr[t];
-    const double zero1 = l == 0 ? zero_l0 : (l == 1 ? zero_l1 : (l == 2 ? zero_l2 : zero_l3));
     const double R2 = 2. * gs.Rp2delta2;
     const double d2p4 = gs.delta2p4;
 
     // zero beyond the cut-off (Numerov.h:427-428)
-    for (int i = steps + 1 + (int)threadIdx.x; i < N; i += 128) P[i] = 0;
+    for (int i = steps + 1 + (int)threadIdx.x; i < N; i += NT) P[i] = 0;
 
     // may the division use the refined reciprocal?  (same range argument as in the sweeps: d in (0.5, 1.5) from the
     // slot bounds, |w| checked every 16 steps with 16 steps of margin)
     bool fast = false;
-    if (bounds) {
-        const double2 bd = bounds[(size_t)slot * bstride];
+    if (bounds_slot) {
+        const double2 bd = bounds_slot[0];
         fast = (bd.x + fabs(E) * bd.y + d2p4 < 6.0);
     }
     // batch b: inward nodes i0(b) - k, outward nodes j0(b) + k, k = 0 .. 63
@@ -1172,8 +1176,8 @@ __global__ __launch_bounds__(128) void k_match(const double2* __restrict__ tab, 
         if (lane == 0) {
             const double2 ts = T[steps];
             const double2 t1 = T[steps - 1];
-            const double us = usArr[t];
-            u = us1Arr[t];
+            const double us = us0;
+            u = us10;
             P[steps] = us;
             P[steps - 1] = u;
             fprev = f_of(ts.x, ts.y, E, gs);
@@ -1258,9 +1262,15 @@ __global__ __launch_bounds__(128) void k_match(const double2* __restrict__ tab, 
             PIPE_BARRIER();      // LDS only: the helper's stores to Psi / the scratch stay in flight
             if (sh.quit[b & 1]) break;
         }
+    } else if (role >= 2) {
+        // ---------------- not needed: the same barriers as the two working waves
+        for (int b = 0;; ++b) {
+            PIPE_BARRIER();
+            if (sh.quit[b & 1]) break;
+        }
     } else {
         // ---------------- helper: drains batch b - 1, produces batch b + 1 while the integrator works on batch b
-        double ulast = us1Arr[t];            // Psi at the node above the first one of the batch being drained
+        double ulast = us10;            // Psi at the node above the first one of the batch being drained
         int found = (i00 < 1) ? 1 : 0, mp = 2;
         bool d1 = false;
         for (int b = 0;; ++b) {
@@ -1317,14 +1327,33 @@ __global__ __launch_bounds__(128) void k_match(const double2* __restrict__ tab, 
     // already overwritten Psi[1] (Numerov.h:475) before the division at Numerov.h:497
     const double factor = sol / (mp >= 2 ? P[mp] : zero1);
     __syncthreads();
-    for (int k = lane128; k <= steps; k += 128) {
+    for (int k = lane128; k <= steps; k += NT) {
         double v;
         if (k < mp) v = (k == 0) ? 0.0 : Qt[k];
         else if (k == mp) v = sol;
         else v = P[k] * factor;
         P[k] = v;
     }
-    if (lane128 == 0) matchPoint[t] = mp;
+    return mp;
+}
+
+__global__ __launch_bounds__(128) void k_match(const double2* __restrict__ tab, const int* __restrict__ trial_slot,
+                                               const double* __restrict__ Earr, const int* __restrict__ startArr,
+                                               const double* __restrict__ usArr, const double* __restrict__ us1Arr,
+                                               const int* __restrict__ larr, double zero_l0, double zero_l1, double zero_l2,
+                                               double zero_l3, GridScalars gs, const double2* __restrict__ bounds, int bstride,
+                                               double* __restrict__ Psi, double* __restrict__ Q, int* __restrict__ matchPoint)
+{
+    __shared__ MatchShared sh;
+    const int t = blockIdx.x;
+    const int steps = startArr[t];
+    if (steps < 0) return;               // frozen job (levels.hip): Psi of its last solve stands
+    const int slot = trial_slot[t];
+    const int l = larr[t];
+    const double zero1 = l == 0 ? zero_l0 : (l == 1 ? zero_l1 : (l == 2 ? zero_l2 : zero_l3));
+    const int mp = match_solve<128>(sh, tab + (size_t)slot * gs.N, Earr[t], steps, usArr[t], us1Arr[t], zero1, gs,
+                                    bounds ? bounds + (size_t)slot * bstride : nullptr, Psi + (size_t)t * gs.N, Q + (size_t)t * gs.N);
+    if (threadIdx.x == 0) matchPoint[t] = mp;
 }
 
 // ---- uniform grid (Numerov.h:16-70 and the IsUniform() branches of Numerov.h:272-504) -------------------------------------
@@ -1583,7 +1612,149 @@ void host_boundary(const dfta_grid* g, double E, int* start, double* us, double*
     *us1 = far(static_cast<int>(maxIndex) - 1);
 }
 
+
+#include "levels_device.inc"
+#include "persist.inc"
+
 }  // namespace
+
+// ---- device-side level search (persist.inc): buffers and launch ------------------------------------------------------------------
+void dfta_persist_destroy(dfta_persist_buffers* pb)
+{
+    if (!pb) return;
+    for (void* q : {(void*)pb->d_ctl, (void*)pb->E, (void*)pb->us, (void*)pb->us1, (void*)pb->u0, (void*)pb->phi, (void*)pb->limit, (void*)pb->start,
+                    (void*)pb->count, (void*)pb->istop, (void*)pb->trip, (void*)pb->blk, (void*)pb->candP, (void*)pb->candQ}) if (q) (void)hipFree(q);
+    *pb = dfta_persist_buffers();
+}
+
+int dfta_persist_create(dfta_ctx* ctx, const dfta_grid* g, int nlive_cap, dfta_persist_buffers* pb)
+{
+    dfta_persist_destroy(pb);
+    int nblocks = std::min(ctx->num_cu, kPersistMaxBlocks);
+    if (const char* e = dfta_knob("LEVELS_PERSIST_BLOCKS")) nblocks = std::max(2, std::min(atoi(e), nblocks));     // measurements
+    pb->nblocks = nblocks;
+    pb->tmax = 64 * nblocks;                       // a level never has more trials in a round than the machine has lanes
+    pb->nlive_cap = std::min(nlive_cap, kPersistMaxJobs);
+    pb->trace_cap = 4096;
+    const size_t nt = (size_t)pb->nlive_cap * pb->tmax;
+    pb->ctl_bytes = sizeof(PersistCtl) + sizeof(unsigned long long) * kPersistMaxBlocks + sizeof(PersistJob) * kPersistMaxJobs;
+    hipError_t e = hipMalloc(&pb->d_ctl, pb->ctl_bytes + sizeof(unsigned long long) * 4 * pb->trace_cap);
+    auto alloc = [&](auto& ptr, size_t count) { if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&ptr), sizeof(*ptr) * count); };
+    alloc(pb->E, nt); alloc(pb->us, nt); alloc(pb->us1, nt); alloc(pb->u0, nt); alloc(pb->phi, nt);
+    alloc(pb->limit, nt); alloc(pb->start, nt); alloc(pb->count, nt); alloc(pb->istop, nt); alloc(pb->trip, nt);
+    alloc(pb->blk, (size_t)3 * kPersistMaxBlocks);
+    // speculative matches of the last round's candidate eigenvalues: a wavefunction and a scratch vector per workgroup (0.5 GB at 131 073 nodes)
+    if ((size_t)nblocks * g->N * 16 <= ((size_t)2 << 30) && dfta_knob("LEVELS_PERSIST_NOCAND") == nullptr) { alloc(pb->candP, (size_t)nblocks * g->N); alloc(pb->candQ, (size_t)nblocks * g->N); }
+    if (e == hipSuccess) e = hipMemset(pb->count, 0, sizeof(int) * nt);
+    if (e == hipSuccess) e = hipMemset(pb->u0, 0, sizeof(double) * nt);
+    if (e == hipSuccess) e = hipMemset(pb->trip, 0, sizeof(int) * nt);
+    if (e != hipSuccess) {
+        snprintf(ctx->err, sizeof(ctx->err), "device-side level search: %s", hipGetErrorString(e));
+        dfta_persist_destroy(pb);
+        return DFTA_ERR_HIP;
+    }
+    return DFTA_OK;
+}
+
+// Launches the search of the live levels `live` (host, indices into d_jobs, whose records carry phase = first bisection, tbase = position
+// in `live` x pb->tmax).  *aborted = 1: a worker was lost (time-out) -- nothing is valid, the caller repeats the solve with host rounds.
+int dfta_launch_levels_persist(dfta_ctx* ctx, const dfta_grid* g, dfta_persist_buffers* pb, dfta::Job* d_jobs, const int* live, int nlive,
+                               const double2* d_tab, const double2* d_bounds, double* d_Psi, double* d_Q, int* d_jstart_keep,
+                               unsigned long long* d_counters, bool stats, int nopredict, int integ_rule, const double* tuning /* noise rel, abs, secant, kappa */,
+                               int fixed_point, int* rounds, int* aborted, std::vector<unsigned long long>* trace_out, const int* share)
+{
+    *aborted = 0;
+    if (nlive < 1 || nlive > pb->nlive_cap || g->uniform) return DFTA_ERR_INVALID;
+    const int nblocks = pb->nblocks;
+    const int base = nblocks / nlive;
+    if (base < 2) return DFTA_ERR_INVALID;
+    hipStream_t st = ctx->stream;
+    {   // this translation unit's copies of the prediction constants (levels_device.inc)
+        static double last[4] = {-1, -1, -1, -1};
+        static int last_fp = -1;
+        if (memcmp(last, tuning, sizeof(last)) != 0 || last_fp != fixed_point) {
+            DFTA_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(g_noise_rel), &tuning[0], sizeof(double)));
+            DFTA_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(g_noise_abs), &tuning[1], sizeof(double)));
+            DFTA_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(g_secant_noise), &tuning[2], sizeof(double)));
+            DFTA_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(g_secant_kappa), &tuning[3], sizeof(double)));
+            DFTA_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(g_fixed_point), &fixed_point, sizeof(int)));
+            memcpy(last, tuning, sizeof(last));
+            last_fp = fixed_point;
+        }
+    }
+    // control block: pool, counters, mailboxes (the first workgroup of every level plans its first round), the levels' workgroups
+    std::vector<unsigned char>& hb = pb->h_stage;
+    hb.assign(pb->ctl_bytes, 0);
+    PersistCtl* hc = reinterpret_cast<PersistCtl*>(hb.data());
+    unsigned long long* hm = reinterpret_cast<unsigned long long*>(hb.data() + sizeof(PersistCtl));
+    PersistJob* hj = reinterpret_cast<PersistJob*>(hb.data() + sizeof(PersistCtl) + sizeof(unsigned long long) * kPersistMaxBlocks);
+    hc->live = (unsigned)nlive;
+    int next = 0;
+    for (int k = 0; k < nlive; ++k) {
+        const int mine = share ? std::max(2, std::min(share[k], base)) : base;      // (a level never starts with more than an equal share)
+        hj[k].job = live[k];
+        hj[k].base = mine;
+        hj[k].nown = mine;
+        for (int q = 0; q < mine; ++q) hj[k].blocks[q] = static_cast<unsigned short>(next + q);
+        hm[next] = persist_msg(kCmdPlan, k, 0);
+        next += mine;
+    }
+    for (int q = next; q < nblocks; ++q) hc->pool[q >> 6] |= 1ull << (q & 63);
+    unsigned char* dctl = static_cast<unsigned char*>(pb->d_ctl);
+    DFTA_HIP(ctx, hipMemcpyAsync(dctl, hb.data(), pb->ctl_bytes, hipMemcpyHostToDevice, st));
+
+    SweepArgs a;
+    a.slot_l = nullptr;
+    a.phi = pb->phi; a.istop = pb->istop;
+    a.kind = DFTA_SWEEP_COUNT; a.blk_kind = nullptr; a.bounds = d_bounds; a.bstride = dfta_bounds_stride(g);
+    a.tab = d_tab; a.blk_slot = pb->blk; a.blk_first = pb->blk + kPersistMaxBlocks; a.blk_cnt = pb->blk + 2 * kPersistMaxBlocks;
+    a.E = pb->E; a.limit = pb->limit; a.start = pb->start; a.us = pb->us; a.us1 = pb->us1; a.count = pb->count; a.u0 = pb->u0;
+    a.trip = stats ? pb->trip : nullptr; a.total_trips = stats ? d_counters + 1 : nullptr;
+    PersistArgs pa;
+    pa.jobs = d_jobs;
+    pa.ctl = reinterpret_cast<PersistCtl*>(dctl);
+    pa.mbox = reinterpret_cast<unsigned long long*>(dctl + sizeof(PersistCtl));
+    pa.pj = reinterpret_cast<PersistJob*>(dctl + sizeof(PersistCtl) + sizeof(unsigned long long) * kPersistMaxBlocks);
+    pa.r = g->d_r;
+    pa.nblocks = nblocks;
+    pa.nopredict = nopredict;
+    pa.timeout_ticks = static_cast<long long>(100e6 * (3.0 + 4.0 * g->N / 131072.0));      // wall clock at 100 MHz
+    if (const char* e = dfta_knob("LEVELS_PERSIST_TIMEOUT_MS")) pa.timeout_ticks = static_cast<long long>(1e5 * atof(e));
+    pa.E = pb->E; pa.us = pb->us; pa.us1 = pb->us1; pa.limit = pb->limit; pa.start = pb->start;
+    pa.blk_slot = pb->blk; pa.blk_first = pb->blk + kPersistMaxBlocks; pa.blk_cnt = pb->blk + 2 * kPersistMaxBlocks;
+    pa.Psi = d_Psi; pa.Q = d_Q; pa.jstart_keep = d_jstart_keep;
+    pa.candP = pb->candP; pa.candQ = pb->candQ;
+    pa.eh = g->d_eh; pa.cnst = g->d_cnst;
+    for (int q = 0; q < 4; ++q) pa.zero1[q] = g->zero1[q];
+    pa.step = 1.0;
+    pa.rule = integ_rule;
+    pa.issued = d_counters;
+    pa.trace = trace_out ? reinterpret_cast<unsigned long long*>(dctl + pb->ctl_bytes) : nullptr;
+    pa.trace_cap = (unsigned)pb->trace_cap;
+    GridScalars gs = scalars_of(g);
+    // the workers wait for each other: co-residency is the launch's business (one workgroup per compute unit: 140 KB of LDS).  Under a
+    // profiler the launch is an ordinary one (rocprofiler-sdk 7.2 crashes in an exit handler after a cooperative launch, see poisson.hip)
+    const bool plain = getenv("ROCP_TOOL_LIBRARIES") != nullptr || dfta_knob("LEVELS_PERSIST_PLAIN_LAUNCH") != nullptr;
+    if (plain) {
+        hipLaunchKernelGGL(k_levels_persist, dim3(nblocks), dim3(kPipeThreads), 0, st, a, gs, pa);
+        DFTA_CHECK_LAUNCH(ctx);
+    } else {
+        void* args[] = {&a, &gs, &pa};
+        const hipError_t e = hipLaunchCooperativeKernel(reinterpret_cast<const void*>(k_levels_persist), dim3(nblocks), dim3(kPipeThreads), args, 0, st);
+        if (e != hipSuccess) { (void)hipGetLastError(); *aborted = 1; return DFTA_OK; }      // not co-resident: host rounds
+    }
+    PersistCtl out;
+    DFTA_HIP(ctx, hipMemcpyAsync(&out, dctl, sizeof(out), hipMemcpyDeviceToHost, st));
+    DFTA_HIP(ctx, hipStreamSynchronize(st));
+    if (out.abort || out.live != 0) { *aborted = 1; return DFTA_OK; }
+    if (rounds) *rounds = (int)out.max_rounds;
+    if (trace_out) {
+        const unsigned int n = std::min(out.trace_n, (unsigned)pb->trace_cap);
+        trace_out->resize((size_t)4 * n);
+        if (n) DFTA_HIP(ctx, hipMemcpy(trace_out->data(), dctl + pb->ctl_bytes, sizeof(unsigned long long) * 4 * n, hipMemcpyDeviceToHost));
+    }
+    return DFTA_OK;
+}
 
 // per slot: [0] the fast-division bounds, [1 ..] {min, max} of veff per block of kPipeChunk points, [stride-1] the bounds over
 // i >= kTinyFrom (series reciprocal)
