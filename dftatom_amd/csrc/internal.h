@@ -36,6 +36,12 @@ struct dfta_persist_buffers {
     double *candP = nullptr, *candQ = nullptr;     // per workgroup: wavefunction + scratch of a speculative match (null: none)
     int* blk = nullptr;            // per workgroup: table slot, first trial, trial count of its running block
     int nblocks = 0, tmax = 0, nlive_cap = 0, trace_cap = 0;
+    // $DFTA_DEBUG knobs, read when the buffers are made (as every other knob of a solver)
+    int fault_block = -1;          // FAULT_PERSIST_WORKER: this workgroup drops its first block (tests)
+    double timeout_ms = 0;         // LEVELS_PERSIST_TIMEOUT_MS (0: from the grid size)
+    bool plain_launch = false;     // LEVELS_PERSIST_PLAIN_LAUNCH: no cooperative launch
+    bool equal_shares = false;     // LEVELS_PERSIST_EQUAL: node-less levels keep their whole share
+    bool want_trace = false;       // LEVELS_PERSIST_TRACE
     std::vector<unsigned char> h_stage;
 };
 int dfta_persist_create(dfta_ctx* ctx, const dfta_grid* g, int nlive_cap, dfta_persist_buffers* pb);

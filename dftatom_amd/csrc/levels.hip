@@ -988,12 +988,12 @@ int LevelSolver::run(const double* dV, const double* job_bottom, int run_mode, d
         DFTA_HIP(ctx, hipMemsetAsync(d_jstart_keep, 0xff, sizeof(int) * njobs, st));      // -1: frozen (the live levels write their cut-off index)
         if (stats) DFTA_HIP(ctx, hipEventRecord(ev[0], st));
         int aborted = 0;
-        const bool want_trace = dfta_knob("LEVELS_PERSIST_TRACE") != nullptr;
+        const bool want_trace = pb.want_trace;
         // A level without nodes has no second bisection (walk_job takes it without a sweep): a third of the search less, so half of its equal
         // share goes to the pool, from which the levels whose phases need one decision more than their trees hold take deeper ones
         std::vector<int> share(plive.size());
         const int equal = pb.nblocks / (int)plive.size();
-        const bool float_shares = dfta_knob("LEVELS_PERSIST_EQUAL") == nullptr && equal >= 8;
+        const bool float_shares = !pb.equal_shares && equal >= 8;
         for (size_t q = 0; q < plive.size(); ++q) share[q] = (float_shares && jobs[plive[q]].nodes == 0) ? equal - equal / 2 : equal;
         rc = dfta_launch_levels_persist(ctx, g, &pb, d_jobs, plive.data(), (int)plive.size(), d_tab, d_bounds, d_Psi, d_Q, d_jstart_keep, d_counters, stats != nullptr,
                                         use_prediction ? 0 : 1, integ_rule, tuning, fixed_point, &persist_rounds, &aborted, want_trace ? &persist_trace : nullptr, share.data());

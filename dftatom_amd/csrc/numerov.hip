@@ -1636,6 +1636,11 @@ int dfta_persist_create(dfta_ctx* ctx, const dfta_grid* g, int nlive_cap, dfta_p
     pb->tmax = 64 * nblocks;                       // a level never has more trials in a round than the machine has lanes
     pb->nlive_cap = std::min(nlive_cap, kPersistMaxJobs);
     pb->trace_cap = 4096;
+    pb->fault_block = dfta_knob("FAULT_PERSIST_WORKER") ? 1 : -1;
+    pb->timeout_ms = dfta_knob("LEVELS_PERSIST_TIMEOUT_MS") ? atof(dfta_knob("LEVELS_PERSIST_TIMEOUT_MS")) : 0.0;
+    pb->plain_launch = dfta_knob("LEVELS_PERSIST_PLAIN_LAUNCH") != nullptr;
+    pb->equal_shares = dfta_knob("LEVELS_PERSIST_EQUAL") != nullptr;
+    pb->want_trace = dfta_knob("LEVELS_PERSIST_TRACE") != nullptr;
     const size_t nt = (size_t)pb->nlive_cap * pb->tmax;
     pb->ctl_bytes = sizeof(PersistCtl) + sizeof(unsigned long long) * kPersistMaxBlocks + sizeof(PersistJob) * kPersistMaxJobs;
     hipError_t e = hipMalloc(&pb->d_ctl, pb->ctl_bytes + sizeof(unsigned long long) * 4 * pb->trace_cap);
@@ -1643,8 +1648,8 @@ int dfta_persist_create(dfta_ctx* ctx, const dfta_grid* g, int nlive_cap, dfta_p
     alloc(pb->E, nt); alloc(pb->us, nt); alloc(pb->us1, nt); alloc(pb->u0, nt); alloc(pb->phi, nt);
     alloc(pb->limit, nt); alloc(pb->start, nt); alloc(pb->count, nt); alloc(pb->istop, nt); alloc(pb->trip, nt);
     alloc(pb->blk, (size_t)3 * kPersistMaxBlocks);
-    // speculative matches of the last round's candidate eigenvalues: a wavefunction and a scratch vector per workgroup (0.5 GB at 131 073 nodes)
-    if ((size_t)nblocks * g->N * 16 <= ((size_t)2 << 30) && dfta_knob("LEVELS_PERSIST_NOCAND") == nullptr) { alloc(pb->candP, (size_t)nblocks * g->N); alloc(pb->candQ, (size_t)nblocks * g->N); }
+    // speculative matches of the last round's candidate eigenvalues: a wavefunction and a scratch vector per workgroup (0.5 GB at 131 073 nodes, 4.3 GB at 1 048 577)
+    if ((size_t)nblocks * g->N * 16 <= ((size_t)8 << 30) && dfta_knob("LEVELS_PERSIST_NOCAND") == nullptr) { alloc(pb->candP, (size_t)nblocks * g->N); alloc(pb->candQ, (size_t)nblocks * g->N); }
     if (e == hipSuccess) e = hipMemset(pb->count, 0, sizeof(int) * nt);
     if (e == hipSuccess) e = hipMemset(pb->u0, 0, sizeof(double) * nt);
     if (e == hipSuccess) e = hipMemset(pb->trip, 0, sizeof(int) * nt);
@@ -1669,17 +1674,18 @@ int dfta_launch_levels_persist(dfta_ctx* ctx, const dfta_grid* g, dfta_persist_b
     const int base = nblocks / nlive;
     if (base < 2) return DFTA_ERR_INVALID;
     hipStream_t st = ctx->stream;
-    {   // this translation unit's copies of the prediction constants (levels_device.inc)
-        static double last[4] = {-1, -1, -1, -1};
-        static int last_fp = -1;
-        if (memcmp(last, tuning, sizeof(last)) != 0 || last_fp != fixed_point) {
+    {   // this translation unit's copies of the prediction constants (levels_device.inc), per device
+        static double last[16][4];
+        static int last_fp[16];
+        static bool have[16];
+        const int dv = ctx->device >= 0 && ctx->device < 16 ? ctx->device : -1;
+        if (dv < 0 || !have[dv] || memcmp(last[dv], tuning, sizeof(last[dv])) != 0 || last_fp[dv] != fixed_point) {
             DFTA_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(g_noise_rel), &tuning[0], sizeof(double)));
             DFTA_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(g_noise_abs), &tuning[1], sizeof(double)));
             DFTA_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(g_secant_noise), &tuning[2], sizeof(double)));
             DFTA_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(g_secant_kappa), &tuning[3], sizeof(double)));
             DFTA_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(g_fixed_point), &fixed_point, sizeof(int)));
-            memcpy(last, tuning, sizeof(last));
-            last_fp = fixed_point;
+            if (dv >= 0) { memcpy(last[dv], tuning, sizeof(last[dv])); last_fp[dv] = fixed_point; have[dv] = true; }
         }
     }
     // control block: pool, counters, mailboxes (the first workgroup of every level plans its first round), the levels' workgroups
@@ -1719,7 +1725,7 @@ int dfta_launch_levels_persist(dfta_ctx* ctx, const dfta_grid* g, dfta_persist_b
     pa.nblocks = nblocks;
     pa.nopredict = nopredict;
     pa.timeout_ticks = static_cast<long long>(100e6 * (3.0 + 4.0 * g->N / 131072.0));      // wall clock at 100 MHz
-    if (const char* e = dfta_knob("LEVELS_PERSIST_TIMEOUT_MS")) pa.timeout_ticks = static_cast<long long>(1e5 * atof(e));
+    if (pb->timeout_ms > 0) pa.timeout_ticks = static_cast<long long>(1e5 * pb->timeout_ms);
     pa.E = pb->E; pa.us = pb->us; pa.us1 = pb->us1; pa.limit = pb->limit; pa.start = pb->start;
     pa.blk_slot = pb->blk; pa.blk_first = pb->blk + kPersistMaxBlocks; pa.blk_cnt = pb->blk + 2 * kPersistMaxBlocks;
     pa.Psi = d_Psi; pa.Q = d_Q; pa.jstart_keep = d_jstart_keep;
@@ -1731,10 +1737,11 @@ int dfta_launch_levels_persist(dfta_ctx* ctx, const dfta_grid* g, dfta_persist_b
     pa.issued = d_counters;
     pa.trace = trace_out ? reinterpret_cast<unsigned long long*>(dctl + pb->ctl_bytes) : nullptr;
     pa.trace_cap = (unsigned)pb->trace_cap;
+    pa.fault_block = pb->fault_block;
     GridScalars gs = scalars_of(g);
     // the workers wait for each other: co-residency is the launch's business (one workgroup per compute unit: 140 KB of LDS).  Under a
     // profiler the launch is an ordinary one (rocprofiler-sdk 7.2 crashes in an exit handler after a cooperative launch, see poisson.hip)
-    const bool plain = getenv("ROCP_TOOL_LIBRARIES") != nullptr || dfta_knob("LEVELS_PERSIST_PLAIN_LAUNCH") != nullptr;
+    const bool plain = getenv("ROCP_TOOL_LIBRARIES") != nullptr || pb->plain_launch;
     if (plain) {
         hipLaunchKernelGGL(k_levels_persist, dim3(nblocks), dim3(kPipeThreads), 0, st, a, gs, pa);
         DFTA_CHECK_LAUNCH(ctx);

@@ -366,7 +366,7 @@ def test_l20_batch_layouts_agree(ctx, grid20):
         st1 = one.step()
     ref_e = one.energies()[0][0].as_list()
     ref_lv = [one.levels(0, sp)["E"].copy() for sp in range(2)]
-    assert int(st1.levels_layout) == 1
+    assert int(st1.levels_layout) == 5               # one atom: the device-side search (persist.inc)
     one.close()
     b = D.Scf(ctx, grid20, [86] * 8, lsda=True)
     for _ in range(2):
