@@ -218,6 +218,75 @@ def counter_rate(d, kernel, workload):
 
 
 # ---------------------------------------------------------------------------------------------------------------
+# what the tests assert for the mode a number was measured in (so that a reader of the line sees what kind of number it is)
+# ---------------------------------------------------------------------------------------------------------------
+def parity_gates(poisson_mode, sweep_mode):
+    """poisson_mode / sweep_mode: 'exact', 'tolerance', 'adaptive'.  Values = the gates of tests/ against the compiled reference's goldens
+    (test_gpu_parity / test_gpu_configs: exact; test_gpu_scan, test_gpu_resident, test_frontend::test_readme_tables_in_the_opt_in_modes: opt-in)."""
+    exact_sweeps = sweep_mode == "exact"
+    g = {"node_counts": "bit-exact (counts, cut-offs, loop trips = the compiled reference's)" if exact_sweeps else
+                        "exact outside the round-off band: decisions identical while the interval is wider than 1.5e-10|E|+2e-9 Ha",
+         "per_level_dE": "2e-12 Ha (the reference's midpoints, same sweep counts)" if exact_sweeps else "6e-11|E|+6e-10 Ha vs the exact path (same V)",
+         "converged_dE": "README six decimals (Ar 5, Rn 15 eigenvalues); 2e-7 Ha+1e-10|E| vs the reference's last steps",
+         "etotal_rel": 1e-9 if (exact_sweeps and poisson_mode == "exact") else 2e-9,
+         "vcycles_per_solve": 100 if poisson_mode != "adaptive" else "6-8 (stops on the round-off floor; the reference runs 100)"}
+    if poisson_mode != "exact":
+        g["poisson_U"] = "2e-9 Z vs the exact solve"
+    return g
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# BASELINE config 4: the periodic-table sweep, sharded by atom (dftatom_amd/sweep.py), one all_gather of the records
+# ---------------------------------------------------------------------------------------------------------------
+def periodic_table(D, ctx, grid, levels, world, rank, dist, torch, shared, zmax, max_steps=100):
+    """every rank advances its partition_atoms shard of Z = 1..zmax to the reference's stop test (or its 100-step cap), then ONE all_gather
+    of the fixed-size records (RCCL; gloo in the shared-GPU test mode).  Returns (on every rank) the whole-job wall time = max over ranks."""
+    from dftatom_amd import sweep
+    Zs = list(range(1, zmax + 1))
+    shards = sweep.partition_atoms(Zs, world)
+    mine = shards[rank]
+    cap = max(len(sh) for sh in shards)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.time()
+    steps = 0
+    if mine:
+        scf = D.Scf(ctx, grid, mine, lsda=False)
+        while steps < max_steps:
+            scf.step(want_stats=False)
+            steps += 1
+            _, fin = scf.energies()
+            if fin.all():
+                break
+    block = torch.zeros((cap, D.RECORD_DOUBLES), dtype=torch.float64, device="cuda")
+    if mine:
+        scf.records_into(block.data_ptr())
+    ctx.synchronize()
+    t_mine = time.time() - t0
+    table = sweep.gather_records(block.cpu() if shared else block, dist if world > 1 else None)
+    torch.cuda.synchronize()
+    t_all = time.time() - t0
+    if mine:
+        scf.close()
+    times = [t_mine]
+    if world > 1:
+        tt = torch.tensor([t_mine, t_all], dtype=torch.float64, device="cpu" if shared else "cuda")
+        allt = [torch.empty_like(tt) for _ in range(world)]
+        dist.all_gather(allt, tt)
+        times = [float(x[0]) for x in allt]
+        t_all = max(float(x[1]) for x in allt)
+    rows = [sweep.record_fields(table[z]) for z in sorted(table)]
+    return {"workload": "Z = 1..%d LDA @ %d levels (%d pts), atoms sharded over %d rank(s) by predicted shard time, every atom to the "
+                        "reference's stop test or its 100-step cap, one all_gather of %d doubles per atom" % (zmax, levels, grid.N, world, D.RECORD_DOUBLES),
+            "seconds": t_all, "shard_seconds": times, "slowest_rank": int(max(range(len(times)), key=lambda k: times[k])),
+            "atoms_per_rank": [len(sh) for sh in shards], "atoms": len(rows), "finished": int(sum(r["finished"] for r in rows)),
+            "atom_steps": int(sum(r["steps"] for r in rows)), "mode": "exact kernels (default path)",
+            "etotal_rn": next((r["Etotal"] for r in rows if r["Z"] == 86), None),
+            "measured": "this run, %d GPU(s)" % world}
+
+
+# ---------------------------------------------------------------------------------------------------------------
 # one measured workload
 # ---------------------------------------------------------------------------------------------------------------
 def run_workload(D, ctx, grid, levels, atoms, lsda, steps, warmup, tree_depth, barrier, torch, after_steps=None, poisson_mode=None, sweep_mode=None):
@@ -248,8 +317,10 @@ def run_workload(D, ctx, grid, levels, atoms, lsda, steps, warmup, tree_depth, b
     tot["tree_depth"] = scf.tree_depth
     tot["levels_layout"] = {0: "one block of 2^depth trials per job", 1: "latency mode (slots re-allotted every round)",
                             2: "packed rounds (depth chosen per round, floor = tree depth)", 3: "latency mode over the live jobs",
-                            4: "scan sweeps (tolerance mode: one workgroup per level, no rounds)"}.get(int(st.levels_layout), "?")
+                            4: "scan sweeps (tolerance mode: one workgroup per level, no rounds)",
+                            5: "device-side exact search (one persistent kernel, every level at its own pace)"}.get(int(st.levels_layout), "?")
     tot["scan"] = int(st.levels_layout) == 4
+    tot["persist"] = int(st.levels_layout) == 5
     tot["poisson_G"] = scf.poisson_info()[0]
     tot["energies"] = scf.energies()[0][0].as_list()
     return scf, tot
@@ -261,9 +332,10 @@ def kernel_figures(tot, levels, N, atoms, workload=None):
     make it exceed what HBM moves); `hbm_GBps_counters` = rocprofv3 FETCH/WRITE bytes of the committed profile of `workload` / time."""
     forced = os.environ.get("DFTA_SWEEP_KERNEL", "")
     piped = forced == "pipe" or (forced != "fused" and tot["trials_per_round"] // 64 <= 768)
-    sname = "k_scan_levels" if tot.get("scan") else ("k_sweep_pipe" if piped else "k_sweep")
+    sname = "k_scan_levels" if tot.get("scan") else ("k_levels_persist" if tot.get("persist") else ("k_sweep_pipe" if piped else "k_sweep"))
     t_sw = tot["ms_sweep_kernels"] * 1e-3
-    launches = max(tot["rounds"], 1)
+    # host rounds: one launch per round; the device-side search: ONE launch per SCF step (sweeps of every round, walk, match, normalisation)
+    launches = max(tot["steps"], 1) if tot.get("persist") else max(tot["rounds"], 1)
     b_issued = NUMEROV_BYTES_PER_POINT * tot["points_traversed"]
     b_ref = NUMEROV_BYTES_PER_POINT * tot["points_reference"]
     block_points = tot["points_traversed"] / 64.0       # lower bound: 64 live lanes in every block
@@ -274,11 +346,15 @@ def kernel_figures(tot, levels, N, atoms, workload=None):
              "frac": b_ref / t_sw / 1e9 / HBM_PEAK_GBS if t_sw else None,
              "bytes_per_launch_issued": b_issued / launches, "bytes_per_launch": b_ref / launches,
              "binding_resource": ("fp64 VALU issue of one compute unit per level (transfer-matrix scan of one trial by 512 lanes, ~150 sweeps back to back)"
-                                  if tot.get("scan") else "fp64 VALU issue of the integrator wave (one block of 64 trials per CU; sequential three-term recurrence)"),
+                                  if tot.get("scan") else
+                                  "fp64 VALU issue of the integrator wave (one block of 64 trials per CU; sequential three-term recurrence), "
+                                  "x the ~7 dependent rounds of a level's three bisections inside the one launch" if tot.get("persist") else
+                                  "fp64 VALU issue of the integrator wave (one block of 64 trials per CU; sequential three-term recurrence)"),
              "valu_issue": {"wave_instr_per_block_point": SWEEP_VALU_PER_BLOCK_POINT, "block_points_per_s": block_points / t_sw if t_sw else None,
                             "ceiling_wave_instr_per_s": VALU_WAVE_INSTR_PER_S,
                             "frac": SWEEP_VALU_PER_BLOCK_POINT * block_points / t_sw / VALU_WAVE_INSTR_PER_S if t_sw else None,
-                            "ns_per_point_per_block": 1e9 * t_sw / (launches * N) if t_sw else None,
+                            "ns_per_point_per_block": 1e9 * t_sw / (max(tot["rounds"], 1) * N) if t_sw else None,
+                            "rounds_per_step": tot["rounds"] / max(tot["steps"], 1),
                             "note": "static instruction count from numerov.hip x measured points; profiles/*_sq_counters.json holds SQ_INSTS_VALU"},
              "note": "8 B per traversed grid point per trial (SURVEY 8d). frac = only the trials on the reference's bisection path (what its "
                      "sequential loop integrates); frac_issued = every trial of the speculative trees. The 64 trials of a block share "
@@ -292,6 +368,8 @@ def kernel_figures(tot, levels, N, atoms, workload=None):
             "unit": "GB/s", "launches": psolves, "avg_launch_ms": tot["ms_poisson"] / psolves,
             "algorithmic_GBps": b_ps / t_ps / 1e9 if t_ps else None, "frac": b_ps / t_ps / 1e9 / HBM_PEAK_GBS if t_ps else None,
             "bytes_per_launch": b_ps / psolves, "vcycles_per_s": tot["vcycles"] / t_ps if t_ps else None,
+            # "a fully fused cycle's compulsory traffic is only 24 N": read S, read and write Phi of the finest level once per V-cycle
+            "frac_compulsory": 24.0 * N * tot["vcycles"] / t_ps / 1e9 / HBM_PEAK_GBS if t_ps else None,
             "workgroups": atoms * tot["poisson_G"],
             "binding_resource": ("latency of the ordered Gauss-Seidel recurrence: %d atom(s) x %d workgroups on 256 CUs; " % (atoms, tot["poisson_G"])) +
                                 ("resident groups keep the finest levels in LDS (one fused 3-sweep pass of 112+C+2 dependent "
@@ -345,7 +423,7 @@ def compact_line(full):
     """the driver's schema keys + roofline (dominant kernel) + cpu_baseline + one flat object per extra workload.  Pure function of the
     full result (tests/test_bench_line.py feeds it a canned one)."""
     sweep_keys = ("kernel", "launches", "avg_launch_ms", "frac", "frac_issued", "bytes_per_launch", "hbm_GBps_counters", "frac_counters")
-    pois_keys = ("kernel", "launches", "avg_launch_ms", "frac", "bytes_per_launch", "vcycles_per_s", "workgroups", "hbm_GBps_counters", "frac_counters")
+    pois_keys = ("kernel", "launches", "avg_launch_ms", "frac", "frac_compulsory", "bytes_per_launch", "vcycles_per_s", "workgroups", "hbm_GBps_counters", "frac_counters")
     out = {k: _r(full[k]) if not isinstance(full[k], (dict, list)) else full[k]
            for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
                      "data", "config") if k in full}
@@ -369,19 +447,34 @@ def compact_line(full):
             if isinstance(c.get(name), dict):
                 out["cpu_baseline"][name + "_value"] = _r(c[name].get("value"))
                 out["cpu_baseline"][name + "_cores"] = c[name].get("cores")
+    if "parity_gates" in full:
+        out["parity_gates"] = full["parity_gates"]
     if "extra" in full:
         ex = {}
         for name, e in full["extra"].items():
+            if name == "periodic_table":
+                ex[name] = {k: (_r(v) if not isinstance(v, list) else [_r(x, 4) for x in v]) for k, v in e.items()
+                            if k in ("seconds", "shard_seconds", "slowest_rank", "atoms_per_rank", "atoms", "finished", "atom_steps", "mode", "measured")}
+                continue
             if "ms_per_step" not in e:
                 ex[name] = {k: _r(v) for k, v in e.items() if not isinstance(v, (dict, list))} or {"see": "side file"}
                 continue
             k2 = e.get("kernels", {})
             ph = e.get("phase_ms_per_step", {})
+            pk = k2.get("poisson", {})
+            pfrac, pcnt = pk.get("frac"), pk.get("frac_counters")
             ex[name] = {"ms_per_step": _r(e["ms_per_step"], 5), "sweeps_per_s": _r(e.get("sweeps_executed_per_s"), 5), "vcycles_per_s": _r(e.get("vcycles_per_s"), 5),
                         "levels_ms": _r(ph.get("levels"), 4), "poisson_ms": _r(ph.get("poisson"), 4),
                         "issued_per_useful": _r(e.get("issued_per_useful"), 3),
-                        "sweep_frac": _r(k2.get("sweep", {}).get("frac"), 3), "poisson_frac": _r(k2.get("poisson", {}).get("frac"), 3),
-                        "poisson_frac_counters": _r(k2.get("poisson", {}).get("frac_counters"), 3)}
+                        "sweep_frac": _r(k2.get("sweep", {}).get("frac"), 3),
+                        # an algorithmic fraction above 1 shows fusion, not bandwidth: never printed without the counter figure next to it
+                        "poisson_frac": _r(pfrac, 3) if (pfrac is None or pfrac <= 1.0 or pcnt is not None) else "withheld (>1 by SURVEY-8d bytes, no counters)",
+                        "poisson_frac_counters": _r(pcnt, 3), "poisson_frac_compulsory": _r(pk.get("frac_compulsory"), 3)}
+            g = e.get("parity_gates")
+            if g:
+                ex[name]["gates"] = {"counts": "exact" if str(g.get("node_counts", "")).startswith("bit-exact") else "exact outside band 1.5e-10|E|+2e-9",
+                                     "dE": "2e-12" if "2e-12" in str(g.get("per_level_dE")) else "6e-11|E|+6e-10", "Etot": g.get("etotal_rel"),
+                                     "vcyc": _r(e.get("vcycles_per_solve"), 3)}
         out["extra"] = ex
     if full.get("full_result"):
         out["full_result"] = full["full_result"]
@@ -429,6 +522,8 @@ def main():
     ap.add_argument("--all-extras", action="store_true", help="also: LSDA in tolerance mode, a 1024-atom batch, the dense-K sweep benchmark")
     ap.add_argument("--no-cpu-all-cores", action="store_true", help="CPU baseline: skip the one-replica-per-physical-core leg")
     ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--no-periodic-table", action="store_true", help="skip BASELINE config 4 (Z = 1..86, sharded by atom over the ranks) after the timed steps")
+    ap.add_argument("--pt-zmax", type=int, default=86, help="last atom of the periodic-table sweep (tests shorten it)")
     args = ap.parse_args()
 
     import torch            # before dftatom_amd: one HIP runtime per process
@@ -512,6 +607,12 @@ def main():
     else:
         ref_all, issued_all, vc_all, exe_all = (float(tot[k]) for k in ("sweeps_reference", "sweeps_issued", "vcycles", "sweeps_reference_executed"))
     scf.close()
+    pt_extra = None
+    if not args.no_periodic_table and not args.no_extras and args.atoms == 1 and not args.lsda and not args.tolerance and not args.scan_sweeps:
+        t_w = time.time()
+        pt_extra = periodic_table(D, ctx, grid, args.levels, world, rank, dist, torch, shared, args.pt_zmax)
+        if rank == 0:
+            sys.stderr.write("bench.py: periodic table: %.1f s\n" % (time.time() - t_w))
 
     if rank == 0:
         ncu, devname = ctx.device_info()
@@ -574,6 +675,7 @@ def main():
             "device": devname, "compute_units": ncu,
             "roofline": roof,
             "kernels": {"sweep": sweep, "poisson": pois},
+            "parity_gates": parity_gates("tolerance" if args.tolerance else "exact", "tolerance" if args.scan_sweeps else "exact"),
         }
         cpu_job = None
         if world == 1 and not args.no_cpu:      # rank 0 at N = 1 only: the other ranks of a larger job would sit at the final barrier
@@ -586,23 +688,26 @@ def main():
             # --all-extras adds LSDA in tolerance mode, the 1024-atom batch and the dense-K sweep benchmark of SURVEY 8d.
             extra = {}
             TOL, SCAN, ADAPT = D.POISSON_TOLERANCE, D.SWEEPS_TOLERANCE, D.POISSON_ADAPTIVE
-            sel = [("rn_lda_scan_sweeps", args.levels, 1, False, 10, 5, None, SCAN, "scan"),
-                   ("rn_lda_both_tolerance_modes", args.levels, 1, False, 10, 5, TOL, SCAN, "scan_tol"),
-                   ("rn_lda_poisson_tolerance", args.levels, 1, False, 10, 5, TOL, None, "tolerance"),
+            # default: one object per BASELINE config that fits one GPU (configs[2] Rn LSDA, configs[4] 1 048 577 nodes x 1 and x 16) and the
+            # opt-in modes of the headline workload; everything else behind --all-extras (the default run stays within two minutes)
+            sel = [("rn_lda_both_tolerance_modes", args.levels, 1, False, 10, 5, TOL, SCAN, "scan_tol"),
                    # DFTA_POISSON_ADAPTIVE: the V-cycles stop on the round-off floor (6 .. 8 per solve) instead of at the reference's cap of 100
-                   ("rn_lda_scan_sweeps_adaptive_vcycles", args.levels, 1, False, 10, 5, ADAPT, SCAN, None),
+                   ("rn_lda_scan_sweeps_adaptive_vcycles", args.levels, 1, False, 10, 5, ADAPT, SCAN, "scan_adaptive"),
                    ("rn_lsda", args.levels, 1, True, 10, 5, None, None, "rn_lsda"),
-                   ("rn_lsda_both_tolerance_modes", args.levels, 1, True, 10, 5, TOL, SCAN, None),
                    ("batch256_lda", args.levels, 256, False, 6, 5, None, None, "batch256"),
-                   ("batch256_lda_scan_sweeps", args.levels, 256, False, 6, 5, None, SCAN, None),
-                   ("batch256_lda_both_tolerance_modes", args.levels, 256, False, 6, 5, TOL, SCAN, None),
-                   ("batch256_lda_scan_sweeps_adaptive_vcycles", args.levels, 256, False, 6, 5, ADAPT, SCAN, None),
-                   ("rn_lsda_l20", 20, 1, True, 6, 6, None, None, None), ("rn_lsda_l20_scan_sweeps", 20, 1, True, 6, 6, None, SCAN, None),
-                   ("rn_lsda_l20_both_tolerance_modes", 20, 1, True, 6, 6, TOL, SCAN, None),
-                   ("rn_lsda_l20_batch16", 20, 16, True, 4, 6, None, None, "l20_batch16"),
-                   ("rn_lsda_l20_batch16_both_tolerance_modes", 20, 16, True, 4, 6, TOL, SCAN, None)]
+                   ("rn_lsda_l20", 20, 1, True, 6, 6, None, None, "l20"),
+                   ("rn_lsda_l20_batch16", 20, 16, True, 4, 6, None, None, "l20_batch16")]
             if args.all_extras:
-                sel += [("rn_lsda_poisson_tolerance", args.levels, 1, True, 10, 5, TOL, None, None),
+                sel += [("batch256_lda_both_tolerance_modes", args.levels, 256, False, 6, 5, TOL, SCAN, "batch256_scan_tol"),
+                        ("rn_lda_scan_sweeps", args.levels, 1, False, 10, 5, None, SCAN, "scan"),
+                        ("rn_lda_poisson_tolerance", args.levels, 1, False, 10, 5, TOL, None, "tolerance"),
+                        ("rn_lsda_both_tolerance_modes", args.levels, 1, True, 10, 5, TOL, SCAN, None),
+                        ("batch256_lda_scan_sweeps", args.levels, 256, False, 6, 5, None, SCAN, "batch256_scan"),
+                        ("batch256_lda_scan_sweeps_adaptive_vcycles", args.levels, 256, False, 6, 5, ADAPT, SCAN, None),
+                        ("rn_lsda_l20_scan_sweeps", 20, 1, True, 6, 6, None, SCAN, None),
+                        ("rn_lsda_l20_both_tolerance_modes", 20, 1, True, 6, 6, TOL, SCAN, "l20_scan_tol"),
+                        ("rn_lsda_l20_batch16_both_tolerance_modes", 20, 16, True, 4, 6, TOL, SCAN, "l20_batch16_scan_tol"),
+                        ("rn_lsda_poisson_tolerance", args.levels, 1, True, 10, 5, TOL, None, None),
                         ("batch1024_lda", args.levels, 1024, False, 4, 2, None, None, None),
                         ("batch1024_lda_scan_sweeps", args.levels, 1024, False, 4, 2, None, SCAN, None)]
             for name, lv, atoms, lsda, st, wu, pm, sm, wl2 in sel:
@@ -611,11 +716,16 @@ def main():
                 else:
                     d2, r2 = GRIDS[lv]
                     g2 = D.Grid(ctx, lv, d2, r2)
+                t_w = time.time()
                 s2, t2 = run_workload(D, ctx, g2, lv, atoms, lsda, st, wu, 0, barrier, torch, poisson_mode=pm, sweep_mode=sm)
                 s2.close()
+                sys.stderr.write("bench.py: extra %s: %.1f s\n" % (name, time.time() - t_w))
                 extra[name] = summarize(t2, lv, g2.N, atoms, lsda, world, d2, r2, wl2 if args.levels == 17 else None)
                 extra[name]["poisson_mode"] = {D.POISSON_TOLERANCE: "tolerance", D.POISSON_ADAPTIVE: "adaptive (tolerance kernels, V-cycles stop on the round-off floor)"}.get(pm, "exact")
                 extra[name]["sweep_mode"] = "tolerance (scan)" if sm == D.SWEEPS_TOLERANCE else "exact"
+                extra[name]["parity_gates"] = parity_gates({D.POISSON_TOLERANCE: "tolerance", D.POISSON_ADAPTIVE: "adaptive"}.get(pm, "exact"),
+                                                           "tolerance" if sm == D.SWEEPS_TOLERANCE else "exact")
+                extra[name]["vcycles_per_solve"] = t2["vcycles"] / max(t2["steps"] * atoms, 1)
                 extra[name]["warmup"] = wu
                 if g2 is not grid:
                     g2.close()
@@ -627,8 +737,12 @@ def main():
                 except Exception as e:                      # the isolated sweep-kernel benchmark must not cost the line
                     extra["dense_k_sweeps"] = {"error": repr(e)}
             out["extra"] = extra
+        if pt_extra is not None:
+            out.setdefault("extra", {})["periodic_table"] = pt_extra
         if cpu_job is not None:
+            t_w = time.time()
             out["cpu_baseline"] = cpu_baseline_finish(cpu_job, not args.no_cpu_all_cores)
+            sys.stderr.write("bench.py: waiting for the CPU legs (+ all-core replicas): %.1f s\n" % (time.time() - t_w))
         if shared:
             out["data"] += " -- SHARED-GPU TEST MODE (all ranks on device 0, gloo): not a measurement"
         out["full_result"] = write_full(out)

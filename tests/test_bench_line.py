@@ -47,6 +47,11 @@ def full_result(bench):
         full["extra"][name] = bench.summarize(canned_tot(atoms, 10), 17, 131073, atoms, False, 1, 1e-4, 50.0, None)
         full["extra"][name]["warmup"] = 5
     full["extra"]["dense_k_sweeps"] = {"K512_count_nodes": {"sweeps": 7680, "note": "q" * 2000}, "error": None}
+    full["parity_gates"] = bench.parity_gates("exact", "exact")
+    full["extra"]["rn_lda_both_tolerance_modes"]["parity_gates"] = bench.parity_gates("tolerance", "tolerance")
+    full["extra"]["rn_lda_both_tolerance_modes"]["vcycles_per_solve"] = 100.0
+    full["extra"]["periodic_table"] = {"workload": "w" * 300, "seconds": 19.0123456, "shard_seconds": [19.0123456], "slowest_rank": 0, "atoms_per_rank": [86],
+                                       "atoms": 86, "finished": 61, "atom_steps": 5721, "mode": "exact kernels (default path)", "measured": "this run, 1 GPU(s)"}
     return full
 
 
@@ -69,9 +74,35 @@ def test_line_is_compact_and_complete():
     assert c["value"] == 573.6 and c["cores"] == 1 and c["kind"] == "port" and c["unit"] == "sweeps/s" and len(c["sample"]) <= 200
     assert c["level_parallel_value"] == 2075.0 and c["all_cores_cores"] == 128
     assert set(d["extra"]) >= {"rn_lsda", "batch256_lda", "rn_lsda_l20_batch16", "rn_lda_scan_sweeps", "rn_lda_both_tolerance_modes"}
-    for e in d["extra"].values():
-        assert all(not isinstance(v, (dict, list)) for v in e.values())       # flat
+    for name, e in d["extra"].items():
+        assert all(not isinstance(v, (dict, list)) for k, v in e.items() if k not in ("gates", "shard_seconds", "atoms_per_rank")), name     # flat
     assert d["extra"]["rn_lsda"]["ms_per_step"] > 0 and d["extra"]["rn_lsda"]["poisson_frac"] > 0
+    # what kind of number a line is: the gates of the mode it was measured in travel with it
+    assert d["parity_gates"]["vcycles_per_solve"] == 100 and d["parity_gates"]["etotal_rel"] == 1e-9 and d["parity_gates"]["node_counts"].startswith("bit-exact")
+    g = d["extra"]["rn_lda_both_tolerance_modes"]["gates"]
+    assert g["counts"].startswith("exact outside band") and g["dE"] == "6e-11|E|+6e-10" and g["Etot"] == 2e-9 and g["vcyc"] == 100.0
+    # BASELINE config 4 on the line: seconds of the whole sweep, the ranks' shard times, atoms per rank
+    pt = d["extra"]["periodic_table"]
+    assert pt["seconds"] == 19.0123 and pt["atoms_per_rank"] == [86] and pt["finished"] == 61 and "workload" not in pt
+
+
+def test_fraction_above_one_is_withheld_without_counters():
+    """batch256's multigrid reads 1.01 of the roofline in SURVEY-8d bytes (every pass counted) -- fusion, not bandwidth.
+    The line prints such a figure only with the counter-based fraction next to it; the compulsory-traffic fraction (24 N per V-cycle) is
+    always there."""
+    import bench
+    full = full_result(bench)
+    e = full["extra"]["batch256_lda"]
+    ratio = e["kernels"]["poisson"]["frac_compulsory"] / e["kernels"]["poisson"]["frac"]
+    assert abs(ratio - 24 * 131073 / 49285736) < 1e-12                  # 24 N of the 376 N of SURVEY 8d
+    e["kernels"]["poisson"]["frac"] = 1.01
+    e["kernels"]["poisson"]["frac_counters"] = None
+    d = json.loads(bench.compact_line(full))
+    assert isinstance(d["extra"]["batch256_lda"]["poisson_frac"], str) and "withheld" in d["extra"]["batch256_lda"]["poisson_frac"]
+    assert 0 < d["extra"]["batch256_lda"]["poisson_frac_compulsory"] < 1
+    e["kernels"]["poisson"]["frac_counters"] = 0.495
+    d = json.loads(bench.compact_line(full))
+    assert d["extra"]["batch256_lda"]["poisson_frac"] == 1.01 and d["extra"]["batch256_lda"]["poisson_frac_counters"] == 0.495
 
 
 def test_line_survives_oversized_optional_parts():

@@ -192,3 +192,35 @@ def test_cli_json_lines(tmp_path):
     assert jt[0]["levels_layout"] == 4 and je[0]["levels_layout"] != 4
     for a, b in zip(jt[:20], je[:20]):
         assert abs(a["Etotal"] - b["Etotal"]) <= 1e-8 * abs(b["Etotal"])
+
+
+# ---- the reference's printed tables through the OPT-IN modes (README.md:30-52, 62-74) ---------------------------------------
+README_AR = ([-113.800134, -10.794172, -8.443439, -0.883384, -0.382330], ["0", "1", "0", "2", "1"],
+             [-525.946200, 524.969813, 231.458124, -1253.131983, -29.242154])
+README_RN = ([-3204.756288, -546.577961, -527.533025, -133.369145, -124.172863, -106.945007, -31.230804, -27.108985, -19.449995, -8.953318,
+              -5.889683, -4.408703, -1.911330, -0.626571, -0.293180], ["0", "1", "0", "2", "1", "0", "3", "2", "1", "0", "4", "3", "2", "5", "4"],
+             [-21861.346900, 21854.672704, 8632.016044, -51966.120394, -381.915254])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", [("--sweeps=tolerance", "--poisson=tolerance"), ("--sweeps=tolerance", "--poisson=adaptive"),
+                                  ("--poisson=tolerance",), ("--sweeps=tolerance",)], ids=["both-tolerance", "scan+adaptive", "poisson-tolerance", "scan-sweeps"])
+@pytest.mark.parametrize("atom", ["Ar", "Rn"])
+def test_readme_tables_in_the_opt_in_modes(atom, mode):
+    """`dftatom_cli 18 14 0.5 25 0.0005 0` and `dftatom_cli 86 17 0.5 50 0.0001 0` with the tolerance modes of the sweeps and of the
+    multigrid, and with the adaptive V-cycle count: every eigenvalue the README prints -- five for Ar, fifteen for Rn -- at its SIX
+    DECIMALS, the node counts, and the five energies to 1e-9 relative + one unit of the last printed digit (the gate of the exact
+    default: tests/test_gpu_configs.py, test_gpu_compat.py; the reference's own builds differ in the sixth decimal of Ekin / Eenuc).
+    The step at which "Finished!" appears -- or does not, within the reference's 100 steps -- is round-off noise in every mode and is
+    not compared: the values of the last printed step are."""
+    args, (want, nodes, energies) = ((18, 14, 0.5, 25, 0.0005, 0), README_AR) if atom == "Ar" else ((86, 17, 0.5, 50, 0.0001, 0), README_RN)
+    r = _run(*args, *mode)
+    assert r.returncode == 0, r.stderr[-1000:]
+    lines = r.stdout.strip().splitlines()
+    last = [ln for ln in lines if ln.startswith("Energy")][-len(want):]
+    got = [float(re.search(r": (\S+) Num", ln).group(1)) for ln in last]
+    assert got == want, [(g, w) for g, w in zip(got, want) if g != w]
+    assert [ln.split("Num nodes: ")[1] for ln in last] == nodes
+    et = [ln for ln in lines if ln.startswith("Etotal")][-1]
+    vals = [float(x) for x in re.findall(r"= (-?\d+\.\d+)", et)]
+    assert all(abs(a - b) <= 1e-9 * abs(b) + 1e-6 for a, b in zip(vals, energies)), (vals, energies)

@@ -100,7 +100,7 @@ def test_bench_two_ranks_control_flow():
         port = s.getsockname()[1]
     env = dict(os.environ, DFTA_BENCH_SHARED_GPU="1")
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                          "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                          "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--pt-zmax", "7"],
                          env=env, capture_output=True, text=True, timeout=600, cwd=root)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
@@ -108,6 +108,11 @@ def test_bench_two_ranks_control_flow():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["value"] > 0
     assert d["config"]["parallelism"] == "replicas x2" and "cpu_baseline" not in d and "roofline" in d
+    # BASELINE config 4 under --gpus N: after the replica timing every rank advances its shard of the periodic table
+    # (here Z = 1..7: partition_atoms over two ranks), the records are gathered once, rank 0 reports the sweep on the line
+    pt = d["extra"]["periodic_table"]
+    assert pt["atoms"] == 7 and sum(pt["atoms_per_rank"]) == 7 and len(pt["shard_seconds"]) == 2 and pt["seconds"] >= max(pt["shard_seconds"]) > 0
+    assert pt["finished"] == 7 and pt["slowest_rank"] in (0, 1)
 
 
 @pytest.mark.gpu
@@ -121,7 +126,7 @@ def test_bench_gpus_flag_starts_the_ranks_itself():
     import torch
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
-    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-periodic-table"],
                          env=dict(env, DFTA_BENCH_SHARED_GPU="1"), capture_output=True, text=True, timeout=600, cwd=root)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
