@@ -22,7 +22,7 @@ BOUNDARY_DEVICE, BOUNDARY_HOST = 0, 1
 LEVELS_CHAINED, LEVELS_BATCHED = 0, 1
 LEVELS_SCAN_SWEEPS = 0x10          # OR-ed into the mode of solve_levels: tolerance mode of the sweeps (transfer-matrix scan)
 SWEEPS_EXACT, SWEEPS_TOLERANCE = 0, 1
-ABI_VERSION = 5
+ABI_VERSION = 6
 LEVEL_CONVERGED, LEVEL_ITERATION_CAP, LEVEL_FIXED_POINT, LEVEL_U0_NONFINITE = 1, 2, 4, 8
 POISSON_DEFAULT, POISSON_EXACT, POISSON_TOLERANCE, POISSON_ADAPTIVE = -1, 0, 1, 2    # dfta_poisson_create_ex / dfta_scf_options::poisson_mode
 INT_TRAPEZOID, INT_SIMPSON13, INT_SIMPSON38, INT_BOOLE, INT_ROMBERG = range(5)
@@ -54,11 +54,11 @@ class Energies(C.Structure):
 
 
 class ScfOptions(C.Structure):
-    _fields_ = [("integrator", C.c_int), ("functional", C.c_int), ("aufbau", C.c_int), ("poisson_mode", C.c_int), ("sweep_mode", C.c_int)]
+    _fields_ = [("struct_size", C.c_int), ("integrator", C.c_int), ("functional", C.c_int), ("aufbau", C.c_int), ("poisson_mode", C.c_int), ("sweep_mode", C.c_int)]
 
 
 class StepStats(C.Structure):
-    _fields_ = [("sweeps_issued", C.c_long), ("sweeps_reference", C.c_long), ("points_traversed", C.c_long),
+    _fields_ = [("struct_size", C.c_int), ("levels_fallbacks", C.c_int), ("sweeps_issued", C.c_long), ("sweeps_reference", C.c_long), ("points_traversed", C.c_long),
                 ("vcycles", C.c_long), ("rounds", C.c_int), ("ms_levels", C.c_float), ("ms_poisson", C.c_float),
                 ("ms_tail", C.c_float), ("ms_sweep_kernels", C.c_float), ("ms_poisson_kernel", C.c_float),
                 ("sweeps_reference_executed", C.c_long), ("points_reference", C.c_long),
@@ -153,7 +153,7 @@ def load():
         f = getattr(lib, name)       # AttributeError if a declared symbol is not exported
         f.restype = res
         f.argtypes = args
-    if lib.dfta_abi_version() != ABI_VERSION:      # the struct mirrors above grow with the header (no size fields)
+    if lib.dfta_abi_version() != ABI_VERSION:      # the struct mirrors above follow the header (struct_size first, growth at the end)
         raise DftaError("%s was built from another version of include/dftatom_hip.h (ABI %d, binding %d): rebuild it"
                         % (LIB_PATH, lib.dfta_abi_version(), ABI_VERSION))
     _lib = lib
@@ -481,7 +481,7 @@ class Scf:
         self.natoms = len(self.Z)
         self.lsda = bool(lsda)
         h = vp()
-        opt = ScfOptions(integrator, functional, aufbau, poisson_mode, sweep_mode)
+        opt = ScfOptions(C.sizeof(ScfOptions), integrator, functional, aufbau, poisson_mode, sweep_mode)
         ctx.check(ctx.lib.dfta_scf_create_ex(ctx.h, grid.h, int(self.lsda), self.natoms, _ip(self.Z), alpha, levels_mode,
                                              tree_depth, C.cast(C.byref(opt), vp), C.byref(h)))
         self.h = h
@@ -491,6 +491,7 @@ class Scf:
 
     def step(self, want_stats=True):
         st = StepStats()
+        st.struct_size = C.sizeof(StepStats)
         self.ctx.check(self.ctx.lib.dfta_scf_step(self.h, C.byref(st) if want_stats else None))
         return st
 

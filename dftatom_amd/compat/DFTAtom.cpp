@@ -14,7 +14,7 @@ const char DFTAtom::orb[] = {'s', 'p', 'd', 'f'};
 int DFTAtom::levelsMode = DFTA_LEVELS_BATCHED;
 int DFTAtom::integrator = DFTA_INT_SIMPSON38;
 int DFTAtom::sweepMode = DFTA_SWEEPS_EXACT;
-int DFTAtom::poissonMode = DFTA_POISSON_EXACT;
+int DFTAtom::poissonMode = -1;      // as dfta_poisson_create: exact unless $DFTA_DEBUG POISSON_MODE (--poisson= overrides)
 std::ostream* DFTAtom::jsonOut = nullptr;
 
 namespace {
@@ -72,6 +72,7 @@ void DFTAtom::Run(bool lsda, bool uniform, int Z, int MultigridLevels, double al
 
     dfta_scf* scf = nullptr;
     dfta_scf_options opt = {};                    // zero = what the reference runs
+    opt.struct_size = (int)sizeof(opt);
     opt.integrator = integrator; opt.functional = DFTA_XC_VWN; opt.aufbau = DFTA_AUFBAU_REFERENCE;
     opt.poisson_mode = poissonMode; opt.sweep_mode = sweepMode;
     dfta_compat::check(dfta_scf_create_ex(rt.ctx(), grid, lsda ? 1 : 0, 1, &Z, alpha, levelsMode, 0, &opt, &scf), rt.ctx(), "dfta_scf_create");
@@ -79,6 +80,7 @@ void DFTAtom::Run(bool lsda, bool uniform, int Z, int MultigridLevels, double al
     for (int sp = 0; sp < maxSteps; ++sp) {
         std::cout << "Step: " << sp << std::endl;
         dfta_step_stats stats = {};
+        stats.struct_size = (int)sizeof(stats);
         dfta_compat::check(dfta_scf_step(scf, jsonOut ? &stats : nullptr), rt.ctx(), "dfta_scf_step");
         for (int spin = 0; spin < (lsda ? 2 : 1); ++spin)
             for (const auto& lv : fetch_levels(scf, spin)) {

@@ -30,7 +30,7 @@ public:
     static int levelsMode;      // DFTA_LEVELS_BATCHED (default) or DFTA_LEVELS_CHAINED (the reference's exact bisection path)
     static int integrator;      // DFTA_INT_SIMPSON38 (default: what the reference calls) ... DFTA_INT_ROMBERG (what its README names)
     static int sweepMode;       // DFTA_SWEEPS_EXACT (default) / DFTA_SWEEPS_TOLERANCE (transfer-matrix scans; logarithmic grids of 12 .. 20 levels)
-    static int poissonMode;     // DFTA_POISSON_EXACT (default) / DFTA_POISSON_TOLERANCE / DFTA_POISSON_ADAPTIVE
+    static int poissonMode;     // -1 (default): as dfta_poisson_create, i.e. exact unless $DFTA_DEBUG POISSON_MODE says otherwise; DFTA_POISSON_EXACT / _TOLERANCE / _ADAPTIVE
     // per-step machine-readable output (metrics): when set, every SCF step appends ONE JSON line with 17-digit
     // energies and eigenvalues, per-level status bits (DFTA_LEVEL_*) and sweep counts, rounds, V-cycles and the phases' HIP-event times
     static std::ostream* jsonOut;

@@ -69,6 +69,9 @@ public:
 private:
     Runtime()
     {
+        // the structs of include/dftatom_hip.h this layer was compiled with must be those of the library it was linked to
+        if (dfta_abi_version() != DFTA_ABI_VERSION)
+            throw std::runtime_error("libdftatom_hip: ABI version " + std::to_string(dfta_abi_version()) + ", this compat layer was built against " + std::to_string(DFTA_ABI_VERSION));
         const int rc = dfta_ctx_create(0, nullptr, &m_ctx);
         if (rc != DFTA_OK) throw std::runtime_error("libdftatom_hip: no usable HIP device (status " + std::to_string(rc) + "); there is no CPU fallback");
         const char* e = getenv("DFTA_COMPAT_SWEEPS");

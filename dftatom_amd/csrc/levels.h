@@ -71,7 +71,10 @@ struct Job {
     // device-side search (persist.inc): the certain part of the band (count == nodes) as the planner of the round saw it -- the scouts'
     // grid; the workers of a round must not read a sibling's record while it moves -- and the rounds this job has taken
     double sb_lo, sb_hi;
-    int rounds, pad_;
+    int rounds;
+    // feedback from one SCF step to the next (device-side search): when the level's search ended, in microseconds after the kernel's first
+    // workgroup started; the host gives the levels that ended last in the previous step first call on the pool's workgroups (deep = 1)
+    int t_end_us, deep, pad_;
     long long n_points;              // grid points traversed by the sweeps ON the bisection path (n_count + n_zero executed ones) + the match solve
 };
 

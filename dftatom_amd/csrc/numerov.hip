@@ -1695,6 +1695,7 @@ int dfta_launch_levels_persist(dfta_ctx* ctx, const dfta_grid* g, dfta_persist_b
     unsigned long long* hm = reinterpret_cast<unsigned long long*>(hb.data() + sizeof(PersistCtl));
     PersistJob* hj = reinterpret_cast<PersistJob*>(hb.data() + sizeof(PersistCtl) + sizeof(unsigned long long) * kPersistMaxBlocks);
     hc->live = (unsigned)nlive;
+    hc->t0 = ~0ull;
     int next = 0;
     for (int k = 0; k < nlive; ++k) {
         const int mine = share ? std::max(2, std::min(share[k], base)) : base;      // (a level never starts with more than an equal share)

@@ -242,6 +242,7 @@ struct dfta_scf {
     bool debug_levels = false;            // $DFTA_DEBUG_LEVELS
     int integ_rule = DFTA_INT_SIMPSON38;  // dfta_scf_set_integrator
     int functional = DFTA_XC_VWN;         // dfta_scf_options::functional
+    int fallbacks_seen = 0;               // level-search fallbacks already reported in a step's statistics
     int levels_mode = DFTA_LEVELS_BATCHED;
     int steps_done = 0;
     std::vector<int> spin_nlev[2];      // per atom number of levels per spin
@@ -291,8 +292,18 @@ int dfta_scf_create_ex(dfta_ctx* ctx, const dfta_grid* g, int lsda, int natoms, 
     if (!ctx || !g || !out) return DFTA_ERR_INVALID;
     DFTA_ENTER(ctx);
     DFTA_REQUIRE(ctx, natoms >= 1 && Z && alpha >= 0 && alpha <= 1, "scf arguments");
-    dfta_scf_options opt = {DFTA_INT_SIMPSON38, DFTA_XC_VWN, DFTA_AUFBAU_REFERENCE, -1, DFTA_SWEEPS_EXACT};
-    if (options) opt = *options;
+    dfta_scf_options opt = {(int)sizeof(dfta_scf_options), DFTA_INT_SIMPSON38, DFTA_XC_VWN, DFTA_AUFBAU_REFERENCE, -1, DFTA_SWEEPS_EXACT};
+    if (options) {
+        // the caller's struct may be shorter (an older header) or longer (a newer one) than this library's: read what both know
+        const int sz = options->struct_size;
+        DFTA_REQUIRE(ctx, sz >= (int)(2 * sizeof(int)) && sz % (int)sizeof(int) == 0 && sz <= 4096, "dfta_scf_options::struct_size (set it to sizeof(dfta_scf_options))");
+        dfta_scf_options in = {};
+        memcpy(&in, options, std::min<size_t>((size_t)sz, sizeof(in)));
+        // members the caller's struct does not have keep the defaults above; those it has are taken as they are (0 = the reference's behaviour)
+        const size_t have = std::min<size_t>((size_t)sz, sizeof(in));
+        memcpy(&opt, &in, have);
+        opt.struct_size = (int)sizeof(dfta_scf_options);
+    }
     DFTA_REQUIRE(ctx, opt.poisson_mode >= -1 && opt.poisson_mode <= DFTA_POISSON_ADAPTIVE, "poisson mode");
     DFTA_REQUIRE(ctx, dfta_integral_shape_ok(opt.integrator, g->N), "integration rule / grid size");
     DFTA_REQUIRE(ctx, opt.functional >= DFTA_XC_VWN && opt.functional <= DFTA_XC_CHACHIYO_IMPROVED, "functional");
@@ -537,8 +548,18 @@ int dfta_scf_step(dfta_scf* s, dfta_step_stats* stats)
     DFTA_HIP(ctx, hipMemcpyAsync(s->h_atoms.data(), s->d_atoms, sizeof(AtomState) * natoms, hipMemcpyDeviceToHost, st));
     DFTA_HIP(ctx, hipStreamSynchronize(st));
     if (stats) {
+        // the caller's struct may be an older (shorter) or a newer (longer) one: fill this library's, hand over what both know
+        dfta_step_stats* const user = stats;
+        const int user_size = user->struct_size;
+        DFTA_REQUIRE(ctx, user_size >= (int)(4 * sizeof(int)) && user_size % (int)sizeof(int) == 0 && user_size <= 4096,
+                     "dfta_step_stats::struct_size (set it to sizeof(dfta_step_stats) before the call)");
+        dfta_step_stats mine;
+        stats = &mine;
         DFTA_HIP(ctx, hipEventSynchronize(s->ev[3]));
         memset(stats, 0, sizeof(*stats));
+        stats->struct_size = (int)sizeof(dfta_step_stats);
+        stats->levels_fallbacks = (s->solver.scan_fallbacks + s->solver.persist_fallbacks) - s->fallbacks_seen;
+        s->fallbacks_seen = s->solver.scan_fallbacks + s->solver.persist_fallbacks;
         DFTA_HIP(ctx, hipEventElapsedTime(&stats->ms_levels, s->ev[0], s->ev[1]));
         DFTA_HIP(ctx, hipEventElapsedTime(&stats->ms_poisson, s->ev[1], s->ev[2]));
         DFTA_HIP(ctx, hipEventElapsedTime(&stats->ms_tail, s->ev[2], s->ev[3]));
@@ -570,6 +591,8 @@ int dfta_scf_step(dfta_scf* s, dfta_step_stats* stats)
             vc += vl;
         }
         stats->vcycles = (long)vc;
+        memcpy(user, &mine, std::min<size_t>((size_t)user_size, sizeof(mine)));
+        user->struct_size = user_size;
     }
     return DFTA_OK;
 }

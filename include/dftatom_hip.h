@@ -286,6 +286,10 @@ typedef struct dfta_energies {
 } dfta_energies;
 
 typedef struct dfta_step_stats {
+    int    struct_size;          /* IN: sizeof(dfta_step_stats) of the CALLER's header (set it before every dfta_scf_step); the library
+                                    fills no more than that many bytes, and rejects a value smaller than the version-6 prefix */
+    int    levels_fallbacks;     /* solves of this step's level search that were repeated on another path: a sweep the scan could not decide or a
+                                    lost worker of the device-side search (both: host rounds on the exact kernels, same results) */
     long   sweeps_issued;        /* Numerov sweeps launched (speculative trees)            */
     long   sweeps_reference;     /* sweeps on the reference's bisection path (count+zero+match) */
     long   points_traversed;     /* grid points traversed by issued sweeps                  */
@@ -313,16 +317,18 @@ int  dfta_scf_create(dfta_ctx* ctx, const dfta_grid* g, int lsda, int natoms, co
 #define DFTA_XC_CHACHIYO          1   /* ChachiyoExchCor<ChachiyoExchCorParam>, LDA only (ExcCor.h)           */
 #define DFTA_XC_CHACHIYO_IMPROVED 2   /* ChachiyoExchCor<ChachiyoExchCorImprovedParam> (DFTAtom.cpp:383)      */
 typedef struct dfta_scf_options {
+    int struct_size;  /* sizeof(dfta_scf_options) of the CALLER's header: members beyond it keep their defaults, a value that is no valid
+                         size of this struct (0, or what an older header had in this place) is rejected with DFTA_ERR_INVALID          */
     int integrator;   /* DFTA_INT_*: quadrature of the energy integrals and of the normalisation (default SIMPSON38) */
     int functional;   /* DFTA_XC_*                                                                                */
     int aufbau;       /* DFTA_AUFBAU_*                                                                            */
     int poisson_mode; /* DFTA_POISSON_EXACT (0, default) / DFTA_POISSON_TOLERANCE / DFTA_POISSON_ADAPTIVE; -1: as dfta_poisson_create ($DFTA_POISSON_MODE) */
     int sweep_mode;   /* DFTA_SWEEPS_EXACT (0, default) / DFTA_SWEEPS_TOLERANCE (scan sweeps, see DFTA_LEVELS_SCAN_SWEEPS)                */
 } dfta_scf_options;
-/* The option and statistics structs grow at the END between versions of this header and carry no size field: zero-initialise them
- * (every member's 0 is the reference's behaviour) and build against the header of the library you load -- dfta_abi_version()
- * returns the DFTA_ABI_VERSION the library was built with, for a run-time check. */
-#define DFTA_ABI_VERSION 5
+/* The option and statistics structs start with struct_size (since version 6) and grow at the END between versions of this header:
+ * zero-initialise them, set struct_size = sizeof(...) -- every other member's 0 is the reference's behaviour -- and the library reads /
+ * writes no more than the caller's struct holds.  dfta_abi_version() returns the DFTA_ABI_VERSION the library was built with. */
+#define DFTA_ABI_VERSION 6
 int  dfta_abi_version(void);
 int  dfta_scf_create_ex(dfta_ctx* ctx, const dfta_grid* g, int lsda, int natoms, const int* Z, double alpha, int levels_mode,
                         int tree_depth, const dfta_scf_options* options, dfta_scf** out);
