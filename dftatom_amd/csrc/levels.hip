@@ -859,7 +859,7 @@ int LevelSolver::run(const double* dV, const double* job_bottom, int run_mode, d
         if (use_persist) { j.tbase = plevel[k] * pb.tmax; j.tcap = 0; }      // its own region of the device-side search's trial arrays
         j.rounds = 0;
         j.t_end_us = 0;
-        j.deep = 0;
+        j.deep = -1;
         j.bottom0 = job_bottom[k];
         const bool first = (k == 0 || jobs[k].v != jobs[k - 1].v);
         if (!chained || first) { j.phase = PH_TOP; j.toe = 50; j.boe = j.bottom0; }   // DFTAtom.cpp:499
@@ -900,15 +900,21 @@ int LevelSolver::run(const double* dV, const double* job_bottom, int run_mode, d
         j.phase_done = 0;
     }
     if (use_persist && h_last.size() == jobs.size() && !pb.equal_shares) {
-        // the levels whose search ended last in the previous step get first call on the pool (persist_plan): as many as the pool can serve
+        // Feedback (speculation only): the levels whose search ended last in the previous step get first call on the pool (persist_plan,
+        // deep = 2: as many as the pool can give a second share to), those within 15 % of the last one may match candidate eigenvalues
+        // (deep = 1), the rest have time to spare (deep = 0)
         std::vector<int> order;
         for (int k : plive) if (h_last[k].t_end_us > 0) order.push_back(k);
-        std::sort(order.begin(), order.end(), [&](int x, int y) { return h_last[x].t_end_us > h_last[y].t_end_us; });
-        const int equal = pb.nblocks / (int)plive.size();
-        int pool = pb.nblocks - equal * (int)plive.size();
-        for (int k : plive) if (jobs[k].nodes == 0 && equal >= 8) pool += equal / 2;
-        const int ndeep = std::min<int>((int)order.size(), pool / std::max(equal - 1, 1));
-        for (int q = 0; q < ndeep; ++q) jobs[order[q]].deep = 1;
+        if (order.size() == plive.size()) {
+            std::sort(order.begin(), order.end(), [&](int x, int y) { return h_last[x].t_end_us > h_last[y].t_end_us; });
+            const int equal = pb.nblocks / (int)plive.size();
+            int pool = pb.nblocks - equal * (int)plive.size();
+            for (int k : plive) if (jobs[k].nodes == 0 && equal >= 8) pool += equal / 2;
+            const int ndeep = std::min<int>((int)order.size(), pool / std::max(equal - 1, 1));
+            const int tmax_us = h_last[order[0]].t_end_us;
+            for (size_t q = 0; q < order.size(); ++q)
+                jobs[order[q]].deep = (int)q < ndeep ? 2 : (h_last[order[q]].t_end_us > 0.85 * tmax_us ? 1 : 0);
+        }
     }
     DFTA_HIP(ctx, hipMemcpyAsync(d_jobs, jobs.data(), sizeof(Job) * njobs, hipMemcpyHostToDevice, st));
     DFTA_HIP(ctx, hipMemsetAsync(d_counters, 0, sizeof(unsigned long long) * 4, st));
