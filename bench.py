@@ -217,6 +217,25 @@ def counter_rate(d, kernel, workload):
     d["frac_counters"] = d["hbm_GBps_counters"] / HBM_PEAK_GBS if d["hbm_GBps_counters"] else None
 
 
+def workload_tag(levels, atoms, lsda, poisson_mode, sweep_mode):
+    """name of the committed rocprofv3 profile (profiles/<round>_<tag>_hbm_traffic.json, profiles/collect.sh) of a workload, or None"""
+    mode = {("exact", "exact"): "", ("tolerance", "exact"): "tolerance", ("exact", "tolerance"): "scan", ("tolerance", "tolerance"): "scan_tol",
+            ("adaptive", "tolerance"): "scan_adaptive"}.get((poisson_mode, sweep_mode))
+    if mode is None:
+        return None
+    if levels == 17 and atoms == 1:
+        base = "rn_lsda" if lsda else "default"
+        if lsda:
+            return base if mode == "" else None
+        return mode or base
+    if levels == 17 and atoms == 256 and not lsda:
+        return "batch256" + ("_" + mode if mode else "")
+    if levels == 20 and lsda and atoms in (1, 16):
+        base = "l20" if atoms == 1 else "l20_batch16"
+        return base + ("_" + mode if mode else "")
+    return None
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # what the tests assert for the mode a number was measured in (so that a reader of the line sees what kind of number it is)
 # ---------------------------------------------------------------------------------------------------------------
@@ -330,7 +349,7 @@ def kernel_figures(tot, levels, N, atoms, workload=None):
     """per-kernel roofline figures of a workload (HIP-event times measured inside the library on the launch stream).
     `algorithmic_*` = SURVEY 8d bytes / time: a yardstick, NOT a bandwidth (levels resident in LDS / L2 and trials sharing a table row
     make it exceed what HBM moves); `hbm_GBps_counters` = rocprofv3 FETCH/WRITE bytes of the committed profile of `workload` / time."""
-    forced = os.environ.get("DFTA_SWEEP_KERNEL", "")
+    forced = next((e.split("=", 1)[1] for e in os.environ.get("DFTA_DEBUG", "").split(",") if e.startswith("SWEEP_KERNEL=")), "")
     piped = forced == "pipe" or (forced != "fused" and tot["trials_per_round"] // 64 <= 768)
     sname = "k_scan_levels" if tot.get("scan") else ("k_levels_persist" if tot.get("persist") else ("k_sweep_pipe" if piped else "k_sweep"))
     t_sw = tot["ms_sweep_kernels"] * 1e-3
@@ -515,6 +534,7 @@ def main():
     ap.add_argument("--levels", type=int, default=17)
     ap.add_argument("--lsda", action="store_true")
     ap.add_argument("--tolerance", action="store_true", help="the multigrid smoother's opt-in tolerance mode (DFTA_POISSON_TOLERANCE) for the headline workload")
+    ap.add_argument("--adaptive", action="store_true", help="DFTA_POISSON_ADAPTIVE for the headline workload: the tolerance kernels, V-cycles stop on the round-off floor (6-8 instead of the reference's 100)")
     ap.add_argument("--scan-sweeps", action="store_true", help="the sweeps' opt-in tolerance mode (DFTA_SWEEPS_TOLERANCE: transfer-matrix scans) for the headline workload")
     ap.add_argument("--tree-depth", type=int, default=0)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
@@ -593,7 +613,7 @@ def main():
             dist.all_gather(gathered, mine)
 
     scf, tot = run_workload(D, ctx, grid, args.levels, args.atoms, args.lsda, args.steps, args.warmup, args.tree_depth, barrier, torch, gather,
-                            poisson_mode=D.POISSON_TOLERANCE if args.tolerance else D.POISSON_EXACT,
+                            poisson_mode=D.POISSON_ADAPTIVE if args.adaptive else (D.POISSON_TOLERANCE if args.tolerance else D.POISSON_EXACT),
                             sweep_mode=D.SWEEPS_TOLERANCE if args.scan_sweeps else D.SWEEPS_EXACT)
     elapsed = tot["elapsed"]
     # max over ranks of the elapsed time, sums of the work
@@ -608,7 +628,7 @@ def main():
         ref_all, issued_all, vc_all, exe_all = (float(tot[k]) for k in ("sweeps_reference", "sweeps_issued", "vcycles", "sweeps_reference_executed"))
     scf.close()
     pt_extra = None
-    if not args.no_periodic_table and not args.no_extras and args.atoms == 1 and not args.lsda and not args.tolerance and not args.scan_sweeps:
+    if not args.no_periodic_table and not args.no_extras and args.atoms == 1 and not args.lsda and not args.tolerance and not args.scan_sweeps and not args.adaptive:
         t_w = time.time()
         pt_extra = periodic_table(D, ctx, grid, args.levels, world, rank, dist, torch, shared, args.pt_zmax)
         if rank == 0:
@@ -616,15 +636,8 @@ def main():
 
     if rank == 0:
         ncu, devname = ctx.device_info()
-        wl = None
-        if args.scan_sweeps:
-            wl = ("scan_tol" if args.tolerance else "scan") if (args.atoms == 1 and args.levels == 17 and not args.lsda) else None
-        elif args.atoms == 1 and args.levels == 17:
-            wl = "tolerance" if args.tolerance and not args.lsda else "rn_lsda" if args.lsda and not args.tolerance else "default" if not args.lsda else None
-        elif args.atoms == 256 and args.levels == 17 and not args.lsda:
-            wl = "batch256"
-        elif args.atoms == 16 and args.levels == 20 and args.lsda:
-            wl = "l20_batch16"
+        pmode = "adaptive" if args.adaptive else ("tolerance" if args.tolerance else "exact")
+        wl = workload_tag(args.levels, args.atoms, args.lsda, pmode, "tolerance" if args.scan_sweeps else "exact")
         sweep, pois = kernel_figures(tot, args.levels, grid.N, args.atoms, wl)
         dominant = pois if tot["ms_poisson"] >= tot["ms_sweep_kernels"] else sweep
         roof = {"bound": "hbm", "kernel": dominant["kernel"],
@@ -658,7 +671,7 @@ def main():
             "config": {"workload": "Rn Z=86 %s, %d levels (%d pts), delta=%g, Rmax=%g, mixing 0.5, %d atom(s)/GPU, %s"
                                    % ("LSDA" if args.lsda else "LDA", args.levels, grid.N, delta, rmax, args.atoms, tot["levels_layout"]),
                        "atoms_per_gpu": args.atoms, "parallelism": "replicas x%d" % world,
-                       "poisson_mode": "tolerance" if args.tolerance else "exact", "sweep_mode": "tolerance (scan)" if args.scan_sweeps else "exact"},
+                       "poisson_mode": pmode, "sweep_mode": "tolerance (scan)" if args.scan_sweeps else "exact"},
             "scf_step_ms": 1e3 * elapsed / args.steps,
             "value_definition": "value = sweeps on the reference's bisection path that are actually integrated here (CountNodes + SolutionInZero + "
                                 "Match) / whole-step wall time; value_reference_equivalent also counts the ~52 CountNodes calls per node-less level's "
@@ -675,7 +688,7 @@ def main():
             "device": devname, "compute_units": ncu,
             "roofline": roof,
             "kernels": {"sweep": sweep, "poisson": pois},
-            "parity_gates": parity_gates("tolerance" if args.tolerance else "exact", "tolerance" if args.scan_sweeps else "exact"),
+            "parity_gates": parity_gates(pmode, "tolerance" if args.scan_sweeps else "exact"),
         }
         cpu_job = None
         if world == 1 and not args.no_cpu:      # rank 0 at N = 1 only: the other ranks of a larger job would sit at the final barrier
@@ -720,7 +733,8 @@ def main():
                 s2, t2 = run_workload(D, ctx, g2, lv, atoms, lsda, st, wu, 0, barrier, torch, poisson_mode=pm, sweep_mode=sm)
                 s2.close()
                 sys.stderr.write("bench.py: extra %s: %.1f s\n" % (name, time.time() - t_w))
-                extra[name] = summarize(t2, lv, g2.N, atoms, lsda, world, d2, r2, wl2 if args.levels == 17 else None)
+                pm_name = {D.POISSON_TOLERANCE: "tolerance", D.POISSON_ADAPTIVE: "adaptive"}.get(pm, "exact")
+                extra[name] = summarize(t2, lv, g2.N, atoms, lsda, world, d2, r2, workload_tag(lv, atoms, lsda, pm_name, "tolerance" if sm == D.SWEEPS_TOLERANCE else "exact"))
                 extra[name]["poisson_mode"] = {D.POISSON_TOLERANCE: "tolerance", D.POISSON_ADAPTIVE: "adaptive (tolerance kernels, V-cycles stop on the round-off floor)"}.get(pm, "exact")
                 extra[name]["sweep_mode"] = "tolerance (scan)" if sm == D.SWEEPS_TOLERANCE else "exact"
                 extra[name]["parity_gates"] = parity_gates({D.POISSON_TOLERANCE: "tolerance", D.POISSON_ADAPTIVE: "adaptive"}.get(pm, "exact"),

@@ -62,8 +62,8 @@ struct dfta_device_guard {
 
 // Debug / measurement knobs: ONE environment variable, DFTA_DEBUG, a comma-separated list of NAME or NAME=VALUE entries (names
 // as listed in DESIGN.md section 9, e.g. DFTA_DEBUG="POISSON_GROUP=3,POISSON_NOFOLD,LEVELS_STATIC").  dfta_knob("NAME") returns
-// the value ("" for a bare NAME), or nullptr when the knob is not set.  For scripts written before round 3 a separate variable
-// DFTA_<NAME> is still honoured as an alias.  Knobs never change results (the tests prove it for each), only how they are computed.
+// the value ("" for a bare NAME), or nullptr when the knob is not set.  (The separate DFTA_<NAME> variables of rounds 1-2 are gone.)
+// Knobs never change results (the tests prove it for each), only how they are computed.
 static inline const char* dfta_knob(const char* name)
 {
     static thread_local char val[128];
@@ -83,9 +83,7 @@ static inline const char* dfta_knob(const char* name)
             p = e + 1;
         }
     }
-    char alias[160];
-    snprintf(alias, sizeof(alias), "DFTA_%s", name);
-    return getenv(alias);
+    return nullptr;
 }
 
 #define DFTA_REQUIRE(ctx, cond, msg)                                               \

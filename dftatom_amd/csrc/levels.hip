@@ -617,7 +617,7 @@ int LevelSolver::setup(dfta_ctx* c, const dfta_grid* grid, int mode_, int tree_d
     use_prediction = dfta_knob("LEVELS_NOPREDICT") == nullptr;   // measurements / tests: every spine and scout off
     {   // tuning of the predictions (never of a result): the defaults, or what the environment says, every time a solver is made
         double v[3] = {1e-11, 16e-12, 1.5e-11}, k = 0.25;
-        if (const char* e = dfta_knob("LEVELS_NOISE")) sscanf(e, "%lf,%lf,%lf", &v[0], &v[1], &v[2]);   // "rel,abs,secant" of the noise band
+        if (const char* e = dfta_knob("LEVELS_NOISE")) sscanf(e, "%lf:%lf:%lf", &v[0], &v[1], &v[2]);   // "rel:abs:secant" of the noise band (':' -- the knob list itself is comma-separated)
         if (const char* e = dfta_knob("LEVELS_SECANT_KAPPA")) k = atof(e);                                // trust in the parabolic correction
         (void)hipMemcpyToSymbol(HIP_SYMBOL(g_noise_rel), &v[0], sizeof(double));
         (void)hipMemcpyToSymbol(HIP_SYMBOL(g_noise_abs), &v[1], sizeof(double));

@@ -333,7 +333,7 @@ int dfta_poisson_create_ex(dfta_ctx* ctx, const dfta_grid* g, int batch, int mod
 
 int dfta_poisson_create(dfta_ctx* ctx, const dfta_grid* g, int batch, dfta_poisson** out)
 {
-    // $DFTA_POISSON_MODE = tolerance: measurements and tests of the opt-in mode through callers that do not pass a mode
+    // DFTA_DEBUG="POISSON_MODE=tolerance" (or adaptive): measurements and tests of the opt-in modes through callers that do not pass a mode
     const char* e = dfta_knob("POISSON_MODE");
     return dfta_poisson_create_ex(ctx, g, batch, (e && e[0] == 't') ? DFTA_POISSON_TOLERANCE : ((e && e[0] == 'a') ? DFTA_POISSON_ADAPTIVE : DFTA_POISSON_EXACT), out);
 }

@@ -938,7 +938,8 @@ __global__ void __launch_bounds__(kT) k_scan_levels_group(ScanGrid G0, const dou
     bool sgnBottom = false;
     unsigned rnd = 0;
     while (ph) {
-        ++rnd;
+        ++rnd;                                                             // tags start at 1: 0 is the cleared state of the exchange words
+        if (rnd >= 0xffffu) { if (threadIdx.x == 0) atomicOr(counters + 3, 3ull); return; }     // (a search takes ~40 rounds; the tag has 16 bits)
         // ---- the round's layout: a SPINE of s1 predicted decisions, one member each, and the full tree of depth d at its end.  The
         // prediction is the history bracket of the exact path (levels.h): this step's end point of the running bisection lies within
         // hm = 2 x the last movement of the previous step's; while a midpoint is outside [hT - hm, hT + hm] its decision is known
@@ -1013,16 +1014,21 @@ __global__ void __launch_bounds__(kT) k_scan_levels_group(ScanGrid G0, const dou
         if (threadIdx.x == 0) {
             unsigned long long* slotp = X + (rnd & 1) * 16;
             __hip_atomic_store(slotp + m, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // ONE wall-clock budget for the whole gather of a round (a bound per member added up to many seconds before the
+            // fall-back): two seconds of the 100 MHz clock -- a sweep takes 40 .. 700 us -- then the abort bit, which every member polls
             bool timeout = false;
+            const long long t_gather = wall_clock64();
             for (int q = 0; q < K; ++q) {
                 unsigned long long v = q == m ? mine : 0ull;
                 long spins = 0;
                 while (q != m) {
                     v = __hip_atomic_load(slotp + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if ((v >> 48) == (rnd & 0xffffu)) break;
-                    if (++spins > (1L << 24) || (__hip_atomic_load(counters + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 2ull)) { timeout = true; break; }
+                    if ((++spins & 255) == 0 && (wall_clock64() - t_gather > 200000000ll ||
+                                                 (__hip_atomic_load(counters + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 2ull))) { timeout = true; break; }
                     __builtin_amdgcn_s_sleep(1);
                 }
+                if (timeout) break;
                 sh.xres[q] = v;
             }
             if (timeout) { atomicOr(counters + 3, 3ull); sh.xres[0] = ~0ull; }

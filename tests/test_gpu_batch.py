@@ -16,7 +16,8 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-import dftatom_amd as D                 # noqa: E402
+import dftatom_amd as D
+from _knobs import knobs                 # noqa: E402
 from golden.make_golden import GRIDS    # noqa: E402
 
 
@@ -108,8 +109,7 @@ def test_lost_group_member_is_detected_and_solve_repeated(ctx):
     U0, vc0, _ = good.solve([86], rho)
     assert good.group_info() == (G, False, 0)
     good.close()
-    os.environ["DFTA_FAULT_POISSON_MEMBER"] = "1"
-    try:
+    with knobs(FAULT_POISSON_MEMBER="1"):
         bad = D.Poisson(ctx, grid, 1)
         U1, vc1, _ = bad.solve([86], rho)
         assert bad.group_info() == (G, True, 1)
@@ -122,8 +122,6 @@ def test_lost_group_member_is_detected_and_solve_repeated(ctx):
         scf_bad.step(want_stats=False)
         e_bad = scf_bad.energies()[0][0].as_list()
         scf_bad.close()
-    finally:
-        os.environ.pop("DFTA_FAULT_POISSON_MEMBER", None)
     scf_ok = D.Scf(ctx, grid, [18], lsda=False)
     assert scf_ok.poisson_info()[1:] == (False, 0)
     scf_ok.step(want_stats=False)

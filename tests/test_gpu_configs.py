@@ -32,7 +32,8 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-import dftatom_amd as D                 # noqa: E402
+import dftatom_amd as D
+from _knobs import knobs                 # noqa: E402
 from golden.make_golden import GRIDS, screened_potential   # noqa: E402
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -286,18 +287,10 @@ def test_l20_poisson_vs_reference(ctx, grid20):
     # staged / unstaged and group variants agree bit for bit at this size too
     ref = U[0].view(np.int64)
     for var in ({"DFTA_POISSON_GROUP": "0"}, {"DFTA_POISSON_NOSTAGE": "1"}, {"DFTA_POISSON_GROUP": "3"}, {"DFTA_POISSON_GROUP": "2"}):
-        old = {k: os.environ.get(k) for k in var}
-        os.environ.update(var)
-        try:
+        with knobs(var):
             p2 = D.Poisson(ctx, grid20, 1)
             U2, _, _ = p2.solve([86], rho)
             p2.close()
-        finally:
-            for k, v in old.items():
-                if v is None:
-                    os.environ.pop(k, None)
-                else:
-                    os.environ[k] = v
         assert np.array_equal(U2[0].view(np.int64), ref), var
 
 

@@ -21,6 +21,7 @@ pytestmark = pytest.mark.gpu
 
 import _oracle as O                     # noqa: E402  (checker only)
 import dftatom_amd as D                 # noqa: E402
+from _knobs import knobs as _knobs_ctx    # noqa: E402
 from golden.make_golden import GRIDS, screened_potential   # noqa: E402
 
 
@@ -287,32 +288,20 @@ def test_poisson_workgroup_groups_are_bit_identical(ctx, grid17):
     rr = grid17.r()
     rho = np.stack([86 * np.exp(-2 * rr) / np.pi, 18 * np.exp(-1.3 * rr) * 1.3 ** 3 / (8 * np.pi)])
     ref = None
-    knobs = ("DFTA_POISSON_GROUP", "DFTA_POISSON_NOSTAGE", "DFTA_POISSON_NOSTAGE_SHARED", "DFTA_POISSON_NOSTAGE_WAVE",
-             "DFTA_POISSON_NOFOLD", "DFTA_POISSON_NOCOARSE")
-    old = {k: os.environ.get(k) for k in knobs}
     variants = [{"DFTA_POISSON_GROUP": str(g)} for g in (0, 1, 2, 3, 4)]
     variants += [{"DFTA_POISSON_NOSTAGE": "1"}, {"DFTA_POISSON_NOSTAGE_SHARED": "1"}, {"DFTA_POISSON_NOSTAGE_WAVE": "1"},
                  {"DFTA_POISSON_NOFOLD": "1"}, {"DFTA_POISSON_GROUP": "3", "DFTA_POISSON_NOFOLD": "1"},
                  {"DFTA_POISSON_NOCOARSE": "1"}, {"DFTA_POISSON_GROUP": "0", "DFTA_POISSON_NOCOARSE": "1"}]
-    try:
-        for var in variants:
-            for k in knobs:
-                os.environ.pop(k, None)
-            os.environ.update(var)                                  # read by dfta_poisson_create
+    for var in variants:
+        with _knobs_ctx(var):                                       # DFTA_DEBUG entries, read by dfta_poisson_create
             ps = D.Poisson(ctx, grid17, 2)
             U, vc, err = ps.solve([86, 18], rho)
             ps.close()
-            if ref is None:
-                ref = (U.copy(), vc.copy())
-            else:
-                assert np.array_equal(U.view(np.int64), ref[0].view(np.int64)), var
-                assert np.array_equal(vc, ref[1]), var
-    finally:
-        for k in knobs:
-            if old[k] is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = old[k]
+        if ref is None:
+            ref = (U.copy(), vc.copy())
+        else:
+            assert np.array_equal(U.view(np.int64), ref[0].view(np.int64)), var
+            assert np.array_equal(vc, ref[1]), var
 
 
 def test_vwn_vs_golden(ctx, golden):
@@ -393,16 +382,10 @@ def test_predictions_never_change_results(ctx, grid14):
     """The level solver's speculation (spines from history, sibling, top rule, scouts, secants) only selects which of the
     reference's midpoints are integrated early: with all of it switched off (plain bisection trees) every SCF step gives
     the same bits -- energies, eigenvalues and the reference-equivalent sweep counts"""
-    knobs = ("DFTA_LEVELS_NOPREDICT", "DFTA_LEVELS_NOISE", "DFTA_LEVELS_SECANT_KAPPA", "DFTA_LEVELS_STATIC")
-
     def run(nopredict, **env):
-        old = {k: os.environ.get(k) for k in knobs}
-        try:
-            for k in knobs:
-                os.environ.pop(k, None)
-            if nopredict:
-                os.environ["DFTA_LEVELS_NOPREDICT"] = "1"
-            os.environ.update(env)
+        if nopredict:
+            env = dict(env, DFTA_LEVELS_NOPREDICT="1")
+        with _knobs_ctx(env):
             scf = D.Scf(ctx, grid14, [36], lsda=False)               # Kr: s, p and d levels
             out = []
             for _ in range(5):
@@ -412,12 +395,6 @@ def test_predictions_never_change_results(ctx, grid14):
                 out.append((en[0].as_list(), lv["E"].copy(), int(st.sweeps_reference), int(st.rounds)))
             scf.close()
             return out
-        finally:
-            for k in knobs:
-                if old[k] is None:
-                    os.environ.pop(k, None)
-                else:
-                    os.environ[k] = old[k]
     a, b = run(False), run(True)
     for k, (x, y) in enumerate(zip(a, b)):
         assert x[0] == y[0], k
@@ -426,8 +403,8 @@ def test_predictions_never_change_results(ctx, grid14):
     assert sum(x[3] for x in a) < sum(y[3] for y in b)                # ... in fewer rounds
     # the tuning knobs of the predictions -- reckless guards around the round-off band, blind trust in the parabolic end-point
     # estimate, fixed trial slots -- cost or save rounds, never a bit of the result
-    for env in ({"DFTA_LEVELS_NOISE": "1e-14,1e-13,1e-14", "DFTA_LEVELS_SECANT_KAPPA": "0.001"},
-                {"DFTA_LEVELS_NOISE": "1e-9,1e-9,1e-9", "DFTA_LEVELS_SECANT_KAPPA": "0"},
+    for env in ({"DFTA_LEVELS_NOISE": "1e-14:1e-13:1e-14", "DFTA_LEVELS_SECANT_KAPPA": "0.001"},
+                {"DFTA_LEVELS_NOISE": "1e-9:1e-9:1e-9", "DFTA_LEVELS_SECANT_KAPPA": "0"},
                 {"DFTA_LEVELS_STATIC": "1"}):
         c = run(False, **env)
         for k, (x, y) in enumerate(zip(a, c)):

@@ -76,10 +76,14 @@ def test_gather_world_size_2_gloo():
 
 
 def test_shard_time_model_reproduces_the_recorded_shards():
-    """the constants of sweep.shard_time_ms drift with every kernel change -- they are re-fitted from the recorded
-    emulation (profiles/fit_shard_model.py, profiles/r04_periodic_table_predicted_scaling_<mode>.json: every shard of the 1-, 2-, 4-, 8-rank
-    sweeps run alone on one MI355X) and this test keeps them honest: every recorded shard within 15 %, and the fit itself agrees with the
-    constants in the source to 3 %."""
+    """A CONSISTENCY check, not a validation: the constants of sweep.shard_time_ms are a least-squares fit to the 15 recorded
+    shards of the emulated 1-, 2-, 4-, 8-rank sweeps (profiles/fit_shard_model.py, profiles/r04_periodic_table_predicted_scaling_<mode>.json),
+    and this test checks that the constants in the source ARE that fit (predictions equal to 5 %) and that the fit describes the shards it
+    was made from (15 %).  It is in-sample: the three features are nearly collinear, and fitted on the 1-, 2- and 4-rank shards alone the
+    model misses the 8-rank shards by up to 21 % (exact kernels) / 70 % (tolerance modes) -- it interpolates the recorded partitions, it
+    does not extrapolate to other rank counts or kernels.  The partition it drives is only a load-balancing heuristic; results never
+    depend on it (tests/test_gpu_compat.py::test_periodic_table_two_ranks_equal_one_rank), and the measured number of config 4 is
+    bench.py's `extra.periodic_table` (this run's ranks), not this model."""
     import importlib.util
     import json
     import os
@@ -114,4 +118,4 @@ def test_shard_time_model_reproduces_the_recorded_shards():
     # the prediction itself: an eighth of the table per GPU
     with open(fitm.path_of("tolerance")) as f:
         tol = json.load(f)
-    assert tol["predicted_seconds"]["8"] <= 7.0            # VERDICT r3 target for the 8-GPU prediction
+    assert tol["predicted_seconds"]["8"] <= 7.0            # (reads the recorded file: the emulation of round 4, a PREDICTION from one GPU)
