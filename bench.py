@@ -692,8 +692,11 @@ def main():
             "parity_gates": parity_gates(pmode, "tolerance" if args.scan_sweeps else "exact"),
         }
         cpu_job = None
-        if world == 1 and not args.no_cpu:      # rank 0 at N = 1 only: the other ranks of a larger job would sit at the final barrier
-            cpu_job = cpu_baseline_start(args.levels, args.lsda, args.cpu_steps)      # child processes on the host cores, next to the extras
+        want_cpu = world == 1 and not args.no_cpu      # rank 0 at N = 1 only: the other ranks of a larger job would sit at the final barrier
+        # The CPU legs run in child processes on the host cores NEXT TO the long extras (batches, 2^20+1 nodes) -- but start only after the
+        # short single-atom extras: three Python children importing numpy while a 16 ms step is being timed cost it 3-5 ms of host jitter
+        if want_cpu and args.no_extras:
+            cpu_job = cpu_baseline_start(args.levels, args.lsda, args.cpu_steps)
         if world == 1 and not args.no_extras:
             # further measured workloads with the same per-kernel figures (>= 10 timed steps after >= 5 warm-up steps wherever a step
             # is short enough): the opt-in tolerance mode of the multigrid smoother, LSDA (BASELINE config 3), a machine-filling
@@ -725,6 +728,8 @@ def main():
                         ("batch1024_lda", args.levels, 1024, False, 4, 2, None, None, None),
                         ("batch1024_lda_scan_sweeps", args.levels, 1024, False, 4, 2, None, SCAN, None)]
             for name, lv, atoms, lsda, st, wu, pm, sm, wl2 in sel:
+                if want_cpu and cpu_job is None and (atoms > 1 or lv != args.levels):
+                    cpu_job = cpu_baseline_start(args.levels, args.lsda, args.cpu_steps)
                 if lv == args.levels:
                     g2, d2, r2 = grid, delta, rmax
                 else:
@@ -752,6 +757,8 @@ def main():
                 except Exception as e:                      # the isolated sweep-kernel benchmark must not cost the line
                     extra["dense_k_sweeps"] = {"error": repr(e)}
             out["extra"] = extra
+        if want_cpu and cpu_job is None:
+            cpu_job = cpu_baseline_start(args.levels, args.lsda, args.cpu_steps)
         if pt_extra is not None:
             out.setdefault("extra", {})["periodic_table"] = pt_extra
         if cpu_job is not None:
