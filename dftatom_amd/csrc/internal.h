@@ -49,7 +49,8 @@ void dfta_persist_destroy(dfta_persist_buffers* pb);
 int dfta_launch_levels_persist(dfta_ctx* ctx, const dfta_grid* g, dfta_persist_buffers* pb, dfta::Job* d_jobs, const int* live, int nlive,
                                const double2* d_tab, const double2* d_bounds, double* d_Psi, double* d_Q, int* d_jstart_keep,
                                unsigned long long* d_counters, bool stats, int nopredict, int integ_rule, const double* tuning, int fixed_point,
-                               int* rounds, int* aborted, std::vector<unsigned long long>* trace_out, const int* share = nullptr /* host, nlive: workgroups per level */);
+                               int* rounds, int* aborted, std::vector<unsigned long long>* trace_out, const int* share = nullptr /* host, nlive: workgroups per level */,
+                               int deep_reserve = 0 /* workgroups the pool keeps for the levels marked Job::deep == 2 */);
 
 // scan.hip: the tolerance mode of the sweeps (transfer-matrix scan: one workgroup per trial)
 struct dfta_scan_tables {

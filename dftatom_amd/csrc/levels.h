@@ -140,6 +140,8 @@ struct LevelSolver {
     bool persist_ok = false;        // the solver's shape allows it (decided in setup(); $DFTA_DEBUG LEVELS_NOPERSIST switches it off)
     dfta_persist_buffers pb;
     int persist_fallbacks = 0;      // solves repeated with host rounds after a lost worker
+    int persist_deep_reserve = 0;   // workgroups of the pool kept for the levels that ended last in the previous steps
+    std::vector<int> persist_tend;  // per job: 3 x the search-end times of the last three device-side solves [us] (0: none) -- the feedback ranks by their maximum
     int persist_runs = 0;
     double tuning[4] = {1e-11, 16e-12, 1.5e-11, 0.25};     // noise band (rel, abs, secant) and the secant's kappa, as set in setup()
     int fixed_point = 1;

@@ -899,21 +899,36 @@ int LevelSolver::run(const double* dV, const double* job_bottom, int run_mode, d
         j.spine = 0;           // planned on the device (k_plan below), after the bottoms have been clamped
         j.phase_done = 0;
     }
+    persist_deep_reserve = 0;
     if (use_persist && h_last.size() == jobs.size() && !pb.equal_shares) {
         // Feedback (speculation only): the levels whose search ended last in the previous step get first call on the pool (persist_plan,
         // deep = 2: as many as the pool can give a second share to), those within 15 % of the last one may match candidate eigenvalues
         // (deep = 1), the rest have time to spare (deep = 0)
+        // (ranked by the maximum over the last three steps: a level that gets its deeper trees ends earlier, and a one-step memory would
+        // take them away again in the next step)
+        if (persist_tend.size() != 3 * jobs.size()) persist_tend.assign(3 * jobs.size(), 0);
+        for (int k : plive) {
+            int* h = &persist_tend[3 * (size_t)k];
+            if (h_last[k].t_end_us > 0) { h[2] = h[1]; h[1] = h[0]; h[0] = h_last[k].t_end_us; }
+        }
+        auto score = [&](int k) { const int* h = &persist_tend[3 * (size_t)k]; return std::max(h[0], std::max(h[1], h[2])); };
         std::vector<int> order;
-        for (int k : plive) if (h_last[k].t_end_us > 0) order.push_back(k);
+        for (int k : plive) if (score(k) > 0) order.push_back(k);
         if (order.size() == plive.size()) {
-            std::sort(order.begin(), order.end(), [&](int x, int y) { return h_last[x].t_end_us > h_last[y].t_end_us; });
+            std::sort(order.begin(), order.end(), [&](int x, int y) { return score(x) > score(y); });
             const int equal = pb.nblocks / (int)plive.size();
             int pool = pb.nblocks - equal * (int)plive.size();
             for (int k : plive) if (jobs[k].nodes == 0 && equal >= 8) pool += equal / 2;
             const int ndeep = std::min<int>((int)order.size(), pool / std::max(equal - 1, 1));
-            const int tmax_us = h_last[order[0]].t_end_us;
+            persist_deep_reserve = ndeep * (equal - 1);
+            const int tmax_us = score(order[0]);
             for (size_t q = 0; q < order.size(); ++q)
-                jobs[order[q]].deep = (int)q < ndeep ? 2 : (h_last[order[q]].t_end_us > 0.85 * tmax_us ? 1 : 0);
+                jobs[order[q]].deep = (int)q < ndeep ? 2 : (score(order[q]) > 0.85 * tmax_us ? 1 : 0);
+            if (pb.want_trace) {
+                fprintf(stderr, "persist feedback: pool %d, reserve %d; search ends of the previous step [us]:", pool, persist_deep_reserve);
+                for (size_t q = 0; q < order.size(); ++q) fprintf(stderr, " %d:%d%s", order[q], score(order[q]), jobs[order[q]].deep == 2 ? "*" : "");
+                fprintf(stderr, "\n");
+            }
         }
     }
     DFTA_HIP(ctx, hipMemcpyAsync(d_jobs, jobs.data(), sizeof(Job) * njobs, hipMemcpyHostToDevice, st));
@@ -1015,7 +1030,7 @@ int LevelSolver::run(const double* dV, const double* job_bottom, int run_mode, d
         const bool float_shares = !pb.equal_shares && equal >= 8;
         for (size_t q = 0; q < plive.size(); ++q) share[q] = (float_shares && jobs[plive[q]].nodes == 0) ? equal - equal / 2 : equal;
         rc = dfta_launch_levels_persist(ctx, g, &pb, d_jobs, plive.data(), (int)plive.size(), d_tab, d_bounds, d_Psi, d_Q, d_jstart_keep, d_counters, stats != nullptr,
-                                        use_prediction ? 0 : 1, integ_rule, tuning, fixed_point, &persist_rounds, &aborted, want_trace ? &persist_trace : nullptr, share.data());
+                                        use_prediction ? 0 : 1, integ_rule, tuning, fixed_point, &persist_rounds, &aborted, want_trace ? &persist_trace : nullptr, share.data(), persist_deep_reserve);
         if (rc) return rc;
         if (stats) { DFTA_HIP(ctx, hipEventRecord(ev[1], st)); DFTA_HIP(ctx, hipEventSynchronize(ev[1])); DFTA_HIP(ctx, hipEventElapsedTime(&ms_persist, ev[0], ev[1])); }
         ++persist_runs;

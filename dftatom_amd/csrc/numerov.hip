@@ -1666,7 +1666,7 @@ int dfta_persist_create(dfta_ctx* ctx, const dfta_grid* g, int nlive_cap, dfta_p
 int dfta_launch_levels_persist(dfta_ctx* ctx, const dfta_grid* g, dfta_persist_buffers* pb, dfta::Job* d_jobs, const int* live, int nlive,
                                const double2* d_tab, const double2* d_bounds, double* d_Psi, double* d_Q, int* d_jstart_keep,
                                unsigned long long* d_counters, bool stats, int nopredict, int integ_rule, const double* tuning /* noise rel, abs, secant, kappa */,
-                               int fixed_point, int* rounds, int* aborted, std::vector<unsigned long long>* trace_out, const int* share)
+                               int fixed_point, int* rounds, int* aborted, std::vector<unsigned long long>* trace_out, const int* share, int deep_reserve)
 {
     *aborted = 0;
     if (nlive < 1 || nlive > pb->nlive_cap || g->uniform) return DFTA_ERR_INVALID;
@@ -1739,6 +1739,7 @@ int dfta_launch_levels_persist(dfta_ctx* ctx, const dfta_grid* g, dfta_persist_b
     pa.trace = trace_out ? reinterpret_cast<unsigned long long*>(dctl + pb->ctl_bytes) : nullptr;
     pa.trace_cap = (unsigned)pb->trace_cap;
     pa.fault_block = pb->fault_block;
+    pa.deep_reserve = deep_reserve;
     GridScalars gs = scalars_of(g);
     // the workers wait for each other: co-residency is the launch's business (one workgroup per compute unit: 140 KB of LDS).  Under a
     // profiler the launch is an ordinary one (rocprofiler-sdk 7.2 crashes in an exit handler after a cooperative launch, see poisson.hip)
