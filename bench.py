@@ -189,7 +189,10 @@ def pmc_traffic(kernel, workload="default"):
     (profiles/*<workload>_hbm_traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate passes; FETCH_SIZE doubled as
     MI355X_MICROARCH.md prescribes for gfx950).  bench.py cannot run the profiler on itself: the number is the measured one of
     that profile, returned with its tag -- and withheld (null) when the kernels' sources have changed since it was taken."""
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*%s_hbm_traffic.json" % workload)), key=os.path.getmtime)
+    import re
+    pat = re.compile(r"^r\d+[a-z]?_%s_hbm_traffic\.json$" % re.escape(workload))       # r05_scan_tol_..., not r05_batch256_scan_tol_...
+    files = sorted((f for f in glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.json")) if pat.match(os.path.basename(f))),
+                   key=lambda f: (os.path.basename(f).split("_")[0], os.path.getmtime(f)))
     if not files:
         return None, None
     try:
