@@ -77,6 +77,7 @@ struct MgDesc {
     // workgroup 0 alone, entirely in LDS.  -1: off.  cs_phi / cs_src: offsets of a level's arrays inside the staging memory
     // (doubles), cs_lc: log2(nodes per lane) of its 64-lane interleaved layout, or -1 for natural order.
     int cs_top;
+    int xw_top;      // exact mode: levels xw_top .. levels-1 (65, 33, 17, 9, 5, 3 nodes) of the coarse section with their nodes in registers (xw_section); -1: off
     int rc_src[6];   // ... offsets (doubles, inside the staging memory) of the sources of levels rc_top .. rc_top + 5 (256 C entries each)
     int adaptive;    // DFTA_POISSON_ADAPTIVE: stop the V-cycles at the round-off floor (run_cycles / res_cycles)
     int rc_top;      // tolerance mode, resident groups: the coarse workgroup runs levels rc_top .. levels-1 of a V-cycle with their nodes in registers (coarse_resident_cycle); -1: off
@@ -472,6 +473,11 @@ static int poisson_create_impl(dfta_ctx* ctx, const dfta_grid* g, int batch, int
         }
         if (ok && at <= 2 * kStageArr - 64) D.cs_top = top;
     }
+    // exact mode: the six coarsest levels of the coarse section in registers (poisson_kernels.inc: xw_section), entered from the 129-node level
+    D.xw_top = -1;
+    if (!p->tol && D.cs_top > 0 && D.levels >= 8 && D.levels - 6 > D.cs_top && D.lv[D.levels - 6].n == 65 && D.lv[D.levels - 1].n == 3 &&
+        D.cs_lc[D.levels - 6] < 0 && D.cs_lc[D.levels - 7] == 1 && !dfta_knob("POISSON_NOXW"))
+        D.xw_top = D.levels - 6;
     // tolerance mode: the sub-cycle from the 8193-node level down in registers (poisson_kernels.inc: coarse_resident_cycle) -- 32 nodes per
     // thread on its first level, the levels down to 257 nodes halve the chunk, the 129-node level and below run in one wave.  Resident
     // groups: the coarse workgroup's levels; staged groups and one workgroup per atom: workgroup 0's, from the first level it does not share

@@ -291,7 +291,8 @@ def test_poisson_workgroup_groups_are_bit_identical(ctx, grid17):
     variants = [{"DFTA_POISSON_GROUP": str(g)} for g in (0, 1, 2, 3, 4)]
     variants += [{"DFTA_POISSON_NOSTAGE": "1"}, {"DFTA_POISSON_NOSTAGE_SHARED": "1"}, {"DFTA_POISSON_NOSTAGE_WAVE": "1"},
                  {"DFTA_POISSON_NOFOLD": "1"}, {"DFTA_POISSON_GROUP": "3", "DFTA_POISSON_NOFOLD": "1"},
-                 {"DFTA_POISSON_NOCOARSE": "1"}, {"DFTA_POISSON_GROUP": "0", "DFTA_POISSON_NOCOARSE": "1"}]
+                 {"DFTA_POISSON_NOCOARSE": "1"}, {"DFTA_POISSON_GROUP": "0", "DFTA_POISSON_NOCOARSE": "1"},
+                 {"DFTA_POISSON_NOXW": "1"}, {"DFTA_POISSON_GROUP": "0", "DFTA_POISSON_NOXW": "1"}, {"DFTA_POISSON_GROUP": "4", "DFTA_POISSON_NOXW": "1"}]
     for var in variants:
         with _knobs_ctx(var):                                       # DFTA_DEBUG entries, read by dfta_poisson_create
             ps = D.Poisson(ctx, grid17, 2)

@@ -61,6 +61,25 @@ def test_resident_groups_return_the_one_workgroup_bits(ctx, L, delta, R):
     grid.close()
 
 
+@pytest.mark.parametrize("L,delta,R", [(12, 2e-3, 25.0), (14, 5e-4, 25.0), (17, 1e-4, 50.0), (17, None, 50.0)])
+def test_register_coarse_levels_return_the_lds_bits(ctx, L, delta, R):
+    """Round 5: in exact mode the six coarsest levels of a V-cycle (65 ... 3 nodes) keep Phi and S in registers through the whole visit
+    sequence -- lane-shift sweeps, restriction and prolongation as lane arithmetic (poisson_kernels.inc: xw_section) -- instead of
+    level-by-level sweeps on LDS copies (POISSON_NOXW).  The same operations on the same values in the same order: U, the V-cycle count
+    and the reported error norm are the same bits, for the resident groups, a staged group and one workgroup per atom, for small and
+    large Z (Z = 1 meets the reference's stop test early: the sweep counts of the early-stop rule are exercised), on a uniform grid too."""
+    grid = D.Grid(ctx, L, delta, R)
+    rr = grid.r()
+    for Zs in ([86], [1], [18, 2, 54]):
+        rho = np.stack([z * (1.0 + 0.3 * k) ** 3 * np.exp(-2 * (1.0 + 0.3 * k) * rr) / np.pi for k, z in enumerate(Zs)])
+        for kv in ({}, {"DFTA_POISSON_GROUP": "0"}, {"DFTA_POISSON_RES": "0"}):
+            Ux, vcx, ex, _ = _solve(ctx, grid, Zs, rho, D.POISSON_EXACT, **kv)
+            Ul, vcl, el, _ = _solve(ctx, grid, Zs, rho, D.POISSON_EXACT, DFTA_POISSON_NOXW="1", **kv)
+            assert np.array_equal(Ux.view(np.int64), Ul.view(np.int64)), (L, Zs, kv)
+            assert np.array_equal(vcx, vcl) and np.array_equal(ex.view(np.int64), el.view(np.int64)), (L, Zs, kv, vcx, vcl)
+    grid.close()
+
+
 def test_resident_groups_are_deterministic(ctx):
     """He at 16385 nodes: one shared level, short passes, the cycle stops early -- exchanges follow each other within microseconds.
     Thirty SCF steps twice: every step's U and V-cycle count identical, and identical to the one-workgroup solver's."""
