@@ -20,6 +20,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <numeric>
 #include <type_traits>
 #include <vector>
@@ -1675,6 +1676,8 @@ int dfta_launch_levels_persist(dfta_ctx* ctx, const dfta_grid* g, dfta_persist_b
     if (base < 2) return DFTA_ERR_INVALID;
     hipStream_t st = ctx->stream;
     {   // this translation unit's copies of the prediction constants (levels_device.inc), per device
+        static std::mutex mu;                 // (contexts of several host threads may launch on the same device)
+        std::lock_guard<std::mutex> lock(mu);
         static double last[16][4];
         static int last_fp[16];
         static bool have[16];
