@@ -190,3 +190,47 @@ struct DevBuf {
         return hipMalloc(reinterpret_cast<void**>(&p), count * sizeof(T));
     }
 };
+
+// A pointer that reaches a non-inlined device function has no known address space: the compiler emits FLAT loads and stores, which count
+// against the LDS counter as well and return out of order with it -- every wait for one of them is a wait for ALL of them (`s_waitcnt
+// vmcnt(n) lgkmcnt(0)`), so loads issued ahead of their use hide nothing, and wave-uniform addresses cannot use scalar loads.
+// dfta_as_global / dfta_as_shared re-derive the pointer through its address space (a flat address of global memory IS the global address;
+// the LDS offset is the low half of a flat LDS address): the address-space inference then turns every access that descends from the
+// result into a global / LDS instruction.  (`__builtin_assume(!is_shared && !is_private)` is not enough: it survives only where the
+// assumed value itself is the base of the access.)
+#if defined(__HIPCC__)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define DFTA_AS_CAST(T, N, p) ((T*)(T __attribute__((address_space(N)))*)(unsigned long long)(p))
+#else
+#define DFTA_AS_CAST(T, N, p) (p)      // host pass: the device functions are parsed, never run
+#endif
+template <typename T> __device__ __forceinline__ T* dfta_as_global(T* p) { return DFTA_AS_CAST(T, 1, p); }
+// read-only for the whole kernel (tables built by an earlier launch): the constant address space, so that wave-uniform addresses are
+// read through the scalar cache (`s_load`) -- a non-kernel function cannot prove "not written meanwhile" of a global pointer
+template <typename T> __device__ __forceinline__ const T* dfta_as_constant(const T* p) { return DFTA_AS_CAST(const T, 4, p); }
+template <typename T> __device__ __forceinline__ T* dfta_as_shared(T* p)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (T*)(T __attribute__((address_space(3)))*)(unsigned)(unsigned long long)p;
+#else
+    return p;
+#endif
+}
+// the arguments of a non-kernel function arrive in vector registers and count as divergent: a pointer that is the same in every lane is
+// declared so (two v_readfirstlane), which gives scalar address arithmetic, the `saddr` form of vector loads and scalar loads
+template <typename T> __device__ __forceinline__ T* dfta_uniform(T* p)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    const unsigned long long u = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+    return (T*)(((unsigned long long)hi << 32) | lo);
+#else
+    return p;
+#endif
+}
+#endif
+#if defined(__HIP_DEVICE_COMPILE__)
+#define DFTA_ASSUME_GLOBAL(p) __builtin_assume(!__builtin_amdgcn_is_shared(p) && !__builtin_amdgcn_is_private(p))
+#else
+#define DFTA_ASSUME_GLOBAL(p) ((void)0)
+#endif

@@ -49,11 +49,7 @@ __device__ __forceinline__ double f_of(double veff, double e2, double E, const G
 // A pointer that reaches device code through a struct or a call (not as a kernel argument) is a generic one to the compiler: flat
 // loads and stores, which count against the LDS counter as well -- `s_waitcnt lgkmcnt(0)` before an LDS-only barrier then waits for
 // global memory.  The assumption below (never LDS, never scratch) lets the address-space inference use global instructions.
-#if defined(__HIP_DEVICE_COMPILE__)
-#define DFTA_ASSUME_GLOBAL(p) __builtin_assume(!__builtin_amdgcn_is_shared(p) && !__builtin_amdgcn_is_private(p))
-#else
-#define DFTA_ASSUME_GLOBAL(p) ((void)0)
-#endif
+// (DFTA_ASSUME_GLOBAL: common.h)
 
 // ---- table of wave-uniform per-point inputs -----------------------------------------------------------
 // tab[(slot)*N + i] = { V[v][i] + cl[l][i], e2[i] }   (Numerov.h:93: V + l(l+1)/(r r) * 0.5)
@@ -1117,14 +1113,16 @@ struct MatchShared {
 // The solve for ONE trial by a workgroup of NT threads: wave 0 integrates, wave 1 helps, further waves (the device-side level search of
 // persist.inc runs this with the 320 threads of a sweep workgroup) only keep the barriers company.  Returns the match point to every thread.
 template <int NT>
-__device__ __forceinline__ int match_solve(MatchShared& sh, const double2* __restrict__ T, const double E, const int steps, const double us0, const double us10,
-                                           const double zero1, const GridScalars& gs, const double2* __restrict__ bounds_slot /* the slot's bounds, or null */,
-                                           double* __restrict__ P, double* __restrict__ Qt)
+__device__ __forceinline__ int match_solve(MatchShared& sh, const double2* __restrict__ T_, const double E, const int steps, const double us0, const double us10,
+                                           const double zero1, const GridScalars& gs, const double2* __restrict__ bounds_slot_ /* the slot's bounds, or null */,
+                                           double* __restrict__ P_, double* __restrict__ Qt_)
 {
-    DFTA_ASSUME_GLOBAL(T);
-    DFTA_ASSUME_GLOBAL(P);
-    DFTA_ASSUME_GLOBAL(Qt);
-    if (bounds_slot) DFTA_ASSUME_GLOBAL(bounds_slot);
+    // inside the device-side level search (persist.inc) these arrive as arguments of a real function: no address space, flat accesses --
+    // the helper wave's loads ahead of the integrator would then hide nothing (common.h)
+    const double2* __restrict__ T = dfta_as_global(T_);
+    const double2* __restrict__ bounds_slot = dfta_as_global(bounds_slot_);      // null stays null
+    double* __restrict__ P = dfta_as_global(P_);
+    double* __restrict__ Qt = dfta_as_global(Qt_);
     const int lane = threadIdx.x & 63;
     const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // 0: integrator, 1: helper, 2..: idle
     const int N = gs.N;

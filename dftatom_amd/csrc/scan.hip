@@ -252,51 +252,66 @@ __device__ __forceinline__ void rows_lane(const double* __restrict__ tabv, int t
     }
 }
 
-// all C rows of the wave's lanes (C a multiple of 16), descending, two batches of eight rows in flight; the row pointer and T[k] are
-// wave-uniform (scalar address arithmetic, scalar loads).  PRED: a lane takes only its rows in [klo, khi] (the waves that hold the
+// all C rows of the wave's lanes (C a multiple of 8 NB), descending, NB batches of eight rows in flight (the loads of a batch are issued
+// NB - 1 batches ahead of its arithmetic: a wave keeps 4 NB KB on the way -- what bounds a row loop is latency x bytes in flight, not issue);
+// the row pointer and T[k] are wave-uniform (scalar address arithmetic, scalar loads).  PRED: a lane takes only its rows in [klo, khi] (the waves that hold the
 // cut-off, the exit point or the innermost lane) -- by a 0/1 factor, not by branches.
-template <int V, bool PRED, typename P>
+template <int V, bool PRED, int NB, typename P>
 __device__ __forceinline__ void rows_wave(const double* __restrict__ tabv, int t, const double* __restrict__ T, double Atop, int C, int khi, int klo, double E,
                                           double c4, P& ps)
 {
     const unsigned tu = static_cast<unsigned>(t);      // uniform row pointer + 32-bit lane offset: the load's own addressing mode
     auto rowp = [&](int k) { return tabv + ((size_t)(k < 0 ? 0 : k) << kLogT); };
-    double v0[8], v1[8];
+    static_assert(NB % 2 == 0, "the T batches alternate between two sets of scalar registers");
+    auto tat = [&](int k) { return T[k < 0 ? 0 : k]; };
+    double v[NB][8], tk[2][8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v0[j] = rowp(C - 1 - j)[tu];
-    for (int k = C - 1; k >= 0; k -= 16) {
+    for (int b = 0; b < NB - 1; ++b)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[b][j] = rowp(C - 1 - 8 * b - j)[tu];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) tk[0][j] = tat(C - 1 - j);
+    for (int k = C - 1; k >= 0; k -= 8 * NB) {
         const int ku = __builtin_amdgcn_readfirstlane(k);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v1[j] = rowp(ku - 8 - j)[tu];
-        __builtin_amdgcn_sched_barrier(0);
+        for (int b = 0; b < NB; ++b) {
+            constexpr int kAhead = NB - 1;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const double f = fma(Atop * T[ku - j], v0[j] - E, c4);
-            if (PRED) ps.template row_gated<V>(f, (ku - j <= khi && ku - j >= klo) ? 1. : 0.); else ps.template row<V>(f);
+            for (int j = 0; j < 8; ++j) v[(b + kAhead) % NB][j] = rowp(ku - 8 * (b + kAhead) - j)[tu];     // below row 0 (last turn): row 0 again, unused
+#pragma unroll
+            for (int j = 0; j < 8; ++j) tk[(b + 1) & 1][j] = tat(ku - 8 * (b + 1) - j);                    // the factors of the NEXT batch: scalar loads, one batch ahead
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int kr = ku - 8 * b - j;
+                const double f = fma(Atop * tk[b & 1][j], v[b][j] - E, c4);
+                if (PRED) ps.template row_gated<V>(f, (kr <= khi && kr >= klo) ? 1. : 0.); else ps.template row<V>(f);
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v0[j] = rowp(ku - 16 - j)[tu];       // below row 0 (last turn): row 0 again, unused
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const double f = fma(Atop * T[ku - 8 - j], v1[j] - E, c4);
-            if (PRED) ps.template row_gated<V>(f, (ku - 8 - j <= khi && ku - 8 - j >= klo) ? 1. : 0.); else ps.template row<V>(f);
-        }
-        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
 // the innermost rows (index < 16) are always divided: there f -> l(l+1)/i^2 is far outside the series' range (row 1 of l = 3 has f > 12)
 constexpr int kInnerRows = 16;
+#ifndef DFTA_SCAN_ROW_BATCHES
+#define DFTA_SCAN_ROW_BATCHES 4
+#endif
+constexpr int kRowBatches = DFTA_SCAN_ROW_BATCHES;     // eight-row batches in flight per wave on grids with C >= 8 kRowBatches rows per lane
 
 template <int V, typename P>
 __device__ __forceinline__ void run_rows_v(const double* __restrict__ tabv, int t, const double* __restrict__ T, double Atop, int C, int khi, int klo, bool full,
                                            bool inner, double E, double c4, P& ps)
 {
     if (C >= 16) {
-        if (full) rows_wave<V, false>(tabv, t, T, Atop, C, khi, klo, E, c4, ps);
-        else rows_wave<V, true>(tabv, t, T, Atop, C, khi, inner ? max(klo, kInnerRows) : klo, E, c4, ps);
+        const int klo_w = inner ? max(klo, kInnerRows) : klo;
+        if (C >= 8 * kRowBatches) {
+            if (full) rows_wave<V, false, kRowBatches>(tabv, t, T, Atop, C, khi, klo, E, c4, ps);
+            else rows_wave<V, true, kRowBatches>(tabv, t, T, Atop, C, khi, klo_w, E, c4, ps);
+        } else {
+            if (full) rows_wave<V, false, 2>(tabv, t, T, Atop, C, khi, klo, E, c4, ps);
+            else rows_wave<V, true, 2>(tabv, t, T, Atop, C, khi, klo_w, E, c4, ps);
+        }
         if (inner && klo < kInnerRows && khi >= klo) rows_lane<VDIV>(tabv, t, T, Atop, min(khi, kInnerRows - 1), klo, E, c4, ps);
         return;
     }
@@ -318,9 +333,15 @@ __device__ __forceinline__ void run_rows(const double* __restrict__ tabv, int t,
 // One sweep of one trial by the whole workgroup.  KIND: DFTA_SWEEP_COUNT / DFTA_SWEEP_ZERO.  tabv: the slot's interleaved veff table;
 // mm: per lane {min, max} of veff over the lane's rows ({-inf, +inf} when a row is NaN).
 template <int KIND>
-__device__ SweepOut scan_sweep(const ScanGrid& G, const double* __restrict__ tabv, const double2* __restrict__ mm, double E, int limit, ScanShared& sh, unsigned par,
+__device__ SweepOut scan_sweep(const ScanGrid& G_, const double* __restrict__ tabv_, const double2* __restrict__ mm_, double E, int limit, ScanShared& sh_, unsigned par,
                                int hint = 0, LaneState* ls = nullptr)
 {
+    // this is a real function (two instances, called ~150 times per level): its pointers arrive without an address space (common.h)
+    ScanGrid G = G_;
+    G.r = dfta_as_constant(dfta_uniform(G_.r)); G.Atop = dfta_as_constant(dfta_uniform(G_.Atop)); G.T = dfta_as_constant(dfta_uniform(G_.T));
+    const double* __restrict__ tabv = dfta_as_constant(dfta_uniform(tabv_));
+    const double2* __restrict__ mm = dfta_as_constant(dfta_uniform(mm_));
+    ScanShared& sh = *dfta_as_shared(&sh_);
     const int tid = threadIdx.x;
     const int t = kT - 1 - tid;                 // segment of this lane: thread order = sweep order (descending index)
     const int C = 1 << G.logC;
@@ -591,9 +612,16 @@ __device__ __forceinline__ void match_out_rows(const double* __restrict__ tabv, 
     }
 }
 
-__device__ MatchOut scan_match(const ScanGrid& G, const double* __restrict__ tabv, const double2* __restrict__ mm, double E, double zero1, ScanShared& sh,
-                               unsigned& par, int hint, double* __restrict__ Psi, const double* __restrict__ eh, const double* __restrict__ cnst, int fused_norm)
+__device__ MatchOut scan_match(const ScanGrid& G_, const double* __restrict__ tabv_, const double2* __restrict__ mm, double E, double zero1, ScanShared& sh_,
+                               unsigned& par, int hint, double* __restrict__ Psi_, const double* __restrict__ eh_, const double* __restrict__ cnst_, int fused_norm)
 {
+    ScanGrid G = G_;
+    G.r = dfta_as_constant(dfta_uniform(G_.r)); G.Atop = dfta_as_constant(dfta_uniform(G_.Atop)); G.T = dfta_as_constant(dfta_uniform(G_.T));
+    const double* __restrict__ tabv = dfta_as_constant(dfta_uniform(tabv_));
+    double* __restrict__ Psi = dfta_as_global(dfta_uniform(Psi_));
+    const double* __restrict__ eh = dfta_as_constant(dfta_uniform(eh_));
+    const double* __restrict__ cnst = dfta_as_constant(dfta_uniform(cnst_));
+    ScanShared& sh = *dfta_as_shared(&sh_);
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int C = 1 << G.logC, N = G.N;
     MatchOut mo;
