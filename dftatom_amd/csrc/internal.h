@@ -58,6 +58,10 @@ struct dfta_scan_tables {
     double2* mm = nullptr;     // nslots * 512: {min, max} of veff over a lane's rows
     double* Atop = nullptr;    // 513: A = 2 Rp^2 delta^2 exp(2 i delta) of every lane's top row (and of row N-1)
     double* T = nullptr;       // C: exp(-2 delta (C-1-k))
+    // tabv and T point kScanPadRows rows / 8 entries INTO their allocations: the row loops issue the loads of the next batches
+    // unconditionally (rows below row 0 of slot 0, entries below T[0]: read, never used) -- no clamps, no branches in the loops
+    double* tabv_alloc = nullptr;
+    double* T_alloc = nullptr;
     int nslots = 0;
 };
 int dfta_scan_supported(const dfta_grid* g);

@@ -51,6 +51,7 @@ constexpr int kLogT = 9;
 constexpr int kT = 1 << kLogT;    // lanes per trial = threads per workgroup: 8 waves, two per SIMD, 256 VGPRs each
 constexpr int kW = kT / 64;       // waves per workgroup
 constexpr double kInv12 = 1. / 12.;
+constexpr int kScanPadRows = 32;  // rows of padding in front of the veff tables (dfta_scan_tables::tabv_alloc)
 
 // Tables (device): veff rows lane-interleaved per slot (N doubles: row i = t C + k at k 512 + t, row N-1 at N-1), per slot and lane
 // {min, max} of veff, and per GRID the factors of A_i = 2 Rp^2 delta^2 exp(2 i delta) = Atop[t] T[k]: Atop[t] = A of the lane's top
@@ -252,6 +253,33 @@ __device__ __forceinline__ void rows_lane(const double* __restrict__ tabv, int t
     }
 }
 
+// The lane's column of a slot's table as a BUFFER: address = descriptor base (scalar) + the row's byte offset (ONE scalar register) + the
+// lane's byte offset (a vector register that never changes) -- `buffer_load_dwordx2 v, voff, rsrc, soff offen`: no vector address
+// arithmetic per row (a global load needs a 64-bit per-lane address: two VALU instructions per row, which this loop cannot afford).
+// The descriptor starts kScanPadRows rows in front of the slot's row 0, so that rows -kScanPadRows .. C-1 have offsets >= 0.
+struct RowBuf {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __amdgpu_buffer_rsrc_t rs;
+    unsigned voff;
+    __device__ __forceinline__ RowBuf(const double* tabv, int t, int C)
+    {
+        rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(tabv) - (size_t)kScanPadRows * kT, 0,
+                                               static_cast<int>(sizeof(double) * ((size_t)(C + kScanPadRows) * kT + 1)), 0x00020000);
+        voff = static_cast<unsigned>(t) * 8u;
+    }
+    __device__ __forceinline__ double row(int k) const      // k wave-uniform
+    {
+        typedef unsigned int u2 __attribute__((ext_vector_type(2)));
+        const u2 r = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, (k + kScanPadRows) * (kT * 8), 0);
+        return __builtin_bit_cast(double, r);
+    }
+#else       // host pass: parsed, never run
+    const double* p;
+    __device__ __forceinline__ RowBuf(const double* tabv, int t, int) : p(tabv + t) {}
+    __device__ __forceinline__ double row(int k) const { return p[(size_t)k * kT]; }
+#endif
+};
+
 // all C rows of the wave's lanes (C a multiple of 8 NB), descending, NB batches of eight rows in flight (the loads of a batch are issued
 // NB - 1 batches ahead of its arithmetic: a wave keeps 4 NB KB on the way -- what bounds a row loop is latency x bytes in flight, not issue);
 // the row pointer and T[k] are wave-uniform (scalar address arithmetic, scalar loads).  PRED: a lane takes only its rows in [klo, khi] (the waves that hold the
@@ -260,31 +288,33 @@ template <int V, bool PRED, int NB, typename P>
 __device__ __forceinline__ void rows_wave(const double* __restrict__ tabv, int t, const double* __restrict__ T, double Atop, int C, int khi, int klo, double E,
                                           double c4, P& ps)
 {
-    const unsigned tu = static_cast<unsigned>(t);      // uniform row pointer + 32-bit lane offset: the load's own addressing mode
-    auto rowp = [&](int k) { return tabv + ((size_t)(k < 0 ? 0 : k) << kLogT); };
-    static_assert(NB % 2 == 0, "the T batches alternate between two sets of scalar registers");
-    auto tat = [&](int k) { return T[k < 0 ? 0 : k]; };
-    double v[NB][8], tk[2][8];
+    static_assert(NB % 2 == 0 && 8 * (NB - 1) <= kScanPadRows, "two sets of T registers in turn; the loads ahead of row 0 stay inside the padding");
+    typedef double d8 __attribute__((ext_vector_type(8)));
+    // What bounds this loop is the wave's ISSUE rate (one instruction of any kind per 4 cycles): address arithmetic is kept out of it.
+    // Per row: one scalar add (the row's byte offset) and one buffer load (RowBuf); per batch of eight rows ONE scalar load of the eight
+    // factors T.  Nothing is clamped: the tables are padded in front.
+    const RowBuf rb(tabv, t, C);
+    auto tvec = [&](int k0) { return *reinterpret_cast<const d8*>(T + (k0 - 7)); };      // T[k0 - 7 .. k0], 64-byte aligned, ONE scalar load
+    double v[NB][8];
+    d8 tk[2];
 #pragma unroll
     for (int b = 0; b < NB - 1; ++b)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[b][j] = rowp(C - 1 - 8 * b - j)[tu];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) tk[0][j] = tat(C - 1 - j);
+        for (int j = 0; j < 8; ++j) v[b][j] = rb.row(C - 1 - 8 * b - j);
+    tk[0] = tvec(C - 1);
     for (int k = C - 1; k >= 0; k -= 8 * NB) {
         const int ku = __builtin_amdgcn_readfirstlane(k);
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
             constexpr int kAhead = NB - 1;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[(b + kAhead) % NB][j] = rowp(ku - 8 * (b + kAhead) - j)[tu];     // below row 0 (last turn): row 0 again, unused
-#pragma unroll
-            for (int j = 0; j < 8; ++j) tk[(b + 1) & 1][j] = tat(ku - 8 * (b + 1) - j);                    // the factors of the NEXT batch: scalar loads, one batch ahead
+            for (int j = 0; j < 8; ++j) v[(b + kAhead) % NB][j] = rb.row(ku - 8 * (b + kAhead) - j);     // below row 0 (last turn): the padding, unused
+            tk[(b + 1) & 1] = tvec(ku - 8 * (b + 1));                                                     // the factors of the NEXT batch
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int kr = ku - 8 * b - j;
-                const double f = fma(Atop * tk[b & 1][j], v[b][j] - E, c4);
+                const double f = fma(Atop * tk[b & 1][7 - j], v[b][j] - E, c4);
                 if (PRED) ps.template row_gated<V>(f, (kr <= khi && kr >= klo) ? 1. : 0.); else ps.template row<V>(f);
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -333,12 +363,13 @@ __device__ __forceinline__ void run_rows(const double* __restrict__ tabv, int t,
 // One sweep of one trial by the whole workgroup.  KIND: DFTA_SWEEP_COUNT / DFTA_SWEEP_ZERO.  tabv: the slot's interleaved veff table;
 // mm: per lane {min, max} of veff over the lane's rows ({-inf, +inf} when a row is NaN).
 template <int KIND>
-__device__ SweepOut scan_sweep(const ScanGrid& G_, const double* __restrict__ tabv_, const double2* __restrict__ mm_, double E, int limit, ScanShared& sh_, unsigned par,
+__device__ __noinline__ SweepOut scan_sweep(const ScanGrid& G_, const double* __restrict__ tabv_, const double2* __restrict__ mm_, double E, int limit, ScanShared& sh_, unsigned par,
                                int hint = 0, LaneState* ls = nullptr)
 {
     // this is a real function (two instances, called ~150 times per level): its pointers arrive without an address space (common.h)
     ScanGrid G = G_;
     G.r = dfta_as_constant(dfta_uniform(G_.r)); G.Atop = dfta_as_constant(dfta_uniform(G_.Atop)); G.T = dfta_as_constant(dfta_uniform(G_.T));
+    G.N = __builtin_amdgcn_readfirstlane(G_.N); G.logC = __builtin_amdgcn_readfirstlane(G_.logC);      // the same in every lane: say so (scalar registers)
     const double* __restrict__ tabv = dfta_as_constant(dfta_uniform(tabv_));
     const double2* __restrict__ mm = dfta_as_constant(dfta_uniform(mm_));
     ScanShared& sh = *dfta_as_shared(&sh_);
@@ -612,11 +643,12 @@ __device__ __forceinline__ void match_out_rows(const double* __restrict__ tabv, 
     }
 }
 
-__device__ MatchOut scan_match(const ScanGrid& G_, const double* __restrict__ tabv_, const double2* __restrict__ mm, double E, double zero1, ScanShared& sh_,
+__device__ __noinline__ MatchOut scan_match(const ScanGrid& G_, const double* __restrict__ tabv_, const double2* __restrict__ mm, double E, double zero1, ScanShared& sh_,
                                unsigned& par, int hint, double* __restrict__ Psi_, const double* __restrict__ eh_, const double* __restrict__ cnst_, int fused_norm)
 {
     ScanGrid G = G_;
     G.r = dfta_as_constant(dfta_uniform(G_.r)); G.Atop = dfta_as_constant(dfta_uniform(G_.Atop)); G.T = dfta_as_constant(dfta_uniform(G_.T));
+    G.N = __builtin_amdgcn_readfirstlane(G_.N); G.logC = __builtin_amdgcn_readfirstlane(G_.logC);      // the same in every lane: say so (scalar registers)
     const double* __restrict__ tabv = dfta_as_constant(dfta_uniform(tabv_));
     double* __restrict__ Psi = dfta_as_global(dfta_uniform(Psi_));
     const double* __restrict__ eh = dfta_as_constant(dfta_uniform(eh_));
@@ -1189,7 +1221,7 @@ int dfta_scan_supported(const dfta_grid* g) { return g && !g->uniform && g->leve
 void dfta_scan_tables_destroy(dfta_scan_tables* tb)
 {
     if (!tb) return;
-    for (void* q : {(void*)tb->tabv, (void*)tb->mm, (void*)tb->Atop, (void*)tb->T}) if (q) (void)hipFree(q);
+    for (void* q : {(void*)tb->tabv_alloc, (void*)tb->mm, (void*)tb->Atop, (void*)tb->T_alloc}) if (q) (void)hipFree(q);
     *tb = dfta_scan_tables();
 }
 
@@ -1204,10 +1236,15 @@ int dfta_scan_tables_create(dfta_ctx* ctx, const dfta_grid* g, int nslots, dfta_
     for (int t = 0; t < kT; ++t) Atop[t] = 2. * g->Rp2delta2 * g->h_e2[(size_t)t * C + C - 1];
     Atop[kT] = 2. * g->Rp2delta2 * g->h_e2[N - 1];
     for (int k = 0; k < C; ++k) T[k] = exp(-g->twodelta * static_cast<double>(C - 1 - k));
-    hipError_t e = hipMalloc(reinterpret_cast<void**>(&tb->tabv), sizeof(double) * (size_t)nslots * N);
+    constexpr size_t kPadTab = (size_t)kScanPadRows * kT, kPadT = 8;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&tb->tabv_alloc), sizeof(double) * ((size_t)nslots * N + kPadTab));
+    if (e == hipSuccess) e = hipMemset(tb->tabv_alloc, 0, sizeof(double) * kPadTab);
+    if (e == hipSuccess) tb->tabv = tb->tabv_alloc + kPadTab;
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&tb->mm), sizeof(double2) * (size_t)nslots * kT);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&tb->Atop), sizeof(double) * (kT + 1));
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&tb->T), sizeof(double) * C);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&tb->T_alloc), sizeof(double) * (C + kPadT));
+    if (e == hipSuccess) e = hipMemset(tb->T_alloc, 0, sizeof(double) * kPadT);
+    if (e == hipSuccess) tb->T = tb->T_alloc + kPadT;
     if (e == hipSuccess) e = hipMemcpy(tb->Atop, Atop.data(), sizeof(double) * (kT + 1), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(tb->T, T.data(), sizeof(double) * C, hipMemcpyHostToDevice);
     if (e != hipSuccess) {

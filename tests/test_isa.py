@@ -45,11 +45,14 @@ def test_scan_sweeps_read_their_tables_with_global_and_scalar_loads(tmp_path):
     sweeps = {n: ls for n, ls in fns.items() if "10scan_sweepIL" in n}
     assert len(sweeps) == 2, sorted(fns)          # CountNodes and SolutionInZero: real functions, called ~150 times per level
     for name, lines in sweeps.items():
-        flat, glob, scal = _count(lines, "flat_load"), _count(lines, "global_load"), _count(lines, "s_load")
-        # the row loops: vector loads of the veff rows must be global (in-order vmcnt: 32 rows in flight per wave), the per-row factors
-        # T[k] scalar; a handful of flat accesses to the caller's LaneState / ScanGrid copies in scratch are all that may remain
-        assert glob > 500 and scal > 100, (name, flat, glob, scal)
-        assert flat <= 16, (name, flat, glob, scal)
+        flat, glob, buf, scal = _count(lines, "flat_load"), _count(lines, "global_load"), _count(lines, "buffer_load"), _count(lines, "s_load")
+        # the row loops: the veff rows come through buffer loads (scalar row offset + constant lane offset: no vector address arithmetic,
+        # in-order vmcnt: 32 rows in flight per wave), the eight factors T of a batch through ONE scalar load; the other tables through
+        # global loads; a handful of flat accesses to the caller's LaneState / ScanGrid copies in scratch are all that may remain
+        assert buf > 300 and glob > 50 and scal > 30, (name, flat, glob, buf, scal)
+        assert flat <= 16, (name, flat, glob, buf, scal)
+        assert not any("v_readfirstlane" in ln and i + 12 < len(lines) and any("s_cbranch_execnz" in x for x in lines[i:i + 12]) and
+                       any("buffer_load" in x for x in lines[i:i + 12]) for i, ln in enumerate(lines)), "waterfall loop around a buffer load: the descriptor is not wave-uniform"
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
