@@ -61,7 +61,13 @@ struct Job {
     // once two steps of history exist: a level close to a coarse bisection boundary flips an early decision now and then,
     // and a miss on the spine forfeits the round's tree.)
     double hist_T[3], hist_d[3];
-    int hist_ok;                     // 0: none, 1: end points only, 2: end points and distances
+    // Round 5: with linear mixing the end points converge geometrically -- the movement of one step is a nearly constant multiple q of the
+    // previous one (Rn: q = 0.47 .. 0.49 from step 10 on, the extrapolated point T + q d is off by < 0.01 |d|; Cu LSDA alternates, q = -0.7).
+    // hist_s: signed last movement, hist_q: its ratio to the one before (NaN: unknown); hist_c +- hist_w: the bracket the spine is
+    // planned from -- T +- 2 |d| without ratios, T + q d +- (0.2 + 4 |q - q_prev|) |d| with them (levels.hip; 3 - 4 more predicted
+    // decisions per first round than the two-step rule, scratch/r5_hist.py).
+    double hist_s[3], hist_q[3], hist_c[3], hist_w[3];
+    int hist_ok;                     // 0: none, 1: end points only, 2: end points and distances (3: and ratios)
     int frozen;                      // the job's atom has finished its SCF: the result of its last solve stands, nothing is integrated
     // Trial slots of the job in the current round: [tbase, tbase + tcap).  Static (k * tpj, tpj) when the launch fills the
     // machine; re-allotted every round by k_allot when a handful of jobs leave compute units idle (levels.hip).
@@ -145,6 +151,10 @@ struct LevelSolver {
     int persist_runs = 0;
     double tuning[4] = {1e-11, 16e-12, 1.5e-11, 0.25};     // noise band (rel, abs, secant) and the secant's kappa, as set in setup()
     int fixed_point = 1;
+    // history bracket of the first spines (Job::hist_c / hist_w): extrapolation with the last movement ratio ($DFTA_DEBUG LEVELS_NOEXTRAP: the
+    // two-step rule only; LEVELS_EXTRAP="a:b": half width (a + b |q - q_prev|) |d|)
+    bool hist_extrapolate = true;
+    double hist_kA = 0.2, hist_kB = 4.0;
     std::vector<unsigned long long> persist_trace;          // $DFTA_DEBUG LEVELS_PERSIST_TRACE: 4 words per closed round of the last run
 
     LevelSolver() = default;

@@ -618,6 +618,8 @@ int LevelSolver::setup(dfta_ctx* c, const dfta_grid* grid, int mode_, int tree_d
     {   // tuning of the predictions (never of a result): the defaults, or what the environment says, every time a solver is made
         double v[3] = {1e-11, 16e-12, 1.5e-11}, k = 0.25;
         if (const char* e = dfta_knob("LEVELS_NOISE")) sscanf(e, "%lf:%lf:%lf", &v[0], &v[1], &v[2]);   // "rel:abs:secant" of the noise band (':' -- the knob list itself is comma-separated)
+        hist_extrapolate = dfta_knob("LEVELS_NOEXTRAP") == nullptr;
+        if (const char* e = dfta_knob("LEVELS_EXTRAP")) sscanf(e, "%lf:%lf", &hist_kA, &hist_kB);
         if (const char* e = dfta_knob("LEVELS_SECANT_KAPPA")) k = atof(e);                                // trust in the parabolic correction
         (void)hipMemcpyToSymbol(HIP_SYMBOL(g_noise_rel), &v[0], sizeof(double));
         (void)hipMemcpyToSymbol(HIP_SYMBOL(g_noise_abs), &v[1], sizeof(double));
@@ -877,10 +879,22 @@ int LevelSolver::run(const double* dV, const double* job_bottom, int run_mode, d
             const Job& h = h_last[k];
             const double T[3] = {h.top, h.bottom, h.E};
             for (int ph = 0; ph < 3; ++ph) {
+                constexpr double kHistSafety = 2.0;
+                const double d = h.hist_ok >= 1 ? T[ph] - h.hist_T[ph] : 0.0;
                 j.hist_T[ph] = T[ph];
-                j.hist_d[ph] = h.hist_ok >= 1 ? fabs(T[ph] - h.hist_T[ph]) : -1.0;
+                j.hist_s[ph] = d;
+                j.hist_d[ph] = h.hist_ok >= 1 ? fabs(d) : -1.0;
+                const double q = (h.hist_ok >= 2 && h.hist_s[ph] != 0.0) ? d / h.hist_s[ph] : NAN;
+                j.hist_q[ph] = q;
+                j.hist_c[ph] = T[ph];
+                j.hist_w[ph] = kHistSafety * fabs(d);
+                // geometric convergence: extrapolate with the last ratio; the bracket is as wide as the ratio has been unsteady
+                if (hist_extrapolate && h.hist_ok >= 3 && std::isfinite(q) && std::isfinite(h.hist_q[ph]) && fabs(q) <= 1.0 && fabs(h.hist_q[ph]) <= 1.0) {
+                    const double u = (hist_kA + hist_kB * fabs(q - h.hist_q[ph])) * fabs(d);
+                    if (u < j.hist_w[ph]) { j.hist_c[ph] = T[ph] + q * d; j.hist_w[ph] = u; }
+                }
             }
-            j.hist_ok = h.hist_ok >= 1 ? 2 : 1;
+            j.hist_ok = std::min(h.hist_ok + 1, 3);
         } else {
             j.hist_ok = 0;
         }

@@ -985,11 +985,12 @@ __global__ void __launch_bounds__(kT) k_scan_levels_group(ScanGrid G0, const dou
     int hint = 0;
     const double bottom0 = J->bottom0;
     // history bracket of the three bisections (set by the host from the previous two solves; hm < 0: none)
-    const bool hok = J->hist_ok == 2;
-    const double hT0 = J->hist_T[0], hT1 = J->hist_T[1], hT2 = J->hist_T[2];
-    const double hm0 = hok && J->hist_d[0] >= 0 ? 2.0 * J->hist_d[0] + 1e-10 * fabs(hT0) + 64 * kErr : -1.0;
-    const double hm1 = hok && J->hist_d[1] >= 0 ? 2.0 * J->hist_d[1] + 1e-10 * fabs(hT1) + 64 * kErr : -1.0;
-    const double hm2 = hok && J->hist_d[2] >= 0 ? 2.0 * J->hist_d[2] + 1e-10 * fabs(hT2) + 64 * kErr : -1.0;
+    const bool hok = J->hist_ok >= 2;
+    // centre and half width of the history bracket as the host laid them out (levels.hip: T +- 2 |d|, or the extrapolated point)
+    const double hT0 = J->hist_c[0], hT1 = J->hist_c[1], hT2 = J->hist_c[2];
+    const double hm0 = hok && J->hist_d[0] >= 0 ? J->hist_w[0] + 1e-10 * fabs(hT0) + 64 * kErr : -1.0;
+    const double hm1 = hok && J->hist_d[1] >= 0 ? J->hist_w[1] + 1e-10 * fabs(hT1) + 64 * kErr : -1.0;
+    const double hm2 = hok && J->hist_d[2] >= 0 ? J->hist_w[2] + 1e-10 * fabs(hT2) + 64 * kErr : -1.0;
     int n_count = 0, n_zero = 0, bad = 0, len2 = 0, n_fixed = 0, iter3 = 0, conv = 0, fixed = 0, nonfinite = 0;
     long long pts = 0;
     // ph 1, 2: the two count bisections; 4: the sweep at BottomEnergy; 3: the u(0) bisection; 0: done

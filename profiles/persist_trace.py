@@ -96,9 +96,11 @@ def main():
                    "level_that_ends_last": crit, "its_rounds_mean": mean(crit_rounds), "its_rounds_min": min(crit_rounds),
                    "its_rounds_hist": {str(r): crit_rounds.count(r) for r in sorted(set(crit_rounds))},
                    "its_round_ms_mean": mean(crit_round_ms),
-                   "floor_ms_min_rounds_x_round": min(crit_rounds) * mean(crit_round_ms),
+                   "its_rounds_mode": max(set(crit_rounds), key=crit_rounds.count),
+                   "ms_mode_rounds_x_round": max(set(crit_rounds), key=crit_rounds.count) * mean(crit_round_ms),
+                   "ms_min_rounds_x_round": min(crit_rounds) * mean(crit_round_ms),
                    "note": "level index = position in the batch's level list (Rn LDA: 0 = 1s, 1 = 2s, 2 = 2p, ...); a round of the level that ends last is one "
-                           "full-length sweep of ~118-131 k dependent fp64 steps; floor = its smallest round count x its mean round time, nothing else on the path"}
+                           "full-length sweep of ~118-131 k dependent fp64 steps; 'rounds x round' = what the kernel would take with nothing but the dependent sweeps of that level on its path (mode: the usual round count; min: the steps with the longest predicted spines)"}
     out = {"workload": "Rn %s @ 131 073 nodes, one atom, exact kernels, DFTA_DEBUG=LEVELS_PERSIST_TRACE (the trace adds ~1 %% to the kernel)" % ("LSDA" if a.lsda else "LDA"),
            "summary_steady_state": summary,
            "steps": [{"step": s["step"], "kernel_ms": s["kernel_ms"], "levels_ms": s.get("levels_ms"), "layout": s.get("layout"), "fallbacks": s.get("fallbacks"),

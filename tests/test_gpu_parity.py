@@ -389,7 +389,7 @@ def test_predictions_never_change_results(ctx, grid14):
         with _knobs_ctx(env):
             scf = D.Scf(ctx, grid14, [36], lsda=False)               # Kr: s, p and d levels
             out = []
-            for _ in range(5):
+            for _ in range(8):                                      # (the extrapolated history brackets start with the fifth solve)
                 st = scf.step()
                 en, _ = scf.energies()
                 lv = scf.levels(0, 0)
@@ -406,7 +406,9 @@ def test_predictions_never_change_results(ctx, grid14):
     # estimate, fixed trial slots -- cost or save rounds, never a bit of the result
     for env in ({"DFTA_LEVELS_NOISE": "1e-14:1e-13:1e-14", "DFTA_LEVELS_SECANT_KAPPA": "0.001"},
                 {"DFTA_LEVELS_NOISE": "1e-9:1e-9:1e-9", "DFTA_LEVELS_SECANT_KAPPA": "0"},
-                {"DFTA_LEVELS_STATIC": "1"}):
+                {"DFTA_LEVELS_STATIC": "1"},
+                # history brackets: the two-step rule only / an extrapolation trusted to 0.1 % of the last movement (spines that miss)
+                {"DFTA_LEVELS_NOEXTRAP": "1"}, {"DFTA_LEVELS_EXTRAP": "0.001:0"}):
         c = run(False, **env)
         for k, (x, y) in enumerate(zip(a, c)):
             assert x[0] == y[0], (env, k)
