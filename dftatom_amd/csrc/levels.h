@@ -64,8 +64,8 @@ struct Job {
     // Round 5: with linear mixing the end points converge geometrically -- the movement of one step is a nearly constant multiple q of the
     // previous one (Rn: q = 0.47 .. 0.49 from step 10 on, the extrapolated point T + q d is off by < 0.01 |d|; Cu LSDA alternates, q = -0.7).
     // hist_s: signed last movement, hist_q: its ratio to the one before (NaN: unknown); hist_c +- hist_w: the bracket the spine is
-    // planned from -- T +- 2 |d| without ratios, T + q d +- (0.2 + 4 |q - q_prev|) |d| with them (levels.hip; 3 - 4 more predicted
-    // decisions per first round than the two-step rule, scratch/r5_hist.py).
+    // planned from -- T +- 2 |d| without ratios, T + q d +- (0.2 + 4 |q - q_prev|) |d| with them (levels.hip; 2 - 3 more predicted
+    // decisions per first round than the two-step rule, profiles/history_brackets.py).
     double hist_s[3], hist_q[3], hist_c[3], hist_w[3];
     int hist_ok;                     // 0: none, 1: end points only, 2: end points and distances (3: and ratios)
     int frozen;                      // the job's atom has finished its SCF: the result of its last solve stands, nothing is integrated
