@@ -14,8 +14,10 @@
 #include <math.h>
 
 #include <algorithm>
+#include <cstring>
 #include <vector>
 
+#include "call_stream.h"
 #include "dfta_runtime.h"
 
 namespace DFT {
@@ -121,17 +123,13 @@ public:
     inline void SolveSchrodingerCountNodes(double /*startPoint*/, unsigned int l, double E, long int steps, long int nodesLimit, int& nodesCount)
     {
         whole_grid(steps);
-        const int li = static_cast<int>(l), lim = static_cast<int>(nodesLimit);
-        run(DFTA_SWEEP_COUNT, 1, &li, &E, &lim, &nodesCount, nullptr);
+        nodesCount = one_trial(DFTA_SWEEP_COUNT, static_cast<int>(l), static_cast<int>(nodesLimit), E).count;
     }
     // reference Numerov.h:351-401
     inline double SolveSchrodingerSolutionInZero(double /*startPoint*/, unsigned int l, double E, long int steps)
     {
         whole_grid(steps);
-        const int li = static_cast<int>(l);
-        double u0 = 0;
-        run(DFTA_SWEEP_ZERO, 1, &li, &E, nullptr, nullptr, &u0);
-        return u0;
+        return one_trial(DFTA_SWEEP_ZERO, static_cast<int>(l), 0, E).u0;
     }
     // reference Numerov.h:403-504
     inline std::vector<double> SolveSchrodingerMatchSolutionCompletely(double /*startPoint*/, unsigned int l, double E, long int steps, long int& matchPoint)
@@ -181,7 +179,54 @@ private:
         dfta_compat::check(dfta_potential_sweeps(resident(), kind, rt.sweep_mode(function.grid()), n, l, E, limit, counts, u0, nullptr, nullptr), rt.ctx(),
                            "dfta_potential_sweeps");
     }
+    // One trial of the per-call surface.  Round 5: answered from what call_stream.h had integrated ahead when the caller is the reference's
+    // LoopOverLevels (the same kernels, the same potential, the bit-identical energy); otherwise the trial is integrated now -- together
+    // with every energy that loop can ask for in its next calls.  $DFTA_COMPAT_NOSPECULATE: one trial per call, as in rounds 1-4.
+    dfta_compat::CallStream::Value one_trial(int kind, int l, int limit, double E)
+    {
+        using dfta_compat::CallStream;
+        auto& rt = dfta_compat::Runtime::instance();
+        CallStream::Value v{0, 0.0};
+        if (!rt.speculate()) {
+            run(kind, 1, &l, &E, kind == DFTA_SWEEP_COUNT ? &limit : nullptr, kind == DFTA_SWEEP_COUNT ? &v.count : nullptr, kind == DFTA_SWEEP_ZERO ? &v.u0 : nullptr);
+            return v;
+        }
+        // the reference re-reads the caller's Potential on every call: what was integrated ahead belongs to the values it had then
+        const std::vector<double>& V = function.potential().m_potentialValues;
+        const int mode = rt.sweep_mode(function.grid());
+        if (m_seenV.size() != V.size() || m_seen_mode != mode || memcmp(m_seenV.data(), V.data(), sizeof(double) * V.size()) != 0) {
+            m_seenV = V;
+            m_seen_mode = mode;
+            m_stream.reset();
+        }
+        m_stream.sync(kind, l, limit, E);
+        if (!m_stream.lookup(kind, l, limit, E, v)) {
+            // exact kernels: a launch of 8 191 trials (128 blocks, one per compute unit) takes what one trial takes; scan sweeps: one workgroup
+            // per trial, 255 of them fill the machine once
+            const bool scan = mode == DFTA_SWEEPS_TOLERANCE;
+            m_stream.plan(kind, E, scan ? 8 : 13, scan ? 255 : 8191, m_planE);
+            const int n = static_cast<int>(m_planE.size());
+            m_planL.assign(n, l);
+            m_planLim.assign(n, limit);
+            m_planCount.assign(n, 0);
+            m_planU0.assign(n, 0.0);
+            run(kind, n, m_planL.data(), m_planE.data(), kind == DFTA_SWEEP_COUNT ? m_planLim.data() : nullptr,
+                kind == DFTA_SWEEP_COUNT ? m_planCount.data() : nullptr, kind == DFTA_SWEEP_ZERO ? m_planU0.data() : nullptr);
+            m_stream.store(kind, l, limit, m_planE, kind == DFTA_SWEEP_COUNT ? m_planCount.data() : nullptr, kind == DFTA_SWEEP_ZERO ? m_planU0.data() : nullptr);
+            v = CallStream::Value{m_planCount[0], m_planU0[0]};
+            ++m_launches;
+        } else ++m_hits;
+        m_stream.advance(v);
+        return v;
+    }
     dfta_potential* m_dev = nullptr;
+    dfta_compat::CallStream m_stream;
+    std::vector<double> m_seenV, m_planE, m_planU0;
+    std::vector<int> m_planL, m_planLim, m_planCount;
+    int m_seen_mode = -1;
+
+public:
+    long m_launches = 0, m_hits = 0;      // diagnostics: launches made for per-call trials / calls answered from what was integrated ahead
 };
 
 }  // namespace DFT

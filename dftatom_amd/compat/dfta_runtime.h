@@ -53,6 +53,9 @@ public:
     // How DFT::Numerov's sweeps are integrated: the reference's rounding sequence (default) or the transfer-matrix scans
     // (DFTA_SWEEPS_TOLERANCE: $DFTA_COMPAT_SWEEPS=tolerance or set_sweep_mode; logarithmic grids of 12 .. 20 levels, else exact)
     void set_sweep_mode(int mode) { m_sweep_mode = mode; }
+    // call_stream.h: the per-call trials of DFT::Numerov integrate ahead what the reference's loop asks next ($DFTA_COMPAT_NOSPECULATE: off)
+    bool speculate() const { return m_speculate; }
+    void set_speculate(bool on) { m_speculate = on; }
     int sweep_mode(const dfta_grid* g) const
     {
         if (m_sweep_mode != DFTA_SWEEPS_TOLERANCE || dfta_grid_is_uniform(g)) return DFTA_SWEEPS_EXACT;
@@ -76,6 +79,7 @@ private:
         if (rc != DFTA_OK) throw std::runtime_error("libdftatom_hip: no usable HIP device (status " + std::to_string(rc) + "); there is no CPU fallback");
         const char* e = getenv("DFTA_COMPAT_SWEEPS");
         if (e && std::string(e) == "tolerance") m_sweep_mode = DFTA_SWEEPS_TOLERANCE;
+        if (getenv("DFTA_COMPAT_NOSPECULATE")) m_speculate = false;
     }
     ~Runtime()
     {
@@ -84,6 +88,7 @@ private:
     }
     dfta_ctx* m_ctx = nullptr;
     int m_sweep_mode = DFTA_SWEEPS_EXACT;
+    bool m_speculate = true;
     std::map<std::tuple<int, double, double>, dfta_grid*> m_grids;
 };
 

@@ -65,6 +65,43 @@ def test_reference_shaped_classes_vs_oracle():
     assert "aufbau Rn 15 first 1s2 last 6p6" in out
 
 
+def _run_env(exe, args, env):
+    path = os.path.join(COMPAT, exe)
+    if not os.path.exists(path):
+        subprocess.check_call(["make", "-C", COMPAT])
+    return subprocess.run([path] + [str(a) for a in args], check=True, capture_output=True, text=True, timeout=900, env=dict(os.environ, **env)).stdout
+
+
+def test_per_call_level_search_is_served_from_what_was_integrated_ahead():
+    """The reference's own orchestration asks for ONE trial energy per call (LocateInterval + the u(0) bisection: ~150 calls per level).  The
+    compat layer mirrors that loop from the calls it sees (compat/call_stream.h) and integrates the tree of the caller's possible next
+    energies in the launch it has to make anyway: the calls that follow are answered from the cache.  Same kernels, same potential,
+    bit-identical energies -- so every eigenvalue equals the one-trial-per-call run's and the oracle's; only the number of launches changes
+    (Rn @ 131 073 nodes on the reference's unmodified DFTAtom.cpp: 6.6 -> 0.96 s per SCF step; the CPU reference: 3.9 s)."""
+    args = (18, 12, 0.002, 25, 5)
+    spec = _run_env("percall_levels", args, {})
+    plain = _run_env("percall_levels", args, {"DFTA_COMPAT_NOSPECULATE": "1"})
+    lev = lambda out: [ln for ln in out.splitlines() if ln.startswith("level")]
+    assert lev(spec) == lev(plain) and len(lev(spec)) == 5
+    calls, launches, hits = (int(x) for x in re.search(r"calls (\d+) launches (\d+) hits (\d+)", spec).groups())
+    pc, pl, ph = (int(x) for x in re.search(r"calls (\d+) launches (\d+) hits (\d+)", plain).groups())
+    assert pc == calls and pl == 0 and ph == 0                    # the counters belong to the speculation path
+    assert launches + hits == calls and calls > 600
+    assert launches <= 0.12 * calls, (calls, launches)            # ~13 decisions per launch (8 191 trials), a few single trials while BottomEnergy is inferred
+    # ... and the oracle's LoopOverLevels on the same potential gives the same eigenvalues (chained brackets: level k starts from E_{k-1} - 3)
+    o = O.oracle()
+    g = O.make_grid(12, 2e-3, 25.0)
+    V = O.coulomb_potential(g, 18)
+    lv = O.levels_array(O.subshells(18)[:5])
+    dens = np.zeros(g.N)
+    eel, bottom = C.c_double(0), C.c_double(-18.0 * 18.0 - 1.0)
+    o.dfo_loop_over_levels(C.byref(g), O.dp(V), lv, 5, O.dp(dens), C.byref(eel), C.byref(bottom), 1, None)
+    for k, ln in enumerate(lev(spec)):
+        m = re.match(r"level n (\d+) l (\d+) nodes (\d+) E (\S+) top (\S+) converged (\d)", ln)
+        assert (int(m.group(1)), int(m.group(2))) == (lv[k].n + 1, lv[k].l)
+        assert float(m.group(4)) == lv[k].E, (k, m.group(4), lv[k].E)           # bit-exact
+
+
 def test_headless_front_end_reproduces_readme_argon():
     """BASELINE.json config 1 on the device path: Ar, 14 levels, delta 5e-4, mixing 0.5, Rmax 25 (README.md:76), to
     convergence, console text in the reference's format; final values equal the README's to its six decimals."""
