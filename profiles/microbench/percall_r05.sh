@@ -32,3 +32,10 @@ n = min(len(a), len(b))
 print("Rn, exact kernels: the first %d printed lines with and without speculation identical: %s" % (n, a[:n] == b[:n]))
 PY
 for a in "18 12 0.002 25 5" "86 14 0.0005 25 15" "86 17 0.0001 50 15"; do echo "percall_levels $a: $(dftatom_amd/compat/percall_levels $a | tail -1)"; done
+# LSDA and the uniform grid (modes 1, 2, 3 of ref_l3_cli): whole runs, printed text with / without the speculation
+for args in "6 12 0.5 25 0.002 1" "10 13 0.5 12 0 2" "3 12 0.5 12 0 3" "29 12 0.5 25 0.002 1"; do
+  s=$(date +%s%N); timeout 600 $EXE $args > gpurun_out/l3_a.txt 2>&1; m=$(date +%s%N)
+  DFTA_COMPAT_NOSPECULATE=1 timeout 900 $EXE $args > gpurun_out/l3_b.txt 2>&1; e=$(date +%s%N)
+  if cmp -s gpurun_out/l3_a.txt gpurun_out/l3_b.txt; then r=IDENTICAL; else r=DIFFERENT; fi
+  echo "ref_l3_cli $args: $(wc -l < gpurun_out/l3_a.txt) lines $r; $(( (m - s) / 1000000 )) ms with speculation, $(( (e - m) / 1000000 )) ms without"
+done
