@@ -201,10 +201,10 @@ private:
         }
         m_stream.sync(kind, l, limit, E);
         if (!m_stream.lookup(kind, l, limit, E, v)) {
-            // exact kernels: a launch of 8 191 trials (128 blocks, one per compute unit) takes what one trial takes; scan sweeps: one workgroup
-            // per trial, 255 of them fill the machine once
+            // exact kernels: a launch of 4 095 trials (64 blocks, one per compute unit) takes what one trial takes -- 8 191 cost more on the host
+            // (enumeration, cache) than the launch they save, 16 383 are slower outright; scan sweeps: one workgroup per trial, 255 fill the machine once
             const bool scan = mode == DFTA_SWEEPS_TOLERANCE;
-            m_stream.plan(kind, E, scan ? 8 : 13, scan ? 255 : 8191, m_planE);
+            m_stream.plan(kind, E, scan ? 8 : 12, scan ? 255 : 4095, m_planE);
             const int n = static_cast<int>(m_planE.size());
             m_planL.assign(n, l);
             m_planLim.assign(n, limit);

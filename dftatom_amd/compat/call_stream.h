@@ -5,7 +5,7 @@
 // the answers alone: three bisections per level whose next energy is (toe + boe) / 2 of bounds that are themselves earlier energies (or
 // 50, or the previous level's eigenvalue - 3).  CallStream mirrors that state machine from the calls it sees and the answers it gives, and
 // when a call is not in its cache it has the whole tree of energies the caller can ask for in its next `depth` calls integrated in the
-// SAME launch (a sweep of 8 191 trials costs what a sweep of one costs).  The following calls are answered from the cache.
+// SAME launch (a sweep of 4 095 trials costs what a sweep of one costs).  The following calls are answered from the cache.
 //
 // Nothing here can change an answer: a cached value is returned only for the bit-identical (kind, l, nodesLimit, E) of a trial that was
 // integrated by the same kernels on the same potential; a caller that is not the reference's loop (or uses another energyErr) simply

@@ -1,7 +1,7 @@
 """CPU suite: dftatom_amd/compat/call_stream.h -- the mirror of the reference's per-call level search -- against a synthetic sweep
 (tests/cpp/call_stream_check.cpp: no device).  The speculation may only ever change HOW a call is served: every answer must be the
 direct evaluation's, for the reference's protocol, for a caller with another energyErr and for a caller without any pattern; for the
-reference's protocol the launches must be a small fraction of the calls (one launch carries the tree of the next 13 decisions)."""
+reference's protocol the launches must be a small fraction of the calls (one launch carries the tree of the next 12 - 13 decisions)."""
 import os
 import re
 import shutil

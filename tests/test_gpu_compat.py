@@ -77,7 +77,7 @@ def test_per_call_level_search_is_served_from_what_was_integrated_ahead():
     compat layer mirrors that loop from the calls it sees (compat/call_stream.h) and integrates the tree of the caller's possible next
     energies in the launch it has to make anyway: the calls that follow are answered from the cache.  Same kernels, same potential,
     bit-identical energies -- so every eigenvalue equals the one-trial-per-call run's and the oracle's; only the number of launches changes
-    (Rn @ 131 073 nodes on the reference's unmodified DFTAtom.cpp: 6.6 -> 0.96 s per SCF step; the CPU reference: 3.9 s)."""
+    (Rn @ 131 073 nodes on the reference's unmodified DFTAtom.cpp: 6.6 -> 0.84 s per SCF step; the CPU reference: 3.9 s)."""
     args = (18, 12, 0.002, 25, 5)
     spec = _run_env("percall_levels", args, {})
     plain = _run_env("percall_levels", args, {"DFTA_COMPAT_NOSPECULATE": "1"})
@@ -87,7 +87,7 @@ def test_per_call_level_search_is_served_from_what_was_integrated_ahead():
     pc, pl, ph = (int(x) for x in re.search(r"calls (\d+) launches (\d+) hits (\d+)", plain).groups())
     assert pc == calls and pl == 0 and ph == 0                    # the counters belong to the speculation path
     assert launches + hits == calls and calls > 600
-    assert launches <= 0.12 * calls, (calls, launches)            # ~13 decisions per launch (8 191 trials), a few single trials while BottomEnergy is inferred
+    assert launches <= 0.12 * calls, (calls, launches)            # ~12 decisions per launch (4 095 trials), a few single trials while BottomEnergy is inferred
     # ... and the oracle's LoopOverLevels on the same potential gives the same eigenvalues (chained brackets: level k starts from E_{k-1} - 3)
     o = O.oracle()
     g = O.make_grid(12, 2e-3, 25.0)
