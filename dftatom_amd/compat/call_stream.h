@@ -7,6 +7,12 @@
 // when a call is not in its cache it has the whole tree of energies the caller can ask for in its next `depth` calls integrated in the
 // SAME launch (a sweep of 4 095 trials costs what a sweep of one costs).  The following calls are answered from the cache.
 //
+// Across SCF steps (the reference builds a new Numerov for every step): the three end points of every level -- top and bottom of its band, its
+// eigenvalue -- are remembered per (l, nodes) in a process-wide history; the next time that level is searched, the bisection is followed
+// along the side of those values (a SPINE of predicted decisions, one trial each, while the midpoints stay outside a bracket as wide as
+// the end point has moved lately) and the tree of all answers hangs at the spine's end: ~30 decisions per launch instead of 12.  A
+// prediction that turns out wrong costs a launch and switches the spines off for the rest of that level.
+//
 // Nothing here can change an answer: a cached value is returned only for the bit-identical (kind, l, nodesLimit, E) of a trial that was
 // integrated by the same kernels on the same potential; a caller that is not the reference's loop (or uses another energyErr) simply
 // misses the cache and gets its single trial as before.  The cache is dropped when the potential changes (Numerov.h compares it on every
@@ -17,12 +23,48 @@
 
 #include <cstdint>
 #include <cstring>
+#include <deque>
+#include <map>
 #include <unordered_map>
+#include <utility>
 #include <vector>
 
 #include "../../include/dftatom_hip.h"
 
 namespace dfta_compat {
+
+// end points of the levels searched so far in this process: [0] top, [1] bottom of the band, [2] eigenvalue; newest first, three deep
+class LevelHistory {
+public:
+    static LevelHistory& instance()
+    {
+        static LevelHistory h;
+        return h;
+    }
+    void push(int l, int nodes, double top, double bottom, double E)
+    {
+        auto& q = m_h[std::make_pair(l, nodes)];
+        q.push_front(Ends{{top, bottom, E}});
+        if (q.size() > 3) q.pop_back();
+    }
+    // where will end point `which` of (l, nodes) be this time?  c +- w with c = the newest value and w = twice the larger of its distances to
+    // the two before it (LDA: the last two movements; LSDA: the other spin's value and the movement) + the round-off floor
+    bool bracket(int l, int nodes, int which, double& lo, double& hi) const
+    {
+        auto it = m_h.find(std::make_pair(l, nodes));
+        if (it == m_h.end() || it->second.size() < 3) return false;
+        const double c = it->second[0].T[which], a = fabs(c - it->second[1].T[which]), b = fabs(c - it->second[2].T[which]);
+        const double w = 2 * (a > b ? a : b) + 1e-10 * fabs(c) + 64e-12;
+        lo = c - w;
+        hi = c + w;
+        return true;
+    }
+    void clear() { m_h.clear(); }
+
+private:
+    struct Ends { double T[3]; };
+    std::map<std::pair<int, int>, std::deque<Ends>> m_h;
+};
 
 class CallStream {
 public:
@@ -33,6 +75,7 @@ public:
     void reset()
     {
         m_cache.clear();
+        m_pred.clear();
         m_m = Mirror();
         m_in_sync = false;
     }
@@ -59,15 +102,44 @@ public:
     }
     // The energies to integrate for a call that is not cached: E itself first, then -- when the mirror follows the caller -- every energy
     // the reference's loop can ask for in its next `depth` calls of the same kind (at most `cap` in all).
-    void plan(int kind, double E, int depth, size_t cap, std::vector<double>& out) const
+    void plan(int kind, double E, int depth, size_t cap, std::vector<double>& out)
     {
         out.clear();
         out.push_back(E);
+        m_pred.clear();
         if (!m_in_sync) return;
         std::unordered_map<uint64_t, char> seen;
         seen.emplace(bits(E), 0);
-        std::vector<Mirror> frontier(1, m_m), next;
+        // the spine: while the side of the expected end point decides the pending call, follow it (one trial per decision)
+        Mirror cur = m_m;
+        if (m_spines && !cur.nospine) {
+            const LevelHistory& H = LevelHistory::instance();
+            for (int steps = 0; steps < 56 && out.size() < cap / 2; ++steps) {
+                int k;
+                double Ep;
+                if (!pending(cur, k, Ep) || k != kind) break;
+                if (seen.emplace(bits(Ep), 0).second) out.push_back(Ep);
+                if (cur.ph == P3_FIRST) { apply_outcome(cur, 1); continue; }        // no decision: either sign leads to the same next energy
+                int below = -1;                                                     // 1: the lower bound moves to Ep (Ep lies below the end point), 0: the upper one
+                if (cur.ph == P2 && cur.nodes == 0) below = 0;                      // "count < 0" never holds: certain
+                else {
+                    double lo, hi;
+                    if (!H.bracket(cur.l, cur.nodes, cur.ph == P1 ? 0 : (cur.ph == P2 ? 1 : 2), lo, hi)) break;
+                    if (Ep <= lo) below = 1; else if (Ep >= hi) below = 0; else break;
+                    m_pred[bits(Ep)] = static_cast<char>(below);
+                }
+                apply_side(cur, below == 1);
+            }
+        }
+        // the tree of every answer from there on
+        {
+            int k;
+            double Ep;
+            if (pending(cur, k, Ep) && k == kind && seen.emplace(bits(Ep), 0).second) out.push_back(Ep);
+        }
+        std::vector<Mirror> frontier(1, cur), next;
         for (int d = 0; d < depth && !frontier.empty() && out.size() < cap; ++d) {
+            if (out.size() + 2 * frontier.size() > cap && d > 0) break;                  // a level of the tree that does not fit whole is of little use
             next.clear();
             for (const Mirror& f : frontier) {
                 for (int outcome = 0; outcome < 2 && out.size() < cap; ++outcome) {      // both answers the caller can get for f's pending call
@@ -91,8 +163,21 @@ public:
     // the caller is given this answer: follow it
     void advance(const Value& v)
     {
-        if (m_in_sync) apply(m_m, v.count, v.u0);
+        if (!m_in_sync) return;
+        int k;
+        double E;
+        if (!m_pred.empty() && pending(m_m, k, E)) {
+            auto it = m_pred.find(bits(E));
+            if (it != m_pred.end()) {
+                const bool below = m_m.ph == P1 ? !(v.count > m_m.nodes) : (m_m.ph == P2 ? v.count < m_m.nodes : ((v.u0 > 0) == m_m.sgn));
+                if (below != (it->second == 1)) { m_m.nospine = true; m_pred.clear(); }      // the history misled: plain trees for the rest of this level
+            }
+        }
+        const int before = m_m.ph;
+        apply(m_m, v.count, v.u0);
+        if (before != LEVEL_DONE && m_m.ph == LEVEL_DONE) LevelHistory::instance().push(m_m.l, m_m.nodes, m_m.top, m_m.band_bottom, m_m.e_final);
     }
+    void set_spines(bool on) { m_spines = on; }
     size_t cached() const { return m_cache.size(); }
 
 private:
@@ -110,6 +195,8 @@ private:
         bool sgn = false;
         double e_final = 0;
         bool have_final = false;
+        double band_bottom = 0;        // BottomEnergy as LocateInterval returned it
+        bool nospine = false;          // a predicted decision of this level was wrong
     };
     struct Key {
         int kind, l, limit;
@@ -232,6 +319,7 @@ private:
     static void enter_p3(Mirror& m)
     {
         const double bottom = m.toe;       // BottomEnergy = toe (DFTAtom.cpp:603)
+        m.band_bottom = bottom;
         m.toe = m.top;
         m.boe = bottom;
         m.boe_is_entry = false;
@@ -251,8 +339,21 @@ private:
         }
     }
 
+    // the answer that moves the lower bound (below) or the upper one to the pending energy
+    static void apply_side(Mirror& m, bool below)
+    {
+        switch (m.ph) {
+        case P1: apply_outcome(m, below ? 0 : 1); break;                 // count <= nodes: boe = E
+        case P2: apply_outcome(m, below ? 1 : 0); break;                 // count < nodes: boe = E
+        case P3_LOOP: apply_outcome(m, below == m.sgn ? 1 : 0); break;   // (u0 > 0) == sgnBottom: BottomEnergy = E
+        default: break;
+        }
+    }
+
     Mirror m_m;
     bool m_in_sync = false;
+    bool m_spines = true;
+    std::unordered_map<uint64_t, char> m_pred;      // energies of the last plan's spine -> the side it predicted
     std::unordered_map<Key, Value, KeyHash> m_cache;
 };
 

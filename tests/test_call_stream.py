@@ -26,6 +26,11 @@ def test_call_stream_serves_the_reference_protocol_from_its_cache(tmp_path):
     eig = [float(x) for x in re.findall(r"level \d+ E (\S+)", r.stdout)]
     want = [-3204.75642, -535.87331, -512.1183, -130.2447, -118.90112, -99.3301]
     assert len(eig) == 6 and all(abs(a - b) < 2e-12 * max(1.0, abs(b)) + 2e-12 for a, b in zip(eig, want))
+    # the same levels searched again with slightly moved eigenvalues (a new stream each time, as the reference builds a new Numerov per SCF
+    # step): from the fourth search on the process-wide history of the end points gives every launch a spine of predicted decisions
+    m = re.search(r"history: launches first search (\d+) last search (\d+) wrong (\d+)", r.stdout)
+    first, last, w = (int(x) for x in m.groups())
+    assert w == 0 and last <= 0.8 * first, (first, last)
     for tag in ("other energyErr", "arbitrary caller"):
         m = re.search(tag + r": calls (\d+) launches (\d+) hits (\d+) wrong (\d+)", r.stdout)
         c, la, h, w = (int(x) for x in m.groups())

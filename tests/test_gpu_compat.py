@@ -77,7 +77,7 @@ def test_per_call_level_search_is_served_from_what_was_integrated_ahead():
     compat layer mirrors that loop from the calls it sees (compat/call_stream.h) and integrates the tree of the caller's possible next
     energies in the launch it has to make anyway: the calls that follow are answered from the cache.  Same kernels, same potential,
     bit-identical energies -- so every eigenvalue equals the one-trial-per-call run's and the oracle's; only the number of launches changes
-    (Rn @ 131 073 nodes on the reference's unmodified DFTAtom.cpp: 6.6 -> 0.84 s per SCF step; the CPU reference: 3.9 s)."""
+    (Rn @ 131 073 nodes on the reference's unmodified DFTAtom.cpp: 6.6 -> 0.76 s per SCF step; the CPU reference: 3.9 s)."""
     args = (18, 12, 0.002, 25, 5)
     spec = _run_env("percall_levels", args, {})
     plain = _run_env("percall_levels", args, {"DFTA_COMPAT_NOSPECULATE": "1"})
