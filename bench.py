@@ -261,6 +261,35 @@ def parity_gates(poisson_mode, sweep_mode):
 # ---------------------------------------------------------------------------------------------------------------
 # BASELINE config 4: the periodic-table sweep, sharded by atom (dftatom_amd/sweep.py), one all_gather of the records
 # ---------------------------------------------------------------------------------------------------------------
+def per_call_surface():
+    """The reference's orchestration asks for ONE trial energy per call (SolveSchrodingerCountNodes / SolutionInZero).  dftatom_amd/compat/percall_levels
+    restates that call stream (LocateInterval + the u(0) bisection, DFTAtom.cpp:493-604) on DFT::Numerov's per-call surface for the 15 levels of Rn
+    on a bare Coulomb potential -- exact kernels; compat/call_stream.h serves most calls from what it had integrated ahead.  A child process (its own
+    HIP context; started after the timed region).  None when the binary is not there."""
+    import re
+    import subprocess
+    exe = os.path.join(ROOT, "dftatom_amd", "compat", "percall_levels")
+    if not os.path.exists(exe):
+        return None
+
+    def run(args, env):
+        out = subprocess.run([exe] + args, capture_output=True, text=True, timeout=300, env=dict(os.environ, **env)).stdout
+        m = re.search(r"calls (\d+) launches (\d+) hits (\d+) seconds (\S+)", out)
+        return (int(m.group(1)), int(m.group(2)), float(m.group(4))) if m else None
+    try:
+        big = run(["86", "17", "0.0001", "50", "15"], {})
+        small = run(["86", "14", "0.0005", "25", "15"], {})
+        plain = run(["86", "14", "0.0005", "25", "15"], {"DFTA_COMPAT_NOSPECULATE": "1"})
+    except Exception as e:                      # must not cost the line
+        return {"error": repr(e)[:120]}
+    if not (big and small and plain):
+        return None
+    return {"what": "Rn's 15 levels searched through DFT::Numerov's per-call surface (the reference's call stream), exact kernels, Coulomb potential",
+            "calls": big[0], "launches_131073": big[1], "seconds_131073": big[2], "ms_per_call_131073": 1e3 * big[2] / big[0],
+            "launches_16385": small[1], "seconds_16385": small[2], "seconds_16385_one_trial_per_call": plain[2],
+            "speedup_16385": plain[2] / small[2] if small[2] > 0 else None}
+
+
 def periodic_table(D, ctx, grid, levels, world, rank, dist, torch, shared, zmax, max_steps=100):
     """every rank advances its partition_atoms shard of Z = 1..zmax to the reference's stop test (or its 100-step cap), then ONE all_gather
     of the fixed-size records (RCCL; gloo in the shared-GPU test mode).  Returns (on every rank) the whole-job wall time = max over ranks."""
@@ -765,6 +794,10 @@ def main():
             cpu_job = cpu_baseline_start(args.levels, args.lsda, args.cpu_steps)
         if pt_extra is not None:
             out.setdefault("extra", {})["periodic_table"] = pt_extra
+        if world == 1 and not args.no_extras:
+            pcs = per_call_surface()
+            if pcs is not None:
+                out.setdefault("extra", {})["per_call_surface"] = pcs
         if cpu_job is not None:
             t_w = time.time()
             out["cpu_baseline"] = cpu_baseline_finish(cpu_job, not args.no_cpu_all_cores)
