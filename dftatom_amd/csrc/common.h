@@ -229,8 +229,3 @@ template <typename T> __device__ __forceinline__ T* dfta_uniform(T* p)
 #endif
 }
 #endif
-#if defined(__HIP_DEVICE_COMPILE__)
-#define DFTA_ASSUME_GLOBAL(p) __builtin_assume(!__builtin_amdgcn_is_shared(p) && !__builtin_amdgcn_is_private(p))
-#else
-#define DFTA_ASSUME_GLOBAL(p) ((void)0)
-#endif

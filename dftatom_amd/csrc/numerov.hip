@@ -46,10 +46,8 @@ __device__ __forceinline__ double f_of(double veff, double e2, double E, const G
     return 2. * (veff - E) * gs.Rp2delta2 * e2 + gs.delta2p4;
 }
 
-// A pointer that reaches device code through a struct or a call (not as a kernel argument) is a generic one to the compiler: flat
-// loads and stores, which count against the LDS counter as well -- `s_waitcnt lgkmcnt(0)` before an LDS-only barrier then waits for
-// global memory.  The assumption below (never LDS, never scratch) lets the address-space inference use global instructions.
-// (DFTA_ASSUME_GLOBAL: common.h)
+// (A pointer that reaches device code through a struct or a call, not as a kernel argument, is a generic one to the compiler: flat loads
+// and stores.  The out-of-line parts of the device-side search re-derive theirs through dfta_as_global, common.h.)
 
 // ---- table of wave-uniform per-point inputs -----------------------------------------------------------
 // tab[(slot)*N + i] = { V[v][i] + cl[l][i], e2[i] }   (Numerov.h:93: V + l(l+1)/(r r) * 0.5)
