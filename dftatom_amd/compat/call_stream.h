@@ -79,11 +79,12 @@ public:
         m_m = Mirror();
         m_in_sync = false;
     }
-    bool lookup(int kind, int l, int limit, double E, Value& v) const
+    bool lookup(int kind, int l, int limit, double E, Value& v)
     {
         auto it = m_cache.find(Key{kind, l, limit, bits(E)});
         if (it == m_cache.end()) return false;
         v = it->second;
+        ++m_hits_since_launch;
         return true;
     }
     // Every call starts here: does it continue the mirrored loop, or is it the first call of LocateInterval for another level (then the
@@ -107,7 +108,18 @@ public:
         out.clear();
         out.push_back(E);
         m_pred.clear();
+        // a caller that only LOOKS like the reference's loop (every call "starts a level", nothing integrated ahead is ever asked for) must
+        // not pay for trees: after three launches without a single hit the speculation pauses, for 16, 32, 64 ... calls
+        if (m_last_launch_speculated) m_useless = m_hits_since_launch == 0 ? m_useless + 1 : 0;
+        m_hits_since_launch = 0;
+        m_last_launch_speculated = false;
         if (!m_in_sync) return;
+        if (m_useless >= 3) {
+            if (m_pause == 0) { m_pause = m_pause_len; m_pause_len = m_pause_len < (1 << 20) ? 2 * m_pause_len : m_pause_len; }
+            if (--m_pause > 0) return;
+            m_useless = 2;                       // one more try; a hit resets everything
+        } else if (m_useless == 0) m_pause_len = 16;
+        m_last_launch_speculated = true;
         std::unordered_map<uint64_t, char> seen;
         seen.emplace(bits(E), 0);
         // the spine: while the side of the expected end point decides the pending call, follow it (one trial per decision)
@@ -353,6 +365,9 @@ private:
     Mirror m_m;
     bool m_in_sync = false;
     bool m_spines = true;
+    long m_hits_since_launch = 0;
+    bool m_last_launch_speculated = false;
+    int m_useless = 0, m_pause = 0, m_pause_len = 16;
     std::unordered_map<uint64_t, char> m_pred;      // energies of the last plan's spine -> the side it predicted
     std::unordered_map<Key, Value, KeyHash> m_cache;
 };

@@ -105,6 +105,6 @@ int main()
     Server s3;                                      // no pattern at all
     long c3 = 0;
     for (int i = 0; i < 400; ++i) { const double E = -3000.0 + 7.77 * i; s3.serve(i % 2, i % 4, 3, E); ++c3; }
-    std::printf("arbitrary caller: calls %ld launches %ld hits %ld wrong %ld\n", c3, s3.launches, s3.hits, s3.wrong);
+    std::printf("arbitrary caller: calls %ld launches %ld hits %ld wrong %ld trials %ld\n", c3, s3.launches, s3.hits, s3.wrong, s3.trials);
     return (s1.wrong || s2.wrong || s3.wrong || wrong_steps) ? 1 : 0;
 }

@@ -35,4 +35,6 @@ def test_call_stream_serves_the_reference_protocol_from_its_cache(tmp_path):
         m = re.search(tag + r": calls (\d+) launches (\d+) hits (\d+) wrong (\d+)", r.stdout)
         c, la, h, w = (int(x) for x in m.groups())
         assert w == 0 and la + h == c
-    assert int(re.search(r"arbitrary caller: calls (\d+) launches (\d+)", r.stdout).group(2)) == 400      # nothing to predict: one launch per call
+    m = re.search(r"arbitrary caller: calls (\d+) launches (\d+) hits (\d+) wrong (\d+) trials (\d+)", r.stdout)
+    assert int(m.group(2)) == 400                                      # nothing to predict: one launch per call ...
+    assert int(m.group(5)) <= 12 * 4095 + 400                          # ... and, after three useless trees, single trials (pauses of 16, 32, 64 ... calls)
