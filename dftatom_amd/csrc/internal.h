@@ -20,7 +20,12 @@ int dfta_launch_sweep(dfta_ctx* ctx, const dfta_grid* g, int kind, const int* bl
                       const int* dStart, const double* dUs, const double* dUs1, int* dCount, double* dU0, int* dTrip,
                       unsigned long long* dTotalTrips, const double2* bounds /* per slot, may be null */,
                       double* dPhi = nullptr, int* dIstop = nullptr /* SweepArgs::phi / istop, may be null */,
-                      const int* d_slot_l = nullptr /* uniform grid: l per table slot */);
+                      const int* d_slot_l = nullptr /* uniform grid: l per table slot */,
+                      const int* d_queue = nullptr /* fused kernel: the round's work queue (k_expand of levels.hip), lists of qcap blocks */, int qcap = 0);
+// Balanced launch of the fused sweeps: the blocks of a round are entered into kSweepQueueClasses lists by expected length, and the launch's
+// waves (two per SIMD, all resident) take them longest first through one ticket counter -- see k_sweep_queue
+constexpr int kSweepQueueClasses = 16;
+bool dfta_sweep_is_fused(const dfta_ctx* ctx, int nblocks);
 int dfta_launch_match(dfta_ctx* ctx, const dfta_grid* g, int ntrials, const double2* tab, const int* d_trial_slot,
                       const double* dE, const int* dStart, const double* dUs, const double* dUs1, const int* dL,
                       double* dPsi, double* dQ, int* dMatch, const double2* bounds /* per slot (dfta_bounds_stride), may be null */,
@@ -51,6 +56,12 @@ int dfta_launch_levels_persist(dfta_ctx* ctx, const dfta_grid* g, dfta_persist_b
                                unsigned long long* d_counters, bool stats, int nopredict, int integ_rule, const double* tuning, int fixed_point,
                                int* rounds, int* aborted, std::vector<unsigned long long>* trace_out, const int* share = nullptr /* host, nlive: workgroups per level */,
                                int deep_reserve = 0 /* workgroups the pool keeps for the levels marked Job::deep == 2 */);
+
+// own.inc (compiled with numerov.hip): the exact level search of a batch on the device, one workgroup of W waves per live level, one
+// ordinary launch; d_counters[0] += issued trials, [1] += traversed points (stats), [2] = max rounds of a level (as unsigned int)
+int dfta_launch_levels_own(dfta_ctx* ctx, const dfta_grid* g, dfta::Job* d_jobs, const int* d_live, int nlive, int W, const double2* d_tab, const double2* d_bounds,
+                           int* blk_slot, const int* blk_first, const int* blk_cnt, double* dE, int* dLimit, int* dStart, double* dUs, double* dUs1, int* dCount,
+                           double* dU0, double* dPhi, int* dIstop, int* dTrip, unsigned long long* d_counters, bool stats, int nopredict, int spine_cap);
 
 // scan.hip: the tolerance mode of the sweeps (transfer-matrix scan: one workgroup per trial)
 struct dfta_scan_tables {

@@ -149,6 +149,12 @@ struct LevelSolver {
     int persist_deep_reserve = 0;   // workgroups of the pool kept for the levels that ended last in the previous steps
     std::vector<int> persist_tend;  // per job: 3 x the search-end times of the last three device-side solves [us] (0: none) -- the feedback ranks by their maximum
     int persist_runs = 0;
+    // Own-pace search of a batch (own.inc): more than 64 live levels, one workgroup of W waves per level, one ordinary launch
+    bool own_ok = false;
+    int own_waves = 2048, own_wmax = 8, own_spine_cap = -1, own_last_W = 0;
+    int* d_own_live = nullptr;
+    // balanced launch of the fused sweeps (numerov.hip:k_sweep_queue): [0, C) entries per length class, [C] the ticket counter, then C lists of nwaves blocks
+    int* d_queue = nullptr;
     double tuning[4] = {1e-11, 16e-12, 1.5e-11, 0.25};     // noise band (rel, abs, secant) and the secant's kappa, as set in setup()
     int fixed_point = 1;
     // history bracket of the first spines (Job::hist_c / hist_w): extrapolation with the last movement ratio ($DFTA_DEBUG LEVELS_NOEXTRAP: the

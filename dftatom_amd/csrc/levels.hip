@@ -31,46 +31,62 @@ namespace {
 #include "levels_device.inc"
 
 // ---- expand: trial energies of the current round of every job, plus their far boundary values ----------------------
+// qctl / qlist (may be null): the round's work queue for the balanced launch of the fused sweeps (numerov.hip:k_sweep_queue).  Every
+// 64-trial block with an active trial is entered into one of kSweepQueueClasses lists by its expected length -- the cut-off index of
+// its outermost trial, halved where CountNodes will stop at an inner turning point (l > 0) -- so that the launch's waves take the
+// longest blocks first; blocks without an active trial are not entered at all.
 __global__ __launch_bounds__(256) void k_expand(const dfta::Job* __restrict__ jobs, const int* __restrict__ wave_job, int wshift, int ntrials, const double* __restrict__ r,
                                                 int N, double delta, double far_thr, double* __restrict__ E,
                                                 int* __restrict__ limit, int* __restrict__ start, double* __restrict__ us,
                                                 double* __restrict__ us1, int* __restrict__ wave_kind,
-                                                unsigned long long* __restrict__ issued, int uniform, double Rmax, double hstep)
+                                                unsigned long long* __restrict__ issued, int uniform, double Rmax, double hstep,
+                                                int* __restrict__ qctl, int* __restrict__ qlist, int qcap)
 {
     const int gt = blockIdx.x * blockDim.x + threadIdx.x;
     if (gt >= ntrials) return;       // ntrials is a multiple of 64: whole waves leave
     const int job = wave_job[gt >> wshift];   // one entry per 64-trial block (wshift 6) or per trial (packed rounds: wshift 0)
+    bool active = false, zero_kind = true;
+    int st = 0, key = 0;
     if (job < 0) {                    // slots that no job owns this round
         E[gt] = 0; limit[gt] = 0; start[gt] = 0;
-        if ((gt & 63) == 0) wave_kind[gt >> 6] = DFTA_SWEEP_ZERO;
-        return;
+    } else {
+        const dfta::Job j = jobs[job];
+        const TrialSpec ts = trial_spec<false>(j, jobs, gt - j.tbase);
+        const double e = ts.e;
+        active = ts.active;
+        zero_kind = ts.zero_kind;
+        E[gt] = e;
+        limit[gt] = j.nodes;
+        if (active && uniform) {
+            // uniform grid (Numerov.h:32-35,43-56,274-296): start at min(Rmax, 200 / sqrt(2|E|)), index (long)(startPoint / h)
+            const double s = sqrt(2. * fabs(e));
+            const double mr = 200. / s;
+            const double sp = mr < Rmax ? mr : Rmax;
+            st = static_cast<int>(static_cast<long>(sp / hstep));
+            us[gt] = exp(-sp * s);
+            us1[gt] = exp(-(sp - hstep) * s);
+        } else if (active) {
+            double a, b;
+            st = trial_boundary(e, r, N, delta, far_thr, a, b);
+            us[gt] = a;
+            us1[gt] = b;
+        }
+        start[gt] = st;
+        key = active ? ((zero_kind || j.l == 0) ? st : st / 2) : 0;
     }
-    const dfta::Job j = jobs[job];
-    const TrialSpec ts = trial_spec<false>(j, jobs, gt - j.tbase);
-    const double e = ts.e;
-    const bool active = ts.active;
-    E[gt] = e;
-    limit[gt] = j.nodes;
-    int st = 0;
-    if (active && uniform) {
-        // uniform grid (Numerov.h:32-35,43-56,274-296): start at min(Rmax, 200 / sqrt(2|E|)), index (long)(startPoint / h)
-        const double s = sqrt(2. * fabs(e));
-        const double mr = 200. / s;
-        const double sp = mr < Rmax ? mr : Rmax;
-        st = static_cast<int>(static_cast<long>(sp / hstep));
-        us[gt] = exp(-sp * s);
-        us1[gt] = exp(-(sp - hstep) * s);
-    } else if (active) {
-        double a, b;
-        st = trial_boundary(e, r, N, delta, far_thr, a, b);
-        us[gt] = a;
-        us1[gt] = b;
-    }
-    start[gt] = st;
-    if ((gt & 63) == 0) wave_kind[gt >> 6] = ts.zero_kind ? DFTA_SWEEP_ZERO : DFTA_SWEEP_COUNT;
-    if (issued) {
-        const unsigned long long m = __ballot(active);
-        if ((threadIdx.x & 63) == 0 && m) atomicAdd(issued, (unsigned long long)__popcll(m));
+    // the block's kind: its first trial's (a block of the static / latency layouts has one owner, a packed block one (slot, kind) group)
+    const int kind0 = __shfl(zero_kind ? 1 : 0, 0);
+    if ((gt & 63) == 0) wave_kind[gt >> 6] = kind0 ? DFTA_SWEEP_ZERO : DFTA_SWEEP_COUNT;
+    const unsigned long long m = __ballot(active);
+    if (issued && (threadIdx.x & 63) == 0 && m) atomicAdd(issued, (unsigned long long)__popcll(m));
+    if (qctl) {
+        for (int off = 32; off > 0; off >>= 1) key = max(key, __shfl_xor(key, off));
+        if ((gt & 63) == 0 && m) {
+            int cls = kSweepQueueClasses - 1 - static_cast<int>((static_cast<long long>(key) * kSweepQueueClasses) / N);
+            cls = cls < 0 ? 0 : (cls >= kSweepQueueClasses ? kSweepQueueClasses - 1 : cls);
+            const int pos = atomicAdd(&qctl[cls], 1);
+            qlist[(size_t)cls * qcap + pos] = gt >> 6;
+        }
     }
 }
 
@@ -594,7 +610,8 @@ void LevelSolver::release()
     if (d_jmatched) (void)hipFree(d_jmatched);
     if (d_jstart_keep) (void)hipFree(d_jstart_keep);
     d_jmatched = nullptr; d_jstart_keep = nullptr;
-    for (int** q : {&d_lane_job, &d_slot_off, &d_slot_jobs, &d_gsz, &d_goff, &d_pack_out, &d_live}) { if (*q) (void)hipFree(*q); *q = nullptr; }
+    own_ok = false;
+    for (int** q : {&d_lane_job, &d_slot_off, &d_slot_jobs, &d_gsz, &d_goff, &d_pack_out, &d_live, &d_own_live, &d_queue}) { if (*q) (void)hipFree(*q); *q = nullptr; }
     if (st2) { (void)hipStreamDestroy(st2); st2 = nullptr; }
     if (ev_walk) { (void)hipEventDestroy(ev_walk); ev_walk = nullptr; }
     if (ev_early) { (void)hipEventDestroy(ev_early); ev_early = nullptr; }
@@ -724,6 +741,19 @@ int LevelSolver::setup(dfta_ctx* c, const dfta_grid* grid, int mode_, int tree_d
         ntrials = std::max<long>(std::max(pack_lanes_large, pack_lanes_small), static_cast<long>(njobs) * (kPackSpineCap + (1L << pack_dmin))) + 128L * nslots;
         ntrials = (ntrials + 63) & ~63L;
     }
+    // the own-pace search of a batch (own.inc: one workgroup of W waves per live level, one launch): more than 64 live levels of an
+    // un-chained solve on the logarithmic grid; the host rounds remain for everything else ($DFTA_DEBUG LEVELS_NOOWN, LEVELS_NOPERSIST: host rounds)
+    own_ok = (tree_depth <= 0) && !dynamic && !g->uniform && mode == DFTA_LEVELS_BATCHED && ctx->sweep_kernel != DFTA_SWEEP_PIPELINED &&
+             dfta_knob("LEVELS_OWN") != nullptr && dfta_knob("LEVELS_NOPERSIST") == nullptr && dfta_knob("LEVELS_STATIC") == nullptr;
+    if (own_ok) {
+        own_waves = 2048;                            // two waves per SIMD: what the sweep's registers (177 VGPRs) leave resident
+        if (const char* e = dfta_knob("LEVELS_OWN_WAVES")) own_waves = std::max(64, atoi(e));      // measurements
+        own_wmax = 8;
+        if (const char* e = dfta_knob("LEVELS_OWN_WMAX")) own_wmax = std::min(8, std::max(1, atoi(e)));
+        own_spine_cap = -1;
+        if (const char* e = dfta_knob("LEVELS_OWN_SPINE_CAP")) own_spine_cap = atoi(e);
+        ntrials = std::max<long>(ntrials, 64L * std::max<long>(own_waves, njobs));
+    }
     nwaves = static_cast<int>(ntrials / 64);
     early_match = (dynamic || can_switch) && !g->uniform && dfta_knob("LEVELS_NOEARLYMATCH") == nullptr;
     // the device-side search serves the latency regime (one atom, or the last live atoms of a batch) on the logarithmic grid
@@ -773,6 +803,8 @@ int LevelSolver::setup(dfta_ctx* c, const dfta_grid* grid, int mode_, int tree_d
     ALLOC(d_counters, unsigned long long, 4);
     if (persist_ok) { const int prc = dfta_persist_create(ctx, g, std::min(njobs, 64), &pb); if (prc) return prc; }
     if (can_switch) ALLOC(d_live, int, 64);
+    if (!g->uniform && dfta_knob("LEVELS_NOQUEUE") == nullptr) ALLOC(d_queue, int, kSweepQueueClasses + 1 + (size_t)kSweepQueueClasses * nwaves);
+    if (own_ok) ALLOC(d_own_live, int, njobs);
     ALLOC(d_Psi, double, (size_t)njobs * N);
     ALLOC(d_Q, double, (size_t)njobs * N);
     ALLOC(d_jE, double, njobs); ALLOC(d_jslot, int, njobs); ALLOC(d_jl, int, njobs); ALLOC(d_jstart, int, njobs);
@@ -834,12 +866,16 @@ int LevelSolver::run(const double* dV, const double* job_bottom, int run_mode, d
     else for (int k = 0; k < njobs; ++k) if (!(frozen && frozen[k] && h_last.size() == jobs.size())) plive.push_back(k);
     const bool use_persist = persist_ok && dyn && !chained && sweep_mode != DFTA_SWEEPS_TOLERANCE && !plive.empty() && (int)plive.size() <= pb.nlive_cap &&
                              pb.nblocks / (int)plive.size() >= 2 && debug_rounds == 0;
+    // more than 64 live levels: every level at its own pace all the same, one workgroup of W waves each in ONE ordinary launch (own.inc)
+    const bool use_own = own_ok && !dyn && !chained && sweep_mode != DFTA_SWEEPS_TOLERANCE && !plive.empty() && debug_rounds == 0;
+    int own_W = 1;
+    if (use_own) { while (own_W < own_wmax && (long)plive.size() * own_W * 2 <= own_waves) own_W *= 2; }
     std::vector<int> plevel(njobs, -1);
-    if (use_persist) for (size_t q = 0; q < plive.size(); ++q) plevel[plive[q]] = (int)q;
+    if (use_persist || use_own) for (size_t q = 0; q < plive.size(); ++q) plevel[plive[q]] = (int)q;
     if (sw) {
         DFTA_HIP(ctx, hipMemcpyAsync(d_live, live.data(), sizeof(int) * live.size(), hipMemcpyHostToDevice, st));
         tables_dirty = true;
-    } else if (tables_dirty) {           // back from latency mode: the solver's own block tables
+    } else if (tables_dirty && !use_own) {           // back from latency mode / the own-pace search: the solver's own block tables
         DFTA_HIP(ctx, hipMemcpyAsync(d_wave_job, h_wave_job.data(), sizeof(int) * h_wave_job.size(), hipMemcpyHostToDevice, st));
         DFTA_HIP(ctx, hipMemcpyAsync(d_wave_slot, h_wave_slot.data(), sizeof(int) * h_wave_slot.size(), hipMemcpyHostToDevice, st));
         tables_dirty = false;
@@ -859,6 +895,7 @@ int LevelSolver::run(const double* dV, const double* job_bottom, int run_mode, d
         j.tbase = (pk || sw) ? 0 : k * tpj;      // packed rounds: k_pack lays the trials out (latency mode: k_allot)
         j.tcap = (pk || sw) ? 0 : tpj;
         if (use_persist) { j.tbase = plevel[k] * pb.tmax; j.tcap = 0; }      // its own region of the device-side search's trial arrays
+        if (use_own) { j.tbase = plevel[k] * 64 * own_W; j.tcap = 64 * own_W; }
         j.rounds = 0;
         j.t_end_us = 0;
         j.deep = -1;
@@ -1080,19 +1117,32 @@ int LevelSolver::run(const double* dV, const double* job_bottom, int run_mode, d
             }
         }
     }
-    if (!scan && !persisted) {
+    bool owned = false;
+    if (!scan && !persisted && use_own) {
+        dfta_range r_o("dfta: level search on the device (own pace: one workgroup per level, sweeps + walk)");
+        DFTA_HIP(ctx, hipMemcpyAsync(d_own_live, plive.data(), sizeof(int) * plive.size(), hipMemcpyHostToDevice, st));
+        if (stats) DFTA_HIP(ctx, hipEventRecord(ev[0], st));
+        rc = dfta_launch_levels_own(ctx, g, d_jobs, d_own_live, (int)plive.size(), own_W, d_tab, d_bounds, d_wave_slot, d_wave_first, d_wave_cnt, d_E, d_limit, d_start,
+                                    d_us, d_us1, d_count, d_u0, d_phi, d_istop, d_trip, d_counters, stats != nullptr, use_prediction ? 0 : 1, own_spine_cap);
+        if (rc) return rc;
+        if (stats) DFTA_HIP(ctx, hipEventRecord(ev[1], st));
+        tables_dirty = true;             // the kernel wrote its blocks' table slots
+        owned = true;
+        own_last_W = own_W;
+    }
+    if (!scan && !persisted && !owned) {
         rc = plan();
         if (rc) return rc;
     }
     // trials of the coming round: the whole static / latency-mode layout, or what k_pack has just laid out
     long round_trials = dyn ? budget_trials : static_trials;
     int pack_out[4] = {0, 0, 0, 0};
-    if (pk && !scan && !persisted) {
+    if (pk && !scan && !persisted && !owned) {
         DFTA_HIP(ctx, hipMemcpyAsync(pack_out, d_pack_out, sizeof(pack_out), hipMemcpyDeviceToHost, st));
         DFTA_HIP(ctx, hipStreamSynchronize(st));
         round_trials = pack_out[0];
     }
-    if (early && !scan && !persisted) {
+    if (early && !scan && !persisted && !owned) {
         hipLaunchKernelGGL(k_job_slots, dim3((njobs + 63) / 64), dim3(64), 0, st, d_jobs, njobs, d_jslot, d_jl);
         DFTA_CHECK_LAUNCH(ctx);
         DFTA_HIP(ctx, hipMemsetAsync(d_jE, 0xff, sizeof(double) * njobs, st));      // NaN: "no energy yet" (k_take_ready)
@@ -1103,18 +1153,22 @@ int LevelSolver::run(const double* dV, const double* job_bottom, int run_mode, d
     const int max_rounds = 4096;
     int done_seen = nfrozen;
     bool early_pending = false;
-    while (!scan && !persisted && rounds < max_rounds) {
+    while (!scan && !persisted && !owned && rounds < max_rounds) {
         dfta_range r_round("dfta: level-search round (expand, sweeps, scout, walk, plan)");
         if (round_trials <= 0 || round_trials > ntrials) { snprintf(ctx->err, sizeof(ctx->err), "level solver: packed round of %ld trials (room for %ld)", round_trials, ntrials); return DFTA_ERR_HIP; }
         const int round_waves = static_cast<int>(round_trials / 64);
+        // the fused sweeps of a batch are launched as a queue of blocks, longest first (numerov.hip:k_sweep_queue)
+        // (the pipelined kernel likewise once a round has more blocks than compute units: its second pass is then made of the short blocks)
+        const bool queued = d_queue != nullptr && !g->uniform && (dfta_sweep_is_fused(ctx, round_waves) || round_waves > ctx->num_cu);
+        if (queued) DFTA_HIP(ctx, hipMemsetAsync(d_queue, 0, sizeof(int) * (kSweepQueueClasses + 1), st));
         hipLaunchKernelGGL(k_expand, dim3((unsigned)((round_trials + 255) / 256)), dim3(256), 0, st, d_jobs, pk ? d_lane_job : d_wave_job, pk ? 0 : 6,
                            (int)round_trials, g->d_r, N, g->delta, g->far_arg_threshold, d_E, d_limit, d_start, d_us, d_us1, d_wave_kind, d_counters, g->uniform,
-                           g->Rmax, g->h);
+                           g->Rmax, g->h, queued ? d_queue : nullptr, queued ? d_queue + kSweepQueueClasses + 1 : nullptr, nwaves);
         DFTA_CHECK_LAUNCH(ctx);
         if (stats) DFTA_HIP(ctx, hipEventRecord(ev[0], st));
         rc = dfta_launch_sweep(ctx, g, DFTA_SWEEP_COUNT, d_wave_kind, round_waves, d_tab, d_wave_slot, d_wave_first, d_wave_cnt, d_E,
                                d_limit, d_start, d_us, d_us1, d_count, d_u0, stats ? d_trip : nullptr, stats ? d_counters + 1 : nullptr, g->uniform ? nullptr : d_bounds, d_phi,
-                               d_istop, d_slot_l);
+                               d_istop, d_slot_l, queued ? d_queue : nullptr, nwaves);
         if (rc) return rc;
         if (stats) DFTA_HIP(ctx, hipEventRecord(ev[1], st));
         if (!pk) {          // packed rounds have no scouts (capz == tcap)
@@ -1225,14 +1279,18 @@ int LevelSolver::run(const double* dV, const double* job_bottom, int run_mode, d
         DFTA_CHECK_LAUNCH(ctx);
     }
     if (stats) {
-        unsigned long long cnt[2];
+        unsigned long long cnt[3];
         DFTA_HIP(ctx, hipMemcpyAsync(cnt, d_counters, sizeof(cnt), hipMemcpyDeviceToHost, st));
         DFTA_HIP(ctx, hipStreamSynchronize(st));
+        if (owned) {
+            rounds = (int)(cnt[2] & 0xffffffffull);                 // the most rounds a level took
+            DFTA_HIP(ctx, hipEventElapsedTime(&ms_sweep, ev[0], ev[1]));
+        }
         stats->rounds = rounds;
         stats->sweeps_issued = static_cast<long>(cnt[0]) + 2L * (njobs - nfrozen);    // + inward/outward halves of the match solve
         stats->points_traversed = static_cast<long>(cnt[1]);
         stats->ms_sweep = ms_sweep;
-        stats->layout = persisted ? 5 : (scan ? 4 : (sw ? 3 : (dynamic ? 1 : (pk ? 2 : 0))));
+        stats->layout = owned ? 6 : (persisted ? 5 : (scan ? 4 : (sw ? 3 : (dynamic ? 1 : (pk ? 2 : 0)))));
     }
     return DFTA_OK;
 }

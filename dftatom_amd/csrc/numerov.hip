@@ -506,6 +506,32 @@ __global__ __launch_bounds__(256) void k_sweep(SweepArgs a, GridScalars gs, int 
     else                          sweep_wave<DFTA_SWEEP_ZERO, CH>(a, gs, b, lane);
 }
 
+// The same sweeps launched LONGEST BLOCK FIRST (batches: levels.hip).  A launch of k_sweep hands its blocks out in the order of the trial
+// arrays, all at once when they fit (two waves per SIMD), and ends when the SIMD that happened to get two full-length blocks ends: 131 k
+// points x 2 x 24 instructions at the SIMD's issue rate, while the average block runs 53 k points (an over-limit CountNodes block leaves
+// after a few thousand, an l > 0 one stops at its inner turning point) -- the round-5 batch sat at 0.29 of the fp64 issue ceiling.
+// Here k_expand has entered the blocks that have work into kSweepQueueClasses lists by expected length; workgroup t (ONE wave: its
+// registers go back to the dispatcher the moment its block ends) takes entry t of the lists laid end to end, longest class first.  The
+// dispatcher starts workgroups in index order, so the long blocks start first and the short ones fill the SIMDs as they come free:
+// longest-processing-time-first -- the launch ends within a short block of max(total work / SIMDs, one full-length block).
+template <int CH>
+__global__ __launch_bounds__(64) void k_sweep_queue(SweepArgs a, GridScalars gs, const int* __restrict__ qcnt, const int* __restrict__ qlist, int qcap)
+{
+    const int lane = threadIdx.x & 63;
+    const int t = blockIdx.x;
+    int cls = 0, base = 0;
+    for (; cls < kSweepQueueClasses; ++cls) {
+        const int n = qcnt[cls];
+        if (t < base + n) break;
+        base += n;
+    }
+    if (cls == kSweepQueueClasses) return;            // fewer blocks with work than the round has blocks
+    const int b = __builtin_amdgcn_readfirstlane(qlist[(size_t)cls * qcap + (t - base)]);
+    const int kind = a.blk_kind ? __builtin_amdgcn_readfirstlane(a.blk_kind[b]) : a.kind;
+    if (kind == DFTA_SWEEP_COUNT) sweep_wave<DFTA_SWEEP_COUNT, CH>(a, gs, b, lane);
+    else                          sweep_wave<DFTA_SWEEP_ZERO, CH>(a, gs, b, lane);
+}
+
 // ---- pipelined sweep: one workgroup = one block of 64 trials, its five waves are the stages of a pipeline ----------
 // A SIMD of gfx950 issues one fp64 VALU instruction of a wave64 every 4 cycles, whether it has one wave or several.
 // The fused kernel above spends ~19 of them per grid point in ONE wave (plus exposed v_rcp_f64 / load latency), i.e.
@@ -1026,12 +1052,23 @@ __device__ __forceinline__ void sweep_pipe(const SweepArgs& a, const GridScalars
 constexpr int kPipeThreads = 320;
 
 template <int CH>
-__global__ __launch_bounds__(kPipeThreads) void k_sweep_pipe(SweepArgs a, GridScalars gs, int nblocks)
+__global__ __launch_bounds__(kPipeThreads) void k_sweep_pipe(SweepArgs a, GridScalars gs, int nblocks, const int* __restrict__ qcnt, const int* __restrict__ qlist, int qcap)
 {
     __shared__ PipeShared<CH> sh;
     const int lane = threadIdx.x & 63;
     const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int b = blockIdx.x;
+    int b = blockIdx.x;
+    if (qcnt) {
+        // longest block first (see k_sweep_queue): with more blocks than compute units the second pass is made of the short ones
+        int cls = 0, base = 0;
+        for (; cls < kSweepQueueClasses; ++cls) {
+            const int n = qcnt[cls];
+            if (b < base + n) break;
+            base += n;
+        }
+        if (cls == kSweepQueueClasses) return;
+        b = __builtin_amdgcn_readfirstlane(qlist[(size_t)cls * qcap + (b - base)]);
+    }
     const int kind = a.blk_kind ? __builtin_amdgcn_readfirstlane(a.blk_kind[b]) : a.kind;
     if (kind == DFTA_SWEEP_COUNT) sweep_pipe<DFTA_SWEEP_COUNT, CH>(a, gs, b, lane, role, sh);
     else                          sweep_pipe<DFTA_SWEEP_ZERO, CH>(a, gs, b, lane, role, sh);
@@ -1612,8 +1649,34 @@ void host_boundary(const dfta_grid* g, double E, int* start, double* us, double*
 
 #include "levels_device.inc"
 #include "persist.inc"
+#include "own.inc"
 
 }  // namespace
+
+// ---- own-pace level search of a batch (own.inc): one workgroup of W waves per live level, ONE ordinary launch ---------------------------
+// d_live (device, may be null: level q = job q): the jobs to solve; their records carry phase = first bisection and tbase = q * 64 W.
+// The trial arrays are the level solver's own (room for nlive * 64 W trials; blk_first[b] = 64 b, blk_cnt[b] = 64).
+int dfta_launch_levels_own(dfta_ctx* ctx, const dfta_grid* g, dfta::Job* d_jobs, const int* d_live, int nlive, int W, const double2* d_tab, const double2* d_bounds,
+                           int* blk_slot, const int* blk_first, const int* blk_cnt, double* dE, int* dLimit, int* dStart, double* dUs, double* dUs1, int* dCount,
+                           double* dU0, double* dPhi, int* dIstop, int* dTrip, unsigned long long* d_counters, bool stats, int nopredict, int spine_cap)
+{
+    if (nlive < 1 || W < 1 || W > 8 || (W & (W - 1)) != 0 || g->uniform) return DFTA_ERR_INVALID;
+    SweepArgs a;
+    a.slot_l = nullptr;
+    a.phi = dPhi; a.istop = dIstop;
+    a.kind = DFTA_SWEEP_COUNT; a.blk_kind = nullptr; a.bounds = d_bounds; a.bstride = dfta_bounds_stride(g);
+    a.tab = d_tab; a.blk_slot = blk_slot; a.blk_first = blk_first; a.blk_cnt = blk_cnt;
+    a.E = dE; a.limit = dLimit; a.start = dStart; a.us = dUs; a.us1 = dUs1; a.count = dCount; a.u0 = dU0;
+    a.trip = stats ? dTrip : nullptr; a.total_trips = stats ? d_counters + 1 : nullptr;
+    OwnArgs oa;
+    oa.jobs = d_jobs; oa.live = d_live; oa.r = g->d_r; oa.W = W; oa.nopredict = nopredict; oa.spine_cap = spine_cap;
+    oa.E = dE; oa.us = dUs; oa.us1 = dUs1; oa.limit = dLimit; oa.start = dStart; oa.blk_slot = blk_slot;
+    oa.issued = d_counters;
+    oa.max_rounds = reinterpret_cast<unsigned int*>(d_counters + 2);
+    hipLaunchKernelGGL(k_levels_own, dim3(nlive), dim3(64 * W), 0, ctx->stream, a, scalars_of(g), oa);
+    DFTA_CHECK_LAUNCH(ctx);
+    return DFTA_OK;
+}
 
 // ---- device-side level search (persist.inc): buffers and launch ------------------------------------------------------------------
 void dfta_persist_destroy(dfta_persist_buffers* pb)
@@ -1803,7 +1866,7 @@ int dfta_launch_boundary(dfta_ctx* ctx, const dfta_grid* g, const double* dE, in
 int dfta_launch_sweep(dfta_ctx* ctx, const dfta_grid* g, int kind, const int* blk_kind, int nblocks, const double2* tab,
                       const int* blk_slot, const int* blk_first, const int* blk_cnt, const double* dE, const int* dLimit,
                       const int* dStart, const double* dUs, const double* dUs1, int* dCount, double* dU0, int* dTrip,
-                      unsigned long long* dTotalTrips, const double2* bounds, double* dPhi, int* dIstop, const int* d_slot_l)
+                      unsigned long long* dTotalTrips, const double2* bounds, double* dPhi, int* dIstop, const int* d_slot_l, const int* d_queue, int qcap)
 {
     SweepArgs a;
     a.slot_l = d_slot_l;
@@ -1816,13 +1879,21 @@ int dfta_launch_sweep(dfta_ctx* ctx, const dfta_grid* g, int kind, const int* bl
         if (!d_slot_l) { snprintf(ctx->err, sizeof(ctx->err), "uniform sweeps need the slots' l"); return DFTA_ERR_INVALID; }
         hipLaunchKernelGGL(k_usweep, dim3(nblocks), dim3(64), 0, ctx->stream, a, scalars_of(g), nblocks);
     } else if (pipe) {
-        hipLaunchKernelGGL((k_sweep_pipe<kPipeChunk>), dim3(nblocks), dim3(kPipeThreads), 0, ctx->stream, a, scalars_of(g), nblocks);
+        hipLaunchKernelGGL((k_sweep_pipe<kPipeChunk>), dim3(nblocks), dim3(kPipeThreads), 0, ctx->stream, a, scalars_of(g), nblocks, d_queue,
+                           d_queue ? d_queue + kSweepQueueClasses + 1 : nullptr, qcap);
+    } else if (d_queue) {
+        hipLaunchKernelGGL((k_sweep_queue<kChunk>), dim3(nblocks), dim3(64), 0, ctx->stream, a, scalars_of(g), d_queue, d_queue + kSweepQueueClasses + 1, qcap);
     } else {
         const dim3 grid((nblocks + 3) / 4), block(256);
         hipLaunchKernelGGL((k_sweep<kChunk>), grid, block, 0, ctx->stream, a, scalars_of(g), nblocks);
     }
     DFTA_CHECK_LAUNCH(ctx);
     return DFTA_OK;
+}
+
+bool dfta_sweep_is_fused(const dfta_ctx* ctx, int nblocks)
+{
+    return !(ctx->sweep_kernel == DFTA_SWEEP_AUTO ? nblocks <= kPipeMaxBlocks : ctx->sweep_kernel == DFTA_SWEEP_PIPELINED);
 }
 
 int dfta_launch_match(dfta_ctx* ctx, const dfta_grid* g, int ntrials, const double2* tab, const int* d_trial_slot,
