@@ -147,6 +147,9 @@ def cpu_baseline_finish(job, all_cores=True):
                      "%d V-cycles; setup (flat density + Poisson) %.2f s excluded" % (steps, tag, o["seconds"], o["sweeps"], o["vcycles"], o["setup_s"]),
            "ms_per_step": 1e3 * o["seconds"] / steps, "vcycles_per_s": o["vcycles"] / o["seconds"],
            "cpu_model": cpu_model(), "nproc": nproc,
+           # not timed alone: two more CPU variants (1 + %d threads) and the GPU extras' host thread run on the same host meanwhile
+           "concurrent_with": "the table variant (1 thread), the level-parallel variant (%d threads) and the host thread of the GPU extras, on %d logical CPUs"
+                              % (nlev, nproc),
            "table_variant": {"value": t["sweeps"] / t["seconds"], "unit": "sweeps/s", "cores": 1, "ms_per_step": 1e3 * t["seconds"] / steps,
                              "note": "r_i and exp(2 i delta) looked up instead of re-evaluated per point; results bit-identical"},
            "level_parallel": {"value": par[0]["sweeps"] / par[0]["seconds"], "unit": "sweeps/s", "cores": nlev,
@@ -219,6 +222,40 @@ def counter_rate(d, kernel, workload):
     ms = d.get("avg_launch_ms")
     d["hbm_GBps_counters"] = traffic / (ms * 1e-3) / 1e9 if traffic and ms else None
     d["frac_counters"] = d["hbm_GBps_counters"] / HBM_PEAK_GBS if d["hbm_GBps_counters"] else None
+
+
+def rocprof_launch(kernel, workload="default"):
+    """average launch duration of `kernel` in the newest committed rocprofv3 kernel trace of the same workload
+    (profiles/<round>_<workload>_bench_kernel_stats.csv, profiles/collect.sh + summarize.py), over the TIMED launches of that run where the
+    summary has them (a kernel launched once per SCF step), with the window it describes -- so that the line's HIP-event average can be
+    checked against the profiler's (tests/test_bench_line.py).  (None, None) without a profile."""
+    import csv
+    import re
+    pat = re.compile(r"^r\d+[a-z]?_%s_bench_kernel_stats\.csv$" % re.escape(workload))
+    files = sorted((f for f in glob.glob(os.path.join(ROOT, "profiles", "*_bench_kernel_stats.csv")) if pat.match(os.path.basename(f))),
+                   key=lambda f: (os.path.basename(f).split("_")[0], os.path.getmtime(f)))
+    if not files:
+        return None, None
+    try:
+        with open(files[-1]) as fh:
+            rows = {r["kernel"]: r for r in csv.DictReader(fh)}
+        r = rows.get(kernel)
+        if r is None:
+            return None, None
+        side = files[-1].replace("_bench_kernel_stats.csv", "_bench_under_rocprof.json")
+        wu = st = None
+        if os.path.exists(side):
+            with open(side) as fh:
+                b = json.load(fh)
+            wu, st = b.get("warmup"), b.get("steps")
+        if r.get("timed_avg_us"):
+            return float(r["timed_avg_us"]) / 1e3, {"profile": os.path.basename(files[-1]), "launches": int(r["timed_calls"]),
+                                                    "window": "the timed launches only: SCF steps %s..%s of `bench.py --steps %s --warmup %s` under rocprofv3 --kernel-trace"
+                                                              % (wu, (wu + st - 1) if wu is not None and st else None, st, wu)}
+        return float(r["avg_us"]) / 1e3, {"profile": os.path.basename(files[-1]), "launches": int(r["calls"]),
+                                          "window": "ALL launches of `bench.py --steps %s --warmup %s` under rocprofv3 --kernel-trace (warm-up included)" % (st, wu)}
+    except Exception:
+        return None, None
 
 
 def workload_tag(levels, atoms, lsda, poisson_mode, sweep_mode):
@@ -383,7 +420,10 @@ def kernel_figures(tot, levels, N, atoms, workload=None):
     `algorithmic_*` = SURVEY 8d bytes / time: a yardstick, NOT a bandwidth (levels resident in LDS / L2 and trials sharing a table row
     make it exceed what HBM moves); `hbm_GBps_counters` = rocprofv3 FETCH/WRITE bytes of the committed profile of `workload` / time."""
     forced = next((e.split("=", 1)[1] for e in os.environ.get("DFTA_DEBUG", "").split(",") if e.startswith("SWEEP_KERNEL=")), "")
-    piped = forced == "pipe" or (forced != "fused" and tot["trials_per_round"] // 64 <= 768)
+    # which sweep kernel the rounds ran: the library picks per launch by the blocks of the round (<= 768: pipelined); packed rounds lay out
+    # fewer trials than the solver has room for, so the average issued trials per round decide here, not the capacity
+    per_round = tot["sweeps_issued"] / max(tot["rounds"], 1) if tot.get("rounds") else tot["trials_per_round"]
+    piped = forced == "pipe" or (forced != "fused" and min(tot["trials_per_round"], per_round) // 64 <= 768)
     sname = "k_scan_levels" if tot.get("scan") else ("k_levels_persist" if tot.get("persist") else ("k_sweep_pipe" if piped else "k_sweep"))
     t_sw = tot["ms_sweep_kernels"] * 1e-3
     # host rounds: one launch per round; the device-side search: ONE launch per SCF step (sweeps of every round, walk, match, normalisation)
@@ -434,6 +474,7 @@ def kernel_figures(tot, levels, N, atoms, workload=None):
         d["peak_measured_copy"] = HBM_MEASURED["copy"]
         if workload:
             counter_rate(d, k, workload)
+            d["avg_launch_ms_rocprof"], d["rocprof_window"] = rocprof_launch(k, workload)
     return sweep, pois
 
 
@@ -479,7 +520,7 @@ def compact_line(full):
     out = {k: _r(full[k]) if not isinstance(full[k], (dict, list)) else full[k]
            for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
                      "data", "config") if k in full}
-    for k in ("value_reference_equivalent", "sweeps_issued_per_s", "poisson_vcycles_per_s", "poisson_vcycles_per_s_kernel", "rounds_per_step",
+    for k in ("ranks_seen", "value_reference_equivalent", "sweeps_issued_per_s", "poisson_vcycles_per_s", "poisson_vcycles_per_s_kernel", "rounds_per_step",
               "device", "compute_units"):
         if k in full:
             out[k] = _r(full[k])
@@ -488,12 +529,14 @@ def compact_line(full):
     rf = full["roofline"]
     out["roofline"] = {k: _r(rf.get(k)) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "frac_issued", "traffic", "bytes_per_launch",
                                                    "avg_launch_ms", "launches", "hbm_GBps_counters", "frac_counters", "peak_measured_copy",
-                                                   "achieved_is") if k in rf}
+                                                   "achieved_is", "avg_launch_ms_rocprof") if k in rf}
+    if isinstance(rf.get("rocprof_window"), dict):
+        out["roofline"]["rocprof_window"] = "%s: %s (%s launches)" % (rf["rocprof_window"].get("profile"), rf["rocprof_window"].get("window"), rf["rocprof_window"].get("launches"))
     ks = full.get("kernels", {})
     out["kernels"] = {"sweep": _flat_kernel(ks.get("sweep", {}), sweep_keys), "poisson": _flat_kernel(ks.get("poisson", {}), pois_keys)}
     if "cpu_baseline" in full:
         c = full["cpu_baseline"]
-        out["cpu_baseline"] = {k: _r(c.get(k)) for k in ("value", "unit", "cores", "kind", "ms_per_step", "vcycles_per_s", "cpu_model", "nproc")}
+        out["cpu_baseline"] = {k: _r(c.get(k)) for k in ("value", "unit", "cores", "kind", "ms_per_step", "vcycles_per_s", "cpu_model", "nproc", "concurrent_with") if k in c}
         out["cpu_baseline"]["sample"] = str(c.get("sample", ""))[:200]
         for name in ("table_variant", "level_parallel", "all_cores"):
             if isinstance(c.get(name), dict):
@@ -680,6 +723,8 @@ def main():
                 "hbm_GBps_counters": dominant.get("hbm_GBps_counters"), "frac_counters": dominant.get("frac_counters"),
                 "bytes_per_launch": dominant["bytes_per_launch"],
                 "avg_launch_ms": dominant["avg_launch_ms"], "launches": dominant["launches"],
+                # the same kernel's average in the committed rocprofv3 kernel trace of this workload, and the launches it averages
+                "avg_launch_ms_rocprof": dominant.get("avg_launch_ms_rocprof"), "rocprof_window": dominant.get("rocprof_window"),
                 "peak_measured_copy": HBM_MEASURED["copy"], "peak_measured_triad": HBM_MEASURED["triad"],
                 "share_of_step_ms": {"multigrid kernel": tot["ms_poisson"] / args.steps, "sweep kernel": tot["ms_sweep_kernels"] / args.steps},
                 "binding_resource": dominant["binding_resource"],
@@ -693,6 +738,7 @@ def main():
             "value_reference_equivalent": ref_all / elapsed,
             "unit": "sweeps/s",
             "n_gpus": world,
+            "ranks_seen": (dist.get_world_size() if world > 1 and dist.is_initialized() else 1),     # what the process group really has
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,

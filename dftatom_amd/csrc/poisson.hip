@@ -69,6 +69,7 @@ struct MgDesc {
     int fuse_min_logc;   // global-memory levels of one workgroup: fused visits (gs_fused3) from this many nodes per lane on
     int fuse_coop;       // ... and on the levels the G workgroups of an atom share (0: $DFTA_DEBUG POISSON_NOFUSE_COOP)
     int fuse3;    // visits of three sweeps on staged levels of one workgroup run as ONE fused pass (gs_lds3); 0: $DFTA_POISSON_NOFUSE3
+    int fuse3w;   // ... and those of the one-wave levels with 257 .. 1025 nodes of the coarse section (cs_visit3); 0: POISSON_NOFUSE3 / POISSON_NOFUSE3_WAVE
     int nofold;   // DFTA_POISSON_NOFOLD: restriction / prolongation as separate passes even where they could be folded into a staged copy-in
     int kcoop;       // levels 0 .. kcoop-1 are swept by all G workgroups together (256 G lanes), the others by workgroup 0
     int spin_max;    // bound of the group barriers' spin loops (Atom::spin_max)
@@ -417,6 +418,7 @@ static int poisson_create_impl(dfta_ctx* ctx, const dfta_grid* g, int batch, int
     D.logG = logG;
     D.nofold = dfta_knob("POISSON_NOFOLD") ? 1 : 0;
     D.fuse3 = dfta_knob("POISSON_NOFUSE3") ? 0 : 1;
+    D.fuse3w = (D.fuse3 && !dfta_knob("POISSON_NOFUSE3_WAVE")) ? 1 : 0;
     D.fuse_min_logc = kFuseMinLogC;
     D.fuse_coop = dfta_knob("POISSON_NOFUSE_COOP") ? 0 : 1;
     if (const char* e = dfta_knob("POISSON_FUSE_MIN_LOGC")) D.fuse_min_logc = std::max(kFuseMinLogC, atoi(e));   // measurements (99: never; staged levels -- <= 32 nodes per lane -- have their own fused pass)

@@ -1,13 +1,13 @@
 #!/bin/bash
 # Collect the rocprofv3 evidence behind bench.py's roofline numbers (run on the MI355X box, e.g.
-#   gpurun --timeout 2400 -- 'bash profiles/collect.sh r05'
+#   gpurun --timeout 2400 -- 'bash profiles/collect.sh r06'
 # ) for the headline workload AND the throughput workloads the README quotes.  Per workload four separate passes of the SAME
 # command: kernel trace + stats, the two HBM-side PMC counters (FETCH_SIZE and WRITE_SIZE do not fit one pass; --pmc is never
 # combined with sys/runtime traces), and the SQ counters.  The profiled program comes directly after `--` (python3 bench.py ...).
 # Raw output goes to gpurun_out/<tag>_<workload>/ (scratch); profiles/summarize.py turns it into the committed summaries
 #   profiles/<tag>_<workload>_{bench_kernel_stats.csv, bench_under_rocprof.json, hbm_traffic.json, sq_counters.json}.
 set -u
-TAG=${1:-r05}
+TAG=${1:-r06}
 ONLY=${2:-}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 run_one() {
@@ -23,11 +23,13 @@ run_one() {
     python3 profiles/summarize.py "$OUT" "${TAG}_${name}" "$ARGS"
     tail -2 "$OUT/trace.err"
 }
-run_one default      --steps 5 --warmup 2 --no-cpu --no-extras
+# the headline workload, Rn LSDA and the tolerance mode on bench.py's OWN window (--steps 20 --warmup 5, what the driver's line is
+# measured on): summarize.py averages the timed launches alone, bench.py prints that average next to its HIP-event one
+run_one default      --steps 20 --warmup 5 --no-cpu --no-extras
 run_one scan         --steps 5 --warmup 2 --no-cpu --no-extras --scan-sweeps
 run_one scan_tol     --steps 5 --warmup 2 --no-cpu --no-extras --scan-sweeps --tolerance
-run_one tolerance    --steps 5 --warmup 2 --no-cpu --no-extras --tolerance
-run_one rn_lsda      --lsda --steps 5 --warmup 2 --no-cpu --no-extras
+run_one tolerance    --steps 20 --warmup 5 --no-cpu --no-extras --tolerance
+run_one rn_lsda      --lsda --steps 20 --warmup 5 --no-cpu --no-extras
 run_one scan_adaptive --steps 5 --warmup 2 --no-cpu --no-extras --scan-sweeps --adaptive
 run_one batch256     --atoms 256 --steps 3 --warmup 1 --no-cpu --no-extras
 run_one batch256_scan     --atoms 256 --steps 3 --warmup 1 --no-cpu --no-extras --scan-sweeps

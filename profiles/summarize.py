@@ -1,5 +1,6 @@
 """Turn the raw rocprofv3 output of profiles/collect.sh into the small summaries that are committed:
-    profiles/<tag>_bench_kernel_stats.csv   per-kernel calls / total / average / min / max duration (kernel trace)
+    profiles/<tag>_bench_kernel_stats.csv   per-kernel calls / total / average / min / max duration (kernel trace); timed_*: the same over
+                                            the launches of the TIMED steps only (kernels launched once per step; warm-up skipped by index)
     profiles/<tag>_bench_under_rocprof.json the bench.py line printed by the profiled run
     profiles/<tag>_hbm_traffic.json         FETCH_SIZE / WRITE_SIZE per kernel and launch (separate PMC passes)
     profiles/<tag>_sq_counters.json         SQ counters per kernel and launch
@@ -25,18 +26,34 @@ def short(name):
     return m.group(1) if m else name[:60]
 
 
-def kernel_stats(d):
+def window_of(args):
+    """(warmup, steps) of the profiled bench command"""
+    m_s, m_w = re.search(r"--steps\s+(\d+)", args), re.search(r"--warmup\s+(\d+)", args)
+    return (int(m_w.group(1)) if m_w else 2), (int(m_s.group(1)) if m_s else 5)
+
+
+def kernel_stats(d, warmup=None, steps=None):
+    """per kernel: all launches, and -- for a kernel launched exactly once per SCF step (warmup + steps launches: the device-side level
+    search, the multigrid solve) -- the TIMED launches alone: the last `steps` ones in start order, i.e. the window bench.py's line is
+    measured on (the warm-up launches are skipped by index)"""
     files = find(d, "*kernel_trace.csv")
     agg = defaultdict(list)
     for f in files:
         with open(f) as fh:
             for row in csv.DictReader(fh):
-                agg[short(row["Kernel_Name"])].append(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
+                agg[short(row["Kernel_Name"])].append((int(row["Start_Timestamp"]), int(row["End_Timestamp"]) - int(row["Start_Timestamp"])))
     rows = []
-    total = sum(sum(v) for v in agg.values()) or 1
-    for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
-        rows.append({"kernel": k, "calls": len(v), "total_ms": sum(v) / 1e6, "avg_us": sum(v) / len(v) / 1e3,
-                     "min_us": min(v) / 1e3, "max_us": max(v) / 1e3, "percent": 100.0 * sum(v) / total})
+    total = sum(sum(x[1] for x in v) for v in agg.values()) or 1
+    for k, v in sorted(agg.items(), key=lambda kv: -sum(x[1] for x in kv[1])):
+        v.sort()
+        dur = [x[1] for x in v]
+        r = {"kernel": k, "calls": len(dur), "total_ms": sum(dur) / 1e6, "avg_us": sum(dur) / len(dur) / 1e3,
+             "min_us": min(dur) / 1e3, "max_us": max(dur) / 1e3, "percent": 100.0 * sum(dur) / total,
+             "timed_calls": "", "timed_avg_us": "", "timed_min_us": "", "timed_max_us": ""}
+        if warmup is not None and steps and len(dur) == warmup + steps:
+            t = dur[warmup:]
+            r.update({"timed_calls": len(t), "timed_avg_us": sum(t) / len(t) / 1e3, "timed_min_us": min(t) / 1e3, "timed_max_us": max(t) / 1e3})
+        rows.append(r)
     return rows
 
 
@@ -61,7 +78,8 @@ def main():
     raw, tag = sys.argv[1], sys.argv[2]
     args = sys.argv[3] if len(sys.argv) > 3 else ""
     pdir = os.path.join(ROOT, "profiles")
-    rows = kernel_stats(os.path.join(raw, "trace"))
+    warmup, steps = window_of(args)
+    rows = kernel_stats(os.path.join(raw, "trace"), warmup, steps)
     if rows:
         with open(os.path.join(pdir, tag + "_bench_kernel_stats.csv"), "w", newline="") as fh:
             w = csv.DictWriter(fh, fieldnames=list(rows[0].keys()))

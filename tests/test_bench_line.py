@@ -124,3 +124,45 @@ def test_algorithmic_figures_are_not_called_bandwidth():
     sweep, pois = bench.kernel_figures(canned_tot(256, 10), 17, 131073, 256, None)
     for k in (sweep, pois):
         assert "algorithmic_GBps" in k and "achieved" not in k and "frac_measured" not in k
+
+
+def test_rocprof_average_is_read_from_the_committed_summary(tmp_path, monkeypatch):
+    """the line carries the profiler's average launch duration of the dominant kernel over the TIMED launches of the
+    committed kernel trace of the same workload, with the window it describes"""
+    import bench
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    (prof / "r98_default_bench_kernel_stats.csv").write_text(
+        "kernel,calls,total_ms,avg_us,min_us,max_us,percent,timed_calls,timed_avg_us,timed_min_us,timed_max_us\n"
+        "k_levels_persist,25,770.0,30800.0,27000.0,43000.0,53.0,20,29400.0,27000.0,33000.0\n"
+        "k_expand,300,3.0,10.0,8.0,12.0,0.2,,,,\n")
+    (prof / "r98_default_bench_under_rocprof.json").write_text(json.dumps({"steps": 20, "warmup": 5}))
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    ms, win = bench.rocprof_launch("k_levels_persist", "default")
+    assert ms == 29.4 and win["launches"] == 20 and "steps 5..24" in win["window"] and win["profile"].startswith("r98_default")
+    ms, win = bench.rocprof_launch("k_expand", "default")          # many launches per step: no timed window, all launches
+    assert ms == 0.01 and "ALL launches" in win["window"]
+    assert bench.rocprof_launch("k_nothing", "default") == (None, None)
+    assert bench.rocprof_launch("k_levels_persist", "no_such_workload") == (None, None)
+
+
+def test_committed_line_agrees_with_the_committed_rocprof_summary():
+    """the newest committed bench line of the default workload (profiles/r??_bench_default_line.json) against the rocprofv3 kernel trace
+    committed with it: the HIP-event average of the dominant kernel and the profiler's average over the same window differ by < 5 %,
+    and `frac` follows from the CSV alone: bytes_per_launch / timed_avg / peak"""
+    import csv
+    import glob
+    lines = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_default_line.json")))
+    d = json.load(open(lines[-1]))
+    r = d["roofline"]
+    if "avg_launch_ms_rocprof" not in r:
+        import pytest
+        pytest.skip("the newest committed line predates roofline.avg_launch_ms_rocprof (%s)" % os.path.basename(lines[-1]))
+    assert r["avg_launch_ms_rocprof"] is not None, "the line was printed without a committed kernel trace of its workload"
+    assert abs(r["avg_launch_ms_rocprof"] - r["avg_launch_ms"]) <= 0.05 * r["avg_launch_ms"], (r["avg_launch_ms_rocprof"], r["avg_launch_ms"])
+    assert "timed launches only" in r["rocprof_window"] and "--steps %d --warmup %d" % (d["steps"], d["warmup"]) in r["rocprof_window"]
+    prof = r["rocprof_window"].split(":", 1)[0]
+    rows = {x["kernel"]: x for x in csv.DictReader(open(os.path.join(ROOT, "profiles", prof)))}
+    t_ms = float(rows[r["kernel"]]["timed_avg_us"]) / 1e3
+    frac_from_csv = r["bytes_per_launch"] / (t_ms * 1e-3) / 1e9 / r["peak"]
+    assert abs(frac_from_csv - r["frac"]) <= 0.05 * r["frac"], (frac_from_csv, r["frac"])

@@ -143,7 +143,7 @@ def test_bench_two_ranks_control_flow():
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["value"] > 0
     assert d["config"]["parallelism"] == "replicas x2" and "cpu_baseline" not in d and "roofline" in d
     # BASELINE config 4 under --gpus N: after the replica timing every rank advances its shard of the periodic table
     # (here Z = 1..7: partition_atoms over two ranks), the records are gathered once, rank 0 reports the sweep on the line

@@ -80,6 +80,25 @@ def test_register_coarse_levels_return_the_lds_bits(ctx, L, delta, R):
     grid.close()
 
 
+@pytest.mark.parametrize("L,delta,R", [(12, 2e-3, 25.0), (14, 5e-4, 25.0), (17, 1e-4, 50.0), (17, None, 50.0), (20, 1.25e-5, 50.0)])
+def test_fused_visits_of_the_one_wave_levels_return_the_single_sweep_bits(ctx, L, delta, R):
+    """Round 6: the three sweeps of a visit of the coarse section's 257 ... 1025-node levels run as ONE fused pass on the level's LDS copy
+    (poisson_kernels.inc: cs_visit3 -> gs_lds3 with the 64 lanes of the wave: 112 + C + 2 dependent steps, one prologue, one norm, one
+    wave fence instead of three of each) -- against POISSON_NOFUSE3_WAVE, the sweep-by-sweep visits.  Same arithmetic per node: U, the
+    V-cycle count, the sweep-dependent error norm of level 0 are the same bits, for the resident groups, a staged group and one workgroup
+    per atom; Z = 1 meets the reference's stop rule early on the coarse levels (the fall-back to single sweeps is exercised)."""
+    grid = D.Grid(ctx, L, delta, R)
+    rr = grid.r()
+    for Zs in ([86], [1], [18, 2, 54]):
+        rho = np.stack([z * (1.0 + 0.3 * k) ** 3 * np.exp(-2 * (1.0 + 0.3 * k) * rr) / np.pi for k, z in enumerate(Zs)])
+        for kv in ({}, {"DFTA_POISSON_GROUP": "0"}, {"DFTA_POISSON_RES": "0"}):
+            Uf, vcf, ef, _ = _solve(ctx, grid, Zs, rho, D.POISSON_EXACT, **kv)
+            Us, vcs, es, _ = _solve(ctx, grid, Zs, rho, D.POISSON_EXACT, DFTA_POISSON_NOFUSE3_WAVE="1", **kv)
+            assert np.array_equal(Uf.view(np.int64), Us.view(np.int64)), (L, Zs, kv)
+            assert np.array_equal(vcf, vcs) and np.array_equal(ef.view(np.int64), es.view(np.int64)), (L, Zs, kv, vcf, vcs)
+    grid.close()
+
+
 def test_resident_groups_are_deterministic(ctx):
     """He at 16385 nodes: one shared level, short passes, the cycle stops early -- exchanges follow each other within microseconds.
     Thirty SCF steps twice: every step's U and V-cycle count identical, and identical to the one-workgroup solver's."""

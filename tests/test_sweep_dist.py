@@ -75,6 +75,51 @@ def test_gather_world_size_2_gloo():
     assert f["Z"] == 3 and f["finished"] and f["nlevels"] == 2 and f["eigenvalues"].tolist() == [-1.9, -0.08]
 
 
+def _worker8(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    shards = sweep.partition_atoms(list(range(1, 87)), world)
+    cap = max(len(s) for s in shards)
+    rec = np.zeros((len(shards[rank]), sweep.RECORD_DOUBLES))
+    for k, z in enumerate(shards[rank]):                # fake records: Z, Etotal, finished, steps (= the rank that made it), levels
+        rec[k, 0], rec[k, 1], rec[k, 6], rec[k, 7], rec[k, 8], rec[k, 9] = z, -float(z) ** 2.4, 1, rank, 1, 1
+        rec[k, 10] = -z * z / 2.0
+    table = sweep.gather_records(torch.from_numpy(sweep.pack_records(rec, cap)), dist)
+    seen = dist.get_world_size()
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, seen, [len(s) for s in shards], sorted(table), {int(z): int(table[z][7]) for z in table}))
+
+
+def test_periodic_table_partition_and_gather_world_size_8_gloo():
+    """BASELINE config 4 as the driver will launch it on an 8-GPU node, minus the GPUs: eight ranks over gloo, the
+    partition of Z = 1..86 complete and disjoint and the same on every rank, every rank packs the records of its shard, ONE all_gather
+    returns all 86 to everybody, each made by the rank that owns the atom"""
+    shards = sweep.partition_atoms(list(range(1, 87)), 8)
+    assert sorted(z for s in shards for z in s) == list(range(1, 87)) and sum(len(s) for s in shards) == 86      # complete, disjoint
+    assert all(len(s) >= 1 for s in shards)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker8, args=(r, 8, port, q)) for r in range(8)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    owner = {z: r for r, sh in enumerate(shards) for z in sh}
+    assert sorted(r[0] for r in res) == list(range(8))
+    for rank, seen, per_rank, zs, made_by in res:
+        assert seen == 8 and per_rank == [len(sh) for sh in shards] and sum(per_rank) == 86      # the same partition on every rank
+        assert zs == list(range(1, 87))                                                          # every rank ends with the full table
+        assert made_by == owner
+
+
 def test_shard_time_model_reproduces_the_recorded_shards():
     """A CONSISTENCY check, not a validation: the constants of sweep.shard_time_ms are a least-squares fit to the 15 recorded
     shards of the emulated 1-, 2-, 4-, 8-rank sweeps (profiles/fit_shard_model.py, profiles/r04_periodic_table_predicted_scaling_<mode>.json),
