@@ -80,7 +80,8 @@ struct Job {
     int rounds;
     // feedback from one SCF step to the next (device-side search): when the level's search ended, in microseconds after the kernel's first
     // workgroup started; the host gives the levels that ended last in the previous step first call on the pool's workgroups (deep = 1)
-    int t_end_us, deep, pad_;
+    int t_end_us, deep;
+    int cand_hist;                   // hit-rate budget of the level's candidate wavefunctions (persist.inc: cand_allowed), carried over by the host
     long long n_points;              // grid points traversed by the sweeps ON the bisection path (n_count + n_zero executed ones) + the match solve
 };
 

@@ -899,6 +899,7 @@ int LevelSolver::run(const double* dV, const double* job_bottom, int run_mode, d
         j.rounds = 0;
         j.t_end_us = 0;
         j.deep = -1;
+        j.cand_hist = (use_prediction && h_last.size() == jobs.size() && dfta_knob("LEVELS_PERSIST_NOBUDGET") == nullptr) ? h_last[k].cand_hist : 0;
         j.bottom0 = job_bottom[k];
         const bool first = (k == 0 || jobs[k].v != jobs[k - 1].v);
         if (!chained || first) { j.phase = PH_TOP; j.toe = 50; j.boe = j.bottom0; }   // DFTAtom.cpp:499

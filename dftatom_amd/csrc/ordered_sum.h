@@ -94,10 +94,15 @@ __device__ __forceinline__ double wave_simpson38(const double* __restrict__ v, i
 // lds[0..511], sum2's in lds[512..767] -- then wave 0 adds up the first region while wave 1 adds up the second: the longer chain
 // has 2/3 of the elements of the single-wave version.  EVERY thread of the block must call (block-wide barriers); all return
 // the same value.  lds: kTile doubles, xch: 2 doubles.
-__device__ __forceinline__ double block_simpson38(const double* __restrict__ v, int sz, double delta, double* lds, double* xch)
+// (`load(i)` delivers element i: an array, or an integrand evaluated on the fly.  FETCH0: the first of the 128 threads that fetch the tiles
+// -- 0: the two waves that also run the chains; 128 in a block of >= 256 threads: two other waves, so that the chain waves touch LDS only
+// and an integrand of several loads and flops per element costs the chains nothing)
+template <int FETCH0 = 0, typename Load>
+__device__ __forceinline__ double block_simpson38_of(Load load, int sz, double delta, double* lds, double* xch)
 {
     typedef double v2 __attribute__((ext_vector_type(2)));
-    const int tid = threadIdx.x, wave = tid >> 6;
+    const int wave = threadIdx.x >> 6;
+    const int tid = static_cast<int>(threadIdx.x) - FETCH0;      // fetch lane: 0 .. 127 fetch
     const long count = static_cast<long>(sz) - 2;       // elements j = 0 .. count-1 are the nodes i = j + 1
     constexpr int kPer = kTile / 128;
     double nxt[kPer];
@@ -105,7 +110,7 @@ __device__ __forceinline__ double block_simpson38(const double* __restrict__ v, 
 #pragma unroll
         for (int k = 0; k < kPer; ++k) {
             const long j = base + k * 128 + tid;
-            nxt[k] = (tid < 128 && j < count) ? v[1 + j] : 0.0;
+            nxt[k] = (tid >= 0 && tid < 128 && j < count) ? load(1 + j) : 0.0;
         }
     };
     // one chain: n elements of a region, added in order; reads as 16-byte broadcasts, 32 elements in flight ahead of the adds
@@ -127,7 +132,7 @@ __device__ __forceinline__ double block_simpson38(const double* __restrict__ v, 
     fetch(0);
     for (long base = 0; base < count; base += kTile) {
         const int nt = (count - base) < kTile ? static_cast<int>(count - base) : kTile;
-        if (tid < 128) {
+        if (tid >= 0 && tid < 128) {
 #pragma unroll
             for (int k = 0; k < kPer; ++k) {
                 const int j = k * 128 + tid, t = j / 3, r = j - 3 * t;       // base is a multiple of 3: the pattern restarts per tile
@@ -141,13 +146,17 @@ __device__ __forceinline__ double block_simpson38(const double* __restrict__ v, 
         else if (wave == 1) acc = chain(lds + 512, triples, acc);
         __syncthreads();
     }
-    if (tid == 0) xch[0] = acc;
-    if (tid == 64) xch[1] = acc;
+    if (threadIdx.x == 0) xch[0] = acc;
+    if (threadIdx.x == 64) xch[1] = acc;
     __syncthreads();
-    double sum = v[0] + v[sz - 1];
+    double sum = load(0) + load(static_cast<long>(sz) - 1);
     sum += 3. * xch[0] + 2. * xch[1];
     constexpr double coef = 3. / 8.;
     return sum * delta * coef;
+}
+__device__ __forceinline__ double block_simpson38(const double* __restrict__ v, int sz, double delta, double* lds, double* xch)
+{
+    return block_simpson38_of([v](long i) { return v[i]; }, sz, delta, lds, xch);
 }
 
 // Integral::Romberg(delta, values, 1E-18, 3) (Integral.h:106-155): the trapezoid refinement of level i adds

@@ -33,8 +33,8 @@ def window_of(args):
 
 
 def kernel_stats(d, warmup=None, steps=None):
-    """per kernel: all launches, and -- for a kernel launched exactly once per SCF step (warmup + steps launches: the device-side level
-    search, the multigrid solve) -- the TIMED launches alone: the last `steps` ones in start order, i.e. the window bench.py's line is
+    """per kernel: all launches, and -- for a kernel launched exactly once per SCF step (warmup + steps launches, one more for the multigrid's set-up
+    solve: the device-side level search, the multigrid solve) -- the TIMED launches alone: the last `steps` ones in start order, i.e. the window bench.py's line is
     measured on (the warm-up launches are skipped by index)"""
     files = find(d, "*kernel_trace.csv")
     agg = defaultdict(list)
@@ -50,8 +50,9 @@ def kernel_stats(d, warmup=None, steps=None):
         r = {"kernel": k, "calls": len(dur), "total_ms": sum(dur) / 1e6, "avg_us": sum(dur) / len(dur) / 1e3,
              "min_us": min(dur) / 1e3, "max_us": max(dur) / 1e3, "percent": 100.0 * sum(dur) / total,
              "timed_calls": "", "timed_avg_us": "", "timed_min_us": "", "timed_max_us": ""}
-        if warmup is not None and steps and len(dur) == warmup + steps:
-            t = dur[warmup:]
+        # (+ 1: the solve of the flat start density when the SCF object is made)
+        if warmup is not None and steps and len(dur) in (warmup + steps, warmup + steps + 1):
+            t = dur[-steps:]
             r.update({"timed_calls": len(t), "timed_avg_us": sum(t) / len(t) / 1e3, "timed_min_us": min(t) / 1e3, "timed_max_us": max(t) / 1e3})
         rows.append(r)
     return rows

@@ -120,7 +120,7 @@ def test_device_search_equals_host_rounds_small_grid(ctx, grid14, Z, lsda):
 
 
 @pytest.mark.parametrize("knobs", ["LEVELS_PERSIST_NOCAND", "LEVELS_PERSIST_EQUAL", "LEVELS_PERSIST_BLOCKS=64", "LEVELS_PERSIST_BLOCKS=37,LEVELS_PERSIST_EQUAL",
-                                   "LEVELS_NOPREDICT", "LEVELS_PERSIST_PLAIN_LAUNCH"])
+                                   "LEVELS_NOPREDICT", "LEVELS_PERSIST_PLAIN_LAUNCH", "LEVELS_PERSIST_NOBUDGET"])
 def test_layout_knobs_of_the_device_search_keep_the_bits(ctx, grid14, knobs):
     """no speculative match solves, equal shares, a quarter of the machine, an odd number of workgroups, no predictions at all, an
     ordinary launch: rounds change, results do not"""
