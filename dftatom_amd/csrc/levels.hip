@@ -1108,6 +1108,15 @@ int LevelSolver::run(const double* dV, const double* job_bottom, int run_mode, d
         else {
             // a worker was lost (or the grid cannot be co-resident): the whole solve again with host rounds, from the records as they were
             ++persist_fallbacks;
+            {   // said once per process: the results are the same, the step is slower (dfta_step_stats::levels_fallbacks counts them)
+                static bool told = false;
+                if (!told) {
+                    told = true;
+                    fprintf(stderr, "dftatom_hip: the device-side level search did not finish (a workgroup of its cooperative launch was not scheduled -- "
+                                    "another process on the device, masked compute units -- or timed out); this solve and any later one that fails the "
+                                    "same way run with host-synchronised rounds instead: same results, slower steps\n");
+                }
+            }
             for (int k = 0; k < njobs; ++k)
                 if (!jobs[k].frozen) { jobs[k].tbase = (pk || sw) ? 0 : k * tpj; jobs[k].tcap = (pk || sw) ? 0 : tpj; }
             DFTA_HIP(ctx, hipMemcpyAsync(d_jobs, jobs.data(), sizeof(Job) * njobs, hipMemcpyHostToDevice, st));

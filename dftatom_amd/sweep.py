@@ -37,7 +37,7 @@ def atom_cost(Z):
     return subshell_count(Z) * expected_steps(Z)
 
 
-# Time model of one shard (measured on MI355X, profiles/r04_periodic_table_predicted_scaling*.json): a step of a batch costs a
+# Time model of one shard (measured on MI355X, profiles/r06_periodic_table_predicted_scaling*.json; round 4's constants were 62.5 / 69.4 / 0.221 and 10.8 / 24.0 / 0.144): a step of a batch costs a
 # latency floor -- the level search and the multigrid's dependent sweeps take what they take for one atom or ten -- plus a per-job
 # share once the batch fills the machine:  t_step = FLOOR(live atoms) + JOB_MS x (subshells of the atoms still running).  The floor
 # has two values: with up to RESIDENT_MAX_ATOMS live atoms the multigrid runs in resident groups (and, in tolerance mode, the coarse
@@ -47,8 +47,8 @@ def atom_cost(Z):
 # One triple per mode of the sweeps, least squares over the shards of the emulated 1-, 2-, 4- and 8-rank sweeps (profiles/fit_shard_model.py
 # re-fits them from the recorded files; tests/test_sweep_dist.py checks that the model reproduces every recorded shard time within 15 %).
 RESIDENT_MAX_ATOMS = 7
-SHARD_MODEL = {"exact": (62.5, 69.4, 0.221),        # residuals of the 15 recorded shards: max 14.7 %, rms 5.4 %
-               "tolerance": (10.8, 24.0, 0.144)}    # scan sweeps + the multigrid's tolerance mode: max 12.7 %, rms 7.7 %
+SHARD_MODEL = {"exact": (58.8, 66.7, 0.207),        # round-6 kernels (profiles/r06_periodic_table_predicted_scaling_exact.json): residuals of the 15 recorded shards max 12.2 %, rms 4.1 %
+               "tolerance": (11.5, 17.7, 0.136)}    # scan sweeps + the multigrid's tolerance mode (..._tolerance.json): max 7.6 %, rms 4.8 %
 STEP_FLOOR_MS, JOB_MS = SHARD_MODEL["exact"][1], SHARD_MODEL["exact"][2]
 
 

@@ -1,9 +1,9 @@
 """Re-fit the shard time model of dftatom_amd/sweep.py -- T(shard) = FLOOR_SMALL_MS x (steps with <= 7 live atoms) + FLOOR_BIG_MS x (steps with
 more) + JOB_MS x sum(subshells x expected steps) -- to the recorded shards of the emulated 1-, 2-, 4- and 8-rank periodic-table sweeps (examples/periodic_table.py --emulate-ranks N,
-one GPU; profiles/r04_periodic_table_predicted_scaling_<mode>.json), by least squares, per mode of the sweeps.
+one GPU; profiles/<round>_periodic_table_predicted_scaling_<mode>.json, the newest round), by least squares, per mode of the sweeps.
 
     python profiles/fit_shard_model.py            # prints the pairs to paste into sweep.SHARD_MODEL and the residuals
-    python profiles/fit_shard_model.py --merge gpurun_out/r04_pt_exact_{1,2,4,8}.json --mode exact    # build the recorded file from raw runs
+    python profiles/fit_shard_model.py --merge gpurun_out/r06_pt_exact_{1,2,4,8}.json --mode exact --tag r06    # build the recorded file from raw runs
 """
 import json
 import os
@@ -15,11 +15,16 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def path_of(mode):
-    return os.path.join(ROOT, "profiles", "r04_periodic_table_predicted_scaling_%s.json" % mode)
+def path_of(mode, tag=None):
+    """the recorded emulation of `mode`: profiles/<tag>_periodic_table_predicted_scaling_<mode>.json, tag = the newest round by default"""
+    import glob
+    if tag is None:
+        have = sorted(glob.glob(os.path.join(ROOT, "profiles", "r??_periodic_table_predicted_scaling_%s.json" % mode)))
+        tag = os.path.basename(have[-1]).split("_")[0] if have else "r04"
+    return os.path.join(ROOT, "profiles", "%s_periodic_table_predicted_scaling_%s.json" % (tag, mode))
 
 
-def merge(files, mode):
+def merge(files, mode, tag=None):
     runs = [json.load(open(f)) for f in files]
     runs.sort(key=lambda r: r["emulated_ranks"])
     out = {"what": "periodic table Z = 1..86 at 131 073 nodes on ONE MI355X as the shards of an N-rank sweep, each shard run alone "
@@ -31,9 +36,9 @@ def merge(files, mode):
            "runs": [{"emulated_ranks": r["emulated_ranks"], "shards": [{k: s[k] for k in ("rank", "atoms", "steps", "seconds", "finished")} for s in r["shards"]]} for r in runs]}
     one = out["predicted_seconds"]["1"]
     out["speedup_vs_one_gpu"] = {k: one / v for k, v in out["predicted_seconds"].items()}
-    with open(path_of(mode), "w") as f:
+    with open(path_of(mode, tag), "w") as f:
         json.dump(out, f, indent=1)
-    print("wrote", path_of(mode), out["predicted_seconds"])
+    print("wrote", path_of(mode, tag), out["predicted_seconds"])
 
 
 def shards_of(mode):
@@ -59,7 +64,7 @@ if __name__ == "__main__":
         i = sys.argv.index("--merge")
         mode = sys.argv[sys.argv.index("--mode") + 1]
         files = [a for a in sys.argv[i + 1:] if a.endswith(".json")]
-        merge(files, mode)
+        merge(files, mode, sys.argv[sys.argv.index("--tag") + 1] if "--tag" in sys.argv else None)
         sys.exit(0)
     for mode in ("exact", "tolerance"):
         if os.path.exists(path_of(mode)):

@@ -122,7 +122,7 @@ def test_periodic_table_partition_and_gather_world_size_8_gloo():
 
 def test_shard_time_model_reproduces_the_recorded_shards():
     """A CONSISTENCY check, not a validation: the constants of sweep.shard_time_ms are a least-squares fit to the 15 recorded
-    shards of the emulated 1-, 2-, 4-, 8-rank sweeps (profiles/fit_shard_model.py, profiles/r04_periodic_table_predicted_scaling_<mode>.json),
+    shards of the emulated 1-, 2-, 4-, 8-rank sweeps (profiles/fit_shard_model.py, profiles/<newest round>_periodic_table_predicted_scaling_<mode>.json),
     and this test checks that the constants in the source ARE that fit (predictions equal to 5 %) and that the fit describes the shards it
     was made from (15 %).  It is in-sample: the three features are nearly collinear, and fitted on the 1-, 2- and 4-rank shards alone the
     model misses the 8-rank shards by up to 21 % (exact kernels) / 70 % (tolerance modes) -- it interpolates the recorded partitions, it
@@ -163,4 +163,4 @@ def test_shard_time_model_reproduces_the_recorded_shards():
     # the prediction itself: an eighth of the table per GPU
     with open(fitm.path_of("tolerance")) as f:
         tol = json.load(f)
-    assert tol["predicted_seconds"]["8"] <= 7.0            # (reads the recorded file: the emulation of round 4, a PREDICTION from one GPU)
+    assert tol["predicted_seconds"]["8"] <= 7.0            # (reads the recorded file: the newest emulation, a PREDICTION from one GPU)
