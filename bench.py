@@ -424,7 +424,8 @@ def kernel_figures(tot, levels, N, atoms, workload=None):
     # fewer trials than the solver has room for, so the average issued trials per round decide here, not the capacity
     per_round = tot["sweeps_issued"] / max(tot["rounds"], 1) if tot.get("rounds") else tot["trials_per_round"]
     piped = forced == "pipe" or (forced != "fused" and min(tot["trials_per_round"], per_round) // 64 <= 768)
-    sname = "k_scan_levels" if tot.get("scan") else ("k_levels_persist" if tot.get("persist") else ("k_sweep_pipe" if piped else "k_sweep"))
+    queued = "LEVELS_NOQUEUE" not in os.environ.get("DFTA_DEBUG", "")      # the fused sweeps of a batch are launched longest block first (k_sweep_queue)
+    sname = "k_scan_levels" if tot.get("scan") else ("k_levels_persist" if tot.get("persist") else ("k_sweep_pipe" if piped else ("k_sweep_queue" if queued else "k_sweep")))
     t_sw = tot["ms_sweep_kernels"] * 1e-3
     # host rounds: one launch per round; the device-side search: ONE launch per SCF step (sweeps of every round, walk, match, normalisation)
     launches = max(tot["steps"], 1) if tot.get("persist") else max(tot["rounds"], 1)
@@ -441,7 +442,9 @@ def kernel_figures(tot, levels, N, atoms, workload=None):
                                   if tot.get("scan") else
                                   "fp64 VALU issue of the integrator wave (one block of 64 trials per CU; sequential three-term recurrence), "
                                   "x the ~7 dependent rounds of a level's three bisections inside the one launch" if tot.get("persist") else
-                                  "fp64 VALU issue of the integrator wave (one block of 64 trials per CU; sequential three-term recurrence)"),
+                                  "fp64 VALU issue of the integrator wave (one block of 64 trials per CU; sequential three-term recurrence)" if piped else
+                                  "fp64 VALU issue of the SIMDs (one wave per block of 64 trials, two waves per SIMD, 24 instructions per point; a wave "
+                                  "runs as long as its longest lane -- the lane-based valu_issue figure undercounts the busy time)"),
              "valu_issue": {"wave_instr_per_block_point": SWEEP_VALU_PER_BLOCK_POINT, "block_points_per_s": block_points / t_sw if t_sw else None,
                             "ceiling_wave_instr_per_s": VALU_WAVE_INSTR_PER_S,
                             "frac": SWEEP_VALU_PER_BLOCK_POINT * block_points / t_sw / VALU_WAVE_INSTR_PER_S if t_sw else None,
