@@ -407,7 +407,8 @@ def run_workload(D, ctx, grid, levels, atoms, lsda, steps, warmup, tree_depth, b
     tot["levels_layout"] = {0: "one block of 2^depth trials per job", 1: "latency mode (slots re-allotted every round)",
                             2: "packed rounds (depth chosen per round, floor = tree depth)", 3: "latency mode over the live jobs",
                             4: "scan sweeps (tolerance mode: one workgroup per level, no rounds)",
-                            5: "device-side exact search (one persistent kernel, every level at its own pace)"}.get(int(st.levels_layout), "?")
+                            5: "device-side exact search (one persistent kernel, every level at its own pace)",
+                            6: "own-pace batch search (one workgroup per level in one launch; opt-in)"}.get(int(st.levels_layout), "?")
     tot["scan"] = int(st.levels_layout) == 4
     tot["persist"] = int(st.levels_layout) == 5
     tot["poisson_G"] = scf.poisson_info()[0]
