@@ -464,9 +464,13 @@ static int poisson_create_impl(dfta_ctx* ctx, const dfta_grid* g, int batch, int
                 int lc = 0;
                 while ((64 << lc) < L.n - 1) ++lc;                 // n - 1 == 64 * 2^lc
                 if (lc < 1 || lc > 4) { ok = false; break; }
+                // exact mode: the 129-node level is laid out 4 nodes per lane on 32 lanes (rows of 64 all the same: its last node sits behind
+                // the four rows, cs_idx) so that its visits run as the fused three-sweep pass too (gs_lds3 needs >= 4 nodes per lane)
+                if (lc == 1 && !p->tol && !dfta_knob("POISSON_NOFUSE3") && !dfta_knob("POISSON_NOFUSE3_WAVE") && !dfta_knob("POISSON_NOHALF129")) lc = 2;
+                const int span = std::max(L.n, (64 << lc) + 1);    // the last node's slot: (2^lc) << 6
                 D.cs_lc[l] = lc;
-                D.cs_phi[l] = at + kStagePad; at += kStagePad + L.n + 8;
-                D.cs_src[l] = at + kStagePad; at += kStagePad + L.n + 8;
+                D.cs_phi[l] = at + kStagePad; at += kStagePad + span + 8;
+                D.cs_src[l] = at + kStagePad; at += kStagePad + span + 8;
             } else if (L.seq) {
                 D.cs_lc[l] = -1;
                 D.cs_phi[l] = at; at += L.n + 1;
@@ -478,7 +482,7 @@ static int poisson_create_impl(dfta_ctx* ctx, const dfta_grid* g, int batch, int
     // exact mode: the six coarsest levels of the coarse section in registers (poisson_kernels.inc: xw_section), entered from the 129-node level
     D.xw_top = -1;
     if (!p->tol && D.cs_top > 0 && D.levels >= 8 && D.levels - 6 > D.cs_top && D.lv[D.levels - 6].n == 65 && D.lv[D.levels - 1].n == 3 &&
-        D.cs_lc[D.levels - 6] < 0 && D.cs_lc[D.levels - 7] == 1 && !dfta_knob("POISSON_NOXW"))
+        D.cs_lc[D.levels - 6] < 0 && (D.cs_lc[D.levels - 7] == 1 || D.cs_lc[D.levels - 7] == 2) && D.lv[D.levels - 7].n == 129 && !dfta_knob("POISSON_NOXW"))
         D.xw_top = D.levels - 6;
     // tolerance mode: the sub-cycle from the 8193-node level down in registers (poisson_kernels.inc: coarse_resident_cycle) -- 32 nodes per
     // thread on its first level, the levels down to 257 nodes halve the chunk, the 129-node level and below run in one wave.  Resident
@@ -578,7 +582,7 @@ void dfta_poisson_destroy(dfta_poisson* p)
         unsigned long long hr[2 * 8 * 8];
         if (p->resident && (p->tol ? hipMemcpyFromSymbol(hr, HIP_SYMBOL(mg_tol::g_rprof), sizeof(hr)) : hipMemcpyFromSymbol(hr, HIP_SYMBOL(mg_exact::g_rprof), sizeof(hr))) == hipSuccess) {
             const char* mn[8] = {"pass    ", "publish ", "exchange", "commit  ", "restrict", "prolong ", "handover", "redo    "};
-            const char* cn[8] = {"passive ", "-       ", "iterate ", "coarsesc", "restrict", "prolong ", "handover", "-       "};
+            const char* cn[8] = {"passive ", "cs sweep", "iterate ", "coarsesc", "restrict", "prolong ", "handover", "cs r/p/xw/enter/leave"};
             for (int role = 0; role < 2; ++role)
                 for (int c = 0; c < 8; ++c) {
                     unsigned long long t = 0;
