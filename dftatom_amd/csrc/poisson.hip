@@ -439,6 +439,7 @@ static int poisson_create_impl(dfta_ctx* ctx, const dfta_grid* g, int batch, int
         else {
             L.seq = 0; L.logT = std::min(lg, l < D.kcoop ? 8 + logG : 8); L.logC = lg - L.logT; L.soff = -1;
             if (!dfta_knob("POISSON_NOSTAGE")) {
+                // (round 6: 2 049 nodes tried -- level 6 inside the coarse section, 32 nodes per lane: the solve got 0.5 ms slower)
                 if (l >= D.kcoop && n <= kWaveMaxN && n >= 129 && !dfta_knob("POISSON_NOSTAGE_WAVE")) L.stage = 3;
                 else if (l >= D.kcoop && L.logT == 8 && L.logC <= kStageMaxLogC) L.stage = 1;
                 else if (l < D.kcoop && D.G > 1 && L.logT == 8 + logG && L.logC >= 2 && L.logC <= kStageMaxLogC &&
