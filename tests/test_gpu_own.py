@@ -121,3 +121,14 @@ def test_rn_lsda_batch_at_2_20_nodes(ctx):
         g.close()
     assert all(r["layout"] == 6 for r in dev), [r["layout"] for r in dev]
     _assert_same(dev, host, "8 x Rn LSDA @ 2^20+1")
+
+
+def test_longest_first_launch_on_static_blocks_keeps_the_bits(ctx, grid14):
+    """the default batch path: Z = 75..86 (170 levels, two 64-trial blocks each: 340 blocks on 256 compute units, the pipelined kernel) with
+    the blocks of a round launched longest first (k_expand's queue) against the plain launch in array order (LEVELS_NOQUEUE): same bits --
+    the order in which blocks start is invisible in every result"""
+    Z = list(range(75, 87))
+    q = _run(ctx, grid14, Z, False, 6, "")
+    plain = _run(ctx, grid14, Z, False, 6, "LEVELS_NOQUEUE")
+    assert all(r["layout"] == 0 for r in q) and all(r["layout"] == 0 for r in plain), ([r["layout"] for r in q], [r["layout"] for r in plain])
+    _assert_same(q, plain, "queued vs plain launch")
