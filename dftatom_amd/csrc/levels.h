@@ -141,6 +141,10 @@ struct LevelSolver {
     int* d_scan_live = nullptr;                   // live jobs of a grouped scan search
     unsigned long long* d_scan_xch = nullptr;     // 32 words per job: the members' results of a round, two parities
     int scan_group = 1;             // workgroups per level of the last scan search (1, 3, 7 or 15)
+    int scan_predict = 0;           // $DFTA_DEBUG LEVELS_SCAN_PREDICT (measurements): the scan's first bisection predicts the exact search's first spines
+    double scan_predict_factor = 1.5, scan_predict_shift = 0.0;
+    Job* d_jobs_scan = nullptr;     // ... on a copy of the records
+    unsigned long long* d_counters_scan = nullptr;
     int scan_fallbacks = 0;         // solves the scan handed back to the exact kernels (a trial it could not decide)
     // Device-side exact search (persist.inc): up to 64 live levels of an un-chained solve on the logarithmic grid run their three bisections in ONE
     // persistent kernel, every level at its own pace; the host rounds of run() remain for everything else and as the fallback

@@ -582,6 +582,25 @@ __global__ void k_mask_rest(const dfta::Job* __restrict__ jobs, int njobs, int* 
     else jstart_keep[k] = jstart[k];
 }
 
+// TopEnergy of every live level as the scan search found it (scan.hip, on a copy of the records) becomes the centre of the bracket from
+// which plan_round lays the first spine of the exact search's FIRST bisection -- speculation only.  Half width = `factor` (1.5) x the
+// scan's asserted distance from the exact path, 6e-11 |T| + 6e-10 Ha (tests/test_gpu_scan.py), less the 1e-10 |T| that plan_round adds
+// for brackets from SCF histories.  Measured (Rn, steps 5 - 24): factor 1.5 / 1 / 3 alike, 0.5 and 0.25 lose rounds to missed spines.
+__global__ void k_inject_scan_top(dfta::Job* __restrict__ jobs, const dfta::Job* __restrict__ scanned, const int* __restrict__ live, int nlive,
+                                  const unsigned long long* __restrict__ scan_counters, double factor, double shift)
+{
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nlive || scan_counters[3] != 0ull) return;          // a sweep the scan could not decide / a lost member: no prediction
+    const int k = live[q];
+    const double T = scanned[k].top * (1.0 + shift);             // (shift: tests -- a recklessly wrong prediction changes rounds, never results)
+    if (!(fabs(T) < 1e300)) return;
+    const double w = factor * (6e-11 * fabs(T) + 6e-10) - 1e-10 * fabs(T);
+    jobs[k].hist_c[0] = T;
+    jobs[k].hist_w[0] = w;
+    jobs[k].hist_d[0] = 0.0;
+    if (jobs[k].hist_ok < 2) jobs[k].hist_ok = 2;
+}
+
 // frozen jobs are skipped by the match / normalise kernels: their cut-off index is replaced by -1
 __global__ void k_mask_frozen(const dfta::Job* __restrict__ jobs, int njobs, int* __restrict__ jstart)
 {
@@ -604,6 +623,9 @@ void LevelSolver::release()
     dfta_scan_tables_destroy(&scan_tb);
     dfta_persist_destroy(&pb);
     persist_ok = false;
+    if (d_jobs_scan) (void)hipFree(d_jobs_scan);
+    if (d_counters_scan) (void)hipFree(d_counters_scan);
+    d_jobs_scan = nullptr; d_counters_scan = nullptr;
     if (d_scan_live) (void)hipFree(d_scan_live);
     if (d_scan_xch) (void)hipFree(d_scan_xch);
     d_scan_live = nullptr; d_scan_xch = nullptr;
@@ -819,7 +841,17 @@ int LevelSolver::setup(dfta_ctx* c, const dfta_grid* grid, int mode_, int tree_d
     ALLOC(d_jus, double, njobs); ALLOC(d_jus1, double, njobs); ALLOC(d_jmp, int, njobs);
     ALLOC(d_slot_min, double, nslots);
     ALLOC(d_bounds, double2, (size_t)nslots * dfta_bounds_stride(g));
-    if (sweep_mode == DFTA_SWEEPS_TOLERANCE && dfta_scan_supported(g)) {      // scan.hip: interleaved tables + per-lane {min, max}
+    // Round 6: the scan search (scan.hip: 40 - 60 us per sweep instead of 4 ms) runs the FIRST bisection of every live level ahead of the
+    // device-side exact search and hands its end point to plan_round as the bracket of the exact search's first spine -- speculation only,
+    // as the history bracket it replaces: the exact sweeps at the reference's midpoints take every decision.  One atom / a few atoms
+    // (<= 64 jobs: the solver whose every run is the device-side search); $DFTA_DEBUG LEVELS_NOSCANPREDICT: off.
+    scan_predict = (persist_ok && dynamic && sweep_mode != DFTA_SWEEPS_TOLERANCE && dfta_scan_supported(g) && dfta_knob("LEVELS_NOSCANPREDICT") == nullptr &&
+                    use_prediction) ? 1 : 0;
+    scan_predict_factor = 1.5; scan_predict_shift = 0.0;
+    if (const char* e = dfta_knob("LEVELS_SCAN_PREDICT_W")) scan_predict_factor = atof(e);
+    if (const char* e = dfta_knob("LEVELS_SCAN_PREDICT_SHIFT")) scan_predict_shift = atof(e);
+    if (scan_predict) { ALLOC(d_jobs_scan, Job, njobs); ALLOC(d_counters_scan, unsigned long long, 4); }
+    if ((sweep_mode == DFTA_SWEEPS_TOLERANCE || scan_predict) && dfta_scan_supported(g)) {      // scan.hip: interleaved tables + per-lane {min, max}
         const int trc = dfta_scan_tables_create(ctx, g, nslots, &scan_tb);
         if (trc) return trc;
         ALLOC(d_scan_live, int, njobs);
@@ -1069,6 +1101,23 @@ int LevelSolver::run(const double* dV, const double* job_bottom, int run_mode, d
     bool persisted = false;
     int persist_rounds = 0;
     float ms_persist = 0;
+    if (!scan && use_persist && scan_predict && scan_tb.tabv != nullptr) {
+        // the scan search of the first bisection as a predictor of the exact search's first spines (speculation only)
+        int K = 1;
+        for (int cand : {15, 7, 3}) if ((long)plive.size() * cand <= ctx->num_cu) { K = cand; break; }
+        if (K > 1) {
+            rc = dfta_launch_scan_build_tab(ctx, g, scan_tb, dV, d_slot_v, d_slot_l);
+            if (rc) return rc;
+            DFTA_HIP(ctx, hipMemcpyAsync(d_jobs_scan, d_jobs, sizeof(Job) * njobs, hipMemcpyDeviceToDevice, st));
+            DFTA_HIP(ctx, hipMemcpyAsync(d_scan_live, plive.data(), sizeof(int) * plive.size(), hipMemcpyHostToDevice, st));
+            DFTA_HIP(ctx, hipMemsetAsync(d_counters_scan, 0, sizeof(unsigned long long) * 4, st));
+            const int prc = dfta_launch_scan_levels_group(ctx, g, d_jobs_scan, d_scan_live, (int)plive.size(), K, scan_tb, fixed_point, d_counters_scan, d_scan_xch, -1, nullptr, nullptr);
+            if (prc == DFTA_OK) {
+                hipLaunchKernelGGL(k_inject_scan_top, dim3(((int)plive.size() + 63) / 64), dim3(64), 0, st, d_jobs, d_jobs_scan, d_scan_live, (int)plive.size(), d_counters_scan, scan_predict_factor, scan_predict_shift);
+                DFTA_CHECK_LAUNCH(ctx);
+            } else if (prc != DFTA_ERR_NOT_CONVERGED) return prc;
+        }
+    }
     if (!scan && use_persist) {
         dfta_range r_p("dfta: level search on the device (persistent kernel: sweeps, walk, match, normalisation)");
         DFTA_HIP(ctx, hipMemsetAsync(d_jstart_keep, 0xff, sizeof(int) * njobs, st));      // -1: frozen (the live levels write their cut-off index)

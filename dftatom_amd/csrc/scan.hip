@@ -1150,6 +1150,9 @@ __global__ void __launch_bounds__(kT) k_scan_levels_group(ScanGrid G0, const dou
             // end of a phase?
             if (ph == 1 && !(hi - lo > kErr)) {
                 top = hi; lo = bottom0; ph = 2;
+                // ma.mode < 0: the search is a PREDICTOR for the exact kernels' first spines (levels.hip, LEVELS_SCAN_PREDICT): it ends with the
+                // first bisection -- every member reaches this point in the same round -- and leaves TopEnergy in the record
+                if (ma.mode < 0) { if (m == 0 && threadIdx.x == 0) J->top = top; return; }
                 if (nodes == 0) {                                          // "count < 0" never holds: arithmetic (levels.hip)
                     while (hi - lo > kErr) { hi = (hi + lo) / 2; ++n_count; ++len2; }
                 }

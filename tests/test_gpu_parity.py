@@ -408,7 +408,11 @@ def test_predictions_never_change_results(ctx, grid14):
                 {"DFTA_LEVELS_NOISE": "1e-9:1e-9:1e-9", "DFTA_LEVELS_SECANT_KAPPA": "0"},
                 {"DFTA_LEVELS_STATIC": "1"},
                 # history brackets: the two-step rule only / an extrapolation trusted to 0.1 % of the last movement (spines that miss)
-                {"DFTA_LEVELS_NOEXTRAP": "1"}, {"DFTA_LEVELS_EXTRAP": "0.001:0"}):
+                {"DFTA_LEVELS_NOEXTRAP": "1"}, {"DFTA_LEVELS_EXTRAP": "0.001:0"},
+                # round 6: the scan search's first bisection as the predictor of the exact search's first spines -- off; trusted to a
+                # hundredth of its asserted band (spines that miss); and recklessly WRONG (every end point shifted by 1e-3 of itself)
+                {"DFTA_LEVELS_NOSCANPREDICT": "1"}, {"DFTA_LEVELS_SCAN_PREDICT_W": "0.01"}, {"DFTA_LEVELS_SCAN_PREDICT_SHIFT": "1e-3"},
+                {"DFTA_LEVELS_SCAN_PREDICT_SHIFT": "-3e-6", "DFTA_LEVELS_SCAN_PREDICT_W": "0.5"}):
         c = run(False, **env)
         for k, (x, y) in enumerate(zip(a, c)):
             assert x[0] == y[0], (env, k)

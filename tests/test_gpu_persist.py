@@ -120,10 +120,11 @@ def test_device_search_equals_host_rounds_small_grid(ctx, grid14, Z, lsda):
 
 
 @pytest.mark.parametrize("knobs", ["LEVELS_PERSIST_NOCAND", "LEVELS_PERSIST_EQUAL", "LEVELS_PERSIST_BLOCKS=64", "LEVELS_PERSIST_BLOCKS=37,LEVELS_PERSIST_EQUAL",
-                                   "LEVELS_NOPREDICT", "LEVELS_PERSIST_PLAIN_LAUNCH", "LEVELS_PERSIST_NOBUDGET"])
+                                   "LEVELS_NOPREDICT", "LEVELS_PERSIST_PLAIN_LAUNCH", "LEVELS_PERSIST_NOBUDGET", "LEVELS_NOSCANPREDICT",
+                                   "LEVELS_SCAN_PREDICT_SHIFT=1e-4"])
 def test_layout_knobs_of_the_device_search_keep_the_bits(ctx, grid14, knobs):
     """no speculative match solves, equal shares, a quarter of the machine, an odd number of workgroups, no predictions at all, an
-    ordinary launch: rounds change, results do not"""
+    ordinary launch, no candidate budget, no scan predictor of the first spines, a wrong one: rounds change, results do not"""
     ref = _run(ctx, grid14, [36], False, 5, "")
     alt = _run(ctx, grid14, [36], False, 5, knobs)
     assert all(r["layout"] == 5 for r in alt)
