@@ -592,9 +592,11 @@ __global__ void k_inject_scan_top(dfta::Job* __restrict__ jobs, const dfta::Job*
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= nlive || scan_counters[3] != 0ull) return;          // a sweep the scan could not decide / a lost member: no prediction
     const int k = live[q];
+    if (jobs[k].phase != PH_TOP || jobs[k].frozen) return;
     const double T = scanned[k].top * (1.0 + shift);             // (shift: tests -- a recklessly wrong prediction changes rounds, never results)
     if (!(fabs(T) < 1e300)) return;
-    const double w = factor * (6e-11 * fabs(T) + 6e-10) - 1e-10 * fabs(T);
+    // (scanned.bottom: the half width the scan itself left around T -- 0 from the group search, which bisects to the end)
+    const double w = factor * (6e-11 * fabs(T) + 6e-10) + scanned[k].bottom - 1e-10 * fabs(T);
     jobs[k].hist_c[0] = T;
     jobs[k].hist_w[0] = w;
     jobs[k].hist_d[0] = 0.0;
@@ -845,8 +847,11 @@ int LevelSolver::setup(dfta_ctx* c, const dfta_grid* grid, int mode_, int tree_d
     // device-side exact search and hands its end point to plan_round as the bracket of the exact search's first spine -- speculation only,
     // as the history bracket it replaces: the exact sweeps at the reference's midpoints take every decision.  One atom / a few atoms
     // (<= 64 jobs: the solver whose every run is the device-side search); $DFTA_DEBUG LEVELS_NOSCANPREDICT: off.
-    scan_predict = (persist_ok && dynamic && sweep_mode != DFTA_SWEEPS_TOLERANCE && dfta_scan_supported(g) && dfta_knob("LEVELS_NOSCANPREDICT") == nullptr &&
-                    use_prediction) ? 1 : 0;
+    // Batches (host rounds): the same with one workgroup per level (k_scan_levels, which stops at a quarter of the band); the scan tables of
+    // all the batch's slots must be affordable (<= 2 GB).
+    scan_predict = (sweep_mode != DFTA_SWEEPS_TOLERANCE && dfta_scan_supported(g) && dfta_knob("LEVELS_NOSCANPREDICT") == nullptr && use_prediction &&
+                    mode == DFTA_LEVELS_BATCHED && tree_depth <= 0 &&
+                    ((persist_ok && dynamic) || (!dynamic && (size_t)nslots * N * sizeof(double) <= ((size_t)2 << 30) && dfta_knob("LEVELS_NOSCANPREDICT_BATCH") == nullptr))) ? 1 : 0;
     scan_predict_factor = 1.5; scan_predict_shift = 0.0;
     if (const char* e = dfta_knob("LEVELS_SCAN_PREDICT_W")) scan_predict_factor = atof(e);
     if (const char* e = dfta_knob("LEVELS_SCAN_PREDICT_SHIFT")) scan_predict_shift = atof(e);
@@ -1101,17 +1106,20 @@ int LevelSolver::run(const double* dV, const double* job_bottom, int run_mode, d
     bool persisted = false;
     int persist_rounds = 0;
     float ms_persist = 0;
-    if (!scan && use_persist && scan_predict && scan_tb.tabv != nullptr) {
-        // the scan search of the first bisection as a predictor of the exact search's first spines (speculation only)
+    if (!scan && !chained && scan_predict && scan_tb.tabv != nullptr && !plive.empty() && debug_rounds == 0) {
+        // the scan search of the first bisection as a predictor of the exact search's first spines (speculation only): a group of workgroups per
+        // level ahead of the device-side search, one workgroup per level ahead of the host rounds of a batch
         int K = 1;
-        for (int cand : {15, 7, 3}) if ((long)plive.size() * cand <= ctx->num_cu) { K = cand; break; }
-        if (K > 1) {
+        if (use_persist) for (int cand : {15, 7, 3}) if ((long)plive.size() * cand <= ctx->num_cu) { K = cand; break; }
+        if (K > 1 || !use_persist) {
             rc = dfta_launch_scan_build_tab(ctx, g, scan_tb, dV, d_slot_v, d_slot_l);
             if (rc) return rc;
             DFTA_HIP(ctx, hipMemcpyAsync(d_jobs_scan, d_jobs, sizeof(Job) * njobs, hipMemcpyDeviceToDevice, st));
             DFTA_HIP(ctx, hipMemcpyAsync(d_scan_live, plive.data(), sizeof(int) * plive.size(), hipMemcpyHostToDevice, st));
             DFTA_HIP(ctx, hipMemsetAsync(d_counters_scan, 0, sizeof(unsigned long long) * 4, st));
-            const int prc = dfta_launch_scan_levels_group(ctx, g, d_jobs_scan, d_scan_live, (int)plive.size(), K, scan_tb, fixed_point, d_counters_scan, d_scan_xch, -1, nullptr, nullptr);
+            const int prc = use_persist
+                ? dfta_launch_scan_levels_group(ctx, g, d_jobs_scan, d_scan_live, (int)plive.size(), K, scan_tb, fixed_point, d_counters_scan, d_scan_xch, -1, nullptr, nullptr)
+                : dfta_launch_scan_levels(ctx, g, d_jobs_scan, d_chain_off_b, njobs, 0, scan_tb, fixed_point, d_counters_scan, -1, nullptr, nullptr);
             if (prc == DFTA_OK) {
                 hipLaunchKernelGGL(k_inject_scan_top, dim3(((int)plive.size() + 63) / 64), dim3(64), 0, st, d_jobs, d_jobs_scan, d_scan_live, (int)plive.size(), d_counters_scan, scan_predict_factor, scan_predict_shift);
                 DFTA_CHECK_LAUNCH(ctx);

@@ -174,7 +174,10 @@ def test_packed_rounds_take_the_same_decisions(ctx, lsda):
     # round 6: the blocks of a round are launched longest first through a queue (numerov.hip:k_sweep_queue, k_sweep_pipe with the same
     # indirection); LEVELS_NOQUEUE = the plain launch in array order; DSMALL=20 forces the large budget: ~1 800 blocks, the fused kernel
     for knobs in ("", "LEVELS_PACK_DMIN=1", "LEVELS_PACK_DMIN=6", "LEVELS_PACK_DSMALL=20,LEVELS_PACK_LANES=8192",
-                  "LEVELS_PACK_LANES_SMALL=65536", "LEVELS_NOQUEUE", "LEVELS_PACK_DSMALL=20", "LEVELS_PACK_DSMALL=20,LEVELS_NOQUEUE"):
+                  "LEVELS_PACK_LANES_SMALL=65536", "LEVELS_NOQUEUE", "LEVELS_PACK_DSMALL=20", "LEVELS_PACK_DSMALL=20,LEVELS_NOQUEUE",
+                  # round 6: the scan search's first bisection ahead of the rounds predicts the first spines (speculation only): off, and
+                  # recklessly wrong (every predicted end point shifted by 1e-3 of itself; trusted to 1 % of its band)
+                  "LEVELS_NOSCANPREDICT_BATCH", "LEVELS_SCAN_PREDICT_SHIFT=1e-3", "LEVELS_SCAN_PREDICT_W=0.01"):
         got, pot, issued, info = _with_debug(knobs, run)
         assert info != info_static, knobs                          # the packed layout really ran
         for k, (x, y) in enumerate(zip(ref, got)):

@@ -132,3 +132,9 @@ def test_longest_first_launch_on_static_blocks_keeps_the_bits(ctx, grid14):
     plain = _run(ctx, grid14, Z, False, 6, "LEVELS_NOQUEUE")
     assert all(r["layout"] == 0 for r in q) and all(r["layout"] == 0 for r in plain), ([r["layout"] for r in q], [r["layout"] for r in plain])
     _assert_same(q, plain, "queued vs plain launch")
+    # ... and the scan predictor of the first spines (one workgroup per level ahead of the rounds): off / shifted -- fewer or more rounds, same bits
+    nopred = _run(ctx, grid14, Z, False, 6, "LEVELS_NOSCANPREDICT_BATCH")
+    wrong = _run(ctx, grid14, Z, False, 6, "LEVELS_SCAN_PREDICT_SHIFT=-1e-4")
+    _assert_same(q, nopred, "scan predictor off")
+    _assert_same(q, wrong, "scan predictor shifted")
+    assert sum(r["rounds"] for r in q) < sum(r["rounds"] for r in nopred)
