@@ -888,6 +888,7 @@ int LevelSolver::run(const double* dV, const double* job_bottom, int run_mode, d
     const int run_chains = chained ? nchains_chained : njobs;
     std::vector<Job> jobs = h_jobs_template;
     int nfrozen = 0;
+    bool scan_wanted = false;          // a live level whose history bracket is still wide (or missing): the batch predictor runs
     // this run's layout: the solver's own, or -- a batch most of whose atoms have finished -- latency mode over the live jobs
     std::vector<int> live;
     if (frozen && h_last.size() == jobs.size())
@@ -972,6 +973,10 @@ int LevelSolver::run(const double* dV, const double* job_bottom, int run_mode, d
             j.hist_ok = std::min(h.hist_ok + 1, 3);
         } else {
             j.hist_ok = 0;
+        }
+        {   // does this level still want the scan predictor of its first spine?  (scan.hip:k_scan_levels: the same rule, per level)
+            const double T = j.hist_c[0], band = 6e-11 * fabs(T) + 6e-10;
+            if (!(j.hist_ok >= 2 && j.hist_d[0] >= 0 && j.hist_w[0] + 1e-10 * fabs(T) + 64e-12 <= 4096. * band)) scan_wanted = true;
         }
         j.miss = 0;
         j.capz = 0;
@@ -1106,7 +1111,7 @@ int LevelSolver::run(const double* dV, const double* job_bottom, int run_mode, d
     bool persisted = false;
     int persist_rounds = 0;
     float ms_persist = 0;
-    if (!scan && !chained && scan_predict && scan_tb.tabv != nullptr && !plive.empty() && debug_rounds == 0) {
+    if (!scan && !chained && scan_predict && scan_tb.tabv != nullptr && !plive.empty() && debug_rounds == 0 && (use_persist || scan_wanted)) {
         // the scan search of the first bisection as a predictor of the exact search's first spines (speculation only): a group of workgroups per
         // level ahead of the device-side search, one workgroup per level ahead of the host rounds of a batch
         int K = 1;

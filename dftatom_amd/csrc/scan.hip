@@ -878,6 +878,14 @@ __global__ void __launch_bounds__(kT) k_scan_levels(ScanGrid G0, const double* _
         // (plan_round's: hist_c +- (hist_w + 1e-10 |T| + 64e-12)) and bisects what is left -- ~20 sweeps instead of ~40 at steady state.
         if (ma.mode < 0 && J->hist_ok >= 2 && J->hist_d[0] >= 0) {
             const double T = J->hist_c[0], mh = J->hist_w[0] + 1e-10 * fabs(T) + 64 * kErr;
+            // ... and once that bracket is within 2^12 x the scan's own band (twelve decisions) the prediction is not worth its sweeps: a scan
+            // sweep occupies a compute unit for 50 us -- two exact trial lanes' worth of machine time -- and a decision moved from a tree to
+            // the spine saves about two lanes.  The level keeps its history bracket (Z = 1..86 to its end: the predictor gains 10 - 25 ms per
+            // step up to step 15, breaks even at 16 - 24 and lost 3 - 8 ms per step from there on before this rule).
+            if (mh <= 4096. * (6e-11 * fabs(T) + 6e-10)) {
+                if (threadIdx.x == 0) J->top = NAN;
+                continue;
+            }
             for (int side = 0; side < 2; ++side) {
                 const double E = side ? T + mh : T - mh;
                 if (!(E > boe && E < toe)) continue;
