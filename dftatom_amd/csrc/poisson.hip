@@ -135,6 +135,17 @@ namespace mg_exact {
 #undef DFTA_MG_KWARM
 #undef DFTA_MG_KWARM3
 }  // namespace mg_exact
+// The resident group's second configuration (exact mode): 16 members of 256 lanes + the coarse workgroup per atom, level 0 and the other
+// shared levels taking turns in the members' LDS -- up to 15 atoms per launch (poisson_kernels.inc: DFTA_MG_RES16)
+namespace mg_exact16 {
+#define DFTA_MG_KWARM DFTA_KWARM
+#define DFTA_MG_KWARM3 112
+#define DFTA_MG_RES16 1
+#include "poisson_kernels.inc"
+#undef DFTA_MG_RES16
+#undef DFTA_MG_KWARM
+#undef DFTA_MG_KWARM3
+}  // namespace mg_exact16
 // Tolerance mode (opt-in, DFTA_POISSON_TOLERANCE): the same kernels with 32-node warm-ups.  A lane's start value then carries
 // 0.52^32 ~ 1e-9 of the change its start node undergoes in that sweep -- a perturbation of the ITERATION, not of its fixed point:
 // the cycle still converges to the solution of the same discrete equations, to the same round-off floor (tests: U within
@@ -177,12 +188,15 @@ struct dfta_poisson {
     bool adaptive = false;          // DFTA_POISSON_ADAPTIVE: tolerance mode + the V-cycles stop at the round-off floor
     bool resident = false;          // k_poisson_solve_res: kResWG workgroups per atom, the shared levels live in the members' LDS
     double* d_res_slots = nullptr;  // per atom: res_slot_doubles() exchange slots (sentinel-filled before every launch)
+    bool res16 = false;             // resident, second configuration (mg_exact16): 17 workgroups per atom, level 0 spilled to d_res_spill in turns
+    double* d_res_spill = nullptr;  // res16: per member the two LDS images of level 0
+    int res_wg() const { return res16 ? mg_exact16::kResWG : kResWG; }
     bool grouped() const { return D.G > 1 || resident; }
 };
 
 static int poisson_create_impl(dfta_ctx* ctx, const dfta_grid* g, int batch, int force_logG, int mode, dfta_poisson** out);
 #define K_SOLVE(p) ((p)->tol ? mg_tol::k_poisson_solve : mg_exact::k_poisson_solve)
-#define K_SOLVE_RES(p) ((p)->tol ? mg_tol::k_poisson_solve_res : mg_exact::k_poisson_solve_res)
+#define K_SOLVE_RES(p) ((p)->res16 ? mg_exact16::k_poisson_solve_res : ((p)->tol ? mg_tol::k_poisson_solve_res : mg_exact::k_poisson_solve_res))
 #define K_UNIT(p) ((p)->tol ? mg_tol::k_unit : mg_exact::k_unit)
 
 static long host_addr(const Lvl& L, int i)
@@ -215,14 +229,15 @@ int dfta_poisson_solve_launch(dfta_poisson* p, const int* dZ, const double* dDen
         const double *a_r = p->g->d_rsrc, *a_psrc = p->g->d_psrc;
         int fault = p->fault, src_all = p->g->uniform;
         if (p->plain_launch) {
-            hipLaunchKernelGGL(K_SOLVE_RES(p), dim3(p->batch * kResWG), dim3(kThreads), 0, ctx->stream, a0, p->d_phi0, p->d_phi1, p->d_src, dZ,
-                               dDensity, a_r, a_psrc, dU, dVcycles, dErr, p->d_total_vcycles, p->d_group_ctr, p->d_res_slots, dSkip, fault, src_all);
+            hipLaunchKernelGGL(K_SOLVE_RES(p), dim3(p->batch * p->res_wg()), dim3(kThreads), 0, ctx->stream, a0, p->d_phi0, p->d_phi1, p->d_src, dZ,
+                               dDensity, a_r, a_psrc, dU, dVcycles, dErr, p->d_total_vcycles, p->d_group_ctr, p->d_res_slots, dSkip, fault, src_all,
+                               p->d_res_spill);
             DFTA_CHECK_LAUNCH(ctx);
             return DFTA_OK;
         }
         void* args[] = {&a0, &p->d_phi0, &p->d_phi1, &p->d_src, &dZ, &dDensity, &a_r, &a_psrc, &dU, &dVcycles, &dErr, &p->d_total_vcycles,
-                        &p->d_group_ctr, &p->d_res_slots, &dSkip, &fault, &src_all};
-        const hipError_t e = hipLaunchCooperativeKernel(reinterpret_cast<const void*>(K_SOLVE_RES(p)), dim3(p->batch * kResWG), dim3(kThreads),
+                        &p->d_group_ctr, &p->d_res_slots, &dSkip, &fault, &src_all, &p->d_res_spill};
+        const hipError_t e = hipLaunchCooperativeKernel(reinterpret_cast<const void*>(K_SOLVE_RES(p)), dim3(p->batch * p->res_wg()), dim3(kThreads),
                                                         args, 0, ctx->stream);
         if (e != hipSuccess) {
             (void)hipGetLastError();
@@ -275,7 +290,7 @@ static int check_groups(dfta_poisson* p)
     DFTA_HIP(ctx, hipStreamSynchronize(ctx->stream));
     for (unsigned v : h)
         if (v & 0x80000000u) {
-            const int G = p->resident ? kResWG : p->D.G;
+            const int G = p->resident ? p->res_wg() : p->D.G;
             snprintf(ctx->err, sizeof(ctx->err), "poisson: a group of %d workgroups lost a member at a barrier (the %d workgroups of "
                      "the launch were not all resident)", G, p->batch * G);
             return DFTA_ERR_HIP;
@@ -317,7 +332,7 @@ int dfta_poisson_take_vcycles(dfta_poisson* p, unsigned long long* out)   // rea
 int dfta_poisson_group_state(const dfta_poisson* p, int* G, int* degraded, int* aborts)
 {
     if (!p) return DFTA_ERR_INVALID;
-    if (G) *G = p->resident ? kResWG : p->D.G;
+    if (G) *G = p->resident ? p->res_wg() : p->D.G;
     if (degraded) *degraded = p->degraded ? 1 : 0;
     if (aborts) *aborts = p->aborts;
     return DFTA_OK;
@@ -381,7 +396,14 @@ static int poisson_create_impl(dfta_ctx* ctx, const dfta_grid* g, int batch, int
         // 131073-node solve for 5 .. 7 atoms against 46 .. 48 ms with staged groups of 8)
         bool want = batch * kResWG <= ctx->num_cu && force_logG < 0 && !dfta_knob("POISSON_GROUP") && !dfta_knob("POISSON_NOSTAGE");   // (the hand-over needs the first coarse level staged)
         if (const char* e = dfta_knob("POISSON_RES")) want = atoi(e) != 0 && force_logG < 0 && batch * kResWG <= 256 && !dfta_knob("POISSON_NOSTAGE");
-        const int lanes = kResG * kResNT;
+        // 8 .. 15 atoms (exact mode): 17 workgroups per atom, 16 members of 256 lanes whose level 0 takes turns with their other shared
+        // levels in LDS (mg_exact16); POISSON_RES16 = 0 / 1 switches it off / on (1: for any batch of up to 15 atoms)
+        bool want16 = !want && !p->tol && batch * mg_exact16::kResWG <= ctx->num_cu && force_logG < 0 && !dfta_knob("POISSON_GROUP") &&
+                      !dfta_knob("POISSON_NOSTAGE") && !dfta_knob("POISSON_RES");
+        if (const char* e = dfta_knob("POISSON_RES16"))
+            want16 = atoi(e) != 0 && !p->tol && force_logG < 0 && batch * mg_exact16::kResWG <= ctx->num_cu && !dfta_knob("POISSON_NOSTAGE");
+        if (want16) { want = true; p->res16 = true; }
+        const int lanes = kResG * kResNT;          // (the same 4096 lanes in both configurations)
         if (want && (g->N - 1) % lanes == 0) {
             const int C0 = (g->N - 1) / lanes;
             int lc = 0;
@@ -391,9 +413,10 @@ static int poisson_create_impl(dfta_ctx* ctx, const dfta_grid* g, int batch, int
         if (res_kres > 0) {
             int per_cu = 0;
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, K_SOLVE_RES(p), kThreads, 0) != hipSuccess) per_cu = 0;
-            if (batch * kResWG > per_cu * ctx->num_cu) res_kres = 0;
+            if (batch * p->res_wg() > per_cu * ctx->num_cu) res_kres = 0;
         }
         if (res_kres > 0) { logG = 0; p->resident = true; }
+        else p->res16 = false;
     }
     // rocprofiler-sdk (ROCm 7.2) crashes in an exit handler of a process that has made a cooperative launch -- after its
     // output is written, but the profiled command returns 139.  Under the profiler (rocprofv3 exports ROCP_TOOL_LIBRARIES), or
@@ -533,6 +556,11 @@ static int poisson_create_impl(dfta_ctx* ctx, const dfta_grid* g, int batch, int
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->d_group_ctr), sizeof(unsigned) * batch);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->d_group_part), sizeof(double) * (size_t)batch * group_part_doubles(D.G));
     if (e == hipSuccess && p->resident) e = hipMalloc(reinterpret_cast<void**>(&p->d_res_slots), sizeof(double) * (size_t)batch * res_slot_doubles());
+    if (e == hipSuccess && p->res16) {
+        // per member: Phi and source of level 0 as they lie in LDS (C0 rows of H0 + 256 + 1 columns each)
+        const int C0 = 1 << res_logC0, RS0 = (112 + 3 + C0 - 1) / C0 + mg_exact16::kResNT + 1;
+        e = hipMalloc(reinterpret_cast<void**>(&p->d_res_spill), sizeof(double) * (size_t)batch * mg_exact16::kResG * 2 * C0 * RS0);
+    }
     if (e == hipSuccess) e = hipMemsetAsync(p->d_phi0, 0, tot * sizeof(double), ctx->stream);
     if (e == hipSuccess) e = hipMemsetAsync(p->d_phi1, 0, tot * sizeof(double), ctx->stream);
     if (e == hipSuccess) e = hipMemsetAsync(p->d_src, 0, tot * sizeof(double), ctx->stream);
@@ -581,7 +609,7 @@ void dfta_poisson_destroy(dfta_poisson* p)
 #ifdef DFTA_POISSON_RPROF
     {
         unsigned long long hr[2 * 8 * 8];
-        if (p->resident && (p->tol ? hipMemcpyFromSymbol(hr, HIP_SYMBOL(mg_tol::g_rprof), sizeof(hr)) : hipMemcpyFromSymbol(hr, HIP_SYMBOL(mg_exact::g_rprof), sizeof(hr))) == hipSuccess) {
+        if (p->resident && (p->res16 ? hipMemcpyFromSymbol(hr, HIP_SYMBOL(mg_exact16::g_rprof), sizeof(hr)) : (p->tol ? hipMemcpyFromSymbol(hr, HIP_SYMBOL(mg_tol::g_rprof), sizeof(hr)) : hipMemcpyFromSymbol(hr, HIP_SYMBOL(mg_exact::g_rprof), sizeof(hr)))) == hipSuccess) {
             const char* mn[8] = {"pass    ", "publish ", "exchange", "commit  ", "restrict", "prolong ", "handover", "redo    "};
             const char* cn[8] = {"passive ", "cs sweep", "iterate ", "coarsesc", "restrict", "prolong ", "handover", "cs r/p/xw/enter/leave"};
             for (int role = 0; role < 2; ++role)
@@ -592,12 +620,13 @@ void dfta_poisson_destroy(dfta_poisson* p)
                     fprintf(stderr, "  = %llu\n", t);
                 }
             unsigned long long zz[2 * 8 * 8] = {0};
-            if (p->tol) (void)hipMemcpyToSymbol(HIP_SYMBOL(mg_tol::g_rprof), zz, sizeof(zz));
+            if (p->res16) (void)hipMemcpyToSymbol(HIP_SYMBOL(mg_exact16::g_rprof), zz, sizeof(zz));
+            else if (p->tol) (void)hipMemcpyToSymbol(HIP_SYMBOL(mg_tol::g_rprof), zz, sizeof(zz));
             else (void)hipMemcpyToSymbol(HIP_SYMBOL(mg_exact::g_rprof), zz, sizeof(zz));
         }
     }
 #endif
-    void* ptrs[] = {p->d_phi0, p->d_phi1, p->d_src, p->d_cur, p->d_total_vcycles, p->d_desc, p->d_group_ctr, p->d_group_part, p->d_res_slots};
+    void* ptrs[] = {p->d_phi0, p->d_phi1, p->d_src, p->d_cur, p->d_total_vcycles, p->d_desc, p->d_group_ctr, p->d_group_part, p->d_res_slots, p->d_res_spill};
     for (void* q : ptrs) if (q) (void)hipFree(q);
     delete p;
 }

@@ -214,8 +214,8 @@ __global__ void k_scatter_rows(const double* __restrict__ src, const int* __rest
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) d[i] = s[i];
 }
 
-constexpr int kLiveClasses = 5;
-constexpr int kLiveClassAtoms[kLiveClasses] = {7, 16, 32, 64, 128};
+constexpr int kLiveClasses = 6;
+constexpr int kLiveClassAtoms[kLiveClasses] = {7, 15, 16, 32, 64, 128};     // (7 / 15: the resident multigrid's two configurations)
 
 struct dfta_scf {
     dfta_ctx* ctx = nullptr;

@@ -1,6 +1,6 @@
 """GPU suite (-m gpu): the resident multigrid groups (k_poisson_solve_res: 32 member workgroups keep their stretch of every
-shared level in LDS, one fused three-sweep pass and one exchange per visit, a coarse workgroup below) and the opt-in tolerance
-mode of the smoother.
+shared level in LDS, one fused three-sweep pass and one exchange per visit, a coarse workgroup below; for 8 .. 15 atoms: 16 members
+whose level 0 takes turns with their other shared levels) and the opt-in tolerance mode of the smoother.
 
 EXACT mode (default): U, the V-cycle count and the last error norm are the bits of the one-workgroup solve -- which equals the
 reference's PoissonSolver (tests/test_gpu_parity.py, test_oracle_vs_ref.py) -- for every grid the resident layout serves
@@ -96,6 +96,72 @@ def test_fused_visits_of_the_one_wave_levels_return_the_single_sweep_bits(ctx, L
             Us, vcs, es, _ = _solve(ctx, grid, Zs, rho, D.POISSON_EXACT, DFTA_POISSON_NOFUSE3_WAVE="1", **kv)
             assert np.array_equal(Uf.view(np.int64), Us.view(np.int64)), (L, Zs, kv)
             assert np.array_equal(vcf, vcs) and np.array_equal(ef.view(np.int64), es.view(np.int64)), (L, Zs, kv, vcf, vcs)
+    grid.close()
+
+
+@pytest.mark.parametrize("L,delta,R", [(14, 5e-4, 25.0), (15, 2.5e-4, 30.0), (16, 2e-4, 40.0), (17, 1e-4, 50.0), (17, None, 50.0)])
+def test_second_resident_configuration_returns_the_one_workgroup_bits(ctx, L, delta, R):
+    """Round 6: 8 .. 15 atoms per launch -- 16 members of 256 lanes + the coarse workgroup per atom (17 workgroups; namespace mg_exact16 of
+    poisson.hip), the same lanes, nodes per lane, levels and passes as the 33-workgroup groups; level 0 and the other shared levels take
+    turns in a member's LDS (level 0's Phi waits in the member's global scratch while the cycle is below it).  U, the V-cycle counts and
+    the error norms against one workgroup per atom and against the staged groups of 16 (POISSON_RES16=0), for every grid the layout
+    serves (1 .. 4 shared levels; a uniform grid too), Z = 1 and 2 (the visits' early-stop path) among the atoms."""
+    grid = D.Grid(ctx, L, delta, R)
+    rr = grid.r()
+    for Zs in ([86, 1, 54, 2, 36, 18, 10, 7], [86, 80, 71, 64, 57, 47, 36, 30, 26, 18, 10, 6, 3, 2, 1]):
+        rho = np.stack([z * (1.0 + 0.1 * k) ** 3 * np.exp(-2 * (1.0 + 0.1 * k) * rr) / np.pi for k, z in enumerate(Zs)])
+        U1, vc1, e1, i1 = _solve(ctx, grid, Zs, rho, DFTA_POISSON_GROUP="0", DFTA_POISSON_NOFUSE3="1")
+        Us, vcs, es, i_s = _solve(ctx, grid, Zs, rho, DFTA_POISSON_RES16="0")
+        Ur, vcr, er, ir = _solve(ctx, grid, Zs, rho)
+        assert i1[0] == 1 and i_s[0] == 16 and ir == (17, False, 0), (i1, i_s, ir)
+        assert np.array_equal(Ur.view(np.int64), U1.view(np.int64)), (L, Zs)
+        assert np.array_equal(Ur.view(np.int64), Us.view(np.int64)), (L, Zs)
+        assert np.array_equal(vcr, vc1) and np.all(np.abs(er - e1) <= 1e-14 * np.abs(e1)), (L, Zs, vcr, vc1, er, e1)
+    # forced for a small batch: against the 33-workgroup groups
+    Zs = [86, 1]
+    rho = np.stack([z * np.exp(-2 * rr) / np.pi for z in Zs])
+    Ua, vca, ea, ia = _solve(ctx, grid, Zs, rho)
+    Ub, vcb, eb, ib = _solve(ctx, grid, Zs, rho, DFTA_POISSON_RES16="1")
+    assert ia == (33, False, 0) and ib == (17, False, 0), (ia, ib)
+    assert np.array_equal(Ua.view(np.int64), Ub.view(np.int64)) and np.array_equal(vca, vcb)
+    grid.close()
+
+
+def test_second_resident_configuration_in_an_scf_batch_and_with_a_lost_member(ctx):
+    """nine atoms at 32 769 nodes (two shared levels: the overlay at work), six SCF steps: U of every atom and step with the 17-workgroup
+    groups (default) and with the staged groups (POISSON_RES16=0); twice (run-to-run identical).  Then a member that never arrives:
+    detected, the solve repeated with one workgroup per atom, same bits."""
+    grid = D.Grid(ctx, 15, 2.5e-4, 30.0)
+    Zs = [36, 30, 18, 10, 54, 12, 20, 2, 47]
+    runs = []
+    for kv in ({}, {}, {"DFTA_POISSON_RES16": "0"}):
+        with env(**kv):
+            scf = D.Scf(ctx, grid, Zs, lsda=False)
+            tr = []
+            for _ in range(6):
+                scf.step(want_stats=False)
+                tr.append([scf.array(5, a).copy() for a in range(len(Zs))])
+            runs.append((scf.poisson_info()[0], tr))
+            scf.close()
+    assert runs[0][0] == 17 and runs[2][0] == 16, (runs[0][0], runs[2][0])
+    for k in range(6):
+        for a in range(len(Zs)):
+            for other in (1, 2):
+                assert np.array_equal(runs[0][1][k][a].view(np.int64), runs[other][1][k][a].view(np.int64)), (k, a, other)
+    grid.close()
+    L, d, R = GRIDS["L17"]
+    grid = D.Grid(ctx, L, d, R)
+    rr = grid.r()
+    Zs = [86, 54, 36, 18, 10, 2, 30, 47, 80]
+    rho = np.stack([z * np.exp(-2 * rr) / np.pi for z in Zs])
+    U0, vc0, _, info0 = _solve(ctx, grid, Zs, rho)
+    assert info0 == (17, False, 0)
+    with env(DFTA_FAULT_POISSON_MEMBER="1"):
+        ps = D.Poisson(ctx, grid, len(Zs))
+        U1, vc1, _ = ps.solve(Zs, rho)
+        assert ps.group_info() == (17, True, 1)
+        ps.close()
+    assert np.array_equal(U0.view(np.int64), U1.view(np.int64)) and np.array_equal(vc0, vc1)
     grid.close()
 
 
