@@ -160,6 +160,15 @@ namespace mg_tol {
 #undef DFTA_MG_KWARM
 #undef DFTA_MG_KWARM3
 }  // namespace mg_tol
+namespace mg_tol16 {               // tolerance mode, the resident group's second configuration (8 .. 15 atoms)
+#define DFTA_MG_KWARM 32
+#define DFTA_MG_KWARM3 32
+#define DFTA_MG_RES16 1
+#include "poisson_kernels.inc"
+#undef DFTA_MG_RES16
+#undef DFTA_MG_KWARM
+#undef DFTA_MG_KWARM3
+}  // namespace mg_tol16
 }  // namespace
 
 struct dfta_poisson {
@@ -196,7 +205,8 @@ struct dfta_poisson {
 
 static int poisson_create_impl(dfta_ctx* ctx, const dfta_grid* g, int batch, int force_logG, int mode, dfta_poisson** out);
 #define K_SOLVE(p) ((p)->tol ? mg_tol::k_poisson_solve : mg_exact::k_poisson_solve)
-#define K_SOLVE_RES(p) ((p)->res16 ? mg_exact16::k_poisson_solve_res : ((p)->tol ? mg_tol::k_poisson_solve_res : mg_exact::k_poisson_solve_res))
+#define K_SOLVE_RES(p) ((p)->res16 ? ((p)->tol ? mg_tol16::k_poisson_solve_res : mg_exact16::k_poisson_solve_res) \
+                                   : ((p)->tol ? mg_tol::k_poisson_solve_res : mg_exact::k_poisson_solve_res))
 #define K_UNIT(p) ((p)->tol ? mg_tol::k_unit : mg_exact::k_unit)
 
 static long host_addr(const Lvl& L, int i)
@@ -396,12 +406,12 @@ static int poisson_create_impl(dfta_ctx* ctx, const dfta_grid* g, int batch, int
         // 131073-node solve for 5 .. 7 atoms against 46 .. 48 ms with staged groups of 8)
         bool want = batch * kResWG <= ctx->num_cu && force_logG < 0 && !dfta_knob("POISSON_GROUP") && !dfta_knob("POISSON_NOSTAGE");   // (the hand-over needs the first coarse level staged)
         if (const char* e = dfta_knob("POISSON_RES")) want = atoi(e) != 0 && force_logG < 0 && batch * kResWG <= 256 && !dfta_knob("POISSON_NOSTAGE");
-        // 8 .. 15 atoms (exact mode): 17 workgroups per atom, 16 members of 256 lanes whose level 0 takes turns with their other shared
-        // levels in LDS (mg_exact16); POISSON_RES16 = 0 / 1 switches it off / on (1: for any batch of up to 15 atoms)
-        bool want16 = !want && !p->tol && batch * mg_exact16::kResWG <= ctx->num_cu && force_logG < 0 && !dfta_knob("POISSON_GROUP") &&
+        // 8 .. 15 atoms: 17 workgroups per atom, 16 members of 256 lanes whose level 0 takes turns with their other shared levels in
+        // LDS (mg_exact16 / mg_tol16); POISSON_RES16 = 0 / 1 switches it off / on (1: for any batch of up to 15 atoms)
+        bool want16 = !want && batch * mg_exact16::kResWG <= ctx->num_cu && force_logG < 0 && !dfta_knob("POISSON_GROUP") &&
                       !dfta_knob("POISSON_NOSTAGE") && !dfta_knob("POISSON_RES");
         if (const char* e = dfta_knob("POISSON_RES16"))
-            want16 = atoi(e) != 0 && !p->tol && force_logG < 0 && batch * mg_exact16::kResWG <= ctx->num_cu && !dfta_knob("POISSON_NOSTAGE");
+            want16 = atoi(e) != 0 && force_logG < 0 && batch * mg_exact16::kResWG <= ctx->num_cu && !dfta_knob("POISSON_NOSTAGE");
         if (want16) { want = true; p->res16 = true; }
         const int lanes = kResG * kResNT;          // (the same 4096 lanes in both configurations)
         if (want && (g->N - 1) % lanes == 0) {
@@ -558,7 +568,7 @@ static int poisson_create_impl(dfta_ctx* ctx, const dfta_grid* g, int batch, int
     if (e == hipSuccess && p->resident) e = hipMalloc(reinterpret_cast<void**>(&p->d_res_slots), sizeof(double) * (size_t)batch * res_slot_doubles());
     if (e == hipSuccess && p->res16) {
         // per member: Phi and source of level 0 as they lie in LDS (C0 rows of H0 + 256 + 1 columns each)
-        const int C0 = 1 << res_logC0, RS0 = (112 + 3 + C0 - 1) / C0 + mg_exact16::kResNT + 1;
+        const int C0 = 1 << res_logC0, RS0 = ((p->tol ? mg_tol16::kWarm3 : mg_exact16::kWarm3) + 3 + C0 - 1) / C0 + mg_exact16::kResNT + 1;
         e = hipMalloc(reinterpret_cast<void**>(&p->d_res_spill), sizeof(double) * (size_t)batch * mg_exact16::kResG * 2 * C0 * RS0);
     }
     if (e == hipSuccess) e = hipMemsetAsync(p->d_phi0, 0, tot * sizeof(double), ctx->stream);
@@ -609,7 +619,7 @@ void dfta_poisson_destroy(dfta_poisson* p)
 #ifdef DFTA_POISSON_RPROF
     {
         unsigned long long hr[2 * 8 * 8];
-        if (p->resident && (p->res16 ? hipMemcpyFromSymbol(hr, HIP_SYMBOL(mg_exact16::g_rprof), sizeof(hr)) : (p->tol ? hipMemcpyFromSymbol(hr, HIP_SYMBOL(mg_tol::g_rprof), sizeof(hr)) : hipMemcpyFromSymbol(hr, HIP_SYMBOL(mg_exact::g_rprof), sizeof(hr)))) == hipSuccess) {
+        if (p->resident && (p->res16 ? (p->tol ? hipMemcpyFromSymbol(hr, HIP_SYMBOL(mg_tol16::g_rprof), sizeof(hr)) : hipMemcpyFromSymbol(hr, HIP_SYMBOL(mg_exact16::g_rprof), sizeof(hr))) : (p->tol ? hipMemcpyFromSymbol(hr, HIP_SYMBOL(mg_tol::g_rprof), sizeof(hr)) : hipMemcpyFromSymbol(hr, HIP_SYMBOL(mg_exact::g_rprof), sizeof(hr)))) == hipSuccess) {
             const char* mn[8] = {"pass    ", "publish ", "exchange", "commit  ", "restrict", "prolong ", "handover", "redo    "};
             const char* cn[8] = {"passive ", "cs sweep", "iterate ", "coarsesc", "restrict", "prolong ", "handover", "cs r/p/xw/enter/leave"};
             for (int role = 0; role < 2; ++role)
@@ -620,7 +630,8 @@ void dfta_poisson_destroy(dfta_poisson* p)
                     fprintf(stderr, "  = %llu\n", t);
                 }
             unsigned long long zz[2 * 8 * 8] = {0};
-            if (p->res16) (void)hipMemcpyToSymbol(HIP_SYMBOL(mg_exact16::g_rprof), zz, sizeof(zz));
+            if (p->res16 && p->tol) (void)hipMemcpyToSymbol(HIP_SYMBOL(mg_tol16::g_rprof), zz, sizeof(zz));
+            else if (p->res16) (void)hipMemcpyToSymbol(HIP_SYMBOL(mg_exact16::g_rprof), zz, sizeof(zz));
             else if (p->tol) (void)hipMemcpyToSymbol(HIP_SYMBOL(mg_tol::g_rprof), zz, sizeof(zz));
             else (void)hipMemcpyToSymbol(HIP_SYMBOL(mg_exact::g_rprof), zz, sizeof(zz));
         }

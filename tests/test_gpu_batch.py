@@ -191,13 +191,13 @@ def test_packed_rounds_take_the_same_decisions(ctx, lsda):
     grid.close()
 
 
-@pytest.mark.parametrize("Zs,groups", [([36] * 5 + [18] * 4 + [10] * 3 + [2], [16, 33]),
-                                       ([36] * 5 + [18] * 6 + [10] * 6 + [2] * 3, [8, 16, 33])])
+@pytest.mark.parametrize("Zs,groups", [([36] * 5 + [18] * 4 + [10] * 3 + [2], [17, 33]),
+                                       ([36] * 5 + [18] * 6 + [10] * 6 + [2] * 3, [8, 17, 33])])
 def test_last_live_atoms_switch_layouts_and_keep_the_bits(ctx, Zs, groups):
     """Kr x 5, Ar x 4, Ne x 3, He (72 jobs, 13 atoms) and Kr x 5, Ar x 6, Ne x 6, He x 3 (91 jobs, 20 atoms) on the 16385-node grid, run
-    until all have finished.  While everything is live the level search runs static blocks and the multigrid the staged groups of the
-    batch size (16 / 8 workgroups per atom); as atoms finish the live ones move to the solver of their size class (20 atoms: 16
-    workgroups once <= 16 are live) and, once at most 64 jobs are live, the step statistics report the device-side search over the live jobs
+    until all have finished.  While everything is live the level search runs static blocks and the multigrid the groups of the
+    batch size (13 atoms: the 17-workgroup resident groups of round 6; 20 atoms: staged groups of 8 workgroups per atom); as atoms finish
+    the live ones move to the solver of their size class (20 atoms: 17 workgroups once <= 15 are live) and, once at most 64 jobs are live, the step statistics report the device-side search over the live jobs
     (layout 5: persist.inc; 3 = its host-round twin under LEVELS_NOPERSIST) and, for <= 7 atoms, the 33-workgroup resident groups.  Energies, eigenvalues, potentials and step counts equal each
     atom's own run and the same batch with both switches off."""
     L, d, R = GRIDS["L14"]
@@ -220,7 +220,7 @@ def test_last_live_atoms_switch_layouts_and_keep_the_bits(ctx, Zs, groups):
         return out, seen
 
     got, seen = run_batch()
-    assert seen[0] == (0, groups[0]), seen[:3]                          # static blocks; staged groups of the batch size
+    assert seen[0] == (0, groups[0]), seen[:3]                          # static blocks; the groups of the batch size
     assert (5, 33) in seen, sorted(set(seen))                           # ... and the switched layouts at the end
     assert sorted(set(g for _, g in seen)) == groups, sorted(set(seen))
     plain, seen_plain = _with_debug("LEVELS_NOSWITCH,SCF_NOLIVE", run_batch)
