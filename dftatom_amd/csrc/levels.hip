@@ -699,6 +699,7 @@ int LevelSolver::setup(dfta_ctx* c, const dfta_grid* grid, int mode_, int tree_d
         d = 6;
         if (active <= 768) { while (d < 14 && ((active << (d + 1)) >> 6) <= 384) ++d; }
         else               { while (d < 14 && (active << (d + 1)) <= 131072L) ++d; }   // up to two waves per SIMD: measured optimum at 960 jobs
+        if (const char* e = dfta_knob("LEVELS_DEPTH")) d = atoi(e);                    // measurements: the automatic layout with another tree depth
     }
     d = std::min(std::max(d, 6), 16);
     depth = d;

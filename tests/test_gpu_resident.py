@@ -165,6 +165,31 @@ def test_second_resident_configuration_in_an_scf_batch_and_with_a_lost_member(ct
     grid.close()
 
 
+def test_second_resident_configuration_in_tolerance_mode(ctx):
+    """tolerance mode with 17 workgroups per atom (mg_tol16): the same lanes and chunks as the 33-workgroup groups, hence the bits of every
+    atom solved alone there; within the mode's gate (2e-9 Z) of the exact solve; faster than the staged groups it replaces is bench business"""
+    L, d, R = GRIDS["L17"]
+    grid = D.Grid(ctx, L, d, R)
+    rr = grid.r()
+    Zs = [86, 54, 36, 18, 10, 2, 30, 47, 80, 1]
+    rho = np.stack([z * (1.0 + 0.1 * k) ** 3 * np.exp(-2 * (1.0 + 0.1 * k) * rr) / np.pi for k, z in enumerate(Zs)])
+    Ux, _, _, ix = _solve(ctx, grid, Zs, rho, D.POISSON_EXACT)
+    Ut, vct, et, it = _solve(ctx, grid, Zs, rho, D.POISSON_TOLERANCE)
+    Us, vcs, es, i_s = _solve(ctx, grid, Zs, rho, D.POISSON_TOLERANCE, DFTA_POISSON_RES16="0")
+    assert ix == (17, False, 0) and it == (17, False, 0) and i_s[0] == 16, (ix, it, i_s)
+    for k, z in enumerate(Zs):
+        assert np.max(np.abs(Ut[k] - Ux[k])) <= 2e-9 * z, (z, np.max(np.abs(Ut[k] - Ux[k])))
+        assert np.max(np.abs(Us[k] - Ux[k])) <= 2e-9 * z, (z, np.max(np.abs(Us[k] - Ux[k])))
+        U1, vc1, e1, i1 = _solve(ctx, grid, [z], rho[k:k + 1], D.POISSON_TOLERANCE)
+        assert i1 == (33, False, 0)
+        assert np.array_equal(U1[0].view(np.int64), Ut[k].view(np.int64)) and vc1[0] == vct[k], (z, np.max(np.abs(U1[0] - Ut[k])), vc1, vct[k])
+    Ua, vca, _, ia = _solve(ctx, grid, Zs, rho, D.POISSON_ADAPTIVE)
+    assert ia == (17, False, 0)
+    for k, z in enumerate(Zs):
+        assert np.max(np.abs(Ua[k] - Ux[k])) <= 2e-8 * z and vca[k] <= 40, (z, np.max(np.abs(Ua[k] - Ux[k])), vca[k])
+    grid.close()
+
+
 def test_resident_groups_are_deterministic(ctx):
     """He at 16385 nodes: one shared level, short passes, the cycle stops early -- exchanges follow each other within microseconds.
     Thirty SCF steps twice: every step's U and V-cycle count identical, and identical to the one-workgroup solver's."""
