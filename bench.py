@@ -271,6 +271,8 @@ def workload_tag(levels, atoms, lsda, poisson_mode, sweep_mode):
         return mode or base
     if levels == 17 and atoms == 256 and not lsda:
         return "batch256" + ("_" + mode if mode else "")
+    if levels == 17 and atoms == 12 and not lsda and mode == "":
+        return "batch12"                 # a shard-sized batch: the multigrid's 17-workgroup resident groups
     if levels == 20 and lsda and atoms in (1, 16):
         base = "l20" if atoms == 1 else "l20_batch16"
         return base + ("_" + mode if mode else "")

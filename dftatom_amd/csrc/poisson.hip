@@ -71,6 +71,7 @@ struct MgDesc {
     int fuse3;    // visits of three sweeps on staged levels of one workgroup run as ONE fused pass (gs_lds3); 0: $DFTA_POISSON_NOFUSE3
     int fuse3w;   // ... and those of the one-wave levels with 257 .. 1025 nodes of the coarse section (cs_visit3); 0: POISSON_NOFUSE3 / POISSON_NOFUSE3_WAVE
     int nofold;   // DFTA_POISSON_NOFOLD: restriction / prolongation as separate passes even where they could be folded into a staged copy-in
+    int fold_lds; // the folded restriction reads the finer level from the staging memory where its visit has just left it (POISSON_NOFOLD_LDS: from global)
     int kcoop;       // levels 0 .. kcoop-1 are swept by all G workgroups together (256 G lanes), the others by workgroup 0
     int spin_max;    // bound of the group barriers' spin loops (Atom::spin_max)
     long per_atom;   // doubles per atom and per array (sum of n)
@@ -450,6 +451,7 @@ static int poisson_create_impl(dfta_ctx* ctx, const dfta_grid* g, int batch, int
     if (D.kcoop == 0) logG = 0;
     D.logG = logG;
     D.nofold = dfta_knob("POISSON_NOFOLD") ? 1 : 0;
+    D.fold_lds = dfta_knob("POISSON_NOFOLD_LDS") ? 0 : 1;
     D.fuse3 = dfta_knob("POISSON_NOFUSE3") ? 0 : 1;
     D.fuse3w = (D.fuse3 && !dfta_knob("POISSON_NOFUSE3_WAVE")) ? 1 : 0;
     D.fuse_min_logc = kFuseMinLogC;

@@ -37,6 +37,9 @@ cases = {"pt": (g17, list(range(1, 87)), False, 3, 4), "shard": (g17, list(range
 for name in which:
     if name == "l20":
         g = D.Grid(ctx, *GRIDS["L20"]); case = (g, [86] * 16, True, 2, 3)
+    elif name.startswith("z:"):                    # "z:77-86": Z = 77 .. 86 at 131 073 nodes
+        lo, hi = (int(x) for x in name[2:].split("-"))
+        case = (g17, list(range(lo, hi + 1)), False, 4, 5)
     else:
         case = cases[name]
     for kn in variants:

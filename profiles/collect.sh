@@ -31,6 +31,7 @@ run_one scan_tol     --steps 5 --warmup 2 --no-cpu --no-extras --scan-sweeps --t
 run_one tolerance    --steps 20 --warmup 5 --no-cpu --no-extras --tolerance
 run_one rn_lsda      --lsda --steps 20 --warmup 5 --no-cpu --no-extras
 run_one scan_adaptive --steps 5 --warmup 2 --no-cpu --no-extras --scan-sweeps --adaptive
+run_one batch12      --atoms 12 --steps 5 --warmup 2 --no-cpu --no-extras
 run_one batch256     --atoms 256 --steps 3 --warmup 1 --no-cpu --no-extras
 run_one batch256_scan     --atoms 256 --steps 3 --warmup 1 --no-cpu --no-extras --scan-sweeps
 run_one batch256_scan_tol --atoms 256 --steps 3 --warmup 1 --no-cpu --no-extras --scan-sweeps --tolerance

@@ -190,6 +190,25 @@ def test_second_resident_configuration_in_tolerance_mode(ctx):
     grid.close()
 
 
+@pytest.mark.parametrize("L,delta,R", [(12, 2e-3, 25.0), (14, 5e-4, 25.0), (17, 1e-4, 50.0), (17, None, 50.0), (20, 1.25e-5, 50.0)])
+def test_restriction_from_the_staging_memory_returns_the_global_bits(ctx, L, delta, R):
+    """Round 6: where two consecutive levels of one workgroup are staged (8 193 -> 4 097 -> 2 049 nodes), the restriction folded into the
+    coarser level's copy-in reads the finer level from the staging memory -- where its visit has just left it -- instead of from its global
+    copy (POISSON_NOFOLD_LDS: the global reads of round 5).  Same values, same arithmetic: U, V-cycle counts, error norms, for the resident
+    groups (both configurations), a staged group and one workgroup per atom; Z = 1 stops early (the visit is staged a second time: from
+    global memory, the staging memory having been overwritten)."""
+    grid = D.Grid(ctx, L, delta, R)
+    rr = grid.r()
+    for Zs in ([86], [1], [18, 2, 54]):
+        rho = np.stack([z * (1.0 + 0.3 * k) ** 3 * np.exp(-2 * (1.0 + 0.3 * k) * rr) / np.pi for k, z in enumerate(Zs)])
+        for kv in ({}, {"DFTA_POISSON_GROUP": "0"}, {"DFTA_POISSON_RES": "0"}, {"DFTA_POISSON_RES16": "1"}):
+            Uf, vcf, ef, _ = _solve(ctx, grid, Zs, rho, D.POISSON_EXACT, **kv)
+            Us, vcs, es, _ = _solve(ctx, grid, Zs, rho, D.POISSON_EXACT, DFTA_POISSON_NOFOLD_LDS="1", **kv)
+            assert np.array_equal(Uf.view(np.int64), Us.view(np.int64)), (L, Zs, kv)
+            assert np.array_equal(vcf, vcs) and np.array_equal(ef.view(np.int64), es.view(np.int64)), (L, Zs, kv, vcf, vcs)
+    grid.close()
+
+
 def test_resident_groups_are_deterministic(ctx):
     """He at 16385 nodes: one shared level, short passes, the cycle stops early -- exchanges follow each other within microseconds.
     Thirty SCF steps twice: every step's U and V-cycle count identical, and identical to the one-workgroup solver's."""
