@@ -310,7 +310,7 @@ typedef struct dfta_step_stats {
                                     search (one persistent kernel, every level at its own pace: persist.inc), 6 own-pace search of a batch (one
                                     workgroup per level in one launch: own.inc, opt-in $DFTA_DEBUG LEVELS_OWN) -- never changes a result */
     int    poisson_groups;       /* workgroups per atom of the multigrid solve of this step (33 / 17: resident groups of up to 7 / 15 atoms); the live atoms of
-                                    a batch are solved by a solver of their size class (64 / 32 / 16 / 7 atoms) once that is smaller
+                                    a batch are solved by a solver of their size class (128 / 64 / 32 / 16 / 15 / 7 atoms) once that is smaller
                                     than the batch's own */
 } dfta_step_stats;
 
