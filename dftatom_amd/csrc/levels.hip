@@ -826,7 +826,11 @@ int LevelSolver::setup(dfta_ctx* c, const dfta_grid* grid, int mode_, int tree_d
         DFTA_HIP(ctx, hipStreamSynchronize(st));     // the vectors above are the sources of the copies
     }
     ALLOC(d_counters, unsigned long long, 4);
-    if (persist_ok) { const int prc = dfta_persist_create(ctx, g, std::min(njobs, 64), &pb); if (prc) return prc; }
+    // the device-side search takes up to 128 live levels (two workgroups per level on 256 compute units); LEVELS_PERSIST_WIDE=n: up to
+    // 64 <= n <= 128 (64: one atom's worth, round 5 -- batches of 65 .. 128 live levels then run host rounds)
+    persist_cap = 128;
+    if (const char* e = dfta_knob("LEVELS_PERSIST_WIDE")) persist_cap = std::min(128, std::max(64, atoi(e)));
+    if (persist_ok) { const int prc = dfta_persist_create(ctx, g, std::min(njobs, persist_cap), &pb); if (prc) return prc; }
     if (can_switch) ALLOC(d_live, int, 64);
     if (!g->uniform && dfta_knob("LEVELS_NOQUEUE") == nullptr) ALLOC(d_queue, int, kSweepQueueClasses + 1 + (size_t)kSweepQueueClasses * nwaves);
     if (own_ok) ALLOC(d_own_live, int, njobs);
@@ -903,7 +907,9 @@ int LevelSolver::run(const double* dV, const double* job_bottom, int run_mode, d
     std::vector<int> plive;
     if (sw) plive = live;
     else for (int k = 0; k < njobs; ++k) if (!(frozen && frozen[k] && h_last.size() == jobs.size())) plive.push_back(k);
-    const bool use_persist = persist_ok && dyn && !chained && sweep_mode != DFTA_SWEEPS_TOLERANCE && !plive.empty() && (int)plive.size() <= pb.nlive_cap &&
+    // (wide: 65 .. persist_cap live levels of a batch whose host rounds -- the fallback -- are the solver's own static / packed layout)
+    const bool wide = !dyn && !own_ok && persist_cap > 64 && (int)plive.size() > 64;          // (LEVELS_OWN: that search was asked for)
+    const bool use_persist = persist_ok && (dyn || wide) && !chained && sweep_mode != DFTA_SWEEPS_TOLERANCE && !plive.empty() && (int)plive.size() <= pb.nlive_cap &&
                              pb.nblocks / (int)plive.size() >= 2 && debug_rounds == 0;
     // more than 64 live levels: every level at its own pace all the same, one workgroup of W waves each in ONE ordinary launch (own.inc)
     const bool use_own = own_ok && !dyn && !chained && sweep_mode != DFTA_SWEEPS_TOLERANCE && !plive.empty() && debug_rounds == 0;
@@ -1112,18 +1118,19 @@ int LevelSolver::run(const double* dV, const double* job_bottom, int run_mode, d
     bool persisted = false;
     int persist_rounds = 0;
     float ms_persist = 0;
-    if (!scan && !chained && scan_predict && scan_tb.tabv != nullptr && !plive.empty() && debug_rounds == 0 && (use_persist || scan_wanted)) {
+    if (!scan && !chained && scan_predict && scan_tb.tabv != nullptr && !plive.empty() && debug_rounds == 0 && ((use_persist && !wide) || scan_wanted)) {
         // the scan search of the first bisection as a predictor of the exact search's first spines (speculation only): a group of workgroups per
         // level ahead of the device-side search, one workgroup per level ahead of the host rounds of a batch
         int K = 1;
         if (use_persist) for (int cand : {15, 7, 3}) if ((long)plive.size() * cand <= ctx->num_cu) { K = cand; break; }
-        if (K > 1 || !use_persist) {
+        const bool grouped = use_persist && K > 1;             // (a wide device-side search: one workgroup per level, as for the host rounds)
+        if (grouped || !use_persist || wide) {
             rc = dfta_launch_scan_build_tab(ctx, g, scan_tb, dV, d_slot_v, d_slot_l);
             if (rc) return rc;
             DFTA_HIP(ctx, hipMemcpyAsync(d_jobs_scan, d_jobs, sizeof(Job) * njobs, hipMemcpyDeviceToDevice, st));
             DFTA_HIP(ctx, hipMemcpyAsync(d_scan_live, plive.data(), sizeof(int) * plive.size(), hipMemcpyHostToDevice, st));
             DFTA_HIP(ctx, hipMemsetAsync(d_counters_scan, 0, sizeof(unsigned long long) * 4, st));
-            const int prc = use_persist
+            const int prc = grouped
                 ? dfta_launch_scan_levels_group(ctx, g, d_jobs_scan, d_scan_live, (int)plive.size(), K, scan_tb, fixed_point, d_counters_scan, d_scan_xch, -1, nullptr, nullptr)
                 : dfta_launch_scan_levels(ctx, g, d_jobs_scan, d_chain_off_b, njobs, 0, scan_tb, fixed_point, d_counters_scan, -1, nullptr, nullptr);
             if (prc == DFTA_OK) {

@@ -1752,7 +1752,8 @@ int dfta_launch_levels_persist(dfta_ctx* ctx, const dfta_grid* g, dfta_persist_b
     }
     // control block: pool, counters, mailboxes (the first workgroup of every level plans its first round), the levels' workgroups
     std::vector<unsigned char>& hb = pb->h_stage;
-    hb.assign(pb->ctl_bytes, 0);
+    const size_t ctl_used = sizeof(PersistCtl) + sizeof(unsigned long long) * kPersistMaxBlocks + sizeof(PersistJob) * (size_t)nlive;   // (the records of the levels in use)
+    hb.assign(ctl_used, 0);
     PersistCtl* hc = reinterpret_cast<PersistCtl*>(hb.data());
     unsigned long long* hm = reinterpret_cast<unsigned long long*>(hb.data() + sizeof(PersistCtl));
     PersistJob* hj = reinterpret_cast<PersistJob*>(hb.data() + sizeof(PersistCtl) + sizeof(unsigned long long) * kPersistMaxBlocks);
@@ -1770,7 +1771,7 @@ int dfta_launch_levels_persist(dfta_ctx* ctx, const dfta_grid* g, dfta_persist_b
     }
     for (int q = next; q < nblocks; ++q) hc->pool[q >> 6] |= 1ull << (q & 63);
     unsigned char* dctl = static_cast<unsigned char*>(pb->d_ctl);
-    DFTA_HIP(ctx, hipMemcpyAsync(dctl, hb.data(), pb->ctl_bytes, hipMemcpyHostToDevice, st));
+    DFTA_HIP(ctx, hipMemcpyAsync(dctl, hb.data(), ctl_used, hipMemcpyHostToDevice, st));
 
     SweepArgs a;
     a.slot_l = nullptr;

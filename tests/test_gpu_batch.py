@@ -220,7 +220,7 @@ def test_last_live_atoms_switch_layouts_and_keep_the_bits(ctx, Zs, groups):
         return out, seen
 
     got, seen = run_batch()
-    assert seen[0] == (0, groups[0]), seen[:3]                          # static blocks; the groups of the batch size
+    assert seen[0] == (5, groups[0]), seen[:3]                          # 72 / 91 levels: the device-side search (<= 128 live levels); the multigrid groups of the batch size
     assert (5, 33) in seen, sorted(set(seen))                           # ... and the switched layouts at the end
     assert sorted(set(g for _, g in seen)) == groups, sorted(set(seen))
     plain, seen_plain = _with_debug("LEVELS_NOSWITCH,SCF_NOLIVE", run_batch)

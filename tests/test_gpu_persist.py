@@ -132,9 +132,10 @@ def test_layout_knobs_of_the_device_search_keep_the_bits(ctx, grid14, knobs):
 
 
 def test_batch_whose_last_atoms_search_on_the_device(ctx, grid14):
-    """a batch of 20 atoms starts in static blocks; once at most 64 levels are live its rounds move to the device (layout 5), and every atom
-    ends in the state it reaches alone with host rounds"""
-    Z = list(range(1, 21))
+    """a batch of 30 atoms (148 levels) starts in static blocks; once at most 128 levels are live its rounds move to the device (layout 5:
+    two workgroups per level, later the floating shares of a single atom's search), and every atom ends in the state it reaches alone
+    with host rounds"""
+    Z = list(range(1, 31))
     with _Knobs(""):
         batch = D.Scf(ctx, grid14, Z, lsda=False)
     layouts = []
@@ -146,7 +147,7 @@ def test_batch_whose_last_atoms_search_on_the_device(ctx, grid14):
             break
     eb, _ = batch.energies()
     assert 5 in layouts and layouts[0] != 5, sorted(set(layouts))
-    for ia in (0, 7, 12, 19):
+    for ia in (0, 7, 12, 19, 28):
         with _Knobs("LEVELS_NOPERSIST"):
             one = D.Scf(ctx, grid14, [Z[ia]], lsda=False)
         for _ in range(110):
@@ -159,6 +160,29 @@ def test_batch_whose_last_atoms_search_on_the_device(ctx, grid14):
         assert np.array_equal(lb["E"].view(np.int64), l1["E"].view(np.int64)), Z[ia]
         one.close()
     batch.close()
+
+
+def test_device_search_of_a_batch_with_65_to_128_live_levels(ctx, grid14, grid17):
+    """Round 6: the device-side search takes up to 128 live levels -- two workgroups per level on 256 compute units, every level at its own
+    pace, match solve and normalisation inside (the shards of an 8-rank periodic table start with ~100 levels).  Eleven atoms at 16 385
+    and at 131 073 nodes against the host rounds (LEVELS_NOPERSIST) and against round 5's limit (LEVELS_PERSIST_WIDE=64: static blocks);
+    a lost worker sends the step back to the batch's own host rounds (layout 0)."""
+    Z14 = list(range(20, 31))                                            # 76 levels
+    wide14 = _run(ctx, grid14, Z14, False, 6, "")
+    host14 = _run(ctx, grid14, Z14, False, 6, "LEVELS_NOPERSIST")
+    narrow14 = _run(ctx, grid14, Z14, False, 6, "LEVELS_PERSIST_WIDE=64")
+    assert all(r["layout"] == 5 for r in wide14), [r["layout"] for r in wide14]
+    assert all(r["layout"] == 0 for r in host14) and all(r["layout"] == 0 for r in narrow14)
+    _assert_same(wide14, host14, "wide vs host rounds")
+    _assert_same(wide14, narrow14, "wide vs the 64-level limit")
+    Z17 = [3, 11, 19, 30, 37, 48, 55, 62, 70, 79, 86]                    # 105 levels
+    wide17 = _run(ctx, grid17, Z17, False, 3, "")
+    host17 = _run(ctx, grid17, Z17, False, 3, "LEVELS_NOPERSIST")
+    assert all(r["layout"] == 5 for r in wide17) and all(r["layout"] == 0 for r in host17)
+    _assert_same(wide17, host17, "wide vs host rounds @ 131 073")
+    lost = _run(ctx, grid14, Z14, False, 3, "FAULT_PERSIST_WORKER=1,LEVELS_PERSIST_TIMEOUT_MS=300")
+    assert lost[0]["layout"] == 0, [r["layout"] for r in lost]
+    _assert_same(lost, host14[:3], "lost worker of a wide search")
 
 
 def test_lost_worker_is_detected_and_the_solve_repeated(ctx, grid14):
