@@ -173,7 +173,7 @@ struct LevelSolver {
     LevelSolver& operator=(const LevelSolver&) = delete;
     ~LevelSolver();
     void release();
-    int persist_cap = 128;      // live levels the device-side search takes (LEVELS_PERSIST_WIDE=n: 64 .. 128)
+    int persist_cap = 256;      // live levels the device-side search takes (LEVELS_PERSIST_WIDE=n: 64 .. 256)
     int setup(dfta_ctx* c, const dfta_grid* grid, int mode, int tree_depth, int nV, const std::vector<JobSpec>& specs);
     // frozen (host, njobs, may be null): jobs whose result of the previous run() stands (finished atoms of an SCF batch)
     int run(const double* dV, const double* job_bottom, int run_mode, double* dNewDensity, LevelStats* stats,

@@ -826,10 +826,11 @@ int LevelSolver::setup(dfta_ctx* c, const dfta_grid* grid, int mode_, int tree_d
         DFTA_HIP(ctx, hipStreamSynchronize(st));     // the vectors above are the sources of the copies
     }
     ALLOC(d_counters, unsigned long long, 4);
-    // the device-side search takes up to 128 live levels (two workgroups per level on 256 compute units); LEVELS_PERSIST_WIDE=n: up to
-    // 64 <= n <= 128 (64: one atom's worth, round 5 -- batches of 65 .. 128 live levels then run host rounds)
-    persist_cap = 128;
-    if (const char* e = dfta_knob("LEVELS_PERSIST_WIDE")) persist_cap = std::min(128, std::max(64, atoi(e)));
+    // the device-side search takes up to 256 live levels: one workgroup per level and compute unit, two for as many levels as there are
+    // compute units left (all of them up to 128 levels), the rest in the pool; LEVELS_PERSIST_WIDE=n: up to 64 <= n <= 256 levels (64: one
+    // atom's worth, round 5 -- larger batches then run host rounds)
+    persist_cap = 256;
+    if (const char* e = dfta_knob("LEVELS_PERSIST_WIDE")) persist_cap = std::min(256, std::max(64, atoi(e)));
     if (persist_ok) { const int prc = dfta_persist_create(ctx, g, std::min(njobs, persist_cap), &pb); if (prc) return prc; }
     if (can_switch) ALLOC(d_live, int, 64);
     if (!g->uniform && dfta_knob("LEVELS_NOQUEUE") == nullptr) ALLOC(d_queue, int, kSweepQueueClasses + 1 + (size_t)kSweepQueueClasses * nwaves);
@@ -910,7 +911,7 @@ int LevelSolver::run(const double* dV, const double* job_bottom, int run_mode, d
     // (wide: 65 .. persist_cap live levels of a batch whose host rounds -- the fallback -- are the solver's own static / packed layout)
     const bool wide = !dyn && !own_ok && persist_cap > 64 && (int)plive.size() > 64;          // (LEVELS_OWN: that search was asked for)
     const bool use_persist = persist_ok && (dyn || wide) && !chained && sweep_mode != DFTA_SWEEPS_TOLERANCE && !plive.empty() && (int)plive.size() <= pb.nlive_cap &&
-                             pb.nblocks / (int)plive.size() >= 2 && debug_rounds == 0;
+                             pb.nblocks / (int)plive.size() >= (persist_cap > 128 ? 1 : 2) && debug_rounds == 0;
     // more than 64 live levels: every level at its own pace all the same, one workgroup of W waves each in ONE ordinary launch (own.inc)
     const bool use_own = own_ok && !dyn && !chained && sweep_mode != DFTA_SWEEPS_TOLERANCE && !plive.empty() && debug_rounds == 0;
     int own_W = 1;
@@ -1001,6 +1002,7 @@ int LevelSolver::run(const double* dV, const double* job_bottom, int run_mode, d
         j.phase_done = 0;
     }
     persist_deep_reserve = 0;
+    std::vector<int> second_share;          // more than nblocks / 2 live levels: the levels that get a second workgroup of their own (the others have one)
     if (use_persist && h_last.size() == jobs.size() && !pb.equal_shares) {
         // Feedback (speculation only): the levels whose search ended last in the previous step get first call on the pool (persist_plan,
         // deep = 2: as many as the pool can give a second share to), those within 15 % of the last one may match candidate eigenvalues
@@ -1018,6 +1020,7 @@ int LevelSolver::run(const double* dV, const double* job_bottom, int run_mode, d
         if (order.size() == plive.size()) {
             std::sort(order.begin(), order.end(), [&](int x, int y) { return score(x) > score(y); });
             const int equal = pb.nblocks / (int)plive.size();
+            if (equal == 1) second_share.assign(order.begin(), order.begin() + std::min<size_t>(order.size(), pb.nblocks - (int)plive.size()));
             int pool = pb.nblocks - equal * (int)plive.size();
             for (int k : plive) if (jobs[k].nodes == 0 && equal >= 8) pool += equal / 2;
             const int ndeep = std::min<int>((int)order.size(), pool / std::max(equal - 1, 1));
@@ -1151,6 +1154,12 @@ int LevelSolver::run(const double* dV, const double* job_bottom, int run_mode, d
         const int equal = pb.nblocks / (int)plive.size();
         const bool float_shares = !pb.equal_shares && equal >= 8;
         for (size_t q = 0; q < plive.size(); ++q) share[q] = (float_shares && jobs[plive[q]].nodes == 0) ? equal - equal / 2 : equal;
+        if (equal == 1 && !pb.equal_shares) {
+            // one workgroup per level leaves nblocks - nlive over: second workgroups (scouts, a tree one level deeper) for the levels whose
+            // search ended last in the previous steps; without that feedback, for the first ones of the list
+            if (second_share.empty()) for (size_t q = 0; q < plive.size() && (int)q < pb.nblocks - (int)plive.size(); ++q) share[q] = 2;
+            else for (int k : second_share) share[plevel[k]] = 2;
+        }
         rc = dfta_launch_levels_persist(ctx, g, &pb, d_jobs, plive.data(), (int)plive.size(), d_tab, d_bounds, d_Psi, d_Q, d_jstart_keep, d_counters, stats != nullptr,
                                         use_prediction ? 0 : 1, integ_rule, tuning, fixed_point, &persist_rounds, &aborted, want_trace ? &persist_trace : nullptr, share.data(), persist_deep_reserve);
         if (rc) return rc;

@@ -1732,7 +1732,7 @@ int dfta_launch_levels_persist(dfta_ctx* ctx, const dfta_grid* g, dfta_persist_b
     if (nlive < 1 || nlive > pb->nlive_cap || g->uniform) return DFTA_ERR_INVALID;
     const int nblocks = pb->nblocks;
     const int base = nblocks / nlive;
-    if (base < 2) return DFTA_ERR_INVALID;
+    if (base < 1) return DFTA_ERR_INVALID;
     hipStream_t st = ctx->stream;
     {   // this translation unit's copies of the prediction constants (levels_device.inc), per device
         static std::mutex mu;                 // (contexts of several host threads may launch on the same device)
@@ -1761,7 +1761,8 @@ int dfta_launch_levels_persist(dfta_ctx* ctx, const dfta_grid* g, dfta_persist_b
     hc->t0 = ~0ull;
     int next = 0;
     for (int k = 0; k < nlive; ++k) {
-        const int mine = share ? std::max(2, std::min(share[k], base)) : base;      // (a level never starts with more than an equal share)
+        // (a level never starts with more than an equal share -- except where that share is ONE workgroup: the caller hands the rest out as second ones)
+        const int mine = share ? (base == 1 ? std::min(std::max(share[k], 1), 2) : std::max(2, std::min(share[k], base))) : base;      // (a level never starts with more than an equal share)
         hj[k].job = live[k];
         hj[k].base = mine;
         hj[k].nown = mine;
@@ -1769,6 +1770,7 @@ int dfta_launch_levels_persist(dfta_ctx* ctx, const dfta_grid* g, dfta_persist_b
         hm[next] = persist_msg(kCmdPlan, k, 0);
         next += mine;
     }
+    if (next > nblocks) return DFTA_ERR_INVALID;
     for (int q = next; q < nblocks; ++q) hc->pool[q >> 6] |= 1ull << (q & 63);
     unsigned char* dctl = static_cast<unsigned char*>(pb->d_ctl);
     DFTA_HIP(ctx, hipMemcpyAsync(dctl, hb.data(), ctl_used, hipMemcpyHostToDevice, st));

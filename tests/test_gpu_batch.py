@@ -170,7 +170,10 @@ def test_packed_rounds_take_the_same_decisions(ctx, lsda):
         scf.close()
         return out, pot, issued, info
 
-    ref, pot_ref, issued_static, info_static = _with_debug("LEVELS_NOPACK", run)
+    # (LEVELS_PERSIST_WIDE=64 throughout: round 5's limit of the device-side search, which takes the LDA case's 230 levels by default --
+    # this test is about the host rounds' layouts; the default path is compared at the end)
+    HOST = "LEVELS_PERSIST_WIDE=64"
+    ref, pot_ref, issued_static, info_static = _with_debug(HOST + ",LEVELS_NOPACK", run)
     # round 6: the blocks of a round are launched longest first through a queue (numerov.hip:k_sweep_queue, k_sweep_pipe with the same
     # indirection); LEVELS_NOQUEUE = the plain launch in array order; DSMALL=20 forces the large budget: ~1 800 blocks, the fused kernel
     for knobs in ("", "LEVELS_PACK_DMIN=1", "LEVELS_PACK_DMIN=6", "LEVELS_PACK_DSMALL=20,LEVELS_PACK_LANES=8192",
@@ -178,7 +181,7 @@ def test_packed_rounds_take_the_same_decisions(ctx, lsda):
                   # round 6: the scan search's first bisection ahead of the rounds predicts the first spines (speculation only): off, and
                   # recklessly wrong (every predicted end point shifted by 1e-3 of itself; trusted to 1 % of its band)
                   "LEVELS_NOSCANPREDICT_BATCH", "LEVELS_SCAN_PREDICT_SHIFT=1e-3", "LEVELS_SCAN_PREDICT_W=0.01"):
-        got, pot, issued, info = _with_debug(knobs, run)
+        got, pot, issued, info = _with_debug(HOST + ("," + knobs if knobs else ""), run)
         assert info != info_static, knobs                          # the packed layout really ran
         for k, (x, y) in enumerate(zip(ref, got)):
             assert x[0] == y[0], (knobs, k)
@@ -188,6 +191,12 @@ def test_packed_rounds_take_the_same_decisions(ctx, lsda):
         assert np.array_equal(pot.view(np.int64), pot_ref.view(np.int64)), knobs
         if "LEVELS_PACK_LANES=8192" in knobs:                      # depth 3 plus whatever fills the groups' last blocks
             assert issued < issued_static, (issued, issued_static)
+    got, pot, _, _ = _with_debug("", run)                          # the default path (LDA: 230 levels on the device, LSDA: 460 in packed rounds)
+    for k, (x, y) in enumerate(zip(ref, got)):
+        assert x[0] == y[0] and x[2:] == y[2:], ("default", k)
+        for a, b in zip(x[1], y[1]):
+            assert np.array_equal(a.view(np.int64), b.view(np.int64)), ("default", k)
+    assert np.array_equal(pot.view(np.int64), pot_ref.view(np.int64))
     grid.close()
 
 
@@ -220,7 +229,7 @@ def test_last_live_atoms_switch_layouts_and_keep_the_bits(ctx, Zs, groups):
         return out, seen
 
     got, seen = run_batch()
-    assert seen[0] == (5, groups[0]), seen[:3]                          # 72 / 91 levels: the device-side search (<= 128 live levels); the multigrid groups of the batch size
+    assert seen[0] == (5, groups[0]), seen[:3]                          # 72 / 91 levels: the device-side search (<= 256 live levels); the multigrid groups of the batch size
     assert (5, 33) in seen, sorted(set(seen))                           # ... and the switched layouts at the end
     assert sorted(set(g for _, g in seen)) == groups, sorted(set(seen))
     plain, seen_plain = _with_debug("LEVELS_NOSWITCH,SCF_NOLIVE", run_batch)

@@ -350,10 +350,10 @@ def test_l20_radon_lsda_steps_vs_reference(ctx, grid20, modes):
 
 
 def test_l20_batch_layouts_agree(ctx, grid20):
-    """BASELINE config 5's batch-of-atoms form (bench.py: rn_lsda_l20_batch16): 8 Rn atoms LSDA at 1 048 577 nodes -- 240 jobs: packed
-    rounds of the level search, 16 multigrid workgroups per atom -- two SCF steps; every copy of the atom gets the single atom's
-    energies and eigenvalues bit for bit (latency-mode level search, one atom's multigrid groups), and the packed layout reports
-    itself in the step statistics."""
+    """BASELINE config 5's batch-of-atoms form (bench.py: rn_lsda_l20_batch16): 8 Rn atoms LSDA at 1 048 577 nodes -- 240 jobs: the
+    device-side level search with one workgroup per level (+ 16 second ones; round 5: packed host rounds, LEVELS_PERSIST_WIDE=64), 16
+    multigrid workgroups per atom -- two SCF steps; every copy of the atom gets the single atom's energies and eigenvalues bit for bit,
+    under both layouts, and the layout reports itself in the step statistics."""
     one = D.Scf(ctx, grid20, [86], lsda=True)
     for _ in range(2):
         st1 = one.step()
@@ -361,16 +361,28 @@ def test_l20_batch_layouts_agree(ctx, grid20):
     ref_lv = [one.levels(0, sp)["E"].copy() for sp in range(2)]
     assert int(st1.levels_layout) == 5               # one atom: the device-side search (persist.inc)
     one.close()
-    b = D.Scf(ctx, grid20, [86] * 8, lsda=True)
-    for _ in range(2):
-        st = b.step()
-    assert int(st.levels_layout) == 2 and b.njobs == 240
-    en, _ = b.energies()
-    for a in range(8):
-        assert en[a].as_list() == ref_e, a
-        for sp in range(2):
-            assert np.array_equal(b.levels(a, sp)["E"].view(np.int64), ref_lv[sp].view(np.int64)), (a, sp)
-    b.close()
+    for knobs, layout in (("", 5), ("LEVELS_PERSIST_WIDE=64", 2)):
+        old = os.environ.get("DFTA_DEBUG")
+        if knobs:
+            os.environ["DFTA_DEBUG"] = knobs
+        try:
+            b = D.Scf(ctx, grid20, [86] * 8, lsda=True)
+        finally:
+            if knobs:
+                if old is None:
+                    os.environ.pop("DFTA_DEBUG", None)
+                else:
+                    os.environ["DFTA_DEBUG"] = old
+        for _ in range(2):
+            st = b.step()
+        print("8 x Rn LSDA @ 2^20+1, layout %d: level phase %.1f ms, %d rounds" % (int(st.levels_layout), st.ms_levels, int(st.rounds)))
+        assert int(st.levels_layout) == layout and b.njobs == 240, (knobs, int(st.levels_layout))
+        en, _ = b.energies()
+        for a in range(8):
+            assert en[a].as_list() == ref_e, (knobs, a)
+            for sp in range(2):
+                assert np.array_equal(b.levels(a, sp)["E"].view(np.int64), ref_lv[sp].view(np.int64)), (knobs, a, sp)
+        b.close()
 
 
 def test_l20_third_bisection_on_its_fixed_point(ctx, grid20):

@@ -128,13 +128,17 @@ def test_longest_first_launch_on_static_blocks_keeps_the_bits(ctx, grid14):
     the blocks of a round launched longest first (k_expand's queue) against the plain launch in array order (LEVELS_NOQUEUE): same bits --
     the order in which blocks start is invisible in every result"""
     Z = list(range(75, 87))
-    q = _run(ctx, grid14, Z, False, 6, "")
-    plain = _run(ctx, grid14, Z, False, 6, "LEVELS_NOQUEUE")
+    # (LEVELS_PERSIST_WIDE=64: round 5's limit of the device-side search, which takes batches of up to 256 levels by default)
+    q = _run(ctx, grid14, Z, False, 6, "LEVELS_PERSIST_WIDE=64")
+    plain = _run(ctx, grid14, Z, False, 6, "LEVELS_PERSIST_WIDE=64,LEVELS_NOQUEUE")
     assert all(r["layout"] == 0 for r in q) and all(r["layout"] == 0 for r in plain), ([r["layout"] for r in q], [r["layout"] for r in plain])
     _assert_same(q, plain, "queued vs plain launch")
     # ... and the scan predictor of the first spines (one workgroup per level ahead of the rounds): off / shifted -- fewer or more rounds, same bits
-    nopred = _run(ctx, grid14, Z, False, 6, "LEVELS_NOSCANPREDICT_BATCH")
-    wrong = _run(ctx, grid14, Z, False, 6, "LEVELS_SCAN_PREDICT_SHIFT=-1e-4")
+    nopred = _run(ctx, grid14, Z, False, 6, "LEVELS_PERSIST_WIDE=64,LEVELS_NOSCANPREDICT_BATCH")
+    wrong = _run(ctx, grid14, Z, False, 6, "LEVELS_PERSIST_WIDE=64,LEVELS_SCAN_PREDICT_SHIFT=-1e-4")
+    dev = _run(ctx, grid14, Z, False, 6, "")                              # ... and the default: the device-side search of 174 levels
+    assert all(r["layout"] == 5 for r in dev), [r["layout"] for r in dev]
+    _assert_same(q, dev, "host rounds vs the device-side search")
     _assert_same(q, nopred, "scan predictor off")
     _assert_same(q, wrong, "scan predictor shifted")
     assert sum(r["rounds"] for r in q) < sum(r["rounds"] for r in nopred)

@@ -132,10 +132,10 @@ def test_layout_knobs_of_the_device_search_keep_the_bits(ctx, grid14, knobs):
 
 
 def test_batch_whose_last_atoms_search_on_the_device(ctx, grid14):
-    """a batch of 30 atoms (148 levels) starts in static blocks; once at most 128 levels are live its rounds move to the device (layout 5:
-    two workgroups per level, later the floating shares of a single atom's search), and every atom ends in the state it reaches alone
-    with host rounds"""
-    Z = list(range(1, 31))
+    """a batch of 45 atoms (280 levels) starts in packed host rounds; once at most 256 levels are live its rounds move to the device (layout 5:
+    one or two workgroups per level, later the floating shares of a single atom's search), and every atom ends in the state it reaches
+    alone with host rounds"""
+    Z = list(range(1, 46))
     with _Knobs(""):
         batch = D.Scf(ctx, grid14, Z, lsda=False)
     layouts = []
@@ -147,7 +147,7 @@ def test_batch_whose_last_atoms_search_on_the_device(ctx, grid14):
             break
     eb, _ = batch.energies()
     assert 5 in layouts and layouts[0] != 5, sorted(set(layouts))
-    for ia in (0, 7, 12, 19, 28):
+    for ia in (0, 7, 12, 19, 28, 44):
         with _Knobs("LEVELS_NOPERSIST"):
             one = D.Scf(ctx, grid14, [Z[ia]], lsda=False)
         for _ in range(110):
@@ -163,10 +163,11 @@ def test_batch_whose_last_atoms_search_on_the_device(ctx, grid14):
 
 
 def test_device_search_of_a_batch_with_65_to_128_live_levels(ctx, grid14, grid17):
-    """Round 6: the device-side search takes up to 128 live levels -- two workgroups per level on 256 compute units, every level at its own
-    pace, match solve and normalisation inside (the shards of an 8-rank periodic table start with ~100 levels).  Eleven atoms at 16 385
-    and at 131 073 nodes against the host rounds (LEVELS_NOPERSIST) and against round 5's limit (LEVELS_PERSIST_WIDE=64: static blocks);
-    a lost worker sends the step back to the batch's own host rounds (layout 0)."""
+    """Round 6: the device-side search takes up to 256 live levels -- one workgroup per level, a second one for as many levels as there are
+    compute units left (all of them up to 128 levels: the shards of an 8-rank periodic table start with ~100), every level at its own
+    pace, match solve and normalisation inside.  Eleven atoms (76 / 105 levels) at 16 385 and at 131 073 nodes and 21 atoms (145 levels: 111
+    second workgroups, handed to the levels that ended last in the previous steps) against the host rounds (LEVELS_NOPERSIST) and against
+    round 5's limit (LEVELS_PERSIST_WIDE=64: static blocks); a lost worker sends the step back to the batch's own host rounds (layout 0)."""
     Z14 = list(range(20, 31))                                            # 76 levels
     wide14 = _run(ctx, grid14, Z14, False, 6, "")
     host14 = _run(ctx, grid14, Z14, False, 6, "LEVELS_NOPERSIST")
@@ -180,6 +181,13 @@ def test_device_search_of_a_batch_with_65_to_128_live_levels(ctx, grid14, grid17
     host17 = _run(ctx, grid17, Z17, False, 3, "LEVELS_NOPERSIST")
     assert all(r["layout"] == 5 for r in wide17) and all(r["layout"] == 0 for r in host17)
     _assert_same(wide17, host17, "wide vs host rounds @ 131 073")
+    Z21 = list(range(10, 31))                                            # 145 levels: one workgroup each + 111 second ones
+    wide21 = _run(ctx, grid14, Z21, False, 5, "")
+    host21 = _run(ctx, grid14, Z21, False, 5, "LEVELS_NOPERSIST")
+    mid21 = _run(ctx, grid14, Z21, False, 5, "LEVELS_PERSIST_EQUAL")     # one workgroup per level, the rest in the pool
+    assert all(r["layout"] == 5 for r in wide21) and all(r["layout"] == 5 for r in mid21) and all(r["layout"] == 0 for r in host21)
+    _assert_same(wide21, host21, "145 levels vs host rounds")
+    _assert_same(mid21, host21, "145 levels, equal shares, vs host rounds")
     lost = _run(ctx, grid14, Z14, False, 3, "FAULT_PERSIST_WORKER=1,LEVELS_PERSIST_TIMEOUT_MS=300")
     assert lost[0]["layout"] == 0, [r["layout"] for r in lost]
     _assert_same(lost, host14[:3], "lost worker of a wide search")
