@@ -47,7 +47,7 @@ def atom_cost(Z):
 # One triple per mode of the sweeps, least squares over the shards of the emulated 1-, 2-, 4- and 8-rank sweeps (profiles/fit_shard_model.py
 # re-fits them from the recorded files; tests/test_sweep_dist.py checks that the model reproduces every recorded shard time within 15 %).
 RESIDENT_MAX_ATOMS = 7
-SHARD_MODEL = {"exact": (50.7, 58.8, 0.217),        # round-6 kernels incl. the 17-workgroup resident multigrid of 8 .. 15 atoms (profiles/r06_periodic_table_predicted_scaling_exact.json): residuals of the 15 recorded shards max 6.9 %, rms 3.5 %
+SHARD_MODEL = {"exact": (44.9, 51.3, 0.233),        # round-6 kernels incl. the 17-workgroup resident multigrid of 8 .. 15 atoms and the device-side search of up to 256 levels (profiles/r06_periodic_table_predicted_scaling_exact.json): residuals of the 15 recorded shards max 5.0 %, rms 2.9 %
                "tolerance": (5.6, 11.4, 0.153)}     # scan sweeps + the multigrid's tolerance mode (..._tolerance.json): max 11.1 %, rms 5.5 %
 STEP_FLOOR_MS, JOB_MS = SHARD_MODEL["exact"][1], SHARD_MODEL["exact"][2]
 
