@@ -307,7 +307,7 @@ typedef struct dfta_step_stats {
     int    levels_layout;        /* trial layout of this step's level search: 0 one block of 2^depth trials per job, 1 latency mode
                                     (slots re-allotted every round, <= 64 jobs), 2 packed rounds (batches), 3 latency mode over the
                                     live jobs of a batch most of whose atoms have finished, 4 scan search (tolerance mode of the sweeps), 5 device-side exact
-                                    search (one persistent kernel, every level at its own pace: persist.inc), 6 own-pace search of a batch (one
+                                    search (one persistent kernel, every level at its own pace, up to 256 live levels: persist.inc), 6 own-pace search of a batch (one
                                     workgroup per level in one launch: own.inc, opt-in $DFTA_DEBUG LEVELS_OWN) -- never changes a result */
     int    poisson_groups;       /* workgroups per atom of the multigrid solve of this step (33 / 17: resident groups of up to 7 / 15 atoms); the live atoms of
                                     a batch are solved by a solver of their size class (128 / 64 / 32 / 16 / 15 / 7 atoms) once that is smaller
